@@ -1,0 +1,467 @@
+"""CPU oracle for the CM-TTS inference hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-numpy (fp32) restatement of the reference's algorithm for every row of SURVEY.md §8(a):
+phoneme ids (+ speaker vector) -> FFT-block encoder -> variance adaptor / length regulator ->
+T-step consistency denoiser -> HiFi-GAN generator -> int16 wav.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
+shipped path (``cm-tts_amd/``) never does and fails loudly if the HIP library is missing.
+
+Parity pinning: the reference has no tests.  This oracle is pinned against golden
+vectors produced by importing the reference's own modules in the build container
+(tests/golden/make_golden.py, which needs /root/reference; the .npz fixtures it writes are
+committed) — see tests/test_oracle_golden.py.
+
+All tensors use the reference's layouts: activations [B, L, C] / [B, T, C], conv weights
+[C_out, C_in, k], ConvTranspose1d weights [C_in, C_out, k], mel [B, T, 80].
+Every function names the reference file:line it restates (paths relative to the reference root).
+"""
+import math
+
+import numpy as np
+from scipy.special import erf as _erf
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- primitives
+
+def conv1d(x, w, b=None, padding=0, dilation=1):
+    """torch.nn.functional.conv1d, stride 1.  x [B,Cin,T], w [Cout,Cin,K] -> [B,Cout,T']."""
+    x = np.asarray(x, F32)
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    xp = np.zeros((B, Cin, T + 2 * padding), F32)
+    xp[:, :, padding:padding + T] = x
+    To = T + 2 * padding - dilation * (K - 1)
+    y = np.zeros((B, Cout, To), F32)
+    for k in range(K):
+        y += np.matmul(w[:, :, k], xp[:, :, k * dilation:k * dilation + To])
+    if b is not None:
+        y += b[None, :, None]
+    return y
+
+
+def conv_transpose1d(x, w, b, stride, padding):
+    """torch.nn.functional.conv_transpose1d.  x [B,Cin,T], w [Cin,Cout,K] -> [B,Cout,(T-1)s-2p+K]."""
+    x = np.asarray(x, F32)
+    B, Cin, T = x.shape
+    _, Cout, K = w.shape
+    full = np.zeros((B, Cout, (T - 1) * stride + K), F32)
+    for k in range(K):
+        full[:, :, k:k + (T - 1) * stride + 1:stride] += np.matmul(w[:, :, k].T, x)
+    y = full[:, :, padding:full.shape[2] - padding]
+    return y + b[None, :, None]
+
+
+def linear(x, w, b=None):
+    y = np.matmul(np.asarray(x, F32), w.T)
+    return y if b is None else y + b
+
+
+def layer_norm(x, g, b, eps):
+    """torch.nn.LayerNorm over the last axis (biased variance)."""
+    m = x.mean(-1, keepdims=True, dtype=F32)
+    v = ((x - m) ** 2).mean(-1, keepdims=True, dtype=F32)
+    return ((x - m) / np.sqrt(v + F32(eps))).astype(F32) * g + b
+
+
+def gelu_erf(x):
+    return (x * F32(0.5) * (F32(1.0) + _erf(x * F32(math.sqrt(0.5))).astype(F32))).astype(F32)
+
+
+def sigmoid(x):
+    return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
+
+
+def mish(x):
+    """model/blocks.py:621-623: x * tanh(softplus(x)); softplus with torch's threshold 20."""
+    sp = np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, F32(20.0))))).astype(F32)
+    return (x * np.tanh(sp)).astype(F32)
+
+
+def leaky_relu(x, slope):
+    return np.where(x > 0, x, x * F32(slope)).astype(F32)
+
+
+def get_mask_from_lengths(lengths, max_len):
+    """utils/tools.py:275-283 — True marks padding."""
+    return np.arange(max_len)[None, :] >= np.asarray(lengths)[:, None]
+
+
+def sinusoid_table(n_pos, dim):
+    """model/blocks.py:45-62 SinusoidalPositionalEmbedding.get_embedding (padding row 0 zeroed):
+    row p = [sin(p*w_j) | cos(p*w_j)], w_j = exp(-j*ln(1e4)/(dim/2-1)), halves concatenated."""
+    half = dim // 2
+    e = F32(math.log(10000) / (half - 1))
+    w = np.exp(np.arange(half, dtype=F32) * -e).astype(F32)
+    ang = (np.arange(n_pos, dtype=F32)[:, None] * w[None, :]).astype(F32)
+    tab = np.concatenate([np.sin(ang), np.cos(ang)], 1).astype(F32)
+    tab[0, :] = 0
+    return tab
+
+
+def make_positions(nonpad):
+    """utils/tools.py:810-822 with padding_idx 0: cumsum(nonpad)*nonpad (1-based, pad -> 0)."""
+    nonpad = nonpad.astype(np.int64)
+    return np.cumsum(nonpad, 1) * nonpad
+
+
+def positional_embedding(ref_values, dim):
+    """SinusoidalPositionalEmbedding.forward (model/blocks.py:64-81): positions from `value != 0`."""
+    pos = make_positions(ref_values != 0)
+    tab = sinusoid_table(int(pos.max()) + 2, dim)
+    return tab[pos]
+
+
+# ----------------------------------------------------------------------------- text encoder
+
+def encoder_embedding(sd, texts, hidden=256):
+    """FastspeechEncoder.forward_embedding, model/modules.py:145-151: sqrt(H)*E[tok] + PE[pos]."""
+    E = sd["duration_pitch_energy_net.text_encoder.embed_tokens.weight"]
+    x = F32(math.sqrt(hidden)) * E[texts]
+    return (x + positional_embedding(texts, hidden)).astype(F32)
+
+
+def multihead_self_attention(x, in_w, out_w, key_pad, n_heads):
+    """model/blocks.py:266-312 -> F.multi_head_attention_forward, no biases (bias=False, :585).
+    x [B,L,C]; heads are contiguous channel slices; padded keys get -inf before softmax."""
+    B, L, C = x.shape
+    d = C // n_heads
+    qkv = linear(x, in_w)                                  # [B,L,3C]
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    q = q * F32(1.0 / math.sqrt(d))
+
+    def heads(t):
+        return t.reshape(B, L, n_heads, d).transpose(0, 2, 1, 3)   # [B,H,L,d]
+
+    s = np.matmul(heads(q), heads(k).transpose(0, 1, 3, 2))        # [B,H,L,L]
+    s = np.where(key_pad[:, None, None, :], F32(-np.inf), s)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p = (p / p.sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    o = np.matmul(p, heads(v)).transpose(0, 2, 1, 3).reshape(B, L, C)
+    return linear(o, out_w)
+
+
+def enc_sa_layer(sd, prefix, x, pad_mask, n_heads, kernel):
+    """EncSALayer.forward model/blocks.py:594-618 + TransformerFFNLayer :539-552 (eval mode)."""
+    keep = (~pad_mask).astype(F32)[:, :, None]
+    h = layer_norm(x, sd[prefix + "layer_norm1.weight"], sd[prefix + "layer_norm1.bias"], 1e-12)
+    h = multihead_self_attention(h, sd[prefix + "self_attn.in_proj_weight"],
+                                 sd[prefix + "self_attn.out_proj.weight"], pad_mask, n_heads)
+    x = (x + h) * keep
+    h = layer_norm(x, sd[prefix + "layer_norm2.weight"], sd[prefix + "layer_norm2.bias"], 1e-12)
+    h = conv1d(h.transpose(0, 2, 1), sd[prefix + "ffn.ffn_1.weight"], sd[prefix + "ffn.ffn_1.bias"],
+               padding=kernel // 2)
+    h = gelu_erf(h * F32(kernel ** -0.5)).transpose(0, 2, 1)
+    h = linear(h, sd[prefix + "ffn.ffn_2.weight"], sd[prefix + "ffn.ffn_2.bias"])
+    return ((x + h) * keep).astype(F32)
+
+
+def text_encoder(sd, cfg, texts, src_mask):
+    """FastspeechEncoder.forward / FFTBlocks.forward, model/modules.py:80-105,133-143."""
+    pre = "duration_pitch_energy_net.text_encoder."
+    keep = (~src_mask).astype(F32)[:, :, None]
+    x = encoder_embedding(sd, texts, cfg.hidden) * keep
+    for i in range(cfg.enc_layers):
+        x = enc_sa_layer(sd, f"{pre}layers.{i}.op.", x, src_mask, cfg.enc_heads, cfg.ffn_kernel) * keep
+    x = layer_norm(x, sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5) * keep
+    return x.astype(F32)
+
+
+# ----------------------------------------------------------------------------- variance adaptor
+
+def _pred_convs(sd, prefix, xs, n_layers, kernel, mask=None):
+    """conv stack shared by Duration/Pitch/Energy predictors (model/modules.py:477-487,527-537):
+    zero-pad, Conv1d, ReLU, LayerNorm over channels (eps 1e-12); duration also masks per layer."""
+    h = xs.transpose(0, 2, 1)
+    for li in range(n_layers):
+        h = conv1d(h, sd[f"{prefix}conv.{li}.1.weight"], sd[f"{prefix}conv.{li}.1.bias"],
+                   padding=(kernel - 1) // 2)
+        h = np.maximum(h, 0)
+        h = layer_norm(h.transpose(0, 2, 1), sd[f"{prefix}conv.{li}.3.weight"],
+                       sd[f"{prefix}conv.{li}.3.bias"], 1e-12).transpose(0, 2, 1)
+        if mask is not None:
+            h = h * (~mask).astype(F32)[:, None, :]
+    return h.transpose(0, 2, 1).astype(F32)
+
+
+def duration_predictor(sd, cfg, x, src_mask):
+    """DurationPredictor.forward model/modules.py:498-509 -> log-durations [B,L]."""
+    p = "duration_pitch_energy_net.variance_adaptor.duration_predictor."
+    h = _pred_convs(sd, p, x, cfg.dur_layers, cfg.dur_kernel, src_mask)
+    y = linear(h, sd[p + "linear.weight"], sd[p + "linear.bias"])
+    return (y * (~src_mask).astype(F32)[:, :, None])[..., 0]
+
+
+def pitch_style_predictor(sd, prefix, cfg, xs):
+    """PitchPredictor/EnergyPredictor.forward model/modules.py:542-556: adds alpha*PE at positions
+    counted from `xs[...,0] != 0` (a float-zero test), conv stack without masking, Linear."""
+    pe = positional_embedding(xs[..., 0], xs.shape[-1])
+    xs = (xs + sd[prefix + "pos_embed_alpha"] * pe).astype(F32)
+    h = _pred_convs(sd, prefix, xs, cfg.pred_layers, cfg.pred_kernel, None)
+    return linear(h, sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+
+
+def bucketize(v, bins):
+    """torch.bucketize(right=False): first i with bins[i] >= v (== numpy side='left')."""
+    return np.searchsorted(bins, v, side="left").astype(np.int64)
+
+
+def durations_from_log(log_d, d_control=1.0):
+    """model/modules.py:369-372: clamp(round(exp(log_d)-1)*d_control, min=0); half-to-even round."""
+    return np.maximum(np.rint(np.exp(log_d.astype(F32)) - F32(1.0)) * F32(d_control), 0).astype(F32)
+
+
+def dur_to_mel2ph(dur, src_mask, T=None):
+    """utils/tools.py:768-798: 1-based phoneme id per frame, 0 for padding (int64 [B,T])."""
+    d = np.rint(dur).astype(np.int64) * (~src_mask).astype(np.int64)
+    cum = np.cumsum(d, 1)
+    width = int(cum[:, -1].max()) if T is None else T
+    t = np.arange(width)[None, :]
+    # number of phonemes whose cumulative end is <= t  -> index of the covering phoneme
+    idx = (cum[:, None, :] <= t[:, :, None]).sum(-1)
+    return np.where(t < cum[:, -1:], idx + 1, 0).astype(np.int64)
+
+
+def length_regulate(x, dur, max_len=None):
+    """LengthRegulator model/modules.py:421-448 + pad utils/tools.py:724-742: repeat phoneme i
+    int(d_i) times, zero-pad (or truncate) to max_len.  Returns ([B,T,C], mel_len int64[B])."""
+    B, L, C = x.shape
+    d = np.maximum(dur.astype(np.int64), 0)
+    mel_len = d.sum(1)
+    T = int(mel_len.max()) if max_len is None else int(max_len)
+    out = np.zeros((B, T, C), F32)
+    for b in range(B):
+        rep = np.repeat(x[b], d[b], axis=0)[:T]
+        out[b, :rep.shape[0]] = rep
+    return out, mel_len.astype(np.int64)
+
+
+_F0_MEL_MIN = 1127 * np.log(1 + 50.0 / 700)     # utils/pitch_tools.py:19-23
+_F0_MEL_MAX = 1127 * np.log(1 + 1100.0 / 700)
+
+
+def f0_to_coarse(f0, f0_bin=256):
+    """utils/pitch_tools.py:26-35 (torch branch): mel-scale bucket in [1, 255], (mel+0.5) truncated."""
+    mel = (F32(1127) * np.log(F32(1) + f0 / F32(700))).astype(F32)
+    pos = mel > 0
+    mel = np.where(pos, (mel - F32(_F0_MEL_MIN)) * F32(f0_bin - 2) / F32(_F0_MEL_MAX - _F0_MEL_MIN) + F32(1), mel)
+    mel = np.where(mel <= 1, F32(1), mel)
+    mel = np.where(mel > f0_bin - 1, F32(f0_bin - 1), mel).astype(F32)
+    return (mel + F32(0.5)).astype(np.int64), mel
+
+
+def cwt_to_pitch_index(cwt_out, mean, std, cfg):
+    """VarianceAdaptor.get_pitch_embedding cwt branch, model/modules.py:274-300, with
+    cwt2f0_norm/inverse_cwt_torch/norm_f0/denorm_f0 (utils/pitch_tools.py:244-279,38-47,64-78).
+    cwt_out [B,T,10|11], mean/std [B] (std already * cwt_std_scale)."""
+    spec = cwt_out[:, :, :10]
+    scale = ((np.arange(10, dtype=F32) + F32(1) + F32(2.5)) ** F32(-2.5)).astype(F32)
+    r = (spec * scale[None, None, :]).sum(-1, dtype=F32)
+    r = ((r - r.mean(-1, keepdims=True, dtype=F32)) / r.std(-1, ddof=1, keepdims=True, dtype=F32)).astype(F32)
+    f0 = np.exp(r * std[:, None] + mean[:, None]).astype(F32)
+    f0n = np.log2(f0 + F32(cfg.pitch_norm_eps)).astype(F32)          # norm_f0 'log'
+    f0d = np.exp2(f0n).astype(F32)                                    # denorm_f0: 2 ** f0
+    if cfg.use_uv:
+        uv = cwt_out[:, :, -1] > 0
+        f0d = np.where(uv, F32(0), f0d)
+    idx, mel = f0_to_coarse(f0d)
+    return idx, f0d, mel
+
+
+def variance_adaptor(sd, cfg, enc_out, src_mask, speaker_emb=None, max_len=None):
+    """VarianceAdaptor.forward inference branch, model/modules.py:331-412 (all targets None,
+    controls 1.0).  Returns a dict of every intermediate the parity tests pin."""
+    va = "duration_pitch_energy_net.variance_adaptor."
+    x = enc_out
+    if speaker_emb is not None:
+        x = (x + speaker_emb[:, None, :]).astype(F32)
+    log_d = duration_predictor(sd, cfg, x, src_mask)
+    e_pred = pitch_style_predictor(sd, va + "energy_predictor.", cfg, x)[..., 0]
+    e_idx = bucketize(e_pred, sd[va + "energy_bins"])
+    out1 = (x + sd[va + "energy_embedding.weight"][e_idx]).astype(F32)
+    d_rounded = durations_from_log(log_d)
+    x_lr, mel_len = length_regulate(out1, d_rounded, max_len)
+    T = x_lr.shape[1]
+    mel2ph = dur_to_mel2ph(d_rounded, src_mask)
+    h = linear(x_lr, sd[va + "cwt_predictor.0.weight"], sd[va + "cwt_predictor.0.bias"])
+    cwt_out = pitch_style_predictor(sd, va + "cwt_predictor.1.", cfg, h)
+    s = np.maximum(linear(out1[:, 0, :], sd[va + "cwt_stats_layers.0.weight"], sd[va + "cwt_stats_layers.0.bias"]), 0)
+    s = np.maximum(linear(s, sd[va + "cwt_stats_layers.2.weight"], sd[va + "cwt_stats_layers.2.bias"]), 0)
+    s = linear(s, sd[va + "cwt_stats_layers.4.weight"], sd[va + "cwt_stats_layers.4.bias"])
+    mean, std_raw = s[:, 0], s[:, 1]                                  # f0_mean / f0_std as returned
+    p_idx, f0d, f0_mel = cwt_to_pitch_index(cwt_out, mean, (std_raw * F32(cfg.cwt_std_scale)).astype(F32), cfg)
+    cond = (x_lr + sd[va + "pitch_embed.weight"][p_idx]).astype(F32)
+    return dict(cond=cond, log_d=log_d, d_rounded=d_rounded, mel_len=mel_len, mel2ph=mel2ph,
+                e_pred=e_pred, e_idx=e_idx, out1=out1, x_lr=x_lr, cwt_out=cwt_out,
+                f0_mean=mean, f0_std=std_raw, f0_denorm=f0d, f0_mel=f0_mel, p_idx=p_idx,
+                mel_mask=get_mask_from_lengths(mel_len, T))
+
+
+def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_mel_len=None):
+    """DurationPitchSpeakerNet.forward model/cmtts.py:44-122."""
+    B, L = texts.shape
+    src_mask = get_mask_from_lengths(src_lens, L)
+    enc = text_encoder(sd, cfg, texts, src_mask)
+    spk = None
+    if cfg.multi_speaker:
+        spk = linear(spker_embeds, sd["duration_pitch_energy_net.speaker_emb.weight"],
+                     sd["duration_pitch_energy_net.speaker_emb.bias"]).astype(F32)
+    out = variance_adaptor(sd, cfg, enc, src_mask, spk, max_mel_len)
+    out.update(enc_out=enc, speaker_emb=spk, src_mask=src_mask)
+    return out
+
+
+# ----------------------------------------------------------------------------- denoiser + sampler
+
+def diffusion_embedding(t, dim):
+    """DiffusionEmbedding.forward model/blocks.py:633-640."""
+    half = dim // 2
+    e = F32(math.log(10000) / (half - 1))
+    w = np.exp(np.arange(half, dtype=F32) * -e).astype(F32)
+    a = (t.astype(F32)[:, None] * w[None, :]).astype(F32)
+    return np.concatenate([np.sin(a), np.cos(a)], -1).astype(F32)
+
+
+def denoiser_forward(sd, cfg, x, t, cond, speaker_emb):
+    """CMDenoiserTTS.forward (model/cm_tool/tts_net.py:29-37) = Denoiser.forward
+    (model/modules.py:600-639) + ResidualBlock.forward (model/blocks.py:667-686).
+    x [B,1,T,80] (already scaled by c_in), t [B] (= 250*ln sigma), cond [B,T,256],
+    speaker_emb [B,256] or None  ->  [B,1,T,80]."""
+    C = cfg.res_channels
+    h = x[:, 0].transpose(0, 2, 1)                                   # [B,80,T]
+    h = np.maximum(conv1d(h, sd["net.input_projection.0.conv.weight"], sd["net.input_projection.0.conv.bias"]), 0)
+    e = diffusion_embedding(t, C)
+    e = linear(mish(linear(e, sd["net.mlp.0.linear.weight"])), sd["net.mlp.2.linear.weight"])
+    c = cond.transpose(0, 2, 1)
+    skip_sum = None
+    for i in range(cfg.res_layers):
+        p = f"net.residual_layers.{i}."
+        d = linear(e, sd[p + "diffusion_projection.linear.weight"])[:, :, None]
+        cp = conv1d(c, sd[p + "conditioner_projection.conv.weight"], sd[p + "conditioner_projection.conv.bias"])
+        r = (h + d).astype(F32)
+        u = r + cp
+        if cfg.multi_speaker:
+            u = u + linear(speaker_emb, sd[p + "speaker_projection.linear.weight"])[:, :, None]
+        y = conv1d(u.astype(F32), sd[p + "conv_layer.conv.weight"], sd[p + "conv_layer.conv.bias"], padding=1)
+        z = (sigmoid(y[:, :C]) * np.tanh(y[:, C:])).astype(F32)
+        o = conv1d(z, sd[p + "output_projection.conv.weight"], sd[p + "output_projection.conv.bias"])
+        h = ((o[:, :C] + r) / F32(math.sqrt(2.0))).astype(F32)
+        skip_sum = o[:, C:] if skip_sum is None else skip_sum + o[:, C:]
+    s = (skip_sum / F32(math.sqrt(cfg.res_layers))).astype(F32)
+    s = np.maximum(conv1d(s, sd["net.skip_projection.conv.weight"], sd["net.skip_projection.conv.bias"]), 0)
+    out = conv1d(s, sd["net.output_projection.conv.weight"], sd["net.output_projection.conv.bias"])
+    return out.transpose(0, 2, 1)[:, None].astype(F32)
+
+
+def boundary_scalings(sigma, cfg):
+    """KarrasDenoiser.get_scalings_for_boundary_condition, karras_diffusion.py:87-102."""
+    sd2 = cfg.sigma_data ** 2
+    c_skip = sd2 / ((sigma - cfg.sigma_min) ** 2 + sd2)
+    c_out = (sigma - cfg.sigma_min) * cfg.sigma_data / (sigma ** 2 + sd2) ** 0.5
+    c_in = 1 / (sigma ** 2 + sd2) ** 0.5
+    return c_skip, c_out, c_in
+
+
+def karras_denoise(sd, cfg, x_t, sigma, cond, speaker_emb):
+    """KarrasDenoiser.denoise karras_diffusion.py:392-407 with distillation=True.
+    sigma: fp32 [B].  Returns the denoised sample [B,1,T,80]."""
+    sigma = np.asarray(sigma, F32)
+    c_skip, c_out, c_in = [np.asarray(v, F32)[:, None, None, None] for v in boundary_scalings(sigma, cfg)]
+    t = (F32(1000 * 0.25) * np.log(sigma + F32(1e-44))).astype(F32)
+    f = denoiser_forward(sd, cfg, (c_in * x_t).astype(F32), t, cond, speaker_emb)
+    return (c_out * f + c_skip * x_t).astype(F32)
+
+
+def multistep_schedule(n_steps, cfg):
+    """synthesize.py:111-147 + stochastic_iterative_sampler karras_diffusion.py:830-854.
+    T=1 -> onestep at sigma_max.  T=2/4 -> ts=(0,)*T+(1,), steps=2: every evaluation happens at
+    sigma_max; the re-noising std after evaluation i is sqrt(next_t^2 - sigma_min^2)*0.85 with
+    next_t = sigma_max except after the last evaluation, where next_t = sigma_min -> std 0.
+    Returns (eval_sigmas float64[n], renoise_std float64[n]); onestep has renoise None."""
+    if n_steps == 1:
+        return [cfg.sigma_max], [None]
+    ts = (0,) * n_steps + (1,)
+    steps = 2
+    tmax, tmin = cfg.sigma_max ** (1 / cfg.rho), cfg.sigma_min ** (1 / cfg.rho)
+    sig, std = [], []
+    for i in range(len(ts) - 1):
+        t = (tmax + ts[i] / (steps - 1) * (tmin - tmax)) ** cfg.rho
+        nt = (tmax + ts[i + 1] / (steps - 1) * (tmin - tmax)) ** cfg.rho
+        nt = float(np.clip(nt, cfg.sigma_min, cfg.sigma_max))
+        sig.append(t)
+        std.append(float(np.sqrt(nt ** 2 - cfg.sigma_min ** 2) * 0.85))
+    return sig, std
+
+
+def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise):
+    """karras_sample_tts karras_diffusion.py:480-577 with explicit noise (the reference draws
+    x_T then one randn_like per multistep iteration, random_util.py:17-25).
+    noise: list of [B,1,T,80] N(0,1) arrays — noise[0] -> x_T, noise[1+i] -> re-noise after eval i.
+    Returns mel [B,T,80]."""
+    B = cond.shape[0]
+    sig, std = multistep_schedule(n_steps, cfg)
+    x = (noise[0] * F32(cfg.sigma_max)).astype(F32)
+    for i, s in enumerate(sig):
+        x0 = karras_denoise(sd, cfg, x, np.full((B,), s, F32), cond, speaker_emb)
+        if std[i] is None:
+            x = x0
+        else:
+            x = (x0 + noise[1 + i] * F32(std[i])).astype(F32)   # python-float scalar, as in the reference
+    return x[:, 0]
+
+
+# ----------------------------------------------------------------------------- HiFi-GAN
+
+def hifigan_generator(hsd, hcfg, mel_ct):
+    """hifigan.Generator.forward hifigan/models.py:149-165, ResBlock.forward :96-103.
+    mel_ct [B,80,T] -> wav [B,1,256*T] in (-1,1)."""
+    x = conv1d(mel_ct, hsd["conv_pre.weight"], hsd["conv_pre.bias"], padding=3)
+    nk = len(hcfg.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(hcfg.upsample_rates, hcfg.upsample_kernel_sizes)):
+        x = leaky_relu(x, hcfg.lrelu_slope)
+        x = conv_transpose1d(x, hsd[f"ups.{i}.weight"], hsd[f"ups.{i}.bias"], u, (k - u) // 2)
+        xs = None
+        for j, (rk, dils) in enumerate(zip(hcfg.resblock_kernel_sizes, hcfg.resblock_dilation_sizes)):
+            r = i * nk + j
+            xr = x
+            for m, dil in enumerate(dils):
+                xt = leaky_relu(xr, hcfg.lrelu_slope)
+                xt = conv1d(xt, hsd[f"resblocks.{r}.convs1.{m}.weight"], hsd[f"resblocks.{r}.convs1.{m}.bias"],
+                            padding=(rk * dil - dil) // 2, dilation=dil)
+                xt = leaky_relu(xt, hcfg.lrelu_slope)
+                xt = conv1d(xt, hsd[f"resblocks.{r}.convs2.{m}.weight"], hsd[f"resblocks.{r}.convs2.{m}.bias"],
+                            padding=(rk - 1) // 2)
+                xr = (xt + xr).astype(F32)
+            xs = xr if xs is None else xs + xr
+        x = (xs / F32(nk)).astype(F32)
+    x = leaky_relu(x, hcfg.final_lrelu_slope)
+    x = conv1d(x, hsd["conv_post.weight"], hsd["conv_post.bias"], padding=3)
+    return np.tanh(x).astype(F32)
+
+
+def wav_to_int16(wav, max_wav_value=32768.0):
+    """vocoder_infer utils/model.py:195-198: (wav*32768).astype('int16') — truncation toward zero;
+    +1.0 maps to 32768 which wraps to -32768 (C cast via int32 on x86)."""
+    v = (wav * F32(max_wav_value)).astype(F32)
+    return v.astype(np.int32).astype(np.int16)
+
+
+def vocoder_infer(hsd, hcfg, mel_btc, mel_lens, cfg):
+    """vocoder_infer utils/model.py:187-205 as called from synth_samples utils/tools.py:595-600:
+    mel [B,T,80] -> list of int16 arrays trimmed to mel_len*hop."""
+    wav = hifigan_generator(hsd, hcfg, mel_btc.transpose(0, 2, 1))[:, 0]
+    pcm = wav_to_int16(wav, cfg.max_wav_value)
+    return [pcm[i, : int(mel_lens[i]) * cfg.hop_length] for i in range(len(pcm))], wav
+
+
+# ----------------------------------------------------------------------------- end to end
+
+def synthesize(sd, cfg, texts, src_lens, spker_embeds, n_steps, noise, max_mel_len=None):
+    """CMTotalTTSSynthesize.synthesize synthesize.py:88-153: duration net once (it is bit-identical
+    to re-running it every step with mels=x), then the T-step sampler.
+    Returns (mel [B,T,80], mel_lens, stage dict)."""
+    st = duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds, max_mel_len)
+    mel = karras_sample_tts(sd, cfg, st["cond"], st["speaker_emb"], n_steps, noise)
+    return mel, st["mel_len"], st
