@@ -1,0 +1,83 @@
+"""ctypes binding of libcmtts_hip.so (the C ABI in include/cmtts_hip.h).
+
+``cffi`` is not installed in this image — ctypes binds the same symbols with the
+same signatures.  There is NO fallback: if the shared library is missing or a symbol is absent the
+import of the compute path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmtts_hip.so")
+
+
+class CMTTSConfigStruct(C.Structure):
+    """struct cmtts_config (include/cmtts_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_symbols", "hidden", "enc_layers", "enc_heads", "ffn_kernel",
+        "pred_filter", "pred_layers", "pred_kernel", "dur_layers", "dur_kernel", "cwt_hidden",
+        "pitch_bins", "energy_bins", "use_uv", "multi_speaker", "external_speaker_dim",
+        "n_mels", "res_layers", "res_channels")] + [(n, C.c_float) for n in (
+            "cwt_std_scale", "pitch_norm_eps", "sigma_min", "sigma_max", "sigma_data", "rho")]
+
+
+_vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/cmtts_hip.h declares
+SIGNATURES = {
+    "cmtts_last_error": (C.c_char_p, []),
+    "cmtts_version": (C.c_char_p, []),
+    "cmtts_create": (_i, [C.POINTER(CMTTSConfigStruct), C.POINTER(_vp)]),
+    "cmtts_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "cmtts_finalize": (_i, [_vp]),
+    "cmtts_destroy": (None, [_vp]),
+    "cmtts_text_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "cmtts_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "cmtts_frame_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_length_regulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cmtts_denoiser_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "cmtts_denoiser_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "cmtts_schedule": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f)]),
+    "cmtts_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp]),
+    "cmtts_vocoder_create": (_i, [C.POINTER(_vp)]),
+    "cmtts_vocoder_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "cmtts_vocoder_finalize": (_i, [_vp]),
+    "cmtts_vocoder_destroy": (None, [_vp]),
+    "cmtts_vocoder_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "cmtts_vocoder_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "cmtts_wav_to_int16": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "cmtts_profile_begin": (_i, [_i]),
+    "cmtts_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "cmtts_pack_conv_weight": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i)]),
+    "cmtts_free_device": (None, [_vp]),
+    "cmtts_conv1d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libcmtts_hip.so and bind every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C cm-tts_amd/csrc). "
+            "cmtts_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks the symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cmtts_last_error()
+        raise RuntimeError(f"libcmtts_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,998 @@
+// C ABI of the MI355X-native CM-TTS inference hot path (include/cmtts_hip.h): weight import
+// (re-pack + upload), workspace carving and the host-side launch sequences.  No allocation and no
+// host synchronisation after cmtts_finalize(); everything is enqueued on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cmtts_hip.h"
+#include "conv_args.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) return fail(CMTTS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define CHK(x)                 \
+    do {                       \
+        int r_ = (x);          \
+        if (r_ != 0) return r_; \
+    } while (0)
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t dim(int i) const { return i < (int)shape.size() ? shape[i] : 1; }
+};
+
+struct PackedConv {
+    float* w = nullptr;     // device, [phase][tap][cin][ld]
+    float* bias = nullptr;  // device, [cout] (packed row order)
+    int cout = 0, cin = 0, taps = 0, ld = 0;
+    long tap_stride = 0, phase_stride = 0;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct Allocs {
+    std::vector<void*> ptrs;
+    int upload(const std::vector<float>& h, float** out) {
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, h.size() * sizeof(float) + 256));
+        HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        ptrs.push_back(p);
+        *out = (float*)p;
+        return 0;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+// W [Cout][Cin][K] -> k-major [K][Cin][ld] with ld = round_up(Cout, 4); perm[p] = original row of packed row p
+int pack_conv(Allocs& al, const HostTensor& W, const HostTensor* bias, const std::vector<int>* perm, PackedConv* out) {
+    const int Cout = (int)W.dim(0), Cin = (int)W.dim(1), K = (int)W.dim(2);
+    const int ld = round_up(Cout, 4);
+    std::vector<float> p((size_t)K * Cin * ld, 0.f);
+    for (int k = 0; k < K; ++k)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int r = 0; r < Cout; ++r) {
+                const int co = perm ? (*perm)[r] : r;
+                p[((size_t)k * Cin + ci) * ld + r] = W.data[((size_t)co * Cin + ci) * K + k];
+            }
+    CHK(al.upload(p, &out->w));
+    out->bias = nullptr;
+    if (bias) {
+        std::vector<float> b(Cout);
+        for (int r = 0; r < Cout; ++r) b[r] = bias->data[perm ? (*perm)[r] : r];
+        CHK(al.upload(b, &out->bias));
+    }
+    out->cout = Cout; out->cin = Cin; out->taps = K; out->ld = ld;
+    out->tap_stride = (long)Cin * ld;
+    out->phase_stride = 0;
+    return 0;
+}
+
+// ConvTranspose1d W [Cin][Cout][K], stride s -> polyphase [s][K/s][Cin][ld]: phase r uses taps k = r + s*q
+int pack_conv_transpose(Allocs& al, const HostTensor& W, const HostTensor& bias, int s, PackedConv* out) {
+    const int Cin = (int)W.dim(0), Cout = (int)W.dim(1), K = (int)W.dim(2);
+    const int Q = K / s, ld = round_up(Cout, 4);
+    std::vector<float> p((size_t)s * Q * Cin * ld, 0.f);
+    for (int r = 0; r < s; ++r)
+        for (int q = 0; q < Q; ++q)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < Cout; ++co)
+                    p[(((size_t)r * Q + q) * Cin + ci) * ld + co] = W.data[((size_t)ci * Cout + co) * K + (r + s * q)];
+    CHK(al.upload(p, &out->w));
+    CHK(al.upload(bias.data, &out->bias));
+    out->cout = Cout; out->cin = Cin; out->taps = Q; out->ld = ld;
+    out->tap_stride = (long)Cin * ld;
+    out->phase_stride = (long)Q * Cin * ld;
+    return 0;
+}
+
+// nn.Linear weight [N][K] -> transposed [K][N] (dense_small operand / X operand of a GEMM)
+std::vector<float> transpose2d(const float* w, int N, int K) {
+    std::vector<float> t((size_t)K * N);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w[(size_t)n * K + k];
+    return t;
+}
+
+std::vector<float> omega_table(int C) {
+    // SinusoidalPositionalEmbedding.get_embedding (model/blocks.py:50-54): exp(arange(half) * -ln(1e4)/(half-1)) in fp32
+    const int half = C / 2;
+    const float e = (float)(log(10000.0) / (half - 1));
+    std::vector<float> w(half);
+    for (int j = 0; j < half; ++j) w[j] = (float)exp((double)((float)j * -e));
+    return w;
+}
+
+ConvArgs conv_args(const PackedConv& w, const float* X, int Tin, int ldx, long x_bs, float* Y, int ldy, long y_bs, int N) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = w.w; a.X = X;
+    a.M = w.cout; a.N = N; a.K = w.cin;
+    a.taps = w.taps; a.dil = 1; a.pad = (w.taps - 1) / 2;
+    a.Tin = Tin; a.a_ld = w.ld; a.a_cols = w.ld; a.a_tap_stride = w.tap_stride; a.ldx = ldx;
+    a.zdiv = 1; a.x_zs0 = x_bs;
+    a.pre_div = 1.f; a.pre_slope = 1.f;
+    a.split = INT_MAX;
+    for (int i = 0; i < 2; ++i) {
+        ConvOut& o = a.out[i];
+        o.Y = Y; o.y_zs0 = y_bs; o.ldy = ldy; o.Tout = N; o.ostride = 1;
+        o.bias = w.bias; o.alpha = 1.f; o.act = ACT_NONE; o.div = 1.f;
+    }
+    return a;
+}
+
+int launch(const ConvArgs& a, int epi, int nbatch, hipStream_t s) {
+    const int r = cmtts_launch_conv(&a, epi, nbatch, (void*)s);
+    if (r != 0) return fail(r, "conv launch failed (unsupported shape or HIP launch error)");
+    return 0;
+}
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+// Optional HIP-event instrumentation of the dominant kernel (the gated k=3 conv of the denoiser
+// residual block), recorded on the launch stream: bench.py's live roofline figure.
+struct Profile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;
+} g_prof;
+
+struct EncLayer {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    PackedConv qk, wo, ffn1, ffn2;
+    float* wvT;  // [256 c][256 d]
+};
+struct Predictor {
+    std::vector<PackedConv> convs;
+    std::vector<float*> ln_g, ln_b;
+    float *lin_w = nullptr, *lin_b = nullptr, *alpha = nullptr;
+    int odim = 0;
+};
+struct ResLayer {
+    PackedConv cond, conv3, outp;
+};
+
+}  // namespace
+
+struct cmtts_model {
+    cmtts_config cfg;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    Allocs al;
+    float *embed = nullptr, *omega_h = nullptr, *omega_cwt = nullptr, *omega_res = nullptr;
+    std::vector<EncLayer> enc;
+    float *encln_g = nullptr, *encln_b = nullptr;
+    float *spk_wt = nullptr, *spk_b = nullptr;
+    Predictor dur, energy, cwt;
+    PackedConv cwt_in;
+    float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
+    float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
+    PackedConv in_proj, skip_proj, out_proj;
+    float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
+    std::vector<ResLayer> res;
+};
+
+struct cmtts_vocoder {
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    Allocs al;
+    PackedConv conv_pre;
+    PackedConv ups[4];
+    int up_rate[4] = {8, 8, 2, 2};
+    int up_kernel[4] = {16, 16, 4, 4};
+    int rb_kernel[3] = {3, 7, 11};
+    int rb_dil[3] = {1, 3, 5};
+    PackedConv c1[12][3], c2[12][3];
+    float *post_w = nullptr, *post_b = nullptr;
+    int post_cin = 32, post_k = 7;
+};
+
+namespace {
+
+int set_tensor(std::map<std::string, HostTensor>& host, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!name || !data || ndim < 0 || ndim > 4) return fail(CMTTS_E_INVALID, "set_tensor: bad argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0) return fail(CMTTS_E_INVALID, std::string("set_tensor: bad shape for ") + name);
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data, data + n);
+    host[name] = std::move(t);
+    return 0;
+}
+
+struct Getter {
+    const std::map<std::string, HostTensor>& host;
+    std::string missing;
+    const HostTensor* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = host.find(name);
+        if (it == host.end()) {
+            if (missing.empty()) missing = "missing tensor " + name;
+            return nullptr;
+        }
+        if (it->second.shape != std::vector<int64_t>(shape)) {
+            if (missing.empty()) missing = "wrong shape for tensor " + name;
+            return nullptr;
+        }
+        return &it->second;
+    }
+};
+
+int finalize_model(cmtts_model* m) {
+    const cmtts_config& c = m->cfg;
+    if (c.hidden != 256 || c.res_channels != 256 || c.pred_filter != 256)
+        return fail(CMTTS_E_UNSUPPORTED, "kernels are specialised for hidden = residual_channels = filter_size = 256");
+    if (c.hidden % c.enc_heads) return fail(CMTTS_E_INVALID, "hidden not divisible by heads (model/blocks.py:209)");
+    const int H = c.hidden, C = c.res_channels;
+    Getter g{m->host, ""};
+    Allocs& al = m->al;
+#define GET(var, name, ...)                                     \
+    const HostTensor* var = g.get(name, {__VA_ARGS__});          \
+    if (!var) return fail(CMTTS_E_INVALID, g.missing)
+#define UP(dst, t) CHK(al.upload((t)->data, &(dst)))
+
+    CHK(al.upload(omega_table(H), &m->omega_h));
+    CHK(al.upload(omega_table(c.cwt_hidden), &m->omega_cwt));
+    CHK(al.upload(omega_table(C), &m->omega_res));
+
+    const std::string enc = "duration_pitch_energy_net.text_encoder.";
+    GET(emb, enc + "embed_tokens.weight", c.n_symbols, H);
+    UP(m->embed, emb);
+    m->enc.resize(c.enc_layers);
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const std::string p = enc + "layers." + std::to_string(i) + ".op.";
+        EncLayer& L = m->enc[i];
+        GET(l1g, p + "layer_norm1.weight", H); GET(l1b, p + "layer_norm1.bias", H);
+        GET(l2g, p + "layer_norm2.weight", H); GET(l2b, p + "layer_norm2.bias", H);
+        UP(L.ln1_g, l1g); UP(L.ln1_b, l1b); UP(L.ln2_g, l2g); UP(L.ln2_b, l2b);
+        GET(inw, p + "self_attn.in_proj_weight", 3 * H, H);
+        HostTensor qk; qk.shape = {2 * H, H, 1};
+        qk.data.assign(inw->data.begin(), inw->data.begin() + (size_t)2 * H * H);
+        CHK(pack_conv(al, qk, nullptr, nullptr, &L.qk));
+        CHK(al.upload(transpose2d(inw->data.data() + (size_t)2 * H * H, H, H), &L.wvT));
+        GET(ow, p + "self_attn.out_proj.weight", H, H);
+        HostTensor ow3 = *ow; ow3.shape = {H, H, 1};
+        CHK(pack_conv(al, ow3, nullptr, nullptr, &L.wo));
+        GET(f1w, p + "ffn.ffn_1.weight", 4 * H, H, c.ffn_kernel); GET(f1b, p + "ffn.ffn_1.bias", 4 * H);
+        CHK(pack_conv(al, *f1w, f1b, nullptr, &L.ffn1));
+        GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
+        HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
+        CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2));
+    }
+    GET(eg, enc + "layer_norm.weight", H); GET(eb, enc + "layer_norm.bias", H);
+    UP(m->encln_g, eg); UP(m->encln_b, eb);
+
+    if (c.multi_speaker) {
+        GET(sw, "duration_pitch_energy_net.speaker_emb.weight", H, c.external_speaker_dim);
+        GET(sb, "duration_pitch_energy_net.speaker_emb.bias", H);
+        CHK(al.upload(transpose2d(sw->data.data(), H, c.external_speaker_dim), &m->spk_wt));
+        UP(m->spk_b, sb);
+    }
+
+    const std::string va = "duration_pitch_energy_net.variance_adaptor.";
+    auto load_pred = [&](Predictor& P, const std::string& p, int idim, int n_layers, int k, int odim, bool alpha) -> int {
+        P.convs.resize(n_layers); P.ln_g.resize(n_layers); P.ln_b.resize(n_layers); P.odim = odim;
+        for (int li = 0; li < n_layers; ++li) {
+            const int cin = li == 0 ? idim : c.pred_filter;
+            const std::string q = p + "conv." + std::to_string(li);
+            GET(w, q + ".1.weight", c.pred_filter, cin, k); GET(b, q + ".1.bias", c.pred_filter);
+            CHK(pack_conv(al, *w, b, nullptr, &P.convs[li]));
+            GET(lg, q + ".3.weight", c.pred_filter); GET(lb, q + ".3.bias", c.pred_filter);
+            UP(P.ln_g[li], lg); UP(P.ln_b[li], lb);
+        }
+        GET(lw, p + "linear.weight", odim, c.pred_filter); GET(lb2, p + "linear.bias", odim);
+        UP(P.lin_w, lw); UP(P.lin_b, lb2);
+        if (alpha) { GET(a, p + "pos_embed_alpha", 1); UP(P.alpha, a); }
+        return 0;
+    };
+    CHK(load_pred(m->dur, va + "duration_predictor.", H, c.dur_layers, c.dur_kernel, 1, false));
+    CHK(load_pred(m->energy, va + "energy_predictor.", H, c.pred_layers, c.pred_kernel, 1, true));
+    const int cwt_out = c.use_uv ? 11 : 10;
+    CHK(load_pred(m->cwt, va + "cwt_predictor.1.", c.cwt_hidden, c.pred_layers, c.pred_kernel, cwt_out, true));
+    {
+        GET(w, va + "cwt_predictor.0.weight", c.cwt_hidden, H); GET(b, va + "cwt_predictor.0.bias", c.cwt_hidden);
+        HostTensor w3 = *w; w3.shape = {c.cwt_hidden, H, 1};
+        CHK(pack_conv(al, w3, b, nullptr, &m->cwt_in));
+        GET(bins, va + "energy_bins", c.energy_bins - 1); UP(m->energy_bins, bins);
+        GET(ee, va + "energy_embedding.weight", c.energy_bins, H); UP(m->energy_emb, ee);
+        GET(pe, va + "pitch_embed.weight", c.pitch_bins, H); UP(m->pitch_emb, pe);
+        GET(s0w, va + "cwt_stats_layers.0.weight", c.cwt_hidden, H); GET(s0b, va + "cwt_stats_layers.0.bias", c.cwt_hidden);
+        GET(s2w, va + "cwt_stats_layers.2.weight", c.cwt_hidden, c.cwt_hidden); GET(s2b, va + "cwt_stats_layers.2.bias", c.cwt_hidden);
+        GET(s4w, va + "cwt_stats_layers.4.weight", 2, c.cwt_hidden); GET(s4b, va + "cwt_stats_layers.4.bias", 2);
+        CHK(al.upload(transpose2d(s0w->data.data(), c.cwt_hidden, H), &m->st0_wt)); UP(m->st0_b, s0b);
+        CHK(al.upload(transpose2d(s2w->data.data(), c.cwt_hidden, c.cwt_hidden), &m->st2_wt)); UP(m->st2_b, s2b);
+        CHK(al.upload(transpose2d(s4w->data.data(), 2, c.cwt_hidden), &m->st4_wt)); UP(m->st4_b, s4b);
+    }
+
+    // ---- denoiser
+    {
+        GET(w, "net.input_projection.0.conv.weight", C, c.n_mels, 1); GET(b, "net.input_projection.0.conv.bias", C);
+        CHK(pack_conv(al, *w, b, nullptr, &m->in_proj));
+        GET(m0, "net.mlp.0.linear.weight", 4 * C, C); GET(m2, "net.mlp.2.linear.weight", C, 4 * C);
+        CHK(al.upload(transpose2d(m0->data.data(), 4 * C, C), &m->mlp0_wt));
+        CHK(al.upload(transpose2d(m2->data.data(), C, 4 * C), &m->mlp2_wt));
+    }
+    const int NL = c.res_layers;
+    m->res.resize(NL);
+    std::vector<float> dproj((size_t)C * NL * C), sproj;
+    if (c.multi_speaker) sproj.resize((size_t)H * NL * C);
+    // gate permutation: packed 64-row group g = [rows g*32.. of the sigmoid half | rows C + g*32.. of the tanh half]
+    std::vector<int> perm(2 * C);
+    for (int gidx = 0; gidx < C / 32; ++gidx)
+        for (int i = 0; i < 32; ++i) {
+            perm[gidx * 64 + i] = gidx * 32 + i;
+            perm[gidx * 64 + 32 + i] = C + gidx * 32 + i;
+        }
+    for (int l = 0; l < NL; ++l) {
+        const std::string p = "net.residual_layers." + std::to_string(l) + ".";
+        GET(w3, p + "conv_layer.conv.weight", 2 * C, C, 3); GET(b3, p + "conv_layer.conv.bias", 2 * C);
+        CHK(pack_conv(al, *w3, b3, &perm, &m->res[l].conv3));
+        GET(wc, p + "conditioner_projection.conv.weight", C, H, 1); GET(bc, p + "conditioner_projection.conv.bias", C);
+        CHK(pack_conv(al, *wc, bc, nullptr, &m->res[l].cond));
+        GET(wo, p + "output_projection.conv.weight", 2 * C, C, 1); GET(bo, p + "output_projection.conv.bias", 2 * C);
+        CHK(pack_conv(al, *wo, bo, nullptr, &m->res[l].outp));
+        GET(wd, p + "diffusion_projection.linear.weight", C, C);
+        for (int n = 0; n < C; ++n)
+            for (int k = 0; k < C; ++k) dproj[(size_t)k * NL * C + l * C + n] = wd->data[(size_t)n * C + k];
+        if (c.multi_speaker) {
+            GET(ws, p + "speaker_projection.linear.weight", C, H);
+            for (int n = 0; n < C; ++n)
+                for (int k = 0; k < H; ++k) sproj[(size_t)k * NL * C + l * C + n] = ws->data[(size_t)n * H + k];
+        }
+    }
+    CHK(al.upload(dproj, &m->dproj_wt));
+    if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
+    {
+        GET(w, "net.skip_projection.conv.weight", C, C, 1); GET(b, "net.skip_projection.conv.bias", C);
+        CHK(pack_conv(al, *w, b, nullptr, &m->skip_proj));
+        GET(w2, "net.output_projection.conv.weight", c.n_mels, C, 1); GET(b2, "net.output_projection.conv.bias", c.n_mels);
+        CHK(pack_conv(al, *w2, b2, nullptr, &m->out_proj));
+    }
+#undef GET
+#undef UP
+    m->host.clear();
+    m->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------- workspaces
+struct TextWs {
+    float *x, *h, *qk, *vt, *st, *o, *f, *c1, *c2, *spk, *out1, *logd, *dround, *epred;
+    int* cum;
+    int64_t *eidx, *mlen;
+    size_t bytes;
+};
+TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
+    const int Lp = round_up(L, 4), H = c.hidden;
+    Carver cv(base);
+    TextWs w;
+    const size_t n = (size_t)B * H * Lp;
+    // persistent state (read by cmtts_frame_forward) first
+    w.out1 = cv.take<float>(n);
+    w.cum = cv.take<int>((size_t)B * L);
+    w.spk = cv.take<float>((size_t)B * H);
+    w.x = cv.take<float>(n);
+    w.h = cv.take<float>(n);
+    w.qk = cv.take<float>(2 * n);
+    w.vt = cv.take<float>(n);
+    w.st = cv.take<float>((size_t)B * c.enc_heads * Lp * Lp);
+    w.o = cv.take<float>(n);
+    w.f = cv.take<float>(4 * n);
+    w.c1 = cv.take<float>(n);
+    w.c2 = cv.take<float>(n);
+    w.logd = cv.take<float>((size_t)B * L);
+    w.dround = cv.take<float>((size_t)B * L);
+    w.epred = cv.take<float>((size_t)B * L);
+    w.eidx = cv.take<int64_t>((size_t)B * L);
+    w.mlen = cv.take<int64_t>((size_t)B);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+struct FrameWs {
+    float *xlr, *h128, *hp, *c1, *c2, *cwt, *r, *s1, *s2, *stats, *f0;
+    int64_t* pidx;
+    size_t bytes;
+};
+FrameWs carve_frame(const cmtts_config& c, int B, int T, void* base) {
+    Carver cv(base);
+    FrameWs w;
+    const size_t n = (size_t)B * c.hidden * T;
+    w.xlr = cv.take<float>(n);
+    w.h128 = cv.take<float>((size_t)B * c.cwt_hidden * T);
+    w.hp = cv.take<float>((size_t)B * c.cwt_hidden * T);
+    w.c1 = cv.take<float>(n);
+    w.c2 = cv.take<float>(n);
+    w.cwt = cv.take<float>((size_t)B * T * 16);
+    w.r = cv.take<float>((size_t)B * T);
+    w.s1 = cv.take<float>((size_t)B * c.cwt_hidden);
+    w.s2 = cv.take<float>((size_t)B * c.cwt_hidden);
+    w.stats = cv.take<float>((size_t)B * 2);
+    w.f0 = cv.take<float>((size_t)B * T);
+    w.pidx = cv.take<int64_t>((size_t)B * T);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+struct DenWs {
+    float *hin, *h, *u, *zb, *skip, *emb, *e1, *e2, *dproj, *sproj, *dp, *tbuf, *xcur;
+    size_t bytes;
+};
+DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
+    Carver cv(base);
+    DenWs w;
+    const int C = c.res_channels, NL = c.res_layers;
+    const size_t n = (size_t)B * C * T;
+    w.hin = cv.take<float>((size_t)B * c.n_mels * T);
+    w.h = cv.take<float>(n);
+    w.u = cv.take<float>(n);
+    w.zb = cv.take<float>(n);
+    w.skip = cv.take<float>(n);
+    w.emb = cv.take<float>((size_t)B * C);
+    w.e1 = cv.take<float>((size_t)B * 4 * C);
+    w.e2 = cv.take<float>((size_t)B * C);
+    w.dproj = cv.take<float>((size_t)B * NL * C);
+    w.sproj = cv.take<float>((size_t)B * NL * C);
+    w.dp = cv.take<float>((size_t)B * NL * C);
+    w.tbuf = cv.take<float>((size_t)B);
+    w.xcur = cv.take<float>((size_t)B * T * c.n_mels);
+    w.bytes = cv.off + 256;
+    return w;
+}
+
+// conv stack of Duration/Pitch/Energy predictors (model/modules.py:477-487): Conv1d + ReLU ->
+// LayerNorm over channels (eps 1e-12) [-> mask].  Result ends in bufB.
+int predictor_convs(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* lens,
+                    float* bufA, float* bufB, hipStream_t s) {
+    const float* cur = in;
+    int ldc = ld_in;
+    for (size_t li = 0; li < P.convs.size(); ++li) {
+        const PackedConv& w = P.convs[li];
+        ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, bufA, ld, (long)w.cout * ld, T);
+        a.out[0].act = ACT_RELU;
+        CHK(launch(a, EPI_PLAIN, B, s));
+        k_layernorm_ct(bufA, bufB, P.ln_g[li], P.ln_b[li], 1e-12f, lens, B, T, ld, s);
+        cur = bufB;
+        ldc = ld;
+    }
+    return 0;
+}
+
+// Denoiser.forward (model/modules.py:600-639) on x_src [B][T][80] scaled by in_scale -> F in w.hin [B][80][T]
+int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
+                  const float* cond_ct, const float* spk, int B, int T, hipStream_t s) {
+    const cmtts_config& c = m->cfg;
+    const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
+    const long cs = (long)C * T;
+    k_mel_prep(x_src, nullptr, in_scale, w.hin, B, T, M, s);
+    {
+        ConvArgs a = conv_args(m->in_proj, w.hin, T, T, (long)M * T, w.h, T, cs, T);
+        a.out[0].act = ACT_RELU;   // relu(relu(.)) == relu(.), model/modules.py:575-577,624
+        CHK(launch(a, EPI_PLAIN, B, s));
+    }
+    k_diff_embed(timesteps, m->omega_res, w.emb, B, C, s);
+    k_dense_small(w.emb, C, 1, m->mlp0_wt, nullptr, nullptr, w.e1, B, C, 4 * C, DENSE_MISH, s);
+    k_dense_small(w.e1, 4 * C, 1, m->mlp2_wt, nullptr, nullptr, w.e2, B, 4 * C, C, DENSE_NONE, s);
+    k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, nullptr, w.dproj, B, C, NL * C, DENSE_NONE, s);
+    const float* dp = w.dproj;
+    if (c.multi_speaker) {
+        if (!spk) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
+        k_dense_small(spk, c.hidden, 1, m->sproj_wt, nullptr, nullptr, w.sproj, B, c.hidden, NL * C, DENSE_NONE, s);
+        k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, w.sproj, w.dp, B, C, NL * C, DENSE_NONE, s);
+        dp = w.dp;
+    }
+    for (int l = 0; l < NL; ++l) {
+        const ResLayer& R = m->res[l];
+        {   // u = (x + d [+ p]) + conditioner_projection(cond)      (model/blocks.py:669-677)
+            ConvArgs a = conv_args(R.cond, cond_ct, T, T, (long)c.hidden * T, w.u, T, cs, T);
+            a.out[0].bvec = dp + (long)l * C; a.out[0].bvec_zs = (long)NL * C;
+            a.out[0].res = w.h; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        {   // z = sigmoid(gate) * tanh(filter) of the k=3 conv        (:675-679)
+            ConvArgs a = conv_args(R.conv3, w.u, T, T, cs, w.zb, T, cs, T);
+            const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+            CHK(launch(a, EPI_GATED, B, s));
+            if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
+        }
+        {   // o = output_projection(z); x' = (o[:C] + (x + d)) / sqrt(2); skip += o[C:]   (:681-686)
+            ConvArgs a = conv_args(R.outp, w.zb, T, T, cs, w.h, T, cs, T);
+            a.split = C;
+            a.out[0].res = w.h; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
+            a.out[0].bvec = w.dproj + (long)l * C; a.out[0].bvec_zs = (long)NL * C;
+            a.out[0].div = (float)sqrt(2.0);
+            a.out[1].Y = w.skip; a.out[1].row_off = C; a.out[1].accum = l > 0;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+    }
+    {   // sum(skips)/sqrt(NL) -> skip_projection -> relu -> output_projection   (model/modules.py:634-637)
+        ConvArgs a = conv_args(m->skip_proj, w.skip, T, T, cs, w.u, T, cs, T);
+        a.pre_div = (float)sqrt((double)NL);
+        a.out[0].act = ACT_RELU;
+        CHK(launch(a, EPI_PLAIN, B, s));
+        ConvArgs b = conv_args(m->out_proj, w.u, T, T, cs, w.hin, T, (long)M * T, T);
+        CHK(launch(b, EPI_PLAIN, B, s));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* cmtts_last_error(void) { return g_err.c_str(); }
+const char* cmtts_version(void) { return "cmtts_hip 0.1 (gfx950)"; }
+
+int cmtts_create(const cmtts_config* cfg, cmtts_model** out) {
+    if (!cfg || !out) return fail(CMTTS_E_INVALID, "cmtts_create: null argument");
+    cmtts_model* m = new cmtts_model();
+    m->cfg = *cfg;
+    *out = m;
+    return 0;
+}
+
+int cmtts_set_tensor(cmtts_model* m, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    if (!m || m->finalized) return fail(CMTTS_E_INVALID, "cmtts_set_tensor: model is null or already finalized");
+    return set_tensor(m->host, name, host_data, shape, ndim);
+}
+
+int cmtts_finalize(cmtts_model* m) {
+    if (!m || m->finalized) return fail(CMTTS_E_INVALID, "cmtts_finalize: model is null or already finalized");
+    const int r = finalize_model(m);
+    if (r != 0) m->al.release();
+    return r;
+}
+
+void cmtts_destroy(cmtts_model* m) {
+    if (!m) return;
+    m->al.release();
+    delete m;
+}
+
+size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L) { return carve_text(m->cfg, B, L, nullptr).bytes; }
+size_t cmtts_frame_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_frame(m->cfg, B, T, nullptr).bytes; }
+size_t cmtts_denoiser_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_den(m->cfg, B, T, nullptr).bytes; }
+
+int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
+                       int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
+                       float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
+                       void* text_ws, size_t text_ws_bytes, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!texts || !src_lens || !text_ws || B <= 0 || L <= 0) return fail(CMTTS_E_INVALID, "cmtts_text_forward: bad argument");
+    const cmtts_config& c = m->cfg;
+    if (c.multi_speaker && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
+    TextWs w = carve_text(c, B, L, text_ws);
+    if (text_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "text workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c.hidden, Lp = round_up(L, 4), NH = c.enc_heads, dh = H / NH;
+    const long hs = (long)H * Lp;
+    if (!log_d) log_d = w.logd;
+    if (!d_rounded) d_rounded = w.dround;
+    if (!mel_len) mel_len = w.mlen;
+    if (!e_pred) e_pred = w.epred;
+    if (!e_idx) e_idx = w.eidx;
+
+    k_embed_tokens(texts, src_lens, m->embed, m->omega_h, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const EncLayer& E = m->enc[i];
+        k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+        {   // Q,K = h * W[0:2H]^T, channel-major [B][2H][Lp]
+            ConvArgs a = conv_args(E.qk, w.h, L, Lp, hs, w.qk, Lp, 2 * hs, L);
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        {   // V^T[b] = h[b]^T * Wv^T : [L][H]   (A operand = activation, X operand = weights)
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.A = w.h; a.a_ld = Lp; a.a_cols = Lp; a.M = L; a.K = H; a.taps = 1; a.dil = 1;
+            a.X = E.wvT; a.ldx = H; a.Tin = H; a.N = H;
+            a.zdiv = 1; a.a_zs0 = hs; a.x_zs0 = 0;
+            a.pre_div = 1.f; a.pre_slope = 1.f; a.split = INT_MAX;
+            ConvOut& o = a.out[0];
+            o.Y = w.vt; o.y_zs0 = (long)Lp * H; o.ldy = H; o.Tout = H; o.ostride = 1; o.alpha = 1.f; o.div = 1.f;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        {   // S^T[b,h][j][i] = sum_d K[d][j] Q[d][i] / sqrt(dh)
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.A = w.qk + hs; a.a_ld = Lp; a.a_cols = Lp; a.M = L; a.K = dh; a.taps = 1; a.dil = 1;
+            a.X = w.qk; a.ldx = Lp; a.Tin = L; a.N = L;
+            a.zdiv = NH; a.a_zs0 = 2 * hs; a.a_zs1 = (long)dh * Lp; a.x_zs0 = 2 * hs; a.x_zs1 = (long)dh * Lp;
+            a.pre_div = 1.f; a.pre_slope = 1.f; a.split = INT_MAX;
+            ConvOut& o = a.out[0];
+            o.Y = w.st; o.y_zs0 = (long)NH * Lp * Lp; o.y_zs1 = (long)Lp * Lp; o.ldy = Lp; o.Tout = L; o.ostride = 1;
+            o.alpha = (float)(1.0 / sqrt((double)dh)); o.div = 1.f;
+            CHK(launch(a, EPI_PLAIN, B * NH, s));
+        }
+        k_softmax_cols(w.st, src_lens, B * NH, NH, L, Lp, (long)Lp * Lp, s);
+        {   // O[b,h][d][i] = sum_j V^T[j][d] P^T[j][i]
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.A = w.vt; a.a_ld = H; a.a_cols = dh; a.M = dh; a.K = L; a.taps = 1; a.dil = 1;
+            a.X = w.st; a.ldx = Lp; a.Tin = L; a.N = L;
+            a.zdiv = NH; a.a_zs0 = (long)Lp * H; a.a_zs1 = dh; a.x_zs0 = (long)NH * Lp * Lp; a.x_zs1 = (long)Lp * Lp;
+            a.pre_div = 1.f; a.pre_slope = 1.f; a.split = INT_MAX;
+            ConvOut& o = a.out[0];
+            o.Y = w.o; o.y_zs0 = hs; o.y_zs1 = (long)dh * Lp; o.ldy = Lp; o.Tout = L; o.ostride = 1; o.alpha = 1.f; o.div = 1.f;
+            CHK(launch(a, EPI_PLAIN, B * NH, s));
+        }
+        {   // x = (x + out_proj(o)) * nonpad      (model/blocks.py:609-610)
+            ConvArgs a = conv_args(E.wo, w.o, L, Lp, hs, w.x, Lp, hs, L);
+            a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+        {   // gelu((conv_k9(h) + b) * k^-0.5)      (model/blocks.py:539-546)
+            ConvArgs a = conv_args(E.ffn1, w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
+            a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
+            a.out[0].act = ACT_GELU_ERF;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        {   // x = (x + ffn_2(.)) * nonpad          (:551, :616-617)
+            ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.x, Lp, hs, L);
+            a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+    }
+    k_layernorm_ct(w.x, w.x, m->encln_g, m->encln_b, 1e-5f, src_lens, B, L, Lp, s);
+    if (enc_out_ct)
+        HIPCHK(hipMemcpy2DAsync(enc_out_ct, (size_t)L * 4, w.x, (size_t)Lp * 4, (size_t)L * 4, (size_t)B * H,
+                                hipMemcpyDeviceToDevice, s));
+    if (c.multi_speaker) {
+        k_dense_small(spker_embeds, c.external_speaker_dim, 1, m->spk_wt, m->spk_b, nullptr, w.spk, B,
+                      c.external_speaker_dim, H, DENSE_NONE, s);
+        k_add_rowvec(w.x, w.spk, B, H, L, Lp, s);
+        if (speaker_emb) HIPCHK(hipMemcpyAsync(speaker_emb, w.spk, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+    }
+    // duration predictor (masked) -> log_d
+    CHK(predictor_convs(m->dur, w.x, Lp, B, L, Lp, src_lens, w.c1, w.c2, s));
+    k_chan_linear(w.c2, m->dur.lin_w, m->dur.lin_b, log_d, src_lens, B, c.pred_filter, L, Lp, 1, s);
+    // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
+    k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, B, H, L, Lp, s);
+    CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, w.c1, w.c2, s));
+    k_chan_linear(w.c2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, s);
+    k_energy_embed(w.x, e_pred, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1, e_idx, B, H, L, Lp, s);
+    k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T, float* cond_ct, int64_t* mel2ph,
+                        float* cwt_out, float* f0_denorm, int64_t* p_idx, float* f0_stats, void* frame_ws,
+                        size_t frame_ws_bytes, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!text_ws || !frame_ws || !cond_ct || !mel2ph || B <= 0 || L <= 0 || T <= 0)
+        return fail(CMTTS_E_INVALID, "cmtts_frame_forward: bad argument");
+    const cmtts_config& c = m->cfg;
+    const TextWs tw = carve_text(c, B, L, const_cast<void*>(text_ws));
+    FrameWs w = carve_frame(c, B, T, frame_ws);
+    if (frame_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "frame workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c.hidden, Lp = round_up(L, 4), O = c.use_uv ? 11 : 10, CH = c.cwt_hidden;
+    if (!cwt_out) cwt_out = w.cwt;
+    if (!f0_denorm) f0_denorm = w.f0;
+    if (!p_idx) p_idx = w.pidx;
+    if (!f0_stats) f0_stats = w.stats;
+
+    k_mel2ph(tw.cum, mel2ph, B, L, T, s);
+    k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
+    {   // cwt_predictor[0]: Linear(H -> cwt_hidden)        (model/modules.py:204-205)
+        ConvArgs a = conv_args(m->cwt_in, w.xlr, T, T, (long)H * T, w.h128, T, (long)CH * T, T);
+        CHK(launch(a, EPI_PLAIN, B, s));
+    }
+    k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, B, CH, T, T, s);
+    CHK(predictor_convs(m->cwt, w.hp, T, B, T, T, nullptr, w.c1, w.c2, s));
+    k_chan_linear(w.c2, m->cwt.lin_w, m->cwt.lin_b, cwt_out, nullptr, B, c.pred_filter, T, T, O, s);
+    // cwt_stats_layers on the first phoneme of output_1    (model/modules.py:212-215,279)
+    k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, s);
+    k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, s);
+    k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, s);
+    k_pitch_index(cwt_out, O, c.use_uv, f0_stats, c.cwt_std_scale, c.pitch_norm_eps, w.r, p_idx, f0_denorm, B, T, s);
+    k_gather_add(w.xlr, p_idx, m->pitch_emb, cond_ct, B, H, T, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_length_regulate(const float* x_ct, const float* durations, int B, int C, int L, int T, float* out_ct,
+                          int64_t* mel2ph, int64_t* mel_len, int32_t* scratch_cum, void* stream) {
+    if (!x_ct || !durations || !out_ct || !mel2ph || !mel_len || !scratch_cum || B <= 0 || L <= 0 || T <= 0)
+        return fail(CMTTS_E_INVALID, "cmtts_length_regulate: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    k_cumsum_durations(durations, scratch_cum, mel_len, B, L, s);
+    k_mel2ph(scratch_cum, mel2ph, B, L, T, s);
+    k_length_regulate(x_ct, mel2ph, out_ct, B, C, L, T, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_denoiser_forward(cmtts_model* m, const float* x, const float* timesteps, const float* cond_ct,
+                           const float* speaker_emb, int B, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!x || !timesteps || !cond_ct || !out || !ws || B <= 0 || T <= 0)
+        return fail(CMTTS_E_INVALID, "cmtts_denoiser_forward: bad argument");
+    DenWs w = carve_den(m->cfg, B, T, ws);
+    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, s));
+    k_mel_post(w.hin, nullptr, nullptr, 1.0f, 0.0f, 0.0f, out, B, T, m->cfg.n_mels, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_schedule(const cmtts_model* m, int n_steps, float* sigmas, float* renoise_std) {
+    if (!m || !sigmas || !renoise_std || n_steps < 1) return fail(CMTTS_E_INVALID, "cmtts_schedule: bad argument");
+    const cmtts_config& c = m->cfg;
+    if (n_steps == 1) {   // sample_onestep: sigmas[0] = sigma_max (get_sigmas_karras, karras_diffusion.py:580-586)
+        sigmas[0] = c.sigma_max;
+        renoise_std[0] = -1.0f;   // no re-noising
+        return 0;
+    }
+    // synthesize.py:122-147: sampler="multistep", steps=2, ts=(0,)*T+(1,)
+    const double rho = c.rho, tmax = pow((double)c.sigma_max, 1.0 / rho), tmin = pow((double)c.sigma_min, 1.0 / rho);
+    for (int i = 0; i < n_steps; ++i) {
+        const double tsi = 0.0, tsn = (i + 1 == n_steps) ? 1.0 : 0.0;
+        const double t = pow(tmax + tsi / 1.0 * (tmin - tmax), rho);
+        double nt = pow(tmax + tsn / 1.0 * (tmin - tmax), rho);
+        nt = nt < c.sigma_min ? (double)c.sigma_min : (nt > c.sigma_max ? (double)c.sigma_max : nt);
+        sigmas[i] = (float)t;
+        renoise_std[i] = (float)sqrt(nt * nt - (double)c.sigma_min * (double)c.sigma_min);   // x0.85 is applied in-kernel
+    }
+    return 0;
+}
+
+int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
+                 int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
+                 void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!noise || !cond_ct || !mel || !ws || !sigmas || !renoise_std || B <= 0 || T <= 0 || n_steps < 1)
+        return fail(CMTTS_E_INVALID, "cmtts_sample: bad argument");
+    const cmtts_config& c = m->cfg;
+    DenWs w = carve_den(c, B, T, ws);
+    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const long nel = (long)B * T * c.n_mels;
+    k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
+    const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
+    for (int i = 0; i < n_steps; ++i) {
+        // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
+        const float sg = sigmas[i];
+        const float dm = sg - smin;
+        const float c_skip = sd2 / (dm * dm + sd2);
+        const float rt = sqrtf(sg * sg + sd2);
+        const float c_out = dm * c.sigma_data / rt;
+        const float c_in = 1.0f / rt;
+        const float t_resc = 250.0f * logf(sg + 1e-44f);
+        k_fill_float(w.tbuf, t_resc, B, s);
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, s));
+        const bool last = i + 1 == n_steps;
+        const bool renoise = renoise_std[i] >= 0.0f;
+        k_mel_post(w.hin, w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
+                   renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur, B, T, c.n_mels, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ vocoder
+int cmtts_vocoder_create(cmtts_vocoder** out) {
+    if (!out) return fail(CMTTS_E_INVALID, "cmtts_vocoder_create: null argument");
+    *out = new cmtts_vocoder();
+    return 0;
+}
+int cmtts_vocoder_set_tensor(cmtts_vocoder* v, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    if (!v || v->finalized) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_tensor: null or finalized");
+    return set_tensor(v->host, name, host_data, shape, ndim);
+}
+int cmtts_vocoder_finalize(cmtts_vocoder* v) {
+    if (!v || v->finalized) return fail(CMTTS_E_INVALID, "cmtts_vocoder_finalize: null or finalized");
+    Getter g{v->host, ""};
+    Allocs& al = v->al;
+#define GETV(var, name, ...)                                     \
+    const HostTensor* var = g.get(name, {__VA_ARGS__});           \
+    if (!var) { al.release(); return fail(CMTTS_E_INVALID, g.missing); }
+    GETV(pw, "conv_pre.weight", 512, 80, 7); GETV(pb, "conv_pre.bias", 512);
+    CHK(pack_conv(al, *pw, pb, nullptr, &v->conv_pre));
+    int ch = 512;
+    for (int i = 0; i < 4; ++i) {
+        const int co = ch / 2;
+        GETV(uw, "ups." + std::to_string(i) + ".weight", ch, co, v->up_kernel[i]);
+        GETV(ub, "ups." + std::to_string(i) + ".bias", co);
+        CHK(pack_conv_transpose(al, *uw, *ub, v->up_rate[i], &v->ups[i]));
+        for (int j = 0; j < 3; ++j) {
+            const int r = i * 3 + j;
+            for (int mi = 0; mi < 3; ++mi) {
+                const std::string p = "resblocks." + std::to_string(r);
+                GETV(w1, p + ".convs1." + std::to_string(mi) + ".weight", co, co, v->rb_kernel[j]);
+                GETV(b1, p + ".convs1." + std::to_string(mi) + ".bias", co);
+                GETV(w2, p + ".convs2." + std::to_string(mi) + ".weight", co, co, v->rb_kernel[j]);
+                GETV(b2, p + ".convs2." + std::to_string(mi) + ".bias", co);
+                CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi]));
+                CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi]));
+            }
+        }
+        ch = co;
+    }
+    GETV(qw, "conv_post.weight", 1, ch, 7); GETV(qb, "conv_post.bias", 1);
+    CHK(al.upload(qw->data, &v->post_w));
+    CHK(al.upload(qb->data, &v->post_b));
+    v->post_cin = ch;
+#undef GETV
+    v->host.clear();
+    v->finalized = true;
+    return 0;
+}
+void cmtts_vocoder_destroy(cmtts_vocoder* v) {
+    if (!v) return;
+    v->al.release();
+    delete v;
+}
+size_t cmtts_vocoder_workspace_bytes(const cmtts_vocoder* v, int B, int T) {
+    (void)v;
+    // five stage buffers of B * max_i(C_i * T_i) floats: C_i*T_i = T * {512, 2048, 8192, 8192, 8192}
+    return (size_t)5 * ((size_t)B * T * 8192 * sizeof(float) + 256) + 256;
+}
+int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, float* wav, void* ws, size_t ws_bytes,
+                          void* stream) {
+    if (!v || !v->finalized) return fail(CMTTS_E_INVALID, "vocoder not finalized");
+    if (!mel_ct || !wav || !ws || B <= 0 || T <= 0) return fail(CMTTS_E_INVALID, "cmtts_vocoder_forward: bad argument");
+    if (ws_bytes < cmtts_vocoder_workspace_bytes(v, B, T)) return fail(CMTTS_E_WORKSPACE, "vocoder workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    Carver cv(ws);
+    const size_t nbuf = (size_t)B * T * 8192;
+    float* bufA = cv.take<float>(nbuf);   // stage input
+    float* bufU = cv.take<float>(nbuf);   // upsampled
+    float* bufT = cv.take<float>(nbuf);   // xt
+    float* bufR = cv.take<float>(nbuf);   // running residual inside a ResBlock
+    float* bufS = cv.take<float>(nbuf);   // MRF sum
+    {   // conv_pre (hifigan/models.py:150)
+        ConvArgs a = conv_args(v->conv_pre, mel_ct, T, T, (long)80 * T, bufA, T, (long)512 * T, T);
+        CHK(launch(a, EPI_PLAIN, B, s));
+    }
+    int Ti = T, ch = 512;
+    for (int i = 0; i < 4; ++i) {
+        const int st = v->up_rate[i], K = v->up_kernel[i], pd = (K - st) / 2, co = ch / 2, To = Ti * st;
+        {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
+            const PackedConv& U = v->ups[i];
+            ConvArgs a = conv_args(U, bufA, Ti, Ti, (long)ch * Ti, bufU, To, (long)co * To, Ti + 1);
+            a.dil = -1; a.pad = 0;
+            a.zdiv = st; a.a_zs0 = 0; a.a_zs1 = U.phase_stride; a.x_zs0 = (long)ch * Ti; a.x_zs1 = 0;
+            a.pre_slope = 0.1f;
+            a.pre_div = i > 0 ? 3.0f : 1.0f;     // x = xs / num_kernels of the previous stage (:160)
+            ConvOut& o = a.out[0];
+            o.Tout = To; o.ostride = st; o.ooff_base = -pd; o.ooff_mul = 1; o.y_zs0 = (long)co * To; o.y_zs1 = 0;
+            CHK(launch(a, EPI_PLAIN, B * st, s));
+        }
+        const long cs = (long)co * To;
+        for (int j = 0; j < 3; ++j) {          // MRF: three ResBlocks on the same input (:154-159)
+            const int r = i * 3 + j, rk = v->rb_kernel[j];
+            const float* xr = bufU;
+            for (int mi = 0; mi < 3; ++mi) {   // ResBlock.forward (:96-103)
+                const int dil = v->rb_dil[mi];
+                ConvArgs a = conv_args(v->c1[r][mi], xr, To, To, cs, bufT, To, cs, To);
+                a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
+                CHK(launch(a, EPI_PLAIN, B, s));
+                const bool lastm = mi == 2;
+                ConvArgs b = conv_args(v->c2[r][mi], bufT, To, To, cs, lastm ? bufS : bufR, To, cs, To);
+                b.pre_slope = 0.1f;
+                b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = To;
+                b.out[0].accum = lastm && j > 0;
+                CHK(launch(b, EPI_PLAIN, B, s));
+                xr = bufR;
+            }
+        }
+        float* t = bufA; bufA = bufS; bufS = t;
+        Ti = To; ch = co;
+    }
+    // x = leaky_relu(xs / 3) [slope 0.01] -> conv_post -> tanh (:161-163)
+    k_conv_post(bufA, v->post_w, v->post_b, 3.0f, 0.01f, wav, B, ch, Ti, v->post_k, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_profile_begin(int max_launches) {
+    if (max_launches <= 0) return fail(CMTTS_E_INVALID, "cmtts_profile_begin: bad argument");
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.assign((size_t)max_launches * 2, nullptr);
+    for (auto& e : g_prof.ev) HIPCHK(hipEventCreate(&e));
+    g_prof.used = 0;
+    g_prof.on = true;
+    return 0;
+}
+int cmtts_profile_end(double* total_ms, int* n_launches) {
+    if (!total_ms || !n_launches) return fail(CMTTS_E_INVALID, "cmtts_profile_end: bad argument");
+    g_prof.on = false;
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        HIPCHK(hipEventSynchronize(g_prof.ev[i + 1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = (int)(g_prof.used / 2);
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0;
+    return 0;
+}
+
+int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_value, void* stream) {
+    if (!wav || !pcm || n < 0) return fail(CMTTS_E_INVALID, "cmtts_wav_to_int16: bad argument");
+    if (n) k_wav_to_int16(wav, pcm, (long)n, max_wav_value, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_transpose(const float* in, float* out, int B, int R, int C, void* stream) {
+    if (!in || !out || B <= 0 || R <= 0 || C <= 0) return fail(CMTTS_E_INVALID, "cmtts_transpose: bad argument");
+    k_transpose(in, out, B, R, C, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_pack_conv_weight(const float* host_w, int Cout, int Cin, int K, float** dev_packed, int* ld) {
+    if (!host_w || !dev_packed || !ld || Cout <= 0 || Cin <= 0 || K <= 0) return fail(CMTTS_E_INVALID, "cmtts_pack_conv_weight: bad argument");
+    HostTensor W;
+    W.shape = {Cout, Cin, K};
+    W.data.assign(host_w, host_w + (size_t)Cout * Cin * K);
+    Allocs al;
+    PackedConv p;
+    CHK(pack_conv(al, W, nullptr, nullptr, &p));
+    *dev_packed = p.w;
+    *ld = p.ld;
+    return 0;
+}
+void cmtts_free_device(void* p) {
+    if (p) (void)hipFree(p);
+}
+int cmtts_conv1d(const float* x, const float* packed_w, int ld, const float* bias, int B, int Cin, int Cout, int T, int K,
+                 int dilation, int padding, int act, float* y, void* stream) {
+    if (!x || !packed_w || !y) return fail(CMTTS_E_INVALID, "cmtts_conv1d: bad argument");
+    PackedConv w;
+    w.w = const_cast<float*>(packed_w); w.bias = const_cast<float*>(bias);
+    w.cout = Cout; w.cin = Cin; w.taps = K; w.ld = ld; w.tap_stride = (long)Cin * ld;
+    const int Tout = T + 2 * padding - dilation * (K - 1);
+    if (Tout <= 0) return fail(CMTTS_E_INVALID, "cmtts_conv1d: empty output");
+    ConvArgs a = conv_args(w, x, T, T, (long)Cin * T, y, Tout, (long)Cout * Tout, Tout);
+    a.dil = dilation; a.pad = padding;
+    a.out[0].act = act;
+    CHK(launch(a, EPI_PLAIN, B, (hipStream_t)stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Argument block of the fp32 MFMA implicit-GEMM Conv1D kernel (conv_mfma.hip).
+//
+// One kernel covers every dense contraction on the CM-TTS inference path:
+//   Y[z][m][t_out] = epilogue( sum_{tap, k} A[z][tap][k][m] * pre(X[z][k][n + tap*dil - pad]) )
+// with m = output channel (GEMM M), n = output position (GEMM N), k = input channel (GEMM K).
+// All activations are channel-major ([.., C, T], T contiguous) so the frame axis is the coalesced
+// axis for loads, LDS staging (with the Conv1D halo) and stores.
+#pragma once
+#include <stdint.h>
+
+enum ConvAct { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2, ACT_TANH = 3 };
+enum ConvEpi { EPI_PLAIN = 0, EPI_GATED = 1 };
+
+struct ConvOut {
+    float* Y;             // output base
+    long y_zs0, y_zs1;    // batch strides (z / zdiv, z % zdiv)
+    int ldy;              // row stride
+    int row_off;          // output row = m - row_off
+    int Tout;             // valid output width (store guard: 0 <= t_out < Tout)
+    int ostride;          // t_out = n * ostride + ooff_base + (z % zdiv) * ooff_mul
+    int ooff_base, ooff_mul;
+    const float* bias;    // [M] indexed by m (may be null)
+    const float* bvec;    // per-(z/zdiv) row vector: bvec[(z/zdiv)*bvec_zs + m] (may be null)
+    long bvec_zs;
+    const float* res;     // residual, indexed like Y with its own strides (may be null)
+    long r_zs0, r_zs1;
+    int ldr;
+    const int64_t* lens;  // columns t_out >= lens[z / zdiv] are written as 0 (may be null)
+    float alpha;          // v = (acc + bias) * alpha
+    int act;              // ConvAct
+    float div;            // v = v / div   (1 = skip)
+    int accum;            // Y += v instead of Y = v
+};
+
+struct ConvArgs {
+    const float* A;       // k-major operand: A[tap][k][m], m contiguous (packed weights, or an activation)
+    const float* X;       // X[k][t], t contiguous
+    int M, N, K;          // valid rows of Y / GEMM columns to compute / valid rows of X and A
+    int taps, dil, pad;   // t_in = n + tap*dil - pad   (dil may be negative: transposed conv phases)
+    int Tin;              // valid input width (zero padding outside [0, Tin))
+    int a_ld;             // A row stride in floats (multiple of 4, 16-B aligned rows)
+    int a_cols;           // valid columns per A row (multiple of 4): float4 guard
+    long a_tap_stride;
+    int ldx;
+    int zdiv;             // z -> (z / zdiv, z % zdiv)
+    long a_zs0, a_zs1, x_zs0, x_zs1;
+    float pre_div;        // X is divided by this on load (1 = skip)
+    float pre_slope;      // then leaky_relu with this slope (1 = identity)
+    int split;            // rows m >= split use out[1]
+    ConvOut out[2];
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Chooses the tile configuration from (M, N, taps*|dil|) and launches on `stream`.  epi = ConvEpi.
+// Returns 0 or a negative cmtts status.
+int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,273 @@
+// fp32 MFMA implicit-GEMM Conv1D for gfx950 (CDNA4) — the one dense-contraction kernel of the
+// CM-TTS inference path (denoiser residual blocks, FFT-block QKV/FFN, attention QK^T / PV,
+// variance predictors, HiFi-GAN convs and polyphase transposed convs).
+//
+// Design:
+//  * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain) at the 157 TFLOP/s matrix rate.
+//    A operand lane l = A[m = l&31][k = l>>5], B operand lane l = X[k = l>>5][n = l&31],
+//    C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+//  * 256-thread workgroups = 4 wave64; each wave owns an (MT*32) x (NT*32) output tile held in
+//    MT*NT f32x16 accumulators; tiles 128x128 / 64x256 / 32x256 (M x N).
+//  * K loop over (16-channel chunk, tap).  The X tile [16][BN + halo] is staged ONCE per chunk in
+//    LDS (zero padding and the fused pre-activation applied while staging) and re-read at a
+//    per-tap column offset; the k-major weight tile [16][BM] is staged per (chunk, tap).
+//    Both operands are read from LDS with conflict-free ds_read_b32 (32 consecutive floats per
+//    half-wave).  Global loads for iteration i+1 are issued before the MFMAs of iteration i and
+//    written to the other LDS buffer after them: one barrier per iteration.
+//  * Epilogue fused: bias, alpha, ReLU/GELU/tanh, residual (+ per-batch channel vector), division,
+//    accumulate, length mask, strided output (transposed conv phases), split outputs
+//    (residual/skip halves of the denoiser block) and the sigmoid*tanh gate.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "conv_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int KC = 16;   // input channels per K chunk
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_GELU_ERF: return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void epi_store(const ConvOut& o, float acc, int m, int n, int zq, int zr) {
+    const int t = n * o.ostride + o.ooff_base + zr * o.ooff_mul;
+    if (t < 0 || t >= o.Tout) return;
+    float v = acc;
+    if (o.bias) v += o.bias[m];
+    v *= o.alpha;
+    v = act_apply(v, o.act);
+    const long row = (long)(m - o.row_off);
+    if (o.res) {
+        float r = o.res[zq * o.r_zs0 + zr * o.r_zs1 + row * o.ldr + t];
+        if (o.bvec) r += o.bvec[zq * o.bvec_zs + m];
+        v += r;
+    } else if (o.bvec) {
+        v += o.bvec[zq * o.bvec_zs + m];
+    }
+    if (o.div != 1.0f) v = v / o.div;
+    float* y = o.Y + zq * o.y_zs0 + zr * o.y_zs1 + row * o.ldy + t;
+    if (o.accum) v += *y;
+    if (o.lens && (int64_t)t >= o.lens[zq]) v = 0.f;
+    *y = v;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
+    constexpr int MT = BM / (WM * 32);
+    constexpr int NT = BN / (WN * 32);
+    constexpr int XJ = BN / 64 + 1;                 // columns per lane of an X row (halo <= 64)
+    constexpr int WQ = BM / 4;                      // float4 per weight-tile row
+    constexpr int WV = (KC * WQ + 255) / 256;       // float4 per thread per weight tile
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(EPI != EPI_GATED || MT == 2, "gated epilogue pairs the two m-tiles of a wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int zq = z / a.zdiv, zr = z - zq * a.zdiv;
+
+    const int adil = a.dil < 0 ? -a.dil : a.dil;
+    const int XW = BN + (a.taps - 1) * adil;
+    const int tap_min = a.dil < 0 ? (a.taps - 1) * a.dil : 0;
+    const int tbase = n0 - a.pad + tap_min;
+
+    float* Ws = smem;                    // [2][KC][BM]
+    float* Xs = smem + 2 * KC * BM;      // [2][KC][XW]
+
+    const float* Ab = a.A + zq * a.a_zs0 + zr * a.a_zs1;
+    const float* Xb = a.X + zq * a.x_zs0 + zr * a.x_zs1;
+
+    const int nchunks = (a.K + KC - 1) / KC;
+    const int niter = nchunks * a.taps;
+
+    float4 wreg[WV];
+    float xreg[4][XJ];
+
+    auto load_w = [&](int chunk, int tap) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int i = tid + v * 256;
+            const int row = i / WQ, c4 = i - row * WQ;
+            const int krow = chunk * KC + row;
+            const int m = m0 + c4 * 4;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < KC * WQ && krow < a.K && m < a.a_cols)
+                w = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow * a.a_ld + m);
+            wreg[v] = w;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int i = tid + v * 256;
+            if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + buf * KC * BM + i * 4) = wreg[v];
+        }
+    };
+    auto load_x = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int krow = chunk * KC + wid + 4 * r;
+            const float* xrow = Xb + (long)krow * a.ldx;
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int col = lane + 64 * j;
+                const int t = tbase + col;
+                float v = 0.f;
+                if (col < XW && krow < a.K && t >= 0 && t < a.Tin) v = xrow[t];
+                xreg[r][j] = v;
+            }
+        }
+    };
+    auto store_x = [&](int buf) {
+        float* xs = Xs + buf * KC * XW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int col = lane + 64 * j;
+                float v = xreg[r][j];
+                if (a.pre_div != 1.0f) v = v / a.pre_div;
+                v = v > 0.f ? v : v * a.pre_slope;
+                if (col < XW) xs[(wid + 4 * r) * XW + col] = v;
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: stage iteration 0
+    load_w(0, 0);
+    load_x(0);
+    store_w(0);
+    store_x(0);
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    const int a_off = wm * MT * 32 + (lane & 31);
+    const int b_off = wn * NT * 32 + (lane & 31);
+    const int khalf = lane >> 5;
+
+    for (int it = 0; it < niter; ++it) {
+        int ntap = tap + 1, nchunk = chunk;
+        if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
+        const bool has_next = it + 1 < niter;
+        const bool next_x = has_next && ntap == 0;
+        if (has_next) load_w(nchunk, ntap);
+        if (next_x) load_x(nchunk);
+
+        const float* wsc = Ws + (it & 1) * KC * BM + a_off;
+        const float* xsc = Xs + (chunk & 1) * KC * XW + b_off + (tap * a.dil - tap_min);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            const int kr = kk * 2 + khalf;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = wsc[kr * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = xsc[kr * XW + j * 32];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+
+        if (has_next) store_w((it + 1) & 1);
+        if (next_x) store_x(nchunk & 1);
+        __syncthreads();
+        tap = ntap;
+        chunk = nchunk;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int rbase = 4 * khalf;
+    const int col = lane & 31;
+    if constexpr (EPI == EPI_GATED) {
+        // packed rows: each 64-row group = [32 sigmoid-gate rows | 32 tanh-filter rows] of the same
+        // 32 output channels (weights are permuted at import time).  out rows = M/2.
+        const ConvOut& o = a.out[0];
+        const int zrow0 = (m0 + wm * 64) / 2;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + (wn * NT + j) * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + rbase;
+                const int mg = m0 + wm * 64 + row;          // packed gate row
+                const int mf = mg + 32;                     // packed filter row
+                if (mf < a.M && n < a.N) {
+                    const float g = acc[0][j][r] + o.bias[mg];
+                    const float f = acc[1][j][r] + o.bias[mf];
+                    const float zv = (1.0f / (1.0f + expf(-g))) * tanhf(f);
+                    const int t = n;
+                    if (t < o.Tout)
+                        o.Y[zq * o.y_zs0 + zr * o.y_zs1 + (long)(zrow0 + row) * o.ldy + t] = zv;
+                }
+            }
+        }
+    } else {
+        const ConvOut& o = (m0 >= a.split) ? a.out[1] : a.out[0];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + (wn * NT + j) * 32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m < a.M && n < a.N) epi_store(o, acc[i][j][r], m, n, zq, zr);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_cfg(const ConvArgs& a, int nbatch, hipStream_t stream) {
+    const int adil = a.dil < 0 ? -a.dil : a.dil;
+    const int halo = (a.taps - 1) * adil;
+    if (halo > 64) return -2;
+    const int XW = BN + halo;
+    const size_t lds = (size_t)(2 * KC * BM + 2 * KC * XW) * sizeof(float);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<BM, BN, WM, WN, EPI>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* stream_) {
+    const ConvArgs& a = *ap;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
+    if ((a.a_ld & 3) || (a.a_cols & 3)) return -2;
+    if (epi == EPI_GATED) {
+        if (a.M % 64) return -2;
+        return launch_cfg<128, 128, 2, 2, EPI_GATED>(a, nbatch, stream);
+    }
+    if (a.M > 64) {
+        if (a.split != INT_MAX && (a.split % 128)) return -2;
+        return launch_cfg<128, 128, 2, 2, EPI_PLAIN>(a, nbatch, stream);
+    }
+    if (a.split != INT_MAX) return -2;
+    if (a.M > 32) return launch_cfg<64, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
+    return launch_cfg<32, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
+}

@@ -1,0 +1,44 @@
+// Launch wrappers of the small HBM-bound kernels (kernels.hip).  All activations are channel-major
+// [B][C][ld] with the frame / phoneme axis contiguous; integer tensors are int64 like the
+// reference's (torch.long) unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum DenseAct { DENSE_NONE = 0, DENSE_RELU = 1, DENSE_MISH = 2 };
+
+void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, const float* omega,
+                    float* x, int B, int L, int ld, int C, float scale, hipStream_t s);
+void k_layernorm_ct(const float* in, float* out, const float* gamma, const float* beta, float eps,
+                    const int64_t* lens, int B, int T, int ld, hipStream_t s);          // C = 256
+void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s);
+void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s);
+void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega,
+                     int B, int C, int T, int ld, hipStream_t s);
+void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens,
+                   int B, int C, int T, int ld, int O, hipStream_t s);
+void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,
+                   const float* add, float* out, int B, int K, int N, int act, hipStream_t s);
+void k_energy_embed(const float* x, const float* e_pred, const float* bins, int nbins, const float* E,
+                    float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s);
+void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
+                 int B, int L, hipStream_t s);
+void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);
+void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t s);
+void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl,
+                       int T, hipStream_t s);
+void k_pitch_index(const float* cwt, int O, int use_uv, const float* stats, float std_scale, float eps,
+                   float* r_ws, int64_t* p_idx, float* f0_denorm, int B, int T, hipStream_t s);
+void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T,
+                  hipStream_t s);
+void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s);
+void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
+                float nstd, float* out, int B, int T, int M, hipStream_t s);
+void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s);
+void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope,
+                 float* wav, int B, int C, int T, int KW, hipStream_t s);
+void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s);
+void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s);   // [B][R][Cn] -> [B][Cn][R]
+void k_fill_lens(int64_t* lens, int64_t v, int B, hipStream_t s);
+void k_scale(const float* in, float* out, long n, float sc, hipStream_t s);
+void k_fill_float(float* p, float v, int n, hipStream_t s);

@@ -1,0 +1,522 @@
+// Small HBM-bound kernels of the CM-TTS inference path (gfx950, wave64).
+// Every kernel keeps the frame/phoneme axis on consecutive lanes (coalesced 256-B wave accesses);
+// reductions over channels go through LDS, gathers rely on L2.  Each kernel cites the reference
+// lines it implements (paths relative to the reference root).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float sin_exact(float a) { return (float)sin((double)a); }
+__device__ __forceinline__ float cos_exact(float a) { return (float)cos((double)a); }
+
+// Sinusoidal position embedding value (model/blocks.py:45-62): row p = [sin(p*w_j) | cos(p*w_j)],
+// row 0 (padding) is all zeros.  omega[j] = exp(-j*ln(1e4)/(C/2-1)) is precomputed on the host.
+__device__ __forceinline__ float pos_embed(int p, int c, int C, const float* omega) {
+    if (p == 0) return 0.f;
+    const int half = C >> 1;
+    const int j = c < half ? c : c - half;
+    const float arg = (float)p * omega[j];
+    return c < half ? sin_exact(arg) : cos_exact(arg);
+}
+
+// positions = cumsum(flag) * flag over [0,T) for one batch row (utils/tools.py:810-822), computed by
+// a 256-thread block into LDS `pos`.  `counts` is 256 ints of LDS.
+template <typename FlagFn>
+__device__ void block_positions(FlagFn flag, int T, int* pos, int* counts) {
+    const int tid = threadIdx.x;
+    const int seg = (T + 255) / 256;
+    const int start = tid * seg;
+    const int end = min(T, start + seg);
+    int cnt = 0;
+    for (int t = start; t < end; ++t) cnt += flag(t) ? 1 : 0;
+    counts[tid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int c = counts[i]; counts[i] = run; run += c; }
+    }
+    __syncthreads();
+    int run = counts[tid];
+    for (int t = start; t < end; ++t) {
+        const bool f = flag(t);
+        run += f ? 1 : 0;
+        pos[t] = f ? run : 0;
+    }
+    __syncthreads();
+}
+
+// ---- FastspeechEncoder.forward_embedding (model/modules.py:145-151) + first mask (:94)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts, const int64_t* lens,
+                                                           const float* E, const float* omega, float* x,
+                                                           int L, int ld, int C, float scale) {
+    extern __shared__ int sh[];
+    int* counts = sh;
+    int* pos = sh + 256;
+    const int b = blockIdx.x;
+    const int64_t* tok = texts + (long)b * L;
+    block_positions([&](int t) { return tok[t] != 0; }, L, pos, counts);
+    const int len = (int)lens[b];
+    for (int idx = threadIdx.x; idx < C * L; idx += 256) {
+        const int c = idx / L, l = idx - c * L;
+        float v = 0.f;
+        if (l < len) v = scale * E[tok[l] * C + c] + pos_embed(pos[l], c, C, omega);
+        x[((long)b * C + c) * ld + l] = v;
+    }
+}
+
+// ---- LayerNorm over the 256 channels of a channel-major tensor (model/blocks.py:88-107 eps 1e-12,
+// model/modules.py:74 eps 1e-5); optional zeroing of columns >= lens[b].
+__global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, float* out, const float* gamma,
+                                                           const float* beta, float eps, const int64_t* lens,
+                                                           int T, int ld) {
+    constexpr int C = 256;
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tx;
+    const int b = blockIdx.y;
+    const bool ok = t < T;
+    float v[32];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int c = ty + 8 * i;
+        v[i] = ok ? in[((long)b * C + c) * ld + t] : 0.f;
+        sum += v[i];
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) tot += red[y][tx];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; sq += d * d; }
+    red[ty][tx] = sq;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) var += red[y][tx];
+    var = var / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const bool keep = !(lens && (int64_t)t >= lens[b]);
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = ty + 8 * i;
+            const float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            out[((long)b * C + c) * ld + t] = keep ? y : 0.f;
+        }
+    }
+}
+
+// ---- softmax over keys for transposed scores ST[z][j][i] (F.multi_head_attention_forward via
+// model/blocks.py:303-312): column i = one query; keys j >= lens[b] are masked (-inf -> prob 0).
+__global__ __launch_bounds__(256) void softmax_cols_kernel(float* st, const int64_t* lens, int H, int L, int ld, long zs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int z = blockIdx.y;
+    if (i >= L) return;
+    const int len = min((int)lens[z / H], L);
+    float* col = st + (long)z * zs + i;
+    float mx = -INFINITY;
+    for (int j = 0; j < len; ++j) mx = fmaxf(mx, col[(long)j * ld]);
+    float sum = 0.f;
+    for (int j = 0; j < len; ++j) sum += expf(col[(long)j * ld] - mx);
+    for (int j = 0; j < len; ++j) col[(long)j * ld] = expf(col[(long)j * ld] - mx) / sum;
+    for (int j = len; j < L; ++j) col[(long)j * ld] = 0.f;
+}
+
+// ---- x[b][c][l] += vec[b][c] (speaker embedding broadcast, model/modules.py:349-352)
+__global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int ld) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (l < L) x[((long)b * C + c) * ld + l] += vec[(long)b * C + c];
+}
+
+// ---- PitchPredictor/EnergyPredictor input: xs + alpha * PE[positions(xs[...,0] != 0)]
+// (model/modules.py:548-549; the float-zero test on channel 0 is part of the semantics)
+__global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, float* out, const float* alpha,
+                                                            const float* omega, int C, int T, int ld) {
+    extern __shared__ int sh[];
+    int* counts = sh;
+    int* pos = sh + 256;
+    const int b = blockIdx.x;
+    const float* x0 = x + (long)b * C * ld;
+    block_positions([&](int t) { return x0[t] != 0.f; }, T, pos, counts);
+    const float al = alpha[0];
+    for (long idx = threadIdx.x; idx < (long)C * T; idx += 256) {
+        const int c = (int)(idx / T), t = (int)(idx - (long)c * T);
+        const long off = ((long)b * C + c) * ld + t;
+        out[off] = x[off] + al * pos_embed(pos[t], c, C, omega);
+    }
+}
+
+// ---- Linear(C -> O<=16) over channel-major input, output time-major [B][T][O]
+// (duration/energy/cwt predictor heads, model/modules.py:505-506,554)
+__global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const float* W, const float* bias,
+                                                          float* out, const int64_t* lens, int C, int T, int ld, int O) {
+    extern __shared__ float wsh[];     // [O][C]
+    for (int i = threadIdx.x; i < O * C; i += 256) wsh[i] = W[i];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    const float* xb = x + (long)b * C * ld + t;
+    for (int c = 0; c < C; ++c) {
+        const float xv = xb[(long)c * ld];
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+            if (o < O) acc[o] = fmaf(xv, wsh[o * C + c], acc[o]);
+    }
+    const bool keep = !(lens && (int64_t)t >= lens[b]);
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+        if (o < O) out[((long)b * T + t) * O + o] = keep ? acc[o] + bias[o] : 0.f;
+}
+
+// ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n]
+__global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long in_bs, long in_ks, const float* Wt,
+                                                          const float* bias, const float* add, float* out,
+                                                          int K, int N, int act) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float* ib = in + (long)b * in_bs;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(ib[(long)k * in_ks], Wt[(long)k * N + n], acc);
+    if (bias) acc += bias[n];
+    if (act == DENSE_RELU) acc = acc > 0.f ? acc : 0.f;
+    else if (act == DENSE_MISH) {
+        const float sp = acc > 20.f ? acc : log1pf(expf(acc));
+        acc = acc * tanhf(sp);
+    }
+    if (add) acc += add[(long)b * N + n];
+    out[(long)b * N + n] = acc;
+}
+
+// ---- energy bucketize + embedding add (model/modules.py:319-329,358-363); torch.bucketize
+// right=False = first i with bins[i] >= v
+__global__ void energy_embed_kernel(const float* x, const float* e_pred, const float* bins, int nbins,
+                                    const float* E, float* out1, int64_t* e_idx, int C, int L, int ld) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (l >= L) return;
+    const float v = e_pred[(long)b * L + l];
+    int lo = 0, hi = nbins;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] >= v) hi = mid; else lo = mid + 1; }
+    if (v != v) lo = nbins;   // NaN sorts last
+    e_idx[(long)b * L + l] = lo;
+    const float* e = E + (long)lo * C;
+    for (int c = 0; c < C; ++c) {
+        const long off = ((long)b * C + c) * ld + l;
+        out1[off] = x[off] + e[c];
+    }
+}
+
+// ---- d = clamp(round(exp(log_d) - 1) * d_control, 0) (half-to-even), cumulative sums, mel_len
+// (model/modules.py:369-372, utils/tools.py:788-791)
+__global__ void durations_kernel(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
+                                 int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int run = 0;
+    for (int l = 0; l < L; ++l) {
+        float d = rintf(expf(logd[(long)b * L + l]) - 1.0f) * d_control;
+        d = d > 0.f ? d : 0.f;
+        d_rounded[(long)b * L + l] = d;
+        run += (int)d;            // LengthRegulator.expand: int(expand_size)
+        cum[(long)b * L + l] = run;
+    }
+    mel_len[b] = run;
+}
+
+// ---- cumulative sums of already-rounded durations (LengthRegulator.expand: max(int(d), 0))
+__global__ void cumsum_durations_kernel(const float* dur, int* cum, int64_t* mel_len, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int run = 0;
+    for (int l = 0; l < L; ++l) {
+        const int d = (int)dur[(long)b * L + l];
+        run += d > 0 ? d : 0;
+        cum[(long)b * L + l] = run;
+    }
+    mel_len[b] = run;
+}
+
+// ---- mel2ph[b][t] = 1 + #{l : cum[l] <= t} for t < cum[L-1], else 0 (utils/tools.py:793-797)
+__global__ void mel2ph_kernel(const int* cum, int64_t* mel2ph, int L, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    const int* c = cum + (long)b * L;
+    int64_t r = 0;
+    if (t < c[L - 1]) {
+        int lo = 0, hi = L;           // first l with cum[l] > t
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] > t) hi = mid; else lo = mid + 1; }
+        r = lo + 1;
+    }
+    mel2ph[(long)b * T + t] = r;
+}
+
+// ---- length regulator gather (model/modules.py:421-448): frame t copies phoneme mel2ph-1, pad = 0
+__global__ void length_regulate_kernel(const float* out1, const int64_t* mel2ph, float* xlr, int C, int ldl, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int64_t ph = mel2ph[(long)b * T + t];
+    xlr[((long)b * C + c) * T + t] = ph > 0 ? out1[((long)b * C + c) * ldl + (ph - 1)] : 0.f;
+}
+
+// ---- inverse CWT -> f0 -> coarse pitch bucket (model/modules.py:274-300; utils/pitch_tools.py
+// 244-250 inverse_cwt_torch, 261-279 cwt2f0/_norm, 38-47 norm_f0, 64-78 denorm_f0, 26-35 f0_to_coarse)
+__global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int O, int use_uv, const float* stats,
+                                                          float std_scale, float eps, float* r_ws, int64_t* p_idx,
+                                                          float* f0_denorm, int T) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* cw = cwt + (long)b * T * O;
+    float* r = r_ws + (long)b * T;
+    double s = 0.0;
+    for (int t = tid; t < T; t += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc += cw[(long)t * O + j] * powf((float)j + 1.0f + 2.5f, -2.5f);
+        r[t] = acc;
+        s += (double)acc;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    const float mean_r = (float)(red[0] / (double)T);
+    __syncthreads();
+    double q = 0.0;
+    for (int t = tid; t < T; t += 256) { const double d = (double)r[t] - (double)mean_r; q += d * d; }
+    red[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
+    const float std_r = (float)sqrt(red[0] / (double)(T - 1));       // torch.std: unbiased
+    const float mean = stats[b * 2 + 0];
+    const float stdv = stats[b * 2 + 1] * std_scale;
+    const float mel_min = (float)(1127.0 * log(1.0 + 50.0 / 700.0));
+    const float mel_rng = (float)(1127.0 * log(1.0 + 1100.0 / 700.0) - 1127.0 * log(1.0 + 50.0 / 700.0));
+    for (int t = tid; t < T; t += 256) {
+        const float rn = (r[t] - mean_r) / std_r;
+        const float f0 = expf(rn * stdv + mean);
+        const float f0n = log2f(f0 + eps);
+        float f0d = exp2f(f0n);
+        if (use_uv && cw[(long)t * O + (O - 1)] > 0.f) f0d = 0.f;
+        f0_denorm[(long)b * T + t] = f0d;
+        float mel = 1127.0f * logf(1.0f + f0d / 700.0f);
+        if (mel > 0.f) mel = (mel - mel_min) * 254.0f / mel_rng + 1.0f;
+        if (mel <= 1.0f) mel = 1.0f;
+        if (mel > 255.0f) mel = 255.0f;
+        p_idx[(long)b * T + t] = (int64_t)(mel + 0.5f);
+    }
+}
+
+// ---- out[b][c][t] = x[b][c][t] + E[idx[b][t]][c] (pitch embedding add, model/modules.py:300,395)
+__global__ void gather_add_kernel(const float* x, const int64_t* idx, const float* E, float* out, int C, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long off = ((long)b * C + c) * T + t;
+    out[off] = x[off] + E[idx[(long)b * T + t] * C + c];
+}
+
+// ---- hin[b][m][t] = scale * x[b][t][m]  (c_in pre-scaling + [B,1,T,80] -> [B,80,T],
+// karras_diffusion.py:405, tts_net.py:31)
+__global__ void mel_prep_kernel(const float* x, const float* scale_b, float scale, float* hin, int T, int M) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const float s = scale_b ? scale_b[b] : scale;
+    hin[((long)b * M + m) * T + t] = s * x[((long)b * T + t) * M + m];
+}
+
+// ---- out[b][t][m] = c_out*F[b][m][t] + c_skip*xold[b][t][m] (+ noise*nstd)
+// (karras_diffusion.py:406 and the re-noising of stochastic_iterative_sampler :852)
+__global__ void mel_post_kernel(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
+                                float nstd, float* out, int T, int M) {
+    const int m = threadIdx.x;
+    const int t = blockIdx.x * blockDim.y + threadIdx.y;
+    const int b = blockIdx.y;
+    if (t >= T || m >= M) return;
+    const long o = ((long)b * T + t) * M + m;
+    float v = c_out * F[((long)b * M + m) * T + t];
+    if (xold) v += c_skip * xold[o];
+    if (noise) v += noise[o] * nstd * 0.85f;     // randn_like(x) * sqrt(next_t^2 - t_min^2) * 0.85
+    out[o] = v;
+}
+
+// ---- DiffusionEmbedding (model/blocks.py:633-640): [sin(t*w) | cos(t*w)]
+__global__ void diff_embed_kernel(const float* t, const float* omega, float* emb, int C) {
+    const int c = threadIdx.x, b = blockIdx.x;
+    if (c >= C) return;
+    const int half = C >> 1;
+    const int j = c < half ? c : c - half;
+    const float arg = t[b] * omega[j];
+    emb[(long)b * C + c] = c < half ? sin_exact(arg) : cos_exact(arg);
+}
+
+// ---- HiFi-GAN tail: leaky_relu(x/pre_div, slope) -> Conv1d(C->1, KW) -> tanh (hifigan/models.py:161-163)
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* x, const float* w, const float* bias,
+                                                        float pre_div, float slope, float* wav, int C, int T, int KW) {
+    extern __shared__ float wsh[];
+    for (int i = threadIdx.x; i < C * KW; i += 256) wsh[i] = w[i];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    const int pad = KW / 2;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* xr = x + ((long)b * C + c) * T;
+        for (int k = 0; k < KW; ++k) {
+            const int tt = t + k - pad;
+            float v = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
+            if (pre_div != 1.0f) v = v / pre_div;
+            v = v > 0.f ? v : v * slope;
+            acc = fmaf(wsh[c * KW + k], v, acc);
+        }
+    }
+    wav[(long)b * T + t] = tanhf(acc + bias[0]);
+}
+
+// ---- (wav * 32768).astype(int16): truncation toward zero through int32, low 16 bits kept
+// (utils/model.py:195-198; +1.0 wraps to -32768 exactly as numpy's cast does)
+__global__ void wav_to_int16_kernel(const float* wav, int16_t* pcm, long n, float max_wav) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pcm[i] = (int16_t)(int)(wav[i] * max_wav);
+}
+
+// ---- [B][R][Cn] -> [B][Cn][R] through a 32x33 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int R, int Cn) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cn) ? in[((long)b * R + r) * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cn && r < R) out[((long)b * Cn + c) * R + r] = tile[tx][i];
+    }
+}
+
+__global__ void scale_kernel(const float* in, float* out, long n, float sc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * sc;
+}
+
+__global__ void fill_float_kernel(float* p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void fill_lens_kernel(int64_t* lens, int64_t v, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) lens[i] = v;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, const float* omega, float* x,
+                    int B, int L, int ld, int C, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), (256 + L) * sizeof(int), s, texts, lens, E, omega,
+                       x, L, ld, C, scale);
+}
+void k_layernorm_ct(const float* in, float* out, const float* gamma, const float* beta, float eps,
+                    const int64_t* lens, int B, int T, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_ct_kernel, dim3(cdiv(T, 32), B), dim3(256), 0, s, in, out, gamma, beta, eps, lens, T, ld);
+}
+void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(L, 256), nz), dim3(256), 0, s, st, lens, H, L, ld, zs);
+}
+void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld);
+}
+void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, int B, int C, int T,
+                     int ld, hipStream_t s) {
+    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, C, T, ld);
+}
+void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens, int B,
+                   int C, int T, int ld, int O, hipStream_t s) {
+    hipLaunchKernelGGL(chan_linear_kernel, dim3(cdiv(T, 256), B), dim3(256), (size_t)O * C * sizeof(float), s, x, W,
+                       bias, out, lens, C, T, ld, O);
+}
+void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias, const float* add,
+                   float* out, int B, int K, int N, int act, hipStream_t s) {
+    hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias, add,
+                       out, K, N, act);
+}
+void k_energy_embed(const float* x, const float* e_pred, const float* bins, int nbins, const float* E, float* out1,
+                    int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(energy_embed_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, s, x, e_pred, bins, nbins, E, out1,
+                       e_idx, C, L, ld);
+}
+void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, logd, d_control, d_rounded, cum, mel_len, B, L);
+}
+void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(cumsum_durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, dur, cum, mel_len, B, L);
+}
+void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t s) {
+    hipLaunchKernelGGL(mel2ph_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s, cum, mel2ph, L, T);
+}
+void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl, int T,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(length_regulate_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, out1, mel2ph, xlr, C, ldl, T);
+}
+void k_pitch_index(const float* cwt, int O, int use_uv, const float* stats, float std_scale, float eps,
+                   float* r_ws, int64_t* p_idx, float* f0_denorm, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(pitch_index_kernel, dim3(B), dim3(256), 0, s, cwt, O, use_uv, stats, std_scale, eps, r_ws,
+                       p_idx, f0_denorm, T);
+}
+void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T, hipStream_t s) {
+    hipLaunchKernelGGL(gather_add_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, x, idx, E, out, C, T);
+}
+void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s) {
+    hipLaunchKernelGGL(mel_prep_kernel, dim3(cdiv(T, 256), M, B), dim3(256), 0, s, x, scale_b, scale, hin, T, M);
+}
+void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip, float nstd,
+                float* out, int B, int T, int M, hipStream_t s) {
+    // blockDim = (M rounded to 16 | 3 rows): 80 mels -> (80, 3) = 240 threads
+    const int ty = 256 / M > 0 ? 256 / M : 1;
+    hipLaunchKernelGGL(mel_post_kernel, dim3(cdiv(T, ty), B), dim3(M, ty), 0, s, F, xold, noise, c_out, c_skip, nstd,
+                       out, T, M);
+}
+void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(diff_embed_kernel, dim3(B), dim3(C), 0, s, t, omega, emb, C);
+}
+void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,
+                 int C, int T, int KW, hipStream_t s) {
+    hipLaunchKernelGGL(conv_post_kernel, dim3(cdiv(T, 256), B), dim3(256), (size_t)C * KW * sizeof(float), s, x, w,
+                       bias, pre_div, slope, wav, C, T, KW);
+}
+void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s) {
+    hipLaunchKernelGGL(wav_to_int16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, wav, pcm, n, max_wav);
+}
+void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), B), dim3(256), 0, s, in, out, R, Cn);
+}
+void k_scale(const float* in, float* out, long n, float sc, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, in, out, n, sc);
+}
+void k_fill_float(float* p, float v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_float_kernel, dim3(cdiv(n, 64)), dim3(64), 0, s, p, v, n);
+}
+void k_fill_lens(int64_t* lens, int64_t v, int B, hipStream_t s) {
+    hipLaunchKernelGGL(fill_lens_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, lens, v, B);
+}

@@ -1,0 +1,419 @@
+"""Python host layer: the reference's call surface over the C ABI (include/cmtts_hip.h).
+
+Mirrors, name for name, the callables the reference's inference path is made of:
+
+    CMTotalTTS / CMDenoiserTTS / DurationPitchSpeakerNet   model/cm_tool/tts_net.py, model/cmtts.py
+    KarrasDenoiser.denoise, karras_sample_tts               model/cm_tool/karras_diffusion.py
+    Generator (HiFi-GAN), get_vocoder-style loading,
+    vocoder_infer                                           hifigan/models.py, utils/model.py
+    CMTotalTTSSynthesize.synthesize                         synthesize.py:35-153
+
+PyTorch is plumbing only (device memory, streams, nn.Module container): every operator call goes
+to hand-written HIP kernels through ctypes.  There is no eager/PyTorch fallback — a missing
+``libcmtts_hip.so`` raises at construction time.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import CMTTSConfig, HifiGanConfig
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _i64(t, device):
+    return t.to(device=device, dtype=torch.int64).contiguous()
+
+
+def _push_state_dict(lib, setter, handle, sd):
+    for name, v in sd.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+        if a.ndim == 0:
+            a = a.reshape(1)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        _lib.check(setter(handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+
+class _Workspace:
+    """Caller-owned scratch buffers, cached per size (no allocation on the steady-state path)."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, key, nbytes, device):
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+def get_mask_from_lengths(lengths, max_len=None):
+    """utils/tools.py:275-283 — True = padding."""
+    if max_len is None:
+        max_len = int(lengths.max().item())
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0)
+    return ids >= lengths.unsqueeze(1)
+
+
+class CMTotalTTS(torch.nn.Module):
+    """Drop-in for model/cm_tool/tts_net.py:40-183 (inference side).
+
+    ``load_state_dict`` takes the reference checkpoint's flat state_dict (synthesize.py:79-83) and
+    hands every tensor, under its original key and layout, to ``cmtts_set_tensor``.
+    """
+
+    def __init__(self, config: CMTTSConfig, device="cuda:0"):
+        super().__init__()
+        self.config = config
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        cs = _lib.CMTTSConfigStruct()
+        for name, _ in cs._fields_:
+            setattr(cs, name, type(getattr(cs, name))(getattr(config, name)))
+        self._h = C.c_void_p()
+        _lib.check(self.lib.cmtts_create(C.byref(cs), C.byref(self._h)))
+        self._ready = False
+        self._ws = _Workspace()
+        self.duration_pitch_energy_net = DurationPitchSpeakerNet(self)
+        self.net = CMDenoiserTTS(self)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.cmtts_destroy(h)
+            self._h = C.c_void_p()
+
+    def load_state_dict(self, state_dict, strict=True):
+        with torch.cuda.device(self.device):
+            _push_state_dict(self.lib, self.lib.cmtts_set_tensor, self._h, state_dict)
+            _lib.check(self.lib.cmtts_finalize(self._h))
+        self._ready = True
+        return self
+
+    def eval(self):
+        return self
+
+    def _require(self):
+        if not self._ready:
+            raise RuntimeError("CMTotalTTS: load_state_dict() first")
+
+    def get_segmentation_model(self):
+        """tts_net.py:66-73 -> (duration_pitch_energy_net, denoise_fun)."""
+        return self.duration_pitch_energy_net, self.net.forward
+
+    def forward(self, x, timesteps, speakers=None, texts=None, src_lens=None, spker_embeds=None,
+                p_control=1.0, e_control=1.0, d_control=1.0, **kwargs):
+        """tts_net.py:75-183: re-runs the duration net with max_mel_len = x.size(2), then the denoiser."""
+        out = self.duration_pitch_energy_net(speakers, texts, src_lens, mels=x, spker_embeds=spker_embeds,
+                                             d_control=d_control)
+        return self.net(x, timesteps, out["cond"], out["speaker_emb"], out["mel_masks"])
+
+
+class DurationPitchSpeakerNet(torch.nn.Module):
+    """model/cmtts.py:10-122, inference branch (all targets None)."""
+
+    def __init__(self, owner: CMTotalTTS):
+        super().__init__()
+        self.__dict__["_owner"] = owner
+
+    def forward(self, speakers=None, texts=None, src_lens=None, mels=None, mel_lens=None, spker_embeds=None,
+                p_control=1.0, e_control=1.0, d_control=1.0, max_mel_len=None, **kwargs):
+        o = self._owner
+        o._require()
+        cfg, lib, dev = o.config, o.lib, o.device
+        if p_control != 1.0 or e_control != 1.0:
+            raise NotImplementedError("p_control/e_control are never forwarded by synthesize.py:96-101")
+        texts = _i64(texts, dev)
+        src_lens = _i64(src_lens, dev)
+        B, L = texts.shape
+        spk_in = _f32(spker_embeds, dev) if (cfg.multi_speaker and spker_embeds is not None) else None
+        if cfg.multi_speaker and spk_in is None:
+            raise AssertionError("Speaker embedding should not be None")
+        H = cfg.hidden
+        with torch.cuda.device(dev):
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            log_d, d_rounded, e_pred = f(B, L), f(B, L), f(B, L)
+            mel_len = torch.empty(B, dtype=torch.int64, device=dev)
+            e_idx = torch.empty(B, L, dtype=torch.int64, device=dev)
+            enc_ct = f(B, H, L)
+            spk = f(B, H) if cfg.multi_speaker else None
+            nb = lib.cmtts_text_workspace_bytes(o._h, B, L)
+            tws = o._ws.get("text", nb, dev)
+            _lib.check(lib.cmtts_text_forward(o._h, _ptr(texts), _ptr(src_lens), _ptr(spk_in), B, L, float(d_control),
+                                              _ptr(log_d), _ptr(d_rounded), _ptr(mel_len), _ptr(e_pred), _ptr(e_idx),
+                                              _ptr(enc_ct), _ptr(spk), _ptr(tws), nb, _stream()))
+            if mels is not None:
+                T = int(mels.size(2))                       # model/cmtts.py:61-62
+            elif max_mel_len is not None:
+                T = int(max_mel_len)
+            else:
+                T = int(mel_len.max().item())               # the one host read-back (pad() batch max)
+            O = cfg.cwt_out
+            cond_ct = f(B, H, T)
+            mel2ph = torch.empty(B, T, dtype=torch.int64, device=dev)
+            cwt = f(B, T, O)
+            f0 = f(B, T)
+            p_idx = torch.empty(B, T, dtype=torch.int64, device=dev)
+            stats = f(B, 2)
+            nf = lib.cmtts_frame_workspace_bytes(o._h, B, T)
+            fws = o._ws.get("frame", nf, dev)
+            _lib.check(lib.cmtts_frame_forward(o._h, _ptr(tws), B, L, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
+                                               _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(fws), nf, _stream()))
+        mel_masks = get_mask_from_lengths(mel_len, T)
+        return {
+            "cond": cond_ct.transpose(1, 2),               # [B,T,H] view of the channel-major buffer
+            "cond_ct": cond_ct,
+            "p_targets": None,
+            "p_predictions": {"pitch_pred": None, "f0_denorm": f0, "cwt": cwt,
+                              "f0_mean": stats[:, 0], "f0_std": stats[:, 1], "p_idx": p_idx},
+            "e_predictions": e_pred,
+            "e_idx": e_idx,
+            "log_d_predictions": log_d,
+            "d_rounded": d_rounded,
+            "mel_lens": mel_len,
+            "mel_masks": mel_masks,
+            "mel2ph": mel2ph,
+            "src_masks": get_mask_from_lengths(src_lens, L),
+            "speaker_emb": spk,
+            "src_lens": src_lens,
+            "enc_out": enc_ct.transpose(1, 2),
+        }
+
+
+def _as_cond_ct(conditioner, dev):
+    """[B,T,H] reference layout -> channel-major [B,H,T]; free when it is a view of a _ct buffer."""
+    c = conditioner.to(device=dev, dtype=torch.float32).transpose(1, 2)
+    return c if c.is_contiguous() else c.contiguous()
+
+
+class CMDenoiserTTS(torch.nn.Module):
+    """model/cm_tool/tts_net.py:11-37: forward(x, timesteps, conditioner, speaker_emb, mask)."""
+
+    def __init__(self, owner: CMTotalTTS):
+        super().__init__()
+        self.__dict__["_owner"] = owner
+
+    def forward(self, x, timesteps, conditioner=None, speaker_emb=None, mask=None):
+        o = self._owner
+        o._require()
+        dev, lib = o.device, o.lib
+        x = _f32(x, dev)
+        B, one, T, M = x.shape
+        assert one == 1 and M == o.config.n_mels
+        cond_ct = _as_cond_ct(conditioner, dev)
+        t = _f32(timesteps, dev)
+        spk = _f32(speaker_emb, dev) if speaker_emb is not None else None
+        with torch.cuda.device(dev):
+            out = torch.empty_like(x)
+            nb = lib.cmtts_denoiser_workspace_bytes(o._h, B, T)
+            ws = o._ws.get("den", nb, dev)
+            _lib.check(lib.cmtts_denoiser_forward(o._h, _ptr(x), _ptr(t), _ptr(cond_ct), _ptr(spk), B, T, _ptr(out),
+                                                  _ptr(ws), nb, _stream()))
+        return out
+
+
+class KarrasDenoiser:
+    """model/cm_tool/karras_diffusion.py:35-102,392-407 (inference members only)."""
+
+    def __init__(self, sigma_data=0.5, sigma_max=80.0, sigma_min=0.002, rho=7.0, distillation=True, **kw):
+        self.sigma_data, self.sigma_max, self.sigma_min, self.rho = sigma_data, sigma_max, sigma_min, rho
+        self.distillation = distillation
+
+    def get_scalings_for_boundary_condition(self, sigma):
+        c_skip = self.sigma_data ** 2 / ((sigma - self.sigma_min) ** 2 + self.sigma_data ** 2)
+        c_out = (sigma - self.sigma_min) * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
+    def denoise(self, model, x_t, sigmas, **model_kwargs):
+        """Generic (unfused) form: host-side scalings around any model callable.  The fused
+        path used by karras_sample_tts is cmtts_sample."""
+        c_skip, c_out, c_in = [v[(...,) + (None,) * (x_t.ndim - v.ndim)]
+                               for v in self.get_scalings_for_boundary_condition(sigmas)]
+        rescaled_t = 1000 * 0.25 * torch.log(sigmas + 1e-44)
+        model_output = model(c_in * x_t, rescaled_t, **model_kwargs)
+        return model_output, c_out * model_output + c_skip * x_t
+
+
+class DummyGenerator:
+    """model/cm_tool/random_util.py:17-25."""
+
+    def randn(self, *args, **kwargs):
+        return torch.randn(*args, **kwargs)
+
+    def randn_like(self, *args, **kwargs):
+        return torch.randn_like(*args, **kwargs)
+
+
+def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
+    """T-step consistency sampling on precomputed conditioning (cmtts_sample).
+    noise: fp32 [n_noise,B,1,T,80] on device.  Returns mel [B,T,80]."""
+    model._require()
+    lib, dev, cfg = model.lib, model.device, model.config
+    B, H, T = cond_ct.shape
+    n_noise = 1 if n_steps == 1 else n_steps + 1
+    assert noise.shape[0] >= n_noise and tuple(noise.shape[1:]) == (B, 1, T, cfg.n_mels)
+    sig = (C.c_float * n_steps)()
+    std = (C.c_float * n_steps)()
+    _lib.check(lib.cmtts_schedule(model._h, n_steps, sig, std))
+    with torch.cuda.device(dev):
+        mel = torch.empty(B, T, cfg.n_mels, dtype=torch.float32, device=dev)
+        nb = lib.cmtts_denoiser_workspace_bytes(model._h, B, T)
+        ws = model._ws.get("den", nb, dev)
+        _lib.check(lib.cmtts_sample(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
+                                    _ptr(mel), _ptr(ws), nb, _stream()))
+    return mel
+
+
+def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, progress=False, callback=None,
+                      model_kwargs=None, device=None, sigma_min=0.002, sigma_max=80, rho=7.0, sampler="onestep",
+                      generator=None, ts=None, **unused):
+    """karras_diffusion.py:480-577 for the samplers synthesize.py selects: "onestep", and
+    "multistep" with steps=2, ts=(0,)*T+(1,).  The duration net runs once (bit-identical to the
+    reference's per-step re-run) with max_mel_len = shape[2]."""
+    if generator is None:
+        generator = DummyGenerator()
+    B, one, T, M = shape
+    if sampler == "onestep":
+        n_steps = 1
+    elif sampler == "multistep":
+        if steps != 2 or ts is None or tuple(ts[:-1]) != (0,) * (len(ts) - 1) or ts[-1] != 1:
+            raise NotImplementedError("only the schedules synthesize.py:122-147 uses: steps=2, ts=(0,...,0,1)")
+        n_steps = len(ts) - 1
+    else:
+        raise NotImplementedError(f"sampler {sampler!r} is never selected by synthesize.py")
+    dev = model.device
+    kw = dict(model_kwargs or {})
+    out = model.duration_pitch_energy_net(kw.get("speakers"), kw["texts"], kw["src_lens"],
+                                          spker_embeds=kw.get("spker_embeds"), max_mel_len=T)
+    draws = [generator.randn(*shape, device=dev)]
+    for _ in range(n_steps if n_steps > 1 else 0):
+        draws.append(generator.randn_like(draws[0]))
+    noise = torch.stack([_f32(d, dev) for d in draws], 0)
+    return sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise)
+
+
+class Generator(torch.nn.Module):
+    """hifigan/models.py:112-174 — HiFi-GAN V1 generator; forward(x [B,80,T]) -> [B,1,256*T]."""
+
+    def __init__(self, h: HifiGanConfig = HifiGanConfig(), device="cuda:0"):
+        super().__init__()
+        self.h = h
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self.lib.cmtts_vocoder_create(C.byref(self._h)))
+        self._ready = False
+        self._ws = _Workspace()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.cmtts_vocoder_destroy(h)
+            self._h = C.c_void_p()
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts plain weights or weight_g/weight_v pairs (folded like remove_weight_norm)."""
+        from .weights import fold_weight_norm
+        sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in state_dict.items()}
+        if any(k.endswith("weight_g") for k in sd):
+            sd = fold_weight_norm(sd)
+        with torch.cuda.device(self.device):
+            _push_state_dict(self.lib, self.lib.cmtts_vocoder_set_tensor, self._h, sd)
+            _lib.check(self.lib.cmtts_vocoder_finalize(self._h))
+        self._ready = True
+        return self
+
+    def remove_weight_norm(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def forward(self, x):
+        if not self._ready:
+            raise RuntimeError("Generator: load_state_dict() first")
+        dev = self.device
+        x = _f32(x, dev)
+        B, M, T = x.shape
+        with torch.cuda.device(dev):
+            wav = torch.empty(B, 1, T * self.h.hop, dtype=torch.float32, device=dev)
+            nb = self.lib.cmtts_vocoder_workspace_bytes(self._h, B, T)
+            ws = self._ws.get("voc", nb, dev)
+            _lib.check(self.lib.cmtts_vocoder_forward(self._h, _ptr(x), B, T, _ptr(wav), _ptr(ws), nb, _stream()))
+        return wav
+
+
+def vocoder_infer(mels, vocoder, model_config=None, preprocess_config=None, lengths=None, max_wav_value=32768.0):
+    """utils/model.py:187-205: mels [B,80,T] -> list of int16 numpy arrays trimmed to `lengths`."""
+    if preprocess_config is not None:
+        max_wav_value = preprocess_config["preprocessing"]["audio"]["max_wav_value"]
+    wavs = vocoder(mels).squeeze(1)
+    pcm = torch.empty(wavs.shape, dtype=torch.int16, device=wavs.device)
+    with torch.cuda.device(wavs.device):
+        _lib.check(vocoder.lib.cmtts_wav_to_int16(_ptr(wavs), _ptr(pcm), wavs.numel(), float(max_wav_value), _stream()))
+    out = [w for w in pcm.cpu().numpy()]
+    if lengths is not None:
+        out = [w[: int(lengths[i])] for i, w in enumerate(out)]
+    return out
+
+
+def transpose_last2(x):
+    """[B,R,C] -> [B,C,R] on the HIP transpose kernel (cmtts_transpose)."""
+    x = x.contiguous()
+    B, R, Cn = x.shape
+    out = torch.empty(B, Cn, R, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().cmtts_transpose(_ptr(x), _ptr(out), B, R, Cn, _stream()))
+    return out
+
+
+class CMTotalTTSSynthesize:
+    """synthesize.py:35-153.  The reference reloads the checkpoint for every batch (:203-206); here
+    the model object is built once and handed in."""
+
+    def __init__(self, model: CMTotalTTS, T=1, generator=None):
+        self.model = model
+        self.diffusion = KarrasDenoiser(sigma_data=model.config.sigma_data, sigma_max=model.config.sigma_max,
+                                        sigma_min=model.config.sigma_min, rho=model.config.rho)
+        self.duration_pitch_energy_net, self.denoise_net = model.get_segmentation_model()
+        self.T = int(T)
+        self.generator = generator
+
+    def synthesize(self, batch):
+        """batch = (ids, raw_texts, speakers, texts, src_lens, max_src_len, spker_embeds) after to_device."""
+        kw = {"speakers": batch[2], "texts": batch[3], "src_lens": batch[4], "spker_embeds": batch[-1]}
+        out_dict = self.duration_pitch_energy_net(**kw)
+        B, T, _ = out_dict["cond"].shape
+        cfg = self.model.config
+        if self.T == 1:
+            n_steps, draws = 1, 1
+        elif self.T in (2, 4):
+            n_steps, draws = self.T, self.T + 1
+        else:
+            raise ValueError("T must be 1, 2 or 4 (synthesize.py:111-147)")
+        gen = self.generator or DummyGenerator()
+        x0 = gen.randn(B, 1, T, cfg.n_mels, device=self.model.device)
+        noise = torch.stack([x0] + [gen.randn_like(x0) for _ in range(draws - 1)], 0).float()
+        sample = sample_with_cond(self.model, out_dict["cond_ct"], out_dict["speaker_emb"], n_steps, noise)
+        out_put = [None] * 12
+        out_put[0] = sample
+        out_put[10] = kw["src_lens"]
+        out_put[11] = out_dict["mel_lens"]
+        return out_put

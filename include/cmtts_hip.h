@@ -1,0 +1,145 @@
+/* cmtts_hip.h — C ABI of the MI355X-native CM-TTS inference hot path (libcmtts_hip.so).
+ *
+ * The reference (XiangLi2022/CM-TTS) is pure Python/PyTorch and has no FFI; the path sits behind
+ * Python callables.  Each entry point below replaces one of those callables and
+ * cites it (paths relative to the reference root).  Conventions:
+ *   - plain pointers and sizes only, no torch types; every tensor pointer is a DEVICE pointer unless
+ *     the parameter is documented as host;
+ *   - caller-allocated outputs, caller-provided workspaces (size queries below), no hidden
+ *     allocation and no host synchronisation on the hot path;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - return 0 on success, negative on error (CMTTS_E_*), message via cmtts_last_error();
+ *   - integer tensors are int64 (torch.long) like the reference's; activations fp32;
+ *   - frame-level activations cross the boundary channel-major ("_ct": [B, C, T], T contiguous) —
+ *     the layout the reference itself transposes to before Conv1d (tts_net.py:31-32);
+ *     cmtts_transpose() converts to/from the reference's [B, T, C].
+ */
+#ifndef CMTTS_HIP_H
+#define CMTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMTTS_OK 0
+#define CMTTS_E_INVALID (-1)      /* bad argument / missing tensor */
+#define CMTTS_E_UNSUPPORTED (-2)  /* shape outside what the kernels support */
+#define CMTTS_E_HIP (-3)          /* HIP runtime error */
+#define CMTTS_E_WORKSPACE (-4)    /* workspace too small */
+
+typedef struct cmtts_model cmtts_model;      /* CMTotalTTS weights, packed for the kernels */
+typedef struct cmtts_vocoder cmtts_vocoder;  /* hifigan.Generator weights */
+
+/* Hyper-parameters: config/<dataset>/{model,preprocess,train}.yaml of the reference. */
+typedef struct cmtts_config {
+    int32_t n_symbols, hidden, enc_layers, enc_heads, ffn_kernel;
+    int32_t pred_filter, pred_layers, pred_kernel, dur_layers, dur_kernel, cwt_hidden;
+    int32_t pitch_bins, energy_bins, use_uv, multi_speaker, external_speaker_dim;
+    int32_t n_mels, res_layers, res_channels;
+    float cwt_std_scale, pitch_norm_eps;
+    float sigma_min, sigma_max, sigma_data, rho;
+} cmtts_config;
+
+const char* cmtts_last_error(void);
+const char* cmtts_version(void);
+
+/* ---- weight import: replaces torch.load + load_state_dict (synthesize.py:79-83).
+ * cmtts_set_tensor takes one entry of CMTotalTTS.state_dict() under its original key and in its
+ * original layout (HOST pointer); cmtts_finalize re-packs (k-major / transposed / gate-permuted)
+ * and uploads.  Unknown keys (e.g. *_float_tensor buffers) are ignored. */
+int cmtts_create(const cmtts_config* cfg, cmtts_model** out);
+int cmtts_set_tensor(cmtts_model* m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int cmtts_finalize(cmtts_model* m);
+void cmtts_destroy(cmtts_model* m);
+
+/* ---- DurationPitchSpeakerNet.forward, phoneme-level half (model/cmtts.py:44-122 up to the
+ * duration rounding, model/modules.py:331-372): text encoder, speaker projection, duration and
+ * energy predictors, durations, cumulative sums.  The phoneme-level state needed by
+ * cmtts_frame_forward stays in `text_ws`.  Optional outputs may be NULL.
+ *   texts int64 [B,L] (0 = pad), src_lens int64 [B], spker_embeds fp32 [B,external_speaker_dim]
+ *   (multi-speaker only, else NULL).
+ *   out: log_d fp32 [B,L], d_rounded fp32 [B,L], mel_len int64 [B], e_pred fp32 [B,L],
+ *        e_idx int64 [B,L], enc_out_ct fp32 [B,hidden,L], speaker_emb fp32 [B,hidden]. */
+size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L);
+int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
+                       int B, int L, float d_control,
+                       float* log_d, float* d_rounded, int64_t* mel_len, float* e_pred, int64_t* e_idx,
+                       float* enc_out_ct, float* speaker_emb,
+                       void* text_ws, size_t text_ws_bytes, void* stream);
+
+/* ---- frame-level half (model/modules.py:373-412; LengthRegulator :415-448; dur_to_mel2ph
+ * utils/tools.py:768-798; get_pitch_embedding cwt branch :259-317).  T = padded frame count chosen
+ * by the host (max(mel_len) like the reference, or a static bucket).
+ *   out: cond_ct fp32 [B,hidden,T], mel2ph int64 [B,T], cwt_out fp32 [B,T,10|11] (opt),
+ *        f0_denorm fp32 [B,T] (opt), p_idx int64 [B,T] (opt), f0_stats fp32 [B,2] (opt). */
+size_t cmtts_frame_workspace_bytes(const cmtts_model* m, int B, int T);
+int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T,
+                        float* cond_ct, int64_t* mel2ph, float* cwt_out, float* f0_denorm, int64_t* p_idx,
+                        float* f0_stats, void* frame_ws, size_t frame_ws_bytes, void* stream);
+
+/* ---- length regulator alone (LengthRegulator.forward, model/modules.py:446-448): bit-exact
+ * gather x_ct [B,C,L] -> out_ct [B,C,T] given fp32 durations [B,L]; also emits mel2ph and mel_len.
+ * scratch_cum: int32 [B,L]. */
+int cmtts_length_regulate(const float* x_ct, const float* durations, int B, int C, int L, int T,
+                          float* out_ct, int64_t* mel2ph, int64_t* mel_len, int32_t* scratch_cum, void* stream);
+
+/* ---- CMDenoiserTTS.forward(x, timesteps, conditioner, speaker_emb, mask) (tts_net.py:29-37;
+ * Denoiser.forward model/modules.py:600-639).  x fp32 [B,1,T,80] (already scaled by c_in),
+ * timesteps fp32 [B] (= 250 ln sigma), cond_ct fp32 [B,hidden,T], speaker_emb [B,hidden] or NULL,
+ * out fp32 [B,1,T,80].  `mask` is ignored by the reference and is not a parameter. */
+size_t cmtts_denoiser_workspace_bytes(const cmtts_model* m, int B, int T);
+int cmtts_denoiser_forward(cmtts_model* m, const float* x, const float* timesteps, const float* cond_ct,
+                           const float* speaker_emb, int B, int T, float* out,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ---- karras_sample_tts (karras_diffusion.py:480-577) with sampler onestep (:801-811) for
+ * n_steps = 1 and stochastic_iterative_sampler (:830-854) as synthesize.py:111-147 calls it for
+ * n_steps = 2, 4; KarrasDenoiser.denoise (:392-407) with boundary-condition scalings fused.
+ * The noise is an input (random_util.py:17-25 draws it with th.randn on the reference device):
+ *   noise fp32 [n_noise,B,1,T,80] N(0,1): noise[0] -> x_T, noise[1+i] -> re-noise after eval i
+ *   (n_noise = 1 for n_steps = 1, else n_steps + 1).
+ *   sigmas, renoise_std: HOST fp32 [n_steps] (cmtts_schedule fills them).
+ *   out mel fp32 [B,T,80]. */
+int cmtts_schedule(const cmtts_model* m, int n_steps, float* sigmas_host, float* renoise_std_host);
+int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb,
+                 int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
+                 float* mel, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- hifigan.Generator (hifigan/models.py:112-174) + get_vocoder weight handling
+ * (utils/model.py:155-184; weights with weight-norm already folded). */
+int cmtts_vocoder_create(cmtts_vocoder** out);
+int cmtts_vocoder_set_tensor(cmtts_vocoder* v, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int cmtts_vocoder_finalize(cmtts_vocoder* v);
+void cmtts_vocoder_destroy(cmtts_vocoder* v);
+size_t cmtts_vocoder_workspace_bytes(const cmtts_vocoder* v, int B, int T);
+/* Generator.forward: mel_ct fp32 [B,80,T] -> wav fp32 [B,1,256*T] */
+int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, float* wav,
+                          void* ws, size_t ws_bytes, void* stream);
+/* vocoder_infer's cast (utils/model.py:195-198): pcm = (wav * max_wav_value).astype(int16) */
+int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_value, void* stream);
+
+/* ---- measurement hook (no reference counterpart; the reference's only perf tooling is the
+ * wall-clock Timer of p_rtf_cm.py:64-108): HIP events recorded on the launch stream around every
+ * launch of the dominant kernel (gated k=3 Conv1D of the denoiser residual block) between
+ * begin and end.  end() synchronises on the events and returns the summed duration. */
+int cmtts_profile_begin(int max_launches);
+int cmtts_profile_end(double* total_ms, int* n_launches);
+
+/* ---- layout helper: in [B,R,C] -> out [B,C,R] */
+int cmtts_transpose(const float* in, float* out, int B, int R, int C, void* stream);
+
+/* ---- generic Conv1d on the MFMA kernel, exposed for kernel-level parity tests and roofline
+ * measurement: y[B,Cout,T] = act(conv1d(x[B,Cin,T], w, bias, padding, dilation)).
+ * `packed_w` comes from cmtts_pack_conv_weight (HOST in [Cout,Cin,K] -> DEVICE packed). */
+int cmtts_pack_conv_weight(const float* host_w, int Cout, int Cin, int K, float** dev_packed, int* ld);
+void cmtts_free_device(void* p);
+int cmtts_conv1d(const float* x, const float* packed_w, int ld, const float* bias, int B, int Cin, int Cout,
+                 int T, int K, int dilation, int padding, int act, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMTTS_HIP_H */

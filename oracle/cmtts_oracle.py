@@ -25,6 +25,21 @@ F32 = np.float32
 
 # ----------------------------------------------------------------------------- primitives
 
+_TAP_CACHE = {}
+
+
+def _taps(w):
+    """[Cout,Cin,K] -> contiguous [K,Cout,Cin] (BLAS-friendly per-tap matrices), cached per array."""
+    key = (id(w), w.shape)
+    hit = _TAP_CACHE.get(key)
+    if hit is None or hit[0] is not w:
+        if len(_TAP_CACHE) > 512:
+            _TAP_CACHE.clear()
+        hit = (w, np.ascontiguousarray(np.asarray(w, F32).transpose(2, 0, 1)))
+        _TAP_CACHE[key] = hit
+    return hit[1]
+
+
 def conv1d(x, w, b=None, padding=0, dilation=1):
     """torch.nn.functional.conv1d, stride 1.  x [B,Cin,T], w [Cout,Cin,K] -> [B,Cout,T']."""
     x = np.asarray(x, F32)
@@ -34,8 +49,9 @@ def conv1d(x, w, b=None, padding=0, dilation=1):
     xp[:, :, padding:padding + T] = x
     To = T + 2 * padding - dilation * (K - 1)
     y = np.zeros((B, Cout, To), F32)
+    wt = _taps(w)
     for k in range(K):
-        y += np.matmul(w[:, :, k], xp[:, :, k * dilation:k * dilation + To])
+        y += np.matmul(wt[k], np.ascontiguousarray(xp[:, :, k * dilation:k * dilation + To]))
     if b is not None:
         y += b[None, :, None]
     return y
@@ -47,8 +63,9 @@ def conv_transpose1d(x, w, b, stride, padding):
     B, Cin, T = x.shape
     _, Cout, K = w.shape
     full = np.zeros((B, Cout, (T - 1) * stride + K), F32)
+    wt = _taps(w)                                    # [K, Cin, Cout]
     for k in range(K):
-        full[:, :, k:k + (T - 1) * stride + 1:stride] += np.matmul(w[:, :, k].T, x)
+        full[:, :, k:k + (T - 1) * stride + 1:stride] += np.matmul(np.ascontiguousarray(wt[k].T), x)
     y = full[:, :, padding:full.shape[2] - padding]
     return y + b[None, :, None]
 
@@ -408,7 +425,8 @@ def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise):
         if std[i] is None:
             x = x0
         else:
-            x = (x0 + noise[1 + i] * F32(std[i])).astype(F32)   # python-float scalar, as in the reference
+            # randn_like(x) * np.sqrt(next_t**2 - t_min**2) * 0.85: two fp32 multiplies (karras_diffusion.py:852)
+            x = (x0 + (noise[1 + i] * F32(std[i] / 0.85)).astype(F32) * F32(0.85)).astype(F32)
     return x[:, 0]
 
 

@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: libcmtts_hip.so loads, exports every symbol
+include/cmtts_hip.h declares, and the ctypes table binds exactly that set (no compute calls)."""
+import ctypes
+import os
+import re
+
+import cmtts_amd
+from cmtts_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cmtts_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmtts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cmtts_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_loader_binds_and_reports_errors():
+    lib = _lib.load()
+    assert b"gfx950" in lib.cmtts_version()
+    # invalid-argument paths never touch the GPU
+    assert lib.cmtts_create(None, None) == -1
+    assert b"null" in lib.cmtts_last_error()
+    assert lib.cmtts_profile_begin(0) == -1
+
+
+def test_config_struct_matches_header():
+    text = open(os.path.join(ROOT, "include", "cmtts_hip.h")).read()
+    body = re.search(r"typedef struct cmtts_config \{(.*?)\} cmtts_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, rest = decl.split(None, 1)
+        fields += [(n.strip(), typ) for n in rest.split(",")]
+    got = [(n, "int32_t" if t is ctypes.c_int32 else "float") for n, t in _lib.CMTTSConfigStruct._fields_]
+    assert got == fields
+    # every config field exists on the Python dataclass
+    cfg = cmtts_amd.get_config("VCTK")
+    for n, _ in fields:
+        assert hasattr(cfg, n), n

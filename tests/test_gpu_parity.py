@@ -1,0 +1,337 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against
+(a) the committed golden vectors captured from the reference and (b) the numpy oracle on the same
+seeded inputs.  Tolerances: bit-exact for integer/index work; |delta mel| < 1e-3 (north-star fp32
+bound) for floating point, tighter where the stage is short."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cmtts_amd
+from cmtts_amd import _lib
+from cmtts_amd.config import get_config, HifiGanConfig
+from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
+from oracle import cmtts_oracle as O
+from conftest import golden_noise, pitch_margin_mask
+
+pytestmark = pytest.mark.gpu
+VARIANTS = ["LJSpeech", "VCTK", "LibriTTS"]
+DEV = "cuda:0"
+
+
+def _host():
+    from cmtts_amd import host
+    return host
+
+
+@pytest.fixture(scope="module")
+def models(golden):
+    host = _host()
+    cache = {}
+
+    def get(variant):
+        if variant not in cache:
+            g = golden("cmtts_" + variant)
+            cfg = get_config(variant)
+            sd = synth_cmtts_state_dict(cfg, seed=int(g["seed"]), dur_frames=4.0, dur_spread=0.03)
+            cache[variant] = (g, cfg, sd, host.CMTotalTTS(cfg, DEV).load_state_dict(sd))
+        return cache[variant]
+    return get
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- kernel level
+
+@pytest.mark.parametrize("Cin,Cout,K,dil,T,B", [
+    (256, 512, 3, 1, 300, 2),      # denoiser k3 (128x128 tile)
+    (80, 256, 1, 1, 97, 3),        # input projection, ragged T, Cin not a multiple of 16? (80 = 5 chunks)
+    (256, 80, 1, 1, 130, 2),       # output projection (64x256 tile, Cout not a multiple of 32)
+    (64, 64, 11, 5, 700, 1),       # HiFi-GAN k11 d5 halo 50
+    (32, 32, 7, 3, 1000, 2),       # 32x256 tile
+    (256, 1024, 9, 1, 85, 2),      # FFN k9
+    (128, 11, 5, 1, 40, 2),        # tiny Cout
+    (20, 36, 3, 1, 1, 1),          # degenerate T = 1, odd channel counts
+])
+def test_conv1d_kernel(Cin, Cout, K, dil, T, B):
+    lib = _lib.load()
+    rs = np.random.RandomState(Cin * 7 + Cout + K)
+    x = rs.standard_normal(size=(B, Cin, T)).astype(np.float32)
+    w = (rs.standard_normal(size=(Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    w += (np.arange(Cout)[:, None, None] * 1e-3).astype(np.float32)          # asymmetric: catches transposes
+    b = rs.standard_normal(size=(Cout,)).astype(np.float32)
+    pad = (K - 1) * dil // 2
+    ref = O.conv1d(x, w, b, padding=pad, dilation=dil)
+    xd, bd = torch.from_numpy(x).to(DEV), torch.from_numpy(b).to(DEV)
+    packed, ld = C.c_void_p(), C.c_int()
+    _lib.check(lib.cmtts_pack_conv_weight(w.ctypes.data_as(C.c_void_p), Cout, Cin, K, C.byref(packed), C.byref(ld)))
+    y = torch.full((B, Cout, ref.shape[2]), float("nan"), device=DEV)
+    _lib.check(lib.cmtts_conv1d(xd.data_ptr(), packed, ld.value, bd.data_ptr(), B, Cin, Cout, T, K, dil, pad, 0,
+                                y.data_ptr(), None))
+    torch.cuda.synchronize()
+    lib.cmtts_free_device(packed)
+    np.testing.assert_allclose(_np(y), ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("B,L,C,maxd,T", [(3, 20, 256, 9, None), (4, 7, 32, 3, 10), (256, 171, 256, 12, 1024)])
+def test_length_regulator_bit_exact(B, L, C, maxd, T):
+    """LengthRegulator + dur_to_mel2ph: pure index work -> bit-exact, incl. zero durations, ragged
+    lengths, truncation to T and (last case) the full cfg4 size."""
+    lib = _lib.load()
+    rs = np.random.RandomState(B + L)
+    x = rs.standard_normal(size=(B, L, C)).astype(np.float32)
+    dur = rs.randint(0, maxd + 1, size=(B, L)).astype(np.float32)
+    lens = rs.randint(1, L + 1, size=(B,))
+    pad = np.arange(L)[None, :] >= lens[:, None]
+    dur[pad] = 0
+    ref, ref_len = O.length_regulate(x, dur, T)
+    Tn = ref.shape[1]
+    ref_m2p = O.dur_to_mel2ph(dur, pad, Tn)
+    xd = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(DEV)
+    dd = torch.from_numpy(dur).to(DEV)
+    out = torch.empty(B, C, Tn, device=DEV)
+    m2p = torch.empty(B, Tn, dtype=torch.int64, device=DEV)
+    mlen = torch.empty(B, dtype=torch.int64, device=DEV)
+    cum = torch.empty(B, L, dtype=torch.int32, device=DEV)
+    _lib.check(lib.cmtts_length_regulate(xd.data_ptr(), dd.data_ptr(), B, C, L, Tn, out.data_ptr(), m2p.data_ptr(),
+                                         mlen.data_ptr(), cum.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(mlen), ref_len)
+    assert np.array_equal(_np(m2p), ref_m2p)
+    assert np.array_equal(_np(out).transpose(0, 2, 1), ref)            # bit-exact copy
+    # size-independent property: counting frames per phoneme recovers the (truncated) durations
+    m = _np(m2p)
+    cnt = np.stack([np.bincount(m[b], minlength=L + 1)[1:] for b in range(B)])
+    full = dur.astype(np.int64)
+    assert np.array_equal(cnt.sum(1), np.minimum(full.sum(1), Tn))
+    untrunc = full.sum(1) <= Tn
+    assert np.array_equal(cnt[untrunc], full[untrunc])
+
+
+# ----------------------------------------------------------------------------- stage level vs golden
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_duration_pitch_speaker_net_golden(models, variant):
+    g, cfg, sd, model = models(variant)
+    spk = torch.from_numpy(g["spker_embeds"]) if cfg.multi_speaker else None
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]),
+                                          spker_embeds=spk)
+    torch.cuda.synchronize()
+    L = g["texts"].shape[1]
+    valid = np.arange(L)[None, :] < g["src_lens"][:, None]
+    np.testing.assert_allclose(_np(out["enc_out"]), g["enc_out"], atol=5e-5)
+    np.testing.assert_allclose(_np(out["log_d_predictions"]), g["log_d"], atol=5e-5)
+    np.testing.assert_allclose(_np(out["e_predictions"]), g["e_pred"], atol=1e-4)
+    # integer / index stages: bit-exact
+    assert np.array_equal(_np(out["d_rounded"]), g["d_rounded"])
+    assert np.array_equal(_np(out["mel_lens"]), g["mel_len"])
+    assert np.array_equal(_np(out["mel2ph"]), g["mel2ph"])
+    assert np.array_equal(_np(out["e_idx"])[valid], g["e_idx"][valid])
+    assert np.array_equal(_np(out["mel_masks"]), g["mel_mask"])
+    if cfg.multi_speaker:
+        np.testing.assert_allclose(_np(out["speaker_emb"]), g["speaker_emb"], atol=2e-5)
+    pp = out["p_predictions"]
+    np.testing.assert_allclose(_np(pp["cwt"]), g["cwt_out"], atol=2e-4)
+    np.testing.assert_allclose(_np(pp["f0_mean"]), g["f0_mean"], atol=2e-5)
+    np.testing.assert_allclose(_np(pp["f0_std"]), g["f0_std"], atol=2e-5)
+    np.testing.assert_allclose(_np(pp["f0_denorm"]), g["f0_denorm"], rtol=5e-4, atol=1e-2)
+    ok = pitch_margin_mask(g["f0_denorm"])
+    p_idx = _np(pp["p_idx"])
+    assert np.array_equal(p_idx[ok], g["p_idx"][ok])
+    same = p_idx == g["p_idx"]
+    assert same.mean() > 0.98
+    np.testing.assert_allclose(_np(out["cond"])[same], g["cond"][same], atol=5e-5)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_denoiser_forward_golden(models, variant):
+    """CMDenoiserTTS.forward on the reference's own conditioning."""
+    g, cfg, sd, model = models(variant)
+    spk = torch.from_numpy(g["speaker_emb"]).to(DEV) if cfg.multi_speaker else None
+    out = model.net(torch.from_numpy(g["den_x"]), torch.from_numpy(g["den_t"]), torch.from_numpy(g["cond"]), spk, None)
+    torch.cuda.synchronize()
+    assert out.shape == g["den_out"].shape
+    err = np.abs(_np(out) - g["den_out"]).max()
+    assert err < 1e-3, err
+    assert err < 3e-4, f"suspiciously large fp32 drift {err}"
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n_steps", [1, 2, 4])
+def test_sampler_golden(models, variant, n_steps):
+    """cmtts_sample (hoisted encoder, fused preconditioning) == reference karras_sample_tts."""
+    host = _host()
+    g, cfg, sd, model = models(variant)
+    B, T, _ = g["cond"].shape
+    noise = np.stack(golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5))
+    cond_ct = torch.from_numpy(np.ascontiguousarray(g["cond"].transpose(0, 2, 1))).to(DEV)
+    spk = torch.from_numpy(g["speaker_emb"]).to(DEV) if cfg.multi_speaker else None
+    mel = host.sample_with_cond(model, cond_ct, spk, n_steps, torch.from_numpy(noise).to(DEV))
+    torch.cuda.synchronize()
+    err = np.abs(_np(mel) - g[f"mel_T{n_steps}"]).max()
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
+def test_karras_sample_tts_end_to_end(models, variant):
+    """The reference-shaped call: phoneme ids in, mel out (synthesize.py:111-147), T = 4."""
+    host = _host()
+    g, cfg, sd, model = models(variant)
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        def __init__(self):
+            self.i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[self.i]).to(DEV)
+            self.i += 1
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    kw = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]),
+              spker_embeds=torch.from_numpy(g["spker_embeds"]) if cfg.multi_speaker else None)
+    diffusion = host.KarrasDenoiser()
+    mel = host.karras_sample_tts(diffusion, model, (B, 1, T, cfg.n_mels), steps=2, model_kwargs=kw, device=DEV,
+                                 sampler="multistep", ts=(0, 0, 0, 0, 1), generator=Gen())
+    torch.cuda.synchronize()
+    ref = g["mel_T4"]
+    # frames whose pitch bucket sits on a rounding boundary may take the neighbouring embedding row;
+    # the denoiser's receptive field (+-20 frames) spreads that, so compare where all buckets agree
+    out = model.duration_pitch_energy_net(None, kw["texts"], kw["src_lens"], spker_embeds=kw["spker_embeds"])
+    same = _np(out["p_predictions"]["p_idx"]) == g["p_idx"]
+    err = np.abs(_np(mel) - ref)
+    if same.all():
+        assert err.max() < 1e-3, err.max()
+    else:
+        bad = ~same
+        near = np.zeros_like(bad)
+        for b, t in zip(*np.nonzero(bad)):
+            near[b, max(0, t - 24): t + 25] = True
+        assert err[~near].max() < 1e-3, err[~near].max()
+
+
+def test_hifigan_golden(golden):
+    host = _host()
+    g = golden("hifigan")
+    hcfg = HifiGanConfig()
+    hsd = synth_hifigan_state_dict(hcfg, seed=int(g["seed"]))
+    voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
+    mel_ct = torch.from_numpy(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)))
+    wav = voc(mel_ct)
+    torch.cuda.synchronize()
+    assert tuple(wav.shape) == tuple(g["wav"].shape)
+    err = np.abs(_np(wav) - g["wav"]).max()
+    assert err < 1e-4, err
+    pcm = host.vocoder_infer(mel_ct, voc, lengths=g["mel_lens"] * 256)
+    for i, name in enumerate(["pcm0", "pcm1"]):
+        assert pcm[i].dtype == np.int16 and pcm[i].shape == g[name].shape
+        assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
+
+
+def test_wav_to_int16_wraps_like_numpy():
+    lib = _lib.load()
+    w = np.float32([1.0, -1.0, 0.99999, -0.00002, 0.5, -0.5])
+    wd = torch.from_numpy(w).to(DEV)
+    pcm = torch.empty(w.shape, dtype=torch.int16, device=DEV)
+    _lib.check(lib.cmtts_wav_to_int16(wd.data_ptr(), pcm.data_ptr(), w.size, 32768.0, None))
+    torch.cuda.synchronize()
+    assert _np(pcm).tolist() == O.wav_to_int16(w).tolist() == [-32768, -32768, 32767, 0, 16384, -16384]
+
+
+# ----------------------------------------------------------------------------- vs oracle, larger/other shapes
+
+def test_full_path_vs_oracle_random_batch():
+    """B=4 ragged phoneme lengths, fresh seed, T = 2: HIP path vs numpy oracle end to end
+    (integer stages bit-exact wherever the oracle's own decision margin is comfortable)."""
+    host = _host()
+    cfg = get_config("VCTK")
+    sd = synth_cmtts_state_dict(cfg, seed=11, dur_frames=5.0, dur_spread=0.02)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(5)
+    B, L = 4, 33
+    lens = np.asarray([33, 21, 30, 5], np.int64)
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)
+    st = O.duration_pitch_speaker_net(sd, cfg, texts, lens, spk)
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens),
+                                          spker_embeds=torch.from_numpy(spk))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(_np(out["log_d_predictions"]), st["log_d"], atol=5e-5)
+    pre = np.exp(st["log_d"].astype(np.float64)) - 1
+    valid = np.arange(L)[None, :] < lens[:, None]
+    safe = (np.abs(pre - np.floor(pre) - 0.5) > 1e-3) | ~valid
+    assert np.array_equal(_np(out["d_rounded"])[safe], st["d_rounded"][safe])
+    if safe.all():
+        assert np.array_equal(_np(out["mel_lens"]), st["mel_len"])
+        assert np.array_equal(_np(out["mel2ph"]), st["mel2ph"])
+    T = st["cond"].shape[1]
+    noise = np.stack([rs.standard_normal(size=(B, 1, T, cfg.n_mels)).astype(np.float32) for _ in range(3)])
+    cond_ct = torch.from_numpy(np.ascontiguousarray(st["cond"].transpose(0, 2, 1))).to(DEV)
+    mel = host.sample_with_cond(model, cond_ct, torch.from_numpy(st["speaker_emb"]).to(DEV), 2,
+                                torch.from_numpy(noise).to(DEV))
+    torch.cuda.synchronize()
+    ref = O.karras_sample_tts(sd, cfg, st["cond"], st["speaker_emb"], 2, list(noise))
+    assert np.abs(_np(mel) - ref).max() < 1e-3
+
+
+def test_denoiser_full_size_properties():
+    """cfg2 size (B=32, T=512): no cross-utterance arithmetic exists on the path, so every
+    utterance's output must be bit-identical to running it alone; outputs finite; and a sub-batch
+    spot check against the oracle."""
+    host = _host()
+    cfg = get_config("LJSpeech")
+    sd = synth_cmtts_state_dict(cfg, seed=2)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    B, T = 32, 512
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
+    t = torch.full((B,), 1095.5)
+    full = model.net(x, t, cond, None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all()
+    for b in (0, 17, 31):
+        one = model.net(x[b:b + 1], t[b:b + 1], cond[b:b + 1], None)
+        assert torch.equal(one[0], full[b]), f"utterance {b} depends on its batch"
+    ref = O.denoiser_forward(sd, cfg, x[:2].numpy(), t[:2].numpy(), cond[:2].numpy(), None)
+    assert np.abs(_np(full[:2]) - ref).max() < 1e-3
+
+
+def test_hifigan_vs_oracle_other_shape():
+    host = _host()
+    hcfg = HifiGanConfig()
+    hsd = synth_hifigan_state_dict(hcfg, seed=3)
+    voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
+    rs = np.random.RandomState(9)
+    mel = (rs.standard_normal(size=(3, 80, 33)) * 1.5 - 4.0).astype(np.float32)
+    wav = voc(torch.from_numpy(mel))
+    torch.cuda.synchronize()
+    ref = O.hifigan_generator(hsd, hcfg, mel)
+    assert np.abs(_np(wav) - ref).max() < 1e-4
+    # batch independence at a second size
+    one = voc(torch.from_numpy(mel[1:2]))
+    assert torch.equal(one[0], wav[1])
+
+
+def test_errors_are_loud():
+    host = _host()
+    cfg = get_config("VCTK")
+    model = host.CMTotalTTS(cfg, DEV)
+    with pytest.raises(RuntimeError):
+        model.net(torch.zeros(1, 1, 8, 80), torch.ones(1), torch.zeros(1, 8, 256), torch.zeros(1, 256))
+    sd = synth_cmtts_state_dict(cfg, seed=1)
+    bad = dict(sd)
+    del bad["net.skip_projection.conv.weight"]
+    with pytest.raises(RuntimeError, match="missing tensor"):
+        host.CMTotalTTS(cfg, DEV).load_state_dict(bad)
+    model.load_state_dict(sd)
+    with pytest.raises(AssertionError):      # model/cmtts.py:80
+        model.duration_pitch_energy_net(None, torch.ones(1, 4, dtype=torch.long), torch.tensor([4]))
