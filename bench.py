@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — mel-frames/s of the CM-TTS inference hot path on MI355X.
+
+One "step" = one pass of the whole text->mel hot path over one synthetic batch per GPU:
+FFT-block encoder -> variance adaptor / length regulator -> T=4 consistency sampling
+(BASELINE.json configs[1]: LJSpeech model, batch 32, 80x512 mels, T=4, fp32), inputs and noise
+already resident in HBM.  N>1: one process per GPU (launched by torch.distributed.run), every rank
+runs its own batch (weak scaling, utterances shard with no data-path collective) and the step ends
+with the single RCCL all-gather that collates the mels.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) carrying, besides the
+headline value, `roofline` (dominant kernel: gated k=3 Conv1D of the denoiser block, timed live with
+HIP events on its launch stream) and `cpu_baseline` (the numpy oracle timed on the host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import cmtts_amd  # noqa: E402
+from cmtts_amd import _lib, host, shard  # noqa: E402
+from cmtts_amd.config import get_config, HifiGanConfig  # noqa: E402
+from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict  # noqa: E402
+
+BATCH, PHONEMES, FRAMES_PAD, DUR = 32, 85, 512, 6      # 85 phonemes x 6 frames = 510 valid of 512 padded
+N_STEPS = 4
+FP32_MFMA_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(cfg, seed, device):
+    rs = np.random.RandomState(seed)
+    texts = torch.from_numpy(rs.randint(1, cfg.n_symbols, size=(BATCH, PHONEMES)).astype(np.int64)).to(device)
+    lens = torch.full((BATCH,), PHONEMES, dtype=torch.int64, device=device)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + seed)
+    noise = torch.randn(N_STEPS + 1, BATCH, 1, FRAMES_PAD, cfg.n_mels, generator=gen).to(device)
+    return texts, lens, noise
+
+
+def timed(fn, steps, warmup, world, before=None):
+    for _ in range(warmup):
+        fn()
+    if before is not None:
+        torch.cuda.synchronize()
+        before()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(cfg, sd):
+    """The numpy oracle (oracle/cmtts_oracle.py, pinned to the reference's golden vectors) timed on
+    this box's host cores on a bounded sample of the same workload."""
+    from oracle import cmtts_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rs = np.random.RandomState(0)
+    B = 8
+    texts = rs.randint(1, cfg.n_symbols, size=(B, PHONEMES)).astype(np.int64)
+    lens = np.full((B,), PHONEMES, np.int64)
+    noise = [rs.standard_normal(size=(B, 1, FRAMES_PAD, cfg.n_mels)).astype(np.float32) for _ in range(N_STEPS + 1)]
+    O.synthesize(sd, cfg, texts[:1, :8], np.asarray([8]), None, 1,
+                 [rs.standard_normal(size=(1, 1, 48, cfg.n_mels)).astype(np.float32)])      # warm BLAS threads
+    t0 = time.perf_counter()
+    mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, N_STEPS, noise, max_mel_len=FRAMES_PAD)
+    dt = time.perf_counter() - t0
+    return {"value": round(float(mel_len.sum()) / dt, 1), "unit": "mel-frames/s", "cores": int(threads),
+            "kind": "port",
+            "sample": f"numpy/OpenBLAS oracle, text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
+                      f"T={N_STEPS}, one pass = {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    cfg = get_config("LJSpeech")
+    sd = synth_cmtts_state_dict(cfg, seed=0, dur_frames=float(DUR), dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, device).load_state_dict(sd)
+    texts, lens, noise = make_inputs(cfg, rank, device)
+    lib = _lib.load()
+    state = {}
+
+    def step(n_steps=N_STEPS):
+        out = model.duration_pitch_energy_net(None, texts, lens, max_mel_len=FRAMES_PAD)
+        mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, noise)
+        if world > 1:
+            mel, mlen = shard.allgather_mels(mel, out["mel_lens"])
+        state["mel"], state["mel_len"] = mel, out["mel_lens"]
+
+    step()
+    torch.cuda.synchronize()
+    mel_len = state["mel_len"].cpu().numpy()
+    assert (mel_len == PHONEMES * DUR).all(), mel_len
+    frames_rank = int(mel_len.sum())
+    assert torch.isfinite(state["mel"]).all()
+
+    # ---- headline: timed region with HIP events around the dominant kernel
+    dt = timed(step, args.steps, args.warmup, world,
+               before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers)))
+    tot_ms, n_l = C.c_double(), C.c_int()
+    _lib.check(lib.cmtts_profile_end(C.byref(tot_ms), C.byref(n_l)))
+    frames_total = frames_rank * world * args.steps
+    value = frames_total / dt
+    ms_per_step = dt / args.steps * 1e3
+    audio_s = frames_rank * world * cfg.hop_length / cfg.sampling_rate
+    flops_launch = 2.0 * (2 * cfg.res_channels) * (3 * cfg.res_channels) * BATCH * FRAMES_PAD
+    avg_ms = tot_ms.value / max(n_l.value, 1)
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if n_l.value else 0.0
+    result = {
+        "metric": "mel-frames/s (text->mel hot path, consistency sampling T=4)",
+        "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: LJSpeech model, batch 32/GPU, 80x512 mels "
+                               f"({PHONEMES} phonemes x {DUR} frames = {PHONEMES * DUR} valid), T=4, fp32",
+                   "batch_per_gpu": BATCH, "frames_padded": FRAMES_PAD, "sampler_steps": N_STEPS,
+                   "parallelism": f"dp{world} (utterance shards + one all-gather)"},
+        "rtf_mel_only": round((dt / args.steps) / audio_s, 6),
+        "frames_per_s_per_gpu": round(value / world, 1),
+        "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)",
+                     "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
+                     "flops_per_launch": flops_launch},
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        for n in (1, 2):
+            k = max(4, args.steps // 2)
+            d = timed(lambda: step(n), k, 2, 1)
+            extras[f"frames_per_s_T{n}"] = round(frames_rank * k / d, 1)
+            extras[f"rtf_mel_only_T{n}"] = round((d / k) / audio_s, 6)
+        # end to end with the HiFi-GAN generator (fp32), T=4
+        hcfg = HifiGanConfig()
+        voc = host.Generator(hcfg, device).load_state_dict(synth_hifigan_state_dict(hcfg, seed=0))
+
+        def e2e():
+            step()
+            state["wav"] = voc(state["mel"].transpose(1, 2).contiguous())
+        k = 3
+        d = timed(e2e, k, 1, 1)
+        assert torch.isfinite(state["wav"]).all()
+        extras["frames_per_s_end_to_end_wav_T4"] = round(frames_rank * k / d, 1)
+        extras["rtf_end_to_end_T4"] = round((d / k) / audio_s, 6)
+        result["extras"] = extras
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Multi-GPU sharding of the inference path (new work: the reference's inference is single-process,
+synthesize.py:32,43 — SURVEY.md §2a, §8e).
+
+Independent units = utterances: no cross-utterance arithmetic exists anywhere on the path, so a
+batch shards across ranks with no data-path collective; the only exchange is ONE all-gather that
+collates the padded mel block (and, packed into the same buffer, each utterance's mel_len).
+One process per GPU over ``torch.distributed`` — backend "nccl" is RCCL over xGMI on ROCm; "gloo"
+for the CPU tests.
+
+Because outputs depend on the padded (L_max, T_max) of the sub-batch (batch-padding
+dependence is part of the semantics), shards pad to agreed static buckets rather than their local
+maximum.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+FRAME_BUCKETS = (256, 512, 768, 1024)
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of the items this rank owns; sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def deal_by_length(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Length-sorted round-robin deal: every rank gets a similar mix of long and short utterances,
+    so padded work is balanced.  Returns per-rank index lists (original positions)."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    return [order[r::world] for r in range(world)]
+
+
+def frame_bucket(n_frames: int, buckets: Sequence[int] = FRAME_BUCKETS) -> int:
+    for b in buckets:
+        if n_frames <= b:
+            return int(b)
+    raise ValueError(f"{n_frames} frames exceed the largest bucket {buckets[-1]}")
+
+
+def pack_mels(mel: torch.Tensor, mel_len: torch.Tensor) -> torch.Tensor:
+    """[Bl,T,M] fp32 + int64 [Bl] -> one fp32 buffer [Bl, T*M + 1] (mel_len < 2**24 is exact in fp32)."""
+    Bl = mel.shape[0]
+    buf = torch.empty(Bl, mel.shape[1] * mel.shape[2] + 1, dtype=torch.float32, device=mel.device)
+    buf[:, :-1] = mel.reshape(Bl, -1)
+    buf[:, -1] = mel_len.to(torch.float32)
+    return buf
+
+
+def unpack_mels(buf: torch.Tensor, T: int, M: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    return buf[:, :-1].reshape(buf.shape[0], T, M), buf[:, -1].round().to(torch.int64)
+
+
+def allgather_mels(mel: torch.Tensor, mel_len: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The path's single collective: every rank contributes [Bl,T,M] (same Bl, T on all ranks) and
+    receives [world*Bl, T, M] plus the gathered mel_len, in rank order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mel, mel_len
+    world = dist.get_world_size(group)
+    Bl, T, M = mel.shape
+    buf = pack_mels(mel, mel_len)
+    out = torch.empty(world * Bl, buf.shape[1], dtype=buf.dtype, device=buf.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.chunk(world, 0))
+        dist.all_gather(parts, buf, group=group)
+    else:
+        dist.all_gather_into_tensor(out, buf, group=group)
+    return unpack_mels(out, T, M)

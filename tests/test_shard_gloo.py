@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo run of the one collective on the inference path
+(cmtts_amd.shard.allgather_mels) plus the host-side shard arithmetic."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cmtts_amd
+from cmtts_amd import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Bl, T, M = 3, 16, 80
+    g = torch.Generator().manual_seed(100 + rank)
+    mel = torch.randn(Bl, T, M, generator=g)
+    mel_len = torch.tensor([T - rank, 5 + rank, 9], dtype=torch.int64)
+    all_mel, all_len = shard.allgather_mels(mel, mel_len)
+    q.put((rank, all_mel.numpy(), all_len.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_mels_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect_mel, expect_len = [], []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        expect_mel.append(torch.randn(3, 16, 80, generator=g).numpy())
+        expect_len.append(np.asarray([16 - r, 5 + r, 9]))
+    expect_mel, expect_len = np.concatenate(expect_mel), np.concatenate(expect_len)
+    for _, m, l in res:                       # every rank holds the full, rank-ordered collation
+        assert np.array_equal(m, expect_mel)  # bit-exact: a gather moves bytes
+        assert np.array_equal(l, expect_len)
+
+
+def test_shard_arithmetic():
+    for n, w in [(256, 8), (10, 4), (3, 8), (128, 1)]:
+        spans = [shard.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    lens = [900, 100, 500, 510, 20, 1000, 30, 700]
+    deal = shard.deal_by_length(lens, 4)
+    assert sorted(i for d in deal for i in d) == list(range(8))
+    assert all(len(d) == 2 for d in deal)
+    assert [shard.frame_bucket(t) for t in (1, 256, 257, 1024)] == [256, 256, 512, 1024]
+    mel = torch.arange(2 * 4 * 80, dtype=torch.float32).reshape(2, 4, 80)
+    m2, l2 = shard.unpack_mels(shard.pack_mels(mel, torch.tensor([4, 3])), 4, 80)
+    assert torch.equal(m2, mel) and l2.tolist() == [4, 3]
