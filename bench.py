@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="three-launch residual block (A/B)")
+    ap.add_argument("--stagger", type=str, default="", help="mode,sleeps for cmtts_set_stagger (tuning)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +123,11 @@ def main():
     model = host.CMTotalTTS(cfg, device).load_state_dict(sd)
     texts, lens, noise = make_inputs(cfg, rank, device)
     lib = _lib.load()
+    if args.unfused:
+        lib.cmtts_set_fused_resblock(0)
+    if args.stagger:
+        mode, sleeps = (int(v) for v in args.stagger.split(","))
+        lib.cmtts_set_stagger(mode, sleeps)
     state = {}
 
     def step(n_steps=N_STEPS):
@@ -146,7 +153,20 @@ def main():
     value = frames_total / dt
     ms_per_step = dt / args.steps * 1e3
     audio_s = frames_rank * world * cfg.hop_length / cfg.sampling_rate
-    flops_launch = 2.0 * (2 * cfg.res_channels) * (3 * cfg.res_channels) * BATCH * FRAMES_PAD
+    C_ = cfg.res_channels
+    if args.unfused:   # the timed kernel is the gated k=3 conv alone
+        kname = "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)"
+        flops_launch = 2.0 * (2 * C_) * (3 * C_) * BATCH * FRAMES_PAD
+    else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
+        kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
+        flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD
+    traffic = None
+    try:   # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 pass of this workload
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["resblock_fused_kernel"]
+        if not args.unfused and pmc["B"] == BATCH and pmc["T"] == FRAMES_PAD:
+            traffic = pmc["bytes_per_launch"]
+    except Exception:
+        pass
     avg_ms = tot_ms.value / max(n_l.value, 1)
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if n_l.value else 0.0
     result = {
@@ -160,9 +180,11 @@ def main():
                    "parallelism": f"dp{world} (utterance shards + one all-gather)"},
         "rtf_mel_only": round((dt / args.steps) / audio_s, 6),
         "frames_per_s_per_gpu": round(value / world, 1),
-        "roofline": {"bound": "mfma", "kernel": "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)",
+        "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE (profiles/r01_run2_fused_resblock.md); "
+                                     "algorithmic 83.9 MB -> HBM fraction %.3f" % ((traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                      "flops_per_launch": flops_launch},
     }

@@ -48,6 +48,9 @@ SIGNATURES = {
     "cmtts_vocoder_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_wav_to_int16": (_i, [_vp, _vp, _i64, _f, _vp]),
     "cmtts_profile_begin": (_i, [_i]),
+    "cmtts_set_fused_resblock": (_i, [_i]),
+    "cmtts_set_stagger": (_i, [_i, _i]),
+    "cmtts_set_debug_stamps": (_i, [_vp]),
     "cmtts_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cmtts_pack_conv_weight": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i)]),

@@ -5,6 +5,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -14,6 +15,7 @@
 #include "../../include/cmtts_hip.h"
 #include "conv_args.h"
 #include "kernels.h"
+#include "resblock_args.h"
 
 namespace {
 
@@ -168,6 +170,8 @@ struct Profile {
     size_t used = 0;
 } g_prof;
 
+bool g_fused_resblock = true;
+
 struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     PackedConv qk, wo, ffn1, ffn2;
@@ -199,6 +203,7 @@ struct cmtts_model {
     float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
     float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
     PackedConv in_proj, skip_proj, out_proj;
+    PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
 };
@@ -373,6 +378,21 @@ int finalize_model(cmtts_model* m) {
                 for (int k = 0; k < H; ++k) sproj[(size_t)k * NL * C + l * C + n] = ws->data[(size_t)n * H + k];
         }
     }
+    {   // stacked conditioner projections (one GEMM for all layers; cond does not depend on the step)
+        HostTensor W, Bv;
+        W.shape = {(int64_t)NL * C, H, 1};
+        W.data.resize((size_t)NL * C * H);
+        Bv.shape = {(int64_t)NL * C};
+        Bv.data.resize((size_t)NL * C);
+        for (int l = 0; l < NL; ++l) {
+            const std::string p = "net.residual_layers." + std::to_string(l) + ".";
+            const HostTensor& wc = m->host.at(p + "conditioner_projection.conv.weight");
+            const HostTensor& bc = m->host.at(p + "conditioner_projection.conv.bias");
+            std::copy(wc.data.begin(), wc.data.end(), W.data.begin() + (size_t)l * C * H);
+            std::copy(bc.data.begin(), bc.data.end(), Bv.data.begin() + (size_t)l * C);
+        }
+        CHK(pack_conv(al, W, &Bv, nullptr, &m->cond_all));
+    }
     CHK(al.upload(dproj, &m->dproj_wt));
     if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
     {
@@ -448,7 +468,7 @@ FrameWs carve_frame(const cmtts_config& c, int B, int T, void* base) {
 }
 
 struct DenWs {
-    float *hin, *h, *u, *zb, *skip, *emb, *e1, *e2, *dproj, *sproj, *dp, *tbuf, *xcur;
+    float *hin, *h, *u, *zb, *skip, *emb, *e1, *e2, *dproj, *sproj, *dp, *tbuf, *xcur, *cp;
     size_t bytes;
 };
 DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
@@ -469,6 +489,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
     w.dp = cv.take<float>((size_t)B * NL * C);
     w.tbuf = cv.take<float>((size_t)B);
     w.xcur = cv.take<float>((size_t)B * T * c.n_mels);
+    w.cp = cv.take<float>((size_t)NL * n);       // conditioner projections of all layers [B][NL*C][T]
     w.bytes = cv.off + 256;
     return w;
 }
@@ -492,6 +513,13 @@ int predictor_convs(const Predictor& P, const float* in, int ld_in, int B, int T
 }
 
 // Denoiser.forward (model/modules.py:600-639) on x_src [B][T][80] scaled by in_scale -> F in w.hin [B][80][T]
+// cp[b][l*C + m][t] = conditioner_projection_l(cond)[m][t] + bias: one stacked GEMM, reused by every step
+int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B, int T, hipStream_t s) {
+    const cmtts_config& c = m->cfg;
+    ConvArgs a = conv_args(m->cond_all, cond_ct, T, T, (long)c.hidden * T, w.cp, T, (long)c.res_layers * c.res_channels * T, T);
+    return launch(a, EPI_PLAIN, B, s);
+}
+
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
                   const float* cond_ct, const float* spk, int B, int T, hipStream_t s) {
     const cmtts_config& c = m->cfg;
@@ -514,25 +542,42 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, w.sproj, w.dp, B, C, NL * C, DENSE_NONE, s);
         dp = w.dp;
     }
+    const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
+    float* hcur = w.h;
+    float* halt = w.u;
     for (int l = 0; l < NL; ++l) {
         const ResLayer& R = m->res[l];
+        const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        if (!unfused) {   // ResidualBlock.forward (model/blocks.py:667-686) as one kernel, x ping-pongs
+            ResArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.x_in = hcur; ra.cp = w.cp + (long)l * C * T; ra.cp_bstride = (long)NL * C * T;
+            ra.dp = dp + (long)l * C; ra.d = w.dproj + (long)l * C;
+            ra.x_out = halt; ra.skip = w.skip;
+            ra.W3 = R.conv3.w; ra.b3 = R.conv3.bias; ra.Wo = R.outp.w; ra.bo = R.outp.bias;
+            ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0;
+            if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+            if (cmtts_launch_resblock(&ra, (void*)s) != 0) return fail(CMTTS_E_HIP, "fused residual block launch failed");
+            if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
+            float* t = hcur; hcur = halt; halt = t;
+            continue;
+        }
         {   // u = (x + d [+ p]) + conditioner_projection(cond)      (model/blocks.py:669-677)
-            ConvArgs a = conv_args(R.cond, cond_ct, T, T, (long)c.hidden * T, w.u, T, cs, T);
+            ConvArgs a = conv_args(R.cond, cond_ct, T, T, (long)c.hidden * T, halt, T, cs, T);
             a.out[0].bvec = dp + (long)l * C; a.out[0].bvec_zs = (long)NL * C;
-            a.out[0].res = w.h; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
+            a.out[0].res = hcur; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
             CHK(launch(a, EPI_PLAIN, B, s));
         }
         {   // z = sigmoid(gate) * tanh(filter) of the k=3 conv        (:675-679)
-            ConvArgs a = conv_args(R.conv3, w.u, T, T, cs, w.zb, T, cs, T);
-            const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            ConvArgs a = conv_args(R.conv3, halt, T, T, cs, w.zb, T, cs, T);
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
             CHK(launch(a, EPI_GATED, B, s));
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
         }
         {   // o = output_projection(z); x' = (o[:C] + (x + d)) / sqrt(2); skip += o[C:]   (:681-686)
-            ConvArgs a = conv_args(R.outp, w.zb, T, T, cs, w.h, T, cs, T);
+            ConvArgs a = conv_args(R.outp, w.zb, T, T, cs, hcur, T, cs, T);
             a.split = C;
-            a.out[0].res = w.h; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
+            a.out[0].res = hcur; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
             a.out[0].bvec = w.dproj + (long)l * C; a.out[0].bvec_zs = (long)NL * C;
             a.out[0].div = (float)sqrt(2.0);
             a.out[1].Y = w.skip; a.out[1].row_off = C; a.out[1].accum = l > 0;
@@ -540,11 +585,11 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         }
     }
     {   // sum(skips)/sqrt(NL) -> skip_projection -> relu -> output_projection   (model/modules.py:634-637)
-        ConvArgs a = conv_args(m->skip_proj, w.skip, T, T, cs, w.u, T, cs, T);
+        ConvArgs a = conv_args(m->skip_proj, w.skip, T, T, cs, halt, T, cs, T);
         a.pre_div = (float)sqrt((double)NL);
         a.out[0].act = ACT_RELU;
         CHK(launch(a, EPI_PLAIN, B, s));
-        ConvArgs b = conv_args(m->out_proj, w.u, T, T, cs, w.hin, T, (long)M * T, T);
+        ConvArgs b = conv_args(m->out_proj, halt, T, T, cs, w.hin, T, (long)M * T, T);
         CHK(launch(b, EPI_PLAIN, B, s));
     }
     return 0;
@@ -747,6 +792,7 @@ int cmtts_denoiser_forward(cmtts_model* m, const float* x, const float* timestep
     DenWs w = carve_den(m->cfg, B, T, ws);
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, s));
     CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, s));
     k_mel_post(w.hin, nullptr, nullptr, 1.0f, 0.0f, 0.0f, out, B, T, m->cfg.n_mels, s);
     HIPCHK(hipGetLastError());
@@ -786,6 +832,7 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
     hipStream_t s = (hipStream_t)stream;
     const long nel = (long)B * T * c.n_mels;
     k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
+    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, s));   // once for all n_steps evaluations
     const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
     for (int i = 0; i < n_steps; ++i) {
         // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
@@ -920,6 +967,22 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     // x = leaky_relu(xs / 3) [slope 0.01] -> conv_post -> tanh (:161-163)
     k_conv_post(bufA, v->post_w, v->post_b, 3.0f, 0.01f, wav, B, ch, Ti, v->post_k, s);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int cmtts_set_fused_resblock(int on) {
+    const int prev = g_fused_resblock ? 1 : 0;
+    g_fused_resblock = on != 0;
+    return prev;
+}
+
+int cmtts_set_stagger(int mode, int sleeps) {
+    cmtts_resblock_set_stagger(mode, sleeps);
+    return 0;
+}
+
+int cmtts_set_debug_stamps(void* dev_buf) {
+    cmtts_resblock_set_debug((long long*)dev_buf);
     return 0;
 }
 

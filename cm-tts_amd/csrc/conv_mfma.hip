@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include "conv_args.h"
+#include "gate.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -36,30 +37,55 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-__device__ __forceinline__ void epi_store(const ConvOut& o, float acc, int m, int n, int zq, int zr) {
+// Epilogue of one 32x32 accumulator tile (16 registers per lane: rows m_base + acc_row(r), one
+// column n).  All optional operands (bias, per-batch vector, residual, old Y for accumulate) are
+// first gathered with UNCONDITIONAL loads from clamped in-bounds addresses — 16 loads in flight —
+// and only the final store is predicated; a load under a per-lane branch would be serialised with
+// a vmcnt(0) each.  Branches on the ConvOut pointers are wave-uniform (scalar).
+__device__ __forceinline__ void epi_tile(const ConvOut& o, const f32x16& acc, int m_base, int rbase, int n, int M, int N,
+                                         int zq, int zr) {
     const int t = n * o.ostride + o.ooff_base + zr * o.ooff_mul;
-    if (t < 0 || t >= o.Tout) return;
-    float v = acc;
-    if (o.bias) v += o.bias[m];
-    v *= o.alpha;
-    v = act_apply(v, o.act);
-    const long row = (long)(m - o.row_off);
-    if (o.res) {
-        float r = o.res[zq * o.r_zs0 + zr * o.r_zs1 + row * o.ldr + t];
-        if (o.bvec) r += o.bvec[zq * o.bvec_zs + m];
-        v += r;
-    } else if (o.bvec) {
-        v += o.bvec[zq * o.bvec_zs + m];
+    const bool ok_n = n < N && t >= 0 && t < o.Tout;
+    const int t_c = min(max(t, 0), o.Tout - 1);
+    // wave-uniform bases (SGPR pairs) + 32-bit unsigned per-lane offsets: one VGPR per address
+    float* __restrict__ yb = o.Y + (zq * o.y_zs0 + zr * o.y_zs1);
+    const float* __restrict__ rb = o.res ? o.res + (zq * o.r_zs0 + zr * o.r_zs1) : nullptr;
+    const float* __restrict__ vb = o.bvec ? o.bvec + zq * o.bvec_zs : nullptr;
+    const bool keep = !(o.lens && (int64_t)t >= o.lens[zq]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // two batches of 8 rows
+        float bi[8], rv[8], yv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            const int m_c = min(m_base + (r & 3) + 8 * (r >> 2) + rbase, M - 1);
+            const unsigned row = (unsigned)(m_c - o.row_off);
+            bi[q] = o.bias ? o.bias[(unsigned)m_c] : 0.f;
+            rv[q] = 0.f;
+            if (rb) rv[q] = rb[row * (unsigned)o.ldr + (unsigned)t_c];
+            if (vb) rv[q] += vb[(unsigned)m_c];
+            yv[q] = o.accum ? yb[row * (unsigned)o.ldy + (unsigned)t_c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = h * 8 + q;
+            const int m = m_base + (r & 3) + 8 * (r >> 2) + rbase;
+            float v = acc[r];
+            if (o.bias) v += bi[q];
+            v *= o.alpha;
+            v = act_apply(v, o.act);
+            if (rb || vb) v += rv[q];
+            if (o.div != 1.0f) v = v / o.div;
+            if (o.accum) v += yv[q];
+            if (!keep) v = 0.f;
+            if (ok_n && m < M) yb[(unsigned)(m - o.row_off) * (unsigned)o.ldy + (unsigned)t] = v;
+        }
+        asm volatile("" ::: "memory");
     }
-    if (o.div != 1.0f) v = v / o.div;
-    float* y = o.Y + zq * o.y_zs0 + zr * o.y_zs1 + row * o.ldy + t;
-    if (o.accum) v += *y;
-    if (o.lens && (int64_t)t >= o.lens[zq]) v = 0.f;
-    *y = v;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv1d_mfma_kernel(const ConvArgs a) {
     constexpr int MT = BM / (WM * 32);
     constexpr int NT = BN / (WN * 32);
     constexpr int XJ = BN / 64 + 1;                 // columns per lane of an X row (halo <= 64)
@@ -95,49 +121,55 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
     float4 wreg[WV];
     float xreg[4][XJ];
 
+    // Guarded loads are written as UNCONDITIONAL loads from a clamped (always in-bounds) address
+    // followed by a select: a load under a per-lane branch makes hipcc emit an exec-masked branch and
+    // a vmcnt(0) per element, which serialises the whole prefetch (cdna_hip_programming.md §5 trap c).
+    // The raw loaded values stay untouched in registers until store time (after the MFMAs): the
+    // zero-fill selects and the pre-activation are applied in store_*, so nothing waits on vmcnt
+    // between issuing the prefetch and the MFMA block.
     auto load_w = [&](int chunk, int tap) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int i = min(tid + v * 256, KC * WQ - 1);
+            const int row = i / WQ, c4 = i - row * WQ;
+            const int krow_c = min(chunk * KC + row, a.K - 1), m_c = min(m0 + c4 * 4, a.a_cols - 4);
+            wreg[v] = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow_c * a.a_ld + m_c);
+        }
+    };
+    auto store_w = [&](int buf, int chunk) {
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int i = tid + v * 256;
             const int row = i / WQ, c4 = i - row * WQ;
-            const int krow = chunk * KC + row;
-            const int m = m0 + c4 * 4;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < KC * WQ && krow < a.K && m < a.a_cols)
-                w = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow * a.a_ld + m);
-            wreg[v] = w;
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * 256;
-            if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + buf * KC * BM + i * 4) = wreg[v];
+            const bool ok = chunk * KC + row < a.K && m0 + c4 * 4 < a.a_cols;
+            float4 w = wreg[v];
+            if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + buf * KC * BM + i * 4) = w;
         }
     };
     auto load_x = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int krow = chunk * KC + wid + 4 * r;
-            const float* xrow = Xb + (long)krow * a.ldx;
+            const float* xrow = Xb + (long)min(krow, a.K - 1) * a.ldx;
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int t = tbase + lane + 64 * j;
+                xreg[r][j] = xrow[min(max(t, 0), a.Tin - 1)];
+            }
+        }
+    };
+    auto store_x = [&](int buf, int chunk) {
+        float* xs = Xs + buf * KC * XW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int krow = chunk * KC + wid + 4 * r;
 #pragma unroll
             for (int j = 0; j < XJ; ++j) {
                 const int col = lane + 64 * j;
                 const int t = tbase + col;
-                float v = 0.f;
-                if (col < XW && krow < a.K && t >= 0 && t < a.Tin) v = xrow[t];
-                xreg[r][j] = v;
-            }
-        }
-    };
-    auto store_x = [&](int buf) {
-        float* xs = Xs + buf * KC * XW;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-                const int col = lane + 64 * j;
-                float v = xreg[r][j];
+                const bool ok = krow < a.K && t >= 0 && t < a.Tin;
+                float v = ok ? xreg[r][j] : 0.f;
                 if (a.pre_div != 1.0f) v = v / a.pre_div;
                 v = v > 0.f ? v : v * a.pre_slope;
                 if (col < XW) xs[(wid + 4 * r) * XW + col] = v;
@@ -156,8 +188,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
     // prologue: stage iteration 0
     load_w(0, 0);
     load_x(0);
-    store_w(0);
-    store_x(0);
+    store_w(0, 0);
+    store_x(0, 0);
     __syncthreads();
 
     int chunk = 0, tap = 0;
@@ -175,23 +207,39 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
 
         const float* wsc = Ws + (it & 1) * KC * BM + a_off;
         const float* xsc = Xs + (chunk & 1) * KC * XW + b_off + (tap * a.dil - tap_min);
-#pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            const int kr = kk * 2 + khalf;
+        __builtin_amdgcn_sched_barrier(0);           // prefetch loads stay above the MFMA block
+        {
+            // operands of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued
+            const float* wk = wsc + khalf * BM;
+            const float* xk = xsc + khalf * XW;
             float av[MT], bv[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = wsc[kr * BM + i * 32];
+            for (int i = 0; i < MT; ++i) av[i] = wk[i * 32];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = xsc[kr * XW + j * 32];
+            for (int j = 0; j < NT; ++j) bv[j] = xk[j * 32];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                float nav[MT], nbv[NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) nav[i] = kk + 1 < KC / 2 ? wk[(kk + 1) * 2 * BM + i * 32] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) nbv[j] = kk + 1 < KC / 2 ? xk[(kk + 1) * 2 * XW + j * 32] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = nav[i];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = nbv[j];
+            }
         }
 
-        if (has_next) store_w((it + 1) & 1);
-        if (next_x) store_x(nchunk & 1);
+        if (has_next) store_w((it + 1) & 1, nchunk);
+        if (next_x) store_x(nchunk & 1, nchunk);
         __syncthreads();
         tap = ntap;
         chunk = nchunk;
@@ -216,7 +264,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
                 if (mf < a.M && n < a.N) {
                     const float g = acc[0][j][r] + o.bias[mg];
                     const float f = acc[1][j][r] + o.bias[mf];
-                    const float zv = (1.0f / (1.0f + expf(-g))) * tanhf(f);
+                    const float zv = cmtts_gate(g, f);
                     const int t = n;
                     if (t < o.Tout)
                         o.Y[zq * o.y_zs0 + zr * o.y_zs1 + (long)(zrow0 + row) * o.ldy + t] = zv;
@@ -226,17 +274,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
     } else {
         const ConvOut& o = (m0 >= a.split) ? a.out[1] : a.out[0];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + (wn * NT + j) * 32 + col;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (m < a.M && n < a.N) epi_store(o, acc[i][j][r], m, n, zq, zr);
-                }
-            }
-        }
+            for (int j = 0; j < NT; ++j)
+                epi_tile(o, acc[i][j], m0 + (wm * MT + i) * 32, rbase, n0 + (wn * NT + j) * 32 + col, a.M, a.N, zq, zr);
     }
 }
 

@@ -180,24 +180,54 @@ __global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const 
         if (o < O) out[((long)b * T + t) * O + o] = keep ? acc[o] + bias[o] : 0.f;
 }
 
-// ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n]
+// ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
+// Workgroup = 64 output columns x 4 K-slices (one wave per slice), DB batch rows per thread: Wt (up to
+// 5 MB for the stacked per-layer projections) is streamed once per DB rows, 8 independent loads in
+// flight per thread; in[b][k] is wave-uniform (scalar loads); the 4 partial sums meet in LDS.
+constexpr int DB = 8;
 __global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long in_bs, long in_ks, const float* Wt,
                                                           const float* bias, const float* add, float* out,
-                                                          int K, int N, int act) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (n >= N) return;
-    const float* ib = in + (long)b * in_bs;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(ib[(long)k * in_ks], Wt[(long)k * N + n], acc);
-    if (bias) acc += bias[n];
-    if (act == DENSE_RELU) acc = acc > 0.f ? acc : 0.f;
-    else if (act == DENSE_MISH) {
-        const float sp = acc > 20.f ? acc : log1pf(expf(acc));
-        acc = acc * tanhf(sp);
+                                                          int B, int K, int N, int act) {
+    __shared__ float part[3][DB][64];
+    const int nl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl;
+    const int nc = min(n, N - 1);
+    const int b0 = blockIdx.y * DB;
+    const int kq = (K + 3) / 4;
+    const int k0 = ks * kq, k1 = min(K, k0 + kq);
+    float acc[DB];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) acc[j] = 0.f;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
+        const float wv = Wt[(long)k * N + nc];
+#pragma unroll
+        for (int j = 0; j < DB; ++j) {
+            const int b = min(b0 + j, B - 1);
+            acc[j] = fmaf(in[(long)b * in_bs + (long)k * in_ks], wv, acc[j]);
+        }
     }
-    if (add) acc += add[(long)b * N + n];
-    out[(long)b * N + n] = acc;
+    if (ks > 0) {
+#pragma unroll
+        for (int j = 0; j < DB; ++j) part[ks - 1][j][nl] = acc[j];
+    }
+    __syncthreads();
+    if (ks == 0 && n < N) {
+#pragma unroll
+        for (int j = 0; j < DB; ++j) {
+            const int b = b0 + j;
+            if (b >= B) break;
+            float v = ((acc[j] + part[0][j][nl]) + part[1][j][nl]) + part[2][j][nl];
+            if (bias) v += bias[n];
+            if (act == DENSE_RELU) v = v > 0.f ? v : 0.f;
+            else if (act == DENSE_MISH) {
+                const float sp = v > 20.f ? v : log1pf(expf(v));
+                v = v * tanhf(sp);
+            }
+            if (add) v += add[(long)b * N + n];
+            out[(long)b * N + n] = v;
+        }
+    }
 }
 
 // ---- energy bucketize + embedding add (model/modules.py:319-329,358-363); torch.bucketize
@@ -457,8 +487,8 @@ void k_chan_linear(const float* x, const float* W, const float* bias, float* out
 }
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias, const float* add,
                    float* out, int B, int K, int N, int act, hipStream_t s) {
-    hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias, add,
-                       out, K, N, act);
+    hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias,
+                       add, out, B, K, N, act);
 }
 void k_energy_embed(const float* x, const float* e_pred, const float* bins, int nbins, const float* E, float* out1,
                     int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s) {

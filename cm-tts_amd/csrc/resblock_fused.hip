@@ -1,0 +1,329 @@
+// Fused denoiser residual block for gfx950 — ResidualBlock.forward (model/blocks.py:667-686) of the
+// CM-TTS consistency denoiser as ONE kernel per layer:
+//
+//   u  = (x + d [+ p]) + cp            cp = conditioner_projection(cond) + bias, precomputed for all 20
+//                                      layers by ONE stacked GEMM (it does not depend on the step)
+//   y  = W3 (*) u + b3 ; z = sigmoid(y[:C]) * tanh(y[C:])      conv_layer k=3 pad 1 + gate   (phase B)
+//   o  = Wo * z + bo ; x' = (o[:C] + (x + d)) / sqrt(2) ; skip (+)= o[C:]                    (phase C)
+//
+// One workgroup (4 wave64) owns 32 frames of one utterance; u (with its +-1 frame Conv1D halo) and z
+// never leave LDS (z re-uses u's buffer): per layer HBM sees x, cp in and x', skip in/out only.
+// Both contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) in the same (8-channel chunk, tap, k)
+// order as an fmaf chain over k — identical to conv_mfma.hip's order, so the result is BITWISE equal
+// to the three-launch form (tests/test_gpu_parity.py::test_fused_resblock_bitwise).
+//
+// Occupancy is the design point: 68 KB of LDS and <= 128 VGPRs per wave let TWO workgroups share a CU
+// (2 waves per SIMD), so one workgroup's staging / gate (exp, tanh) / epilogue VALU work runs under
+// the other's MFMAs — with one workgroup per CU the matrix pipe idled 49 % of the time (measured,
+// profiles/r01_pmc_fused_v1.md).  Wave w owns output rows [w*128, +128) (4 accumulator tiles) over
+// all 32 frames and streams ITS weight slice global -> registers -> a private 8 KB LDS ring (double
+// buffered, prefetch issued before the MFMAs of the current iteration, operands of k-step k+1 read
+// before the MFMAs of k-step k), so the main loops contain no workgroup barrier: three s_barriers per
+// workgroup in total (u staged, u dead, z complete).
+#include <hip/hip_runtime.h>
+#include "gate.h"
+#include "resblock_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs
+
+namespace {
+
+constexpr int C = 256;          // residual channels (= encoder hidden)
+constexpr int FN = 32;          // frames per workgroup
+constexpr int U_LD = 36;        // LDS row stride of u / z (34 columns used by u)
+constexpr int KC = 8;           // channels per K chunk
+constexpr int PRIV = 2 * KC * 128;   // floats of private LDS per wave (8 KB): [2][KC][128]
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* u_lds = smem;                         // [C][U_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* pw = smem + C * U_LD + w * PRIV;      // wave-private weight ring [2][KC][128]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FN;
+    const int T = a.T;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* xin = a.x_in + (long)b * C * T;
+    const float* cp = a.cp + (long)b * a.cp_bstride;
+    const float* dp = a.dp + (long)b * a.vec_stride;
+    const float* dv = a.d + (long)b * a.vec_stride;
+
+    const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
+    auto stamp = [&](int slot) {
+        if (a.dbg && tid == 0) a.dbg[(long)bid_dbg * 8 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    stamp(0);
+    if (a.stagger_mode) {   // de-phase the two workgroups that share a CU (they are dispatched together)
+        const int bid = blockIdx.x + gridDim.x * blockIdx.y;
+        bool late;
+        if (a.stagger_mode == 3) {
+            // per-CU arrival parity: the hardware ids are read for SPEED only (placement is undefined by
+            // contract); any value gives correct results, a wrong guess merely forgoes the overlap
+            __shared__ int late_sh;
+            if (tid == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+                const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
+                const unsigned cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                const unsigned idx = ((xcc & 7) * 8 + se) * 32 + sh * 16 + cu;
+                late_sh = atomicAdd(a.cu_arrivals + (idx & 2047), 1u) & 1;
+            }
+            __syncthreads();
+            late = late_sh != 0;
+        } else {
+            late = a.stagger_mode == 1 ? bid >= (int)(gridDim.x * gridDim.y) / 2 : (bid & 1);
+        }
+        if (late)
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    // ---- stage u[m][j] = cp + (x + dp) for frames t0-1+j, j in [0,34); zero outside [0,T) (conv padding).
+    // Unconditional clamped loads, selects at LDS-store time.
+    {
+        const int t = t0 + l31;
+        const int t_c = min(t, T - 1);
+#pragma unroll 4
+        for (int i = 0; i < 32; i += 4) {
+            float xv[4], cv[4], dq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 8 * (i + q) + 2 * w + khalf;
+                xv[q] = xin[(unsigned)(m * T + t_c)];
+                cv[q] = cp[(unsigned)(m * T + t_c)];
+                dq[q] = dp[m];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 8 * (i + q) + 2 * w + khalf;
+                const float uv = cv[q] + (xv[q] + dq[q]);
+                u_lds[m * U_LD + 1 + l31] = t < T ? uv : 0.f;
+            }
+        }
+        const int m = tid;                       // halo columns: thread = row
+        const int tl = t0 - 1, tr = t0 + FN;
+        const int tlc = max(tl, 0), trc = min(tr, T - 1);
+        const float dpm = dp[m];
+        const float ul = cp[(unsigned)(m * T + tlc)] + (xin[(unsigned)(m * T + tlc)] + dpm);
+        const float ur = cp[(unsigned)(m * T + trc)] + (xin[(unsigned)(m * T + trc)] + dpm);
+        u_lds[m * U_LD] = tl >= 0 ? ul : 0.f;
+        u_lds[m * U_LD + FN + 1] = tr < T ? ur : 0.f;
+    }
+    __syncthreads();   // (1) u staged
+    stamp(1);
+
+    f32x16 acc[4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    const int wrow = lane >> 5, wcol = (lane & 31) * 4;
+    auto store_w = [&](int buf, const f32x4 (&wr)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(pw + buf * (KC * 128) + (2 * i + wrow) * 128 + wcol) = wr[i];
+    };
+    // KC/2 = 4 k-steps of 4 MFMAs; the A/B operands of k-step kk+1 are read before the MFMAs of kk
+    auto mma_chunk = [&](int buf, const float* bsrc) {
+        const float* ws = pw + buf * (KC * 128) + l31 + khalf * 128;
+        const float* bs = bsrc + khalf * U_LD;
+        float av[4], bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = ws[i * 32];
+        bv = bs[0];
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            float nav[4] = {0.f, 0.f, 0.f, 0.f}, nbv = 0.f;
+            if (kk + 1 < KC / 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nav[i] = ws[(kk + 1) * 256 + i * 32];
+                nbv = bs[(kk + 1) * 2 * U_LD];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = nav[i];
+            bv = nbv;
+        }
+    };
+
+    // One iteration = 4 ds_write (next tile -> LDS) + 4 global loads (tile +3 -> registers) + 20 ds_read
+    // + 16 MFMA.  A lone wave cannot issue the bookkeeping for free unless it sits BETWEEN MFMAs (each
+    // MFMA occupies the pipe for 64 cycles = ~12 issue slots), so the whole iteration is one
+    // scheduling region with an explicit interleave: the first operands, then per MFMA one DS read
+    // (two on every 4th) and one store / load.
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define SG_MFMA_W(nr) SG(0x008, 1); SG(0x100, nr); SG(0x200, 1);      /* MFMA + operand reads + 1 DS write  */
+#define SG_MFMA_L(nr) SG(0x008, 1); SG(0x100, nr); SG(0x020, 1);      /* MFMA + operand reads + 1 VMEM load */
+#define SG_MFMA_R(nr) SG(0x008, 1); SG(0x100, nr);                    /* MFMA + operand reads               */
+#define INTERLEAVE()                                                                      \
+    SG(0x100, 5);                                                                         \
+    SG_MFMA_W(2) SG_MFMA_W(1) SG_MFMA_W(1) SG_MFMA_W(1)                                   \
+    SG_MFMA_L(2) SG_MFMA_L(1) SG_MFMA_L(1) SG_MFMA_L(1)                                   \
+    SG_MFMA_R(2) SG_MFMA_R(1) SG_MFMA_R(1) SG_MFMA_R(1)                                   \
+    SG(0x008, 4);
+
+    // =============================================================== phase B: gated k=3 conv
+    {
+        zero_acc();
+        f32x4 wr[4];
+        const long tap_stride = (long)C * 2 * C;
+        // iteration order (16-channel chunk, tap, 8-channel half) == conv_mfma.hip's (chunk, tap, k) order.
+        // Two register sets: the tile consumed at iteration i+3 is requested at iteration i and written
+        // to LDS at iteration i+2 — two MFMA blocks (>= 2048 cycles) cover the L2 latency.
+        constexpr int NIT = (C / KC) * 3;
+        auto load_it = [&](f32x4 (&r)[4], int it) {
+            it = min(it, NIT - 1);
+            const int q = it / 6, rr = it - q * 6;
+            const int tap = rr >> 1, c8 = 2 * q + (rr & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                r[i] = *reinterpret_cast<const f32x4*>(a.W3 + tap * tap_stride + (long)(c8 * KC + 2 * i + wrow) * (2 * C) +
+                                                       w * 128 + wcol);
+        };
+        auto bsrc_it = [&](int it) {
+            const int q = it / 6, rr = it - q * 6;
+            return u_lds + ((2 * q + (rr & 1)) * KC) * U_LD + l31 + (rr >> 1);
+        };
+        f32x4 wb[4];
+        load_it(wr, 0);
+        store_w(0, wr);
+        load_it(wr, 1);
+        load_it(wb, 2);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < NIT; it += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(1, wr);                        // tile it+1
+            load_it(wr, it + 3);
+            mma_chunk(0, bsrc_it(it));
+            INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(0, wb);                        // tile it+2
+            load_it(wb, it + 4);
+            mma_chunk(1, bsrc_it(it + 1));
+            INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    stamp(2);
+    __syncthreads();   // (2) every wave is done reading u: its buffer becomes z
+    stamp(3);
+    {
+        // packed rows of this wave: [w*128, +128) = two 64-row groups [32 gate | 32 filter]
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float bg[16], bf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mg = w * 128 + g * 64 + acc_row(r, lane);
+                bg[r] = a.b3[mg];
+                bf[r] = a.b3[mg + 32];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float zv = cmtts_gate(acc[2 * g][r] + bg[r], acc[2 * g + 1][r] + bf[r]);
+                u_lds[(w * 64 + g * 32 + acc_row(r, lane)) * U_LD + l31] = zv;
+            }
+        }
+    }
+    __syncthreads();   // (3) z complete
+    stamp(4);
+
+    // =============================================================== phase C: output projection
+    {
+        zero_acc();
+        f32x4 wr[4];
+        constexpr int NIT = C / KC;
+        auto load_it = [&](f32x4 (&r)[4], int it) {
+            it = min(it, NIT - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                r[i] = *reinterpret_cast<const f32x4*>(a.Wo + (long)(it * KC + 2 * i + wrow) * (2 * C) + w * 128 + wcol);
+        };
+        f32x4 wb[4];
+        load_it(wr, 0);
+        store_w(0, wr);
+        load_it(wr, 1);
+        load_it(wb, 2);
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < NIT; it += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(1, wr);
+            load_it(wr, it + 3);
+            mma_chunk(0, u_lds + (it * KC) * U_LD + l31);
+            INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(0, wb);
+            load_it(wb, it + 4);
+            mma_chunk(1, u_lds + ((it + 1) * KC) * U_LD + l31);
+            INTERLEAVE()
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(5);
+        float* xout = a.x_out + (long)b * C * T;
+        float* skip = a.skip + (long)b * C * T;
+        const bool res_half = w < 2;              // wave-uniform: rows [0,256) -> x', rows [256,512) -> skip
+        const float* src = res_half ? xin : skip;
+        float* dst = res_half ? xout : skip;
+        const bool need_src = res_half || a.accum_skip;
+        const int t = t0 + l31;
+        const int t_c = min(t, T - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mrow0 = (w & 1) * 128 + i * 32;            // row inside the half
+            float sv[16], bo[16], dd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                       // all gathers first: 48 loads in flight
+                const int mr = mrow0 + acc_row(r, lane);
+                sv[r] = need_src ? src[(unsigned)(mr * T + t_c)] : 0.f;
+                bo[r] = a.bo[w * 128 + i * 32 + acc_row(r, lane)];
+                dd[r] = res_half ? dv[mr] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = mrow0 + acc_row(r, lane);
+                const float o = acc[i][r] + bo[r];
+                float v;
+                if (res_half) v = (o + (sv[r] + dd[r])) / 1.41421356237309504880f;
+                else v = a.accum_skip ? o + sv[r] : o;
+                if (t < T) dst[(unsigned)(mr * T + t)] = v;
+            }
+        }
+    }
+    stamp(6);
+}
+
+}  // namespace
+
+static int g_stagger_mode = 0, g_stagger_sleeps = 0;
+static long long* g_dbg = nullptr;
+static unsigned* g_cu_arrivals = nullptr;
+extern "C" void cmtts_resblock_set_debug(long long* dbg) { g_dbg = dbg; }
+extern "C" void cmtts_resblock_set_stagger(int mode, int sleeps) { g_stagger_mode = mode; g_stagger_sleeps = sleeps; }
+
+extern "C" int cmtts_launch_resblock(const ResArgs* a_in, void* stream) {
+    ResArgs a_copy = *a_in;
+    a_copy.stagger_mode = g_stagger_mode;
+    a_copy.stagger_sleeps = g_stagger_sleeps;
+    a_copy.dbg = g_dbg;
+    if (g_stagger_mode == 3 && !g_cu_arrivals) {
+        if (hipMalloc((void**)&g_cu_arrivals, 2048 * sizeof(unsigned)) != hipSuccess) return -3;
+        if (hipMemset(g_cu_arrivals, 0, 2048 * sizeof(unsigned)) != hipSuccess) return -3;
+    }
+    a_copy.cu_arrivals = g_cu_arrivals;
+    const ResArgs* a = &a_copy;
+    static bool attr_set = false;
+    const size_t lds = (size_t)(C * U_LD + 4 * PRIV) * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    if ((long)C * a->T >= (1L << 31)) return -2;
+    dim3 grid((a->T + FN - 1) / FN, a->B);
+    hipLaunchKernelGGL(resblock_fused_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

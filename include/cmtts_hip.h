@@ -126,6 +126,17 @@ int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_
  * launch of the dominant kernel (gated k=3 Conv1D of the denoiser residual block) between
  * begin and end.  end() synchronises on the events and returns the summed duration. */
 int cmtts_profile_begin(int max_launches);
+/* Selects the fused one-kernel-per-layer residual block (default, 1) or the three-launch form (0) of
+ * the denoiser; both are bitwise identical (tests) — the switch exists for A/B measurement.
+ * Returns the previous setting. */
+int cmtts_set_fused_resblock(int on);
+/* Tuning knob of the fused residual block: delay the start of half of the workgroups (mode 1: second
+ * half of the grid, 2: odd workgroups, 0: off) by `sleeps` x ~3.4 us so that the two workgroups sharing
+ * a CU run out of phase.  Affects speed only, never results. */
+int cmtts_set_stagger(int mode, int sleeps);
+/* Debug/tuning: when non-NULL, every workgroup of the fused residual block writes 8 int64 s_memtime
+ * stamps (phase boundaries) to dev_buf[workgroup*8 ...]; NULL switches it off. */
+int cmtts_set_debug_stamps(void* dev_buf);
 int cmtts_profile_end(double* total_ms, int* n_launches);
 
 /* ---- layout helper: in [B,R,C] -> out [B,C,R] */

@@ -305,6 +305,32 @@ def test_denoiser_full_size_properties():
     assert np.abs(_np(full[:2]) - ref).max() < 1e-3
 
 
+@pytest.mark.parametrize("variant,T", [("LJSpeech", 512), ("VCTK", 333), ("VCTK", 40)])
+def test_fused_resblock_bitwise(variant, T):
+    """The fused residual-block kernel keeps the (chunk, tap, k) accumulation order of the three-launch
+    form, so the whole denoiser must agree BITWISE between the two (ragged T exercises the tile edges)."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=4))
+    B = 3
+    gen = torch.Generator(device="cpu").manual_seed(T)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
+    spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
+    t = torch.full((B,), 1095.5)
+    prev = lib.cmtts_set_fused_resblock(1)
+    try:
+        fused = model.net(x, t, cond, spk)
+        lib.cmtts_set_fused_resblock(0)
+        unfused = model.net(x, t, cond, spk)
+    finally:
+        lib.cmtts_set_fused_resblock(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, unfused), float((fused - unfused).abs().max())
+
+
 def test_hifigan_vs_oracle_other_shape():
     host = _host()
     hcfg = HifiGanConfig()
