@@ -306,6 +306,9 @@ extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* 
     }
     if (a.M > 64) {
         if (a.split != INT_MAX && (a.split % 128)) return -2;
+        // small launches (text-side convs: N = phonemes) cannot fill 256 CUs with 128x128 tiles: use 64x64
+        const long big = (long)((a.N + 127) / 128) * ((a.M + 127) / 128) * nbatch;
+        if (big < 256 && a.split == INT_MAX) return launch_cfg<64, 64, 2, 2, EPI_PLAIN>(a, nbatch, stream);
         return launch_cfg<128, 128, 2, 2, EPI_PLAIN>(a, nbatch, stream);
     }
     if (a.split != INT_MAX) return -2;

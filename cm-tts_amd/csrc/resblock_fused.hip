@@ -6,20 +6,21 @@
 //   y  = W3 (*) u + b3 ; z = sigmoid(y[:C]) * tanh(y[C:])      conv_layer k=3 pad 1 + gate   (phase B)
 //   o  = Wo * z + bo ; x' = (o[:C] + (x + d)) / sqrt(2) ; skip (+)= o[C:]                    (phase C)
 //
-// One workgroup (4 wave64) owns 32 frames of one utterance; u (with its +-1 frame Conv1D halo) and z
+// One workgroup (8 wave64) owns 32 frames of one utterance; u (with its +-1 frame Conv1D halo) and z
 // never leave LDS (z re-uses u's buffer): per layer HBM sees x, cp in and x', skip in/out only.
 // Both contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) in the same (8-channel chunk, tap, k)
 // order as an fmaf chain over k — identical to conv_mfma.hip's order, so the result is BITWISE equal
 // to the three-launch form (tests/test_gpu_parity.py::test_fused_resblock_bitwise).
 //
-// Occupancy is the design point: 68 KB of LDS and <= 128 VGPRs per wave let TWO workgroups share a CU
-// (2 waves per SIMD), so one workgroup's staging / gate (exp, tanh) / epilogue VALU work runs under
-// the other's MFMAs — with one workgroup per CU the matrix pipe idled 49 % of the time (measured,
-// profiles/r01_pmc_fused_v1.md).  Wave w owns output rows [w*128, +128) (4 accumulator tiles) over
-// all 32 frames and streams ITS weight slice global -> registers -> a private 8 KB LDS ring (double
-// buffered, prefetch issued before the MFMAs of the current iteration, operands of k-step k+1 read
-// before the MFMAs of k-step k), so the main loops contain no workgroup barrier: three s_barriers per
-// workgroup in total (u staged, u dead, z complete).
+// Occupancy is the design point: 68 KB of LDS and <= 128 VGPRs per wave let TWO 8-wave workgroups share
+// a CU = 4 waves per SIMD.  A lone wave keeps the matrix pipe only ~65 % busy (its LDS stores, prefetch
+// loads and address arithmetic are not hidden), two reach ~90 %, and the staging / gate / epilogue
+// phases of one workgroup run under the MFMAs of the other; with one 4-wave workgroup per CU the pipe
+// idled 49 % of the time (measured, profiles/).  Wave w owns output rows [w*64, +64) (2 accumulator
+// tiles) over all 32 frames and streams ITS weight slice global -> registers -> a private 4 KB LDS
+// ring (double buffered; the tile consumed at iteration i+3 is requested at iteration i; operands of
+// k-step k+1 are read before the MFMAs of k-step k), so the main loops contain no workgroup barrier:
+// three s_barriers per workgroup in total (u staged, u dead, z complete).
 #include <hip/hip_runtime.h>
 #include "gate.h"
 #include "resblock_args.h"
@@ -33,15 +34,18 @@ constexpr int C = 256;          // residual channels (= encoder hidden)
 constexpr int FN = 32;          // frames per workgroup
 constexpr int U_LD = 36;        // LDS row stride of u / z (34 columns used by u)
 constexpr int KC = 8;           // channels per K chunk
-constexpr int PRIV = 2 * KC * 128;   // floats of private LDS per wave (8 KB): [2][KC][128]
+constexpr int NW = 8;           // waves per workgroup
+constexpr int WROWS = 512 / NW; // output rows per wave (64)
+constexpr int MTW = WROWS / 32; // accumulator tiles per wave (2)
+constexpr int PRIV = 2 * KC * WROWS;   // floats of private LDS per wave (4 KB): [2][KC][WROWS]
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a) {
+__global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* u_lds = smem;                         // [C][U_LD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* pw = smem + C * U_LD + w * PRIV;      // wave-private weight ring [2][KC][128]
+    float* pw = smem + C * U_LD + w * PRIV;      // wave-private weight ring [2][KC][WROWS]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * FN;
     const int T = a.T;
@@ -83,111 +87,97 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a)
     {
         const int t = t0 + l31;
         const int t_c = min(t, T - 1);
-#pragma unroll 4
-        for (int i = 0; i < 32; i += 4) {
+#pragma unroll 2
+        for (int i = 0; i < C / (2 * NW); i += 4) {
             float xv[4], cv[4], dq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int m = 8 * (i + q) + 2 * w + khalf;
+                const int m = 2 * NW * (i + q) + 2 * w + khalf;
                 xv[q] = xin[(unsigned)(m * T + t_c)];
                 cv[q] = cp[(unsigned)(m * T + t_c)];
                 dq[q] = dp[m];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int m = 8 * (i + q) + 2 * w + khalf;
+                const int m = 2 * NW * (i + q) + 2 * w + khalf;
                 const float uv = cv[q] + (xv[q] + dq[q]);
                 u_lds[m * U_LD + 1 + l31] = t < T ? uv : 0.f;
             }
         }
-        const int m = tid;                       // halo columns: thread = row
-        const int tl = t0 - 1, tr = t0 + FN;
-        const int tlc = max(tl, 0), trc = min(tr, T - 1);
-        const float dpm = dp[m];
-        const float ul = cp[(unsigned)(m * T + tlc)] + (xin[(unsigned)(m * T + tlc)] + dpm);
-        const float ur = cp[(unsigned)(m * T + trc)] + (xin[(unsigned)(m * T + trc)] + dpm);
-        u_lds[m * U_LD] = tl >= 0 ? ul : 0.f;
-        u_lds[m * U_LD + FN + 1] = tr < T ? ur : 0.f;
+        if (tid < 2 * C) {                       // halo columns: thread = (side, row)
+            const int m = tid & (C - 1);
+            const bool right = tid >= C;
+            const int th = right ? t0 + FN : t0 - 1;
+            const int thc = min(max(th, 0), T - 1);
+            const float uh = cp[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp[m]);
+            u_lds[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < T) ? uh : 0.f;
+        }
     }
     __syncthreads();   // (1) u staged
     stamp(1);
 
-    f32x16 acc[4];
+    f32x16 acc[MTW];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     };
-    const int wrow = lane >> 5, wcol = (lane & 31) * 4;
-    auto store_w = [&](int buf, const f32x4 (&wr)[4]) {
+    constexpr int WL = KC * WROWS / 256;         // f32x4 per lane per weight tile (2)
+    constexpr int LPR = WROWS / 4;               // lanes per tile row (16)
+    const int wrow = lane / LPR, wcol = (lane % LPR) * 4;
+    auto store_w = [&](int buf, const f32x4 (&wr)[WL]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(pw + buf * (KC * 128) + (2 * i + wrow) * 128 + wcol) = wr[i];
+        for (int i = 0; i < WL; ++i)
+            *reinterpret_cast<f32x4*>(pw + buf * (KC * WROWS) + ((64 / LPR) * i + wrow) * WROWS + wcol) = wr[i];
     };
     // KC/2 = 4 k-steps of 4 MFMAs; the A/B operands of k-step kk+1 are read before the MFMAs of kk
     auto mma_chunk = [&](int buf, const float* bsrc) {
-        const float* ws = pw + buf * (KC * 128) + l31 + khalf * 128;
+        const float* ws = pw + buf * (KC * WROWS) + l31 + khalf * WROWS;
         const float* bs = bsrc + khalf * U_LD;
-        float av[4], bv;
+        float av[MTW], bv;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = ws[i * 32];
+        for (int i = 0; i < MTW; ++i) av[i] = ws[i * 32];
         bv = bs[0];
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            float nav[4] = {0.f, 0.f, 0.f, 0.f}, nbv = 0.f;
-            if (kk + 1 < KC / 2) {
+            float nav[MTW], nbv = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nav[i] = ws[(kk + 1) * 256 + i * 32];
-                nbv = bs[(kk + 1) * 2 * U_LD];
-            }
+            for (int i = 0; i < MTW; ++i) nav[i] = kk + 1 < KC / 2 ? ws[(kk + 1) * 2 * WROWS + i * 32] : 0.f;
+            if (kk + 1 < KC / 2) nbv = bs[(kk + 1) * 2 * U_LD];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+            for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MTW + 1, 0);   // DS reads of the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);       // MFMAs of this step
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = nav[i];
+            for (int i = 0; i < MTW; ++i) av[i] = nav[i];
             bv = nbv;
         }
     };
 
-    // One iteration = 4 ds_write (next tile -> LDS) + 4 global loads (tile +3 -> registers) + 20 ds_read
-    // + 16 MFMA.  A lone wave cannot issue the bookkeeping for free unless it sits BETWEEN MFMAs (each
-    // MFMA occupies the pipe for 64 cycles = ~12 issue slots), so the whole iteration is one
-    // scheduling region with an explicit interleave: the first operands, then per MFMA one DS read
-    // (two on every 4th) and one store / load.
-#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#define SG_MFMA_W(nr) SG(0x008, 1); SG(0x100, nr); SG(0x200, 1);      /* MFMA + operand reads + 1 DS write  */
-#define SG_MFMA_L(nr) SG(0x008, 1); SG(0x100, nr); SG(0x020, 1);      /* MFMA + operand reads + 1 VMEM load */
-#define SG_MFMA_R(nr) SG(0x008, 1); SG(0x100, nr);                    /* MFMA + operand reads               */
-#define INTERLEAVE()                                                                      \
-    SG(0x100, 5);                                                                         \
-    SG_MFMA_W(2) SG_MFMA_W(1) SG_MFMA_W(1) SG_MFMA_W(1)                                   \
-    SG_MFMA_L(2) SG_MFMA_L(1) SG_MFMA_L(1) SG_MFMA_L(1)                                   \
-    SG_MFMA_R(2) SG_MFMA_R(1) SG_MFMA_R(1) SG_MFMA_R(1)                                   \
-    SG(0x008, 4);
-
     // =============================================================== phase B: gated k=3 conv
     {
         zero_acc();
-        f32x4 wr[4];
+        f32x4 wr[WL];
         const long tap_stride = (long)C * 2 * C;
         // iteration order (16-channel chunk, tap, 8-channel half) == conv_mfma.hip's (chunk, tap, k) order.
         // Two register sets: the tile consumed at iteration i+3 is requested at iteration i and written
         // to LDS at iteration i+2 — two MFMA blocks (>= 2048 cycles) cover the L2 latency.
         constexpr int NIT = (C / KC) * 3;
-        auto load_it = [&](f32x4 (&r)[4], int it) {
+        auto load_it = [&](f32x4 (&r)[WL], int it) {
             it = min(it, NIT - 1);
             const int q = it / 6, rr = it - q * 6;
             const int tap = rr >> 1, c8 = 2 * q + (rr & 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                r[i] = *reinterpret_cast<const f32x4*>(a.W3 + tap * tap_stride + (long)(c8 * KC + 2 * i + wrow) * (2 * C) +
-                                                       w * 128 + wcol);
+            for (int i = 0; i < WL; ++i)
+                r[i] = *reinterpret_cast<const f32x4*>(a.W3 + tap * tap_stride +
+                                                       (long)(c8 * KC + (64 / LPR) * i + wrow) * (2 * C) + w * WROWS + wcol);
         };
         auto bsrc_it = [&](int it) {
             const int q = it / 6, rr = it - q * 6;
             return u_lds + ((2 * q + (rr & 1)) * KC) * U_LD + l31 + (rr >> 1);
         };
-        f32x4 wb[4];
+        f32x4 wb[WL];
         load_it(wr, 0);
         store_w(0, wr);
         load_it(wr, 1);
@@ -198,12 +188,10 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a)
             store_w(1, wr);                        // tile it+1
             load_it(wr, it + 3);
             mma_chunk(0, bsrc_it(it));
-            INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
             store_w(0, wb);                        // tile it+2
             load_it(wb, it + 4);
             mma_chunk(1, bsrc_it(it + 1));
-            INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -211,21 +199,18 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a)
     __syncthreads();   // (2) every wave is done reading u: its buffer becomes z
     stamp(3);
     {
-        // packed rows of this wave: [w*128, +128) = two 64-row groups [32 gate | 32 filter]
+        // packed rows of this wave: [w*64, +64) = one 64-row group [32 gate | 32 filter] -> z rows [w*32, +32)
+        float bg[16], bf[16];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float bg[16], bf[16];
+        for (int r = 0; r < 16; ++r) {
+            const int mg = w * WROWS + acc_row(r, lane);
+            bg[r] = a.b3[mg];
+            bf[r] = a.b3[mg + 32];
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mg = w * 128 + g * 64 + acc_row(r, lane);
-                bg[r] = a.b3[mg];
-                bf[r] = a.b3[mg + 32];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float zv = cmtts_gate(acc[2 * g][r] + bg[r], acc[2 * g + 1][r] + bf[r]);
-                u_lds[(w * 64 + g * 32 + acc_row(r, lane)) * U_LD + l31] = zv;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float zv = cmtts_gate(acc[0][r] + bg[r], acc[1][r] + bf[r]);
+            u_lds[(w * 32 + acc_row(r, lane)) * U_LD + l31] = zv;
         }
     }
     __syncthreads();   // (3) z complete
@@ -234,15 +219,15 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a)
     // =============================================================== phase C: output projection
     {
         zero_acc();
-        f32x4 wr[4];
+        f32x4 wr[WL];
         constexpr int NIT = C / KC;
-        auto load_it = [&](f32x4 (&r)[4], int it) {
+        auto load_it = [&](f32x4 (&r)[WL], int it) {
             it = min(it, NIT - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                r[i] = *reinterpret_cast<const f32x4*>(a.Wo + (long)(it * KC + 2 * i + wrow) * (2 * C) + w * 128 + wcol);
+            for (int i = 0; i < WL; ++i)
+                r[i] = *reinterpret_cast<const f32x4*>(a.Wo + (long)(it * KC + (64 / LPR) * i + wrow) * (2 * C) + w * WROWS + wcol);
         };
-        f32x4 wb[4];
+        f32x4 wb[WL];
         load_it(wr, 0);
         store_w(0, wr);
         load_it(wr, 1);
@@ -253,32 +238,30 @@ __global__ __launch_bounds__(256, 2) void resblock_fused_kernel(const ResArgs a)
             store_w(1, wr);
             load_it(wr, it + 3);
             mma_chunk(0, u_lds + (it * KC) * U_LD + l31);
-            INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
             store_w(0, wb);
             load_it(wb, it + 4);
             mma_chunk(1, u_lds + ((it + 1) * KC) * U_LD + l31);
-            INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(5);
         float* xout = a.x_out + (long)b * C * T;
         float* skip = a.skip + (long)b * C * T;
-        const bool res_half = w < 2;              // wave-uniform: rows [0,256) -> x', rows [256,512) -> skip
+        const bool res_half = w < NW / 2;         // wave-uniform: rows [0,256) -> x', rows [256,512) -> skip
         const float* src = res_half ? xin : skip;
         float* dst = res_half ? xout : skip;
         const bool need_src = res_half || a.accum_skip;
         const int t = t0 + l31;
         const int t_c = min(t, T - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int mrow0 = (w & 1) * 128 + i * 32;            // row inside the half
+        for (int i = 0; i < MTW; ++i) {
+            const int mrow0 = (w % (NW / 2)) * WROWS + i * 32;   // row inside the half
             float sv[16], bo[16], dd[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                       // all gathers first: 48 loads in flight
                 const int mr = mrow0 + acc_row(r, lane);
                 sv[r] = need_src ? src[(unsigned)(mr * T + t_c)] : 0.f;
-                bo[r] = a.bo[w * 128 + i * 32 + acc_row(r, lane)];
+                bo[r] = a.bo[w * WROWS + i * 32 + acc_row(r, lane)];
                 dd[r] = res_half ? dv[mr] : 0.f;
             }
 #pragma unroll
@@ -315,7 +298,7 @@ extern "C" int cmtts_launch_resblock(const ResArgs* a_in, void* stream) {
     a_copy.cu_arrivals = g_cu_arrivals;
     const ResArgs* a = &a_copy;
     static bool attr_set = false;
-    const size_t lds = (size_t)(C * U_LD + 4 * PRIV) * sizeof(float);
+    const size_t lds = (size_t)(C * U_LD + NW * PRIV) * sizeof(float);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -324,6 +307,6 @@ extern "C" int cmtts_launch_resblock(const ResArgs* a_in, void* stream) {
     }
     if ((long)C * a->T >= (1L << 31)) return -2;
     dim3 grid((a->T + FN - 1) / FN, a->B);
-    hipLaunchKernelGGL(resblock_fused_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(resblock_fused_kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, *a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

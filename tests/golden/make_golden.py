@@ -235,9 +235,30 @@ def golden_hifigan():
                         pcm0=pcm[0], pcm1=pcm[1], seed=np.int64(GOLDEN_SEED))
 
 
+def golden_text():
+    """Vocabulary table (360 symbols -> ids, text/symbols.py:21-29) and text_to_sequence outputs
+    (text/__init__.py:15-41) for val.txt-style `{ARPAbet}` lines (dataset.py:271-283)."""
+    from text import text_to_sequence
+    from text.symbols import symbols
+    assert len(symbols) == 360
+    with open(os.path.join(ROOT, "cm-tts_amd", "symbols.json"), "w") as f:
+        json.dump(list(symbols), f)
+    lines = [
+        "LJ001-0001|LJSpeech|{P R IH1 N T IH0 NG sp IH0 N DH IY0 OW1 N L IY0 S EH1 N S}|Printing, in the only sense",
+        "p225_001|p225|{P L IY1 Z K AO1 L S T EH1 L AH0}|Please call Stella.",
+        "x|spk|{HH AH0 L OW1} , {W ER1 L D} !|hello , world !",
+        "y|spk|{AY1 spn sil NOTAPHONE Z}|unknown symbols are dropped",
+    ]
+    ids = [text_to_sequence(l.split("|")[2], []) for l in lines]
+    with open(os.path.join(HERE, "text.json"), "w") as f:
+        json.dump({"lines": lines, "ids": ids}, f)
+    print("[text]", [len(i) for i in ids])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     import_reference()
     for v in ("LJSpeech", "VCTK", "LibriTTS"):
         golden_cmtts(v)
     golden_hifigan()
+    golden_text()

@@ -217,6 +217,62 @@ def test_karras_sample_tts_end_to_end(models, variant):
         assert err[~near].max() < 1e-3, err[~near].max()
 
 
+def _mask_near_pitch_flips(model, g, kw):
+    out = model.duration_pitch_energy_net(None, kw["texts"], kw["src_lens"], spker_embeds=kw["spker_embeds"])
+    bad = _np(out["p_predictions"]["p_idx"]) != g["p_idx"]
+    near = np.zeros_like(bad)
+    for b, t in zip(*np.nonzero(bad)):
+        near[b, max(0, t - 24): t + 25] = True
+    return ~near
+
+
+@pytest.mark.parametrize("T_steps", [1, 2, 4])
+def test_synthesize_driver(models, T_steps):
+    """CMTotalTTSSynthesize.synthesize (synthesize.py:88-153): the 7-tuple batch in, out_put[0/10/11] out."""
+    host = _host()
+    g, cfg, sd, model = models("VCTK")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[Gen.i]).to(DEV)
+            Gen.i += 1
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    texts, lens = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
+    spk = torch.from_numpy(g["spker_embeds"])
+    batch = (["a", "b", "c"], ["x", "y", "z"], torch.zeros(B, dtype=torch.long), texts, lens, int(lens.max()), spk)
+    out = host.CMTotalTTSSynthesize(model, T=T_steps, generator=Gen()).synthesize(batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(out[11]), g["mel_len"]) and np.array_equal(_np(out[10]), g["src_lens"])
+    ok = _mask_near_pitch_flips(model, g, dict(texts=texts, src_lens=lens, spker_embeds=spk))
+    err = np.abs(_np(out[0]) - g[f"mel_T{T_steps}"])
+    assert ok.mean() > 0.5 and err[ok].max() < 1e-3, err[ok].max()
+
+
+def test_generic_denoise_path_matches_fused_sampler(models):
+    """KarrasDenoiser.denoise around CMTotalTTS.forward (which re-runs the duration net on every call,
+    tts_net.py:132-147) must give the onestep sample the fused cmtts_sample path gives."""
+    host = _host()
+    g, cfg, sd, model = models("LJSpeech")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 1)[0]
+    x_T = torch.from_numpy(noise).to(DEV) * cfg.sigma_max
+    sig = torch.full((B,), cfg.sigma_max, device=DEV)
+    kw = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]), spker_embeds=None)
+    _, den = host.KarrasDenoiser().denoise(model, x_T, sig, **kw)
+    torch.cuda.synchronize()
+    ok = _mask_near_pitch_flips(model, g, kw)
+    err = np.abs(_np(den[:, 0]) - g["mel_T1"])
+    assert err[ok].max() < 1e-3, err[ok].max()
+
+
 def test_hifigan_golden(golden):
     host = _host()
     g = golden("hifigan")
