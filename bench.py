@@ -76,11 +76,8 @@ def cpu_baseline(cfg, sd):
     """The numpy oracle (oracle/cmtts_oracle.py, pinned to the reference's golden vectors) timed on
     this box's host cores on a bounded sample of the same workload."""
     from oracle import cmtts_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    O.set_backend("torch")            # oneDNN/MKL conv + GEMM primitives: what the reference's CPU path runs
+    threads = torch.get_num_threads()
     rs = np.random.RandomState(0)
     B = 8
     texts = rs.randint(1, cfg.n_symbols, size=(B, PHONEMES)).astype(np.int64)
@@ -88,13 +85,18 @@ def cpu_baseline(cfg, sd):
     noise = [rs.standard_normal(size=(B, 1, FRAMES_PAD, cfg.n_mels)).astype(np.float32) for _ in range(N_STEPS + 1)]
     O.synthesize(sd, cfg, texts[:1, :8], np.asarray([8]), None, 1,
                  [rs.standard_normal(size=(1, 1, 48, cfg.n_mels)).astype(np.float32)])      # warm BLAS threads
-    t0 = time.perf_counter()
-    mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, N_STEPS, noise, max_mel_len=FRAMES_PAD)
-    dt = time.perf_counter() - t0
+    best = None
+    for _ in range(3):                 # best of 3 passes (the first also pays one-off weight re-layouts)
+        t0 = time.perf_counter()
+        mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, N_STEPS, noise, max_mel_len=FRAMES_PAD, torch_sampler=True)
+        d = time.perf_counter() - t0
+        best = d if best is None else min(best, d)
+    dt = best
+    O.set_backend("numpy")
     return {"value": round(float(mel_len.sum()) / dt, 1), "unit": "mel-frames/s", "cores": int(threads),
             "kind": "port",
-            "sample": f"numpy/OpenBLAS oracle, text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
-                      f"T={N_STEPS}, one pass = {dt:.1f} s"}
+            "sample": f"oracle graph in stock torch-CPU ops (oneDNN/MKL; sampler end-to-end in torch), text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
+                      f"T={N_STEPS}, best of 3 passes = {dt:.2f} s"}
 
 
 def main():

@@ -25,6 +25,24 @@ F32 = np.float32
 
 # ----------------------------------------------------------------------------- primitives
 
+# Dense primitives can run on two CPU back ends with identical semantics: "numpy" (OpenBLAS GEMM per tap,
+# the default and what the golden tests pin) and "torch" (torch.nn.functional on CPU tensors that alias
+# the numpy arrays — oneDNN/MKL kernels, i.e. what the reference's own CPU path executes).  bench.py's
+# cpu_baseline uses "torch" when available because it is the faster, fairer CPU number.
+_BACKEND = "numpy"
+
+
+def set_backend(name):
+    global _BACKEND
+    assert name in ("numpy", "torch")
+    _BACKEND = name
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
+
+
 _TAP_CACHE = {}
 
 
@@ -43,6 +61,11 @@ def _taps(w):
 def conv1d(x, w, b=None, padding=0, dilation=1):
     """torch.nn.functional.conv1d, stride 1.  x [B,Cin,T], w [Cout,Cin,K] -> [B,Cout,T']."""
     x = np.asarray(x, F32)
+    if _BACKEND == "torch":
+        import torch
+        with torch.no_grad():
+            return torch.nn.functional.conv1d(_t(x), _t(w), None if b is None else _t(b), padding=padding,
+                                              dilation=dilation).numpy()
     B, Cin, T = x.shape
     Cout, _, K = w.shape
     xp = np.zeros((B, Cin, T + 2 * padding), F32)
@@ -60,6 +83,10 @@ def conv1d(x, w, b=None, padding=0, dilation=1):
 def conv_transpose1d(x, w, b, stride, padding):
     """torch.nn.functional.conv_transpose1d.  x [B,Cin,T], w [Cin,Cout,K] -> [B,Cout,(T-1)s-2p+K]."""
     x = np.asarray(x, F32)
+    if _BACKEND == "torch":
+        import torch
+        with torch.no_grad():
+            return torch.nn.functional.conv_transpose1d(_t(x), _t(w), _t(b), stride=stride, padding=padding).numpy()
     B, Cin, T = x.shape
     _, Cout, K = w.shape
     full = np.zeros((B, Cout, (T - 1) * stride + K), F32)
@@ -71,6 +98,10 @@ def conv_transpose1d(x, w, b, stride, padding):
 
 
 def linear(x, w, b=None):
+    if _BACKEND == "torch":
+        import torch
+        with torch.no_grad():
+            return torch.nn.functional.linear(_t(x), _t(w), None if b is None else _t(b)).numpy()
     y = np.matmul(np.asarray(x, F32), w.T)
     return y if b is None else y + b
 
@@ -430,6 +461,60 @@ def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise):
     return x[:, 0]
 
 
+def karras_sample_tts_torch(sd, cfg, cond, speaker_emb, n_steps, noise):
+    """Same computation as karras_sample_tts/denoiser_forward, written end-to-end in stock torch CPU ops
+    (multi-threaded conv/GEMM *and* element-wise kernels) — the layer graph a PyTorch-CPU run of the
+    reference executes.  Used for the timed cpu_baseline and cross-checked against the numpy path in
+    tests/test_oracle_golden.py; the weights are converted once per call."""
+    import torch
+    import torch.nn.functional as Fn
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
+    C = cfg.res_channels
+    W = {k: tt(v) for k, v in sd.items() if k.startswith("net.")}
+    c = tt(cond).transpose(1, 2).contiguous()
+    spk = None if speaker_emb is None else tt(speaker_emb)
+    B = c.shape[0]
+    half = C // 2
+    omega = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    sig, std = multistep_schedule(n_steps, cfg)
+
+    def denoise(x_bt, t):
+        h = Fn.relu(Fn.conv1d(x_bt[:, 0].transpose(1, 2), W["net.input_projection.0.conv.weight"],
+                              W["net.input_projection.0.conv.bias"]))
+        a = t[:, None] * omega[None, :]
+        e = torch.cat([a.sin(), a.cos()], -1)
+        e = Fn.linear(e, W["net.mlp.0.linear.weight"])
+        e = Fn.linear(e * torch.tanh(Fn.softplus(e)), W["net.mlp.2.linear.weight"])
+        skip = None
+        for i in range(cfg.res_layers):
+            p = f"net.residual_layers.{i}."
+            d = Fn.linear(e, W[p + "diffusion_projection.linear.weight"])[:, :, None]
+            cp = Fn.conv1d(c, W[p + "conditioner_projection.conv.weight"], W[p + "conditioner_projection.conv.bias"])
+            r = h + d
+            u = r + cp
+            if cfg.multi_speaker:
+                u = u + Fn.linear(spk, W[p + "speaker_projection.linear.weight"])[:, :, None]
+            y = Fn.conv1d(u, W[p + "conv_layer.conv.weight"], W[p + "conv_layer.conv.bias"], padding=1)
+            z = torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+            o = Fn.conv1d(z, W[p + "output_projection.conv.weight"], W[p + "output_projection.conv.bias"])
+            h = (o[:, :C] + r) / math.sqrt(2.0)
+            skip = o[:, C:] if skip is None else skip + o[:, C:]
+        s_ = skip / math.sqrt(cfg.res_layers)
+        s_ = Fn.relu(Fn.conv1d(s_, W["net.skip_projection.conv.weight"], W["net.skip_projection.conv.bias"]))
+        out = Fn.conv1d(s_, W["net.output_projection.conv.weight"], W["net.output_projection.conv.bias"])
+        return out.transpose(1, 2)[:, None]
+
+    with torch.no_grad():
+        x = tt(noise[0]) * cfg.sigma_max
+        for i, sg in enumerate(sig):
+            sigma = torch.full((B,), sg, dtype=torch.float32)
+            c_skip, c_out, c_in = [v[:, None, None, None] for v in boundary_scalings(sigma, cfg)]
+            f = denoise(c_in * x, 1000 * 0.25 * torch.log(sigma + 1e-44))
+            x0 = c_out * f + c_skip * x
+            x = x0 if std[i] is None else x0 + tt(noise[1 + i]) * (std[i] / 0.85) * 0.85
+    return x[:, 0].numpy()
+
+
 # ----------------------------------------------------------------------------- HiFi-GAN
 
 def hifigan_generator(hsd, hcfg, mel_ct):
@@ -476,10 +561,11 @@ def vocoder_infer(hsd, hcfg, mel_btc, mel_lens, cfg):
 
 # ----------------------------------------------------------------------------- end to end
 
-def synthesize(sd, cfg, texts, src_lens, spker_embeds, n_steps, noise, max_mel_len=None):
+def synthesize(sd, cfg, texts, src_lens, spker_embeds, n_steps, noise, max_mel_len=None, torch_sampler=False):
     """CMTotalTTSSynthesize.synthesize synthesize.py:88-153: duration net once (it is bit-identical
     to re-running it every step with mels=x), then the T-step sampler.
     Returns (mel [B,T,80], mel_lens, stage dict)."""
     st = duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds, max_mel_len)
-    mel = karras_sample_tts(sd, cfg, st["cond"], st["speaker_emb"], n_steps, noise)
+    sampler = karras_sample_tts_torch if torch_sampler else karras_sample_tts
+    mel = sampler(sd, cfg, st["cond"], st["speaker_emb"], n_steps, noise)
     return mel, st["mel_len"], st

@@ -93,3 +93,23 @@ def test_hifigan(golden):
     for i, name in enumerate(["pcm0", "pcm1"]):
         assert pcm[i].shape == g[name].shape
         assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 1
+
+
+def test_torch_backend_agrees_with_numpy_backend(golden):
+    """The optional torch-CPU primitives (used only for the timed cpu_baseline) compute the same graph."""
+    g, cfg, sd = _setup(golden, "VCTK")
+    ref = O.denoiser_forward(sd, cfg, g["den_x"], g["den_t"], g["cond"], g.get("speaker_emb"))
+    O.set_backend("torch")
+    try:
+        out = O.denoiser_forward(sd, cfg, g["den_x"], g["den_t"], g["cond"], g.get("speaker_emb"))
+        st = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], g.get("spker_embeds"))
+    finally:
+        O.set_backend("numpy")
+    np.testing.assert_allclose(out, ref, atol=2e-4)
+    np.testing.assert_allclose(out, g["den_out"], atol=2e-4)
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    mel = O.karras_sample_tts_torch(sd, cfg, g["cond"], g.get("speaker_emb"), 2, noise)
+    np.testing.assert_allclose(mel, g["mel_T2"], atol=2e-4)
+    np.testing.assert_array_equal(st["mel_len"], g["mel_len"])
+    np.testing.assert_array_equal(st["mel2ph"], g["mel2ph"])
