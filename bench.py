@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="three-launch residual block (A/B)")
-    ap.add_argument("--stagger", type=str, default="", help="mode,sleeps for cmtts_set_stagger (tuning)")
+    ap.add_argument("--tile", type=int, default=0, help="frames per workgroup of the fused residual block (tuning)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,9 +127,8 @@ def main():
     lib = _lib.load()
     if args.unfused:
         lib.cmtts_set_fused_resblock(0)
-    if args.stagger:
-        mode, sleeps = (int(v) for v in args.stagger.split(","))
-        lib.cmtts_set_stagger(mode, sleeps)
+    if args.tile:
+        _lib.check(lib.cmtts_set_resblock_tile(args.tile))
     state = {}
 
     def step(n_steps=N_STEPS):

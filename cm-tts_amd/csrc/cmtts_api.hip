@@ -67,7 +67,8 @@ struct Allocs {
 };
 
 // W [Cout][Cin][K] -> k-major [K][Cin][ld] with ld = round_up(Cout, 4); perm[p] = original row of packed row p
-int pack_conv(Allocs& al, const HostTensor& W, const HostTensor* bias, const std::vector<int>* perm, PackedConv* out) {
+int pack_conv(Allocs& al, const HostTensor& W, const HostTensor* bias, const std::vector<int>* perm, PackedConv* out,
+              std::vector<float>* host_copy = nullptr) {
     const int Cout = (int)W.dim(0), Cin = (int)W.dim(1), K = (int)W.dim(2);
     const int ld = round_up(Cout, 4);
     std::vector<float> p((size_t)K * Cin * ld, 0.f);
@@ -78,6 +79,7 @@ int pack_conv(Allocs& al, const HostTensor& W, const HostTensor* bias, const std
                 p[((size_t)k * Cin + ci) * ld + r] = W.data[((size_t)co * Cin + ci) * K + k];
             }
     CHK(al.upload(p, &out->w));
+    if (host_copy) *host_copy = p;
     out->bias = nullptr;
     if (bias) {
         std::vector<float> b(Cout);
@@ -106,6 +108,22 @@ int pack_conv_transpose(Allocs& al, const HostTensor& W, const HostTensor& bias,
     out->tap_stride = (long)Cin * ld;
     out->phase_stride = (long)Q * Cin * ld;
     return 0;
+}
+
+// k-major packed weights [taps][K][M] -> MFMA A-fragment order [taps][K/8][M/32][64 lanes][4]:
+// element (lane, j) of k-group g, m-tile mt is P[tap][8g + 2j + (lane >> 5)][32 mt + (lane & 31)], i.e. the A
+// operand of v_mfma_f32_32x32x2_f32 for k-step j of that group (lane l supplies A[m = l & 31][k = l >> 5]).
+std::vector<float> to_fragment_order(const std::vector<float>& p, int taps, int K, int M) {
+    std::vector<float> f((size_t)taps * K * M);
+    const int G = K / 8, MTn = M / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < G; ++g)
+            for (int mt = 0; mt < MTn; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        f[((((size_t)tap * G + g) * MTn + mt) * 64 + lane) * 4 + j] =
+                            p[((size_t)tap * K + 8 * g + 2 * j + (lane >> 5)) * M + 32 * mt + (lane & 31)];
+    return f;
 }
 
 // nn.Linear weight [N][K] -> transposed [K][N] (dense_small operand / X operand of a GEMM)
@@ -185,6 +203,8 @@ struct Predictor {
 };
 struct ResLayer {
     PackedConv cond, conv3, outp;
+    float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
+    float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
 };
 
 }  // namespace
@@ -364,11 +384,29 @@ int finalize_model(cmtts_model* m) {
     for (int l = 0; l < NL; ++l) {
         const std::string p = "net.residual_layers." + std::to_string(l) + ".";
         GET(w3, p + "conv_layer.conv.weight", 2 * C, C, 3); GET(b3, p + "conv_layer.conv.bias", 2 * C);
+        std::vector<float> hp;
         CHK(pack_conv(al, *w3, b3, &perm, &m->res[l].conv3));
+        {   // fused kernel: every 32-row tile = [16 sigmoid rows | 16 tanh rows] of the same 16 channels
+            std::vector<int> perm16(2 * C);
+            for (int gidx = 0; gidx < C / 16; ++gidx)
+                for (int i = 0; i < 16; ++i) {
+                    perm16[gidx * 32 + i] = gidx * 16 + i;
+                    perm16[gidx * 32 + 16 + i] = C + gidx * 16 + i;
+                }
+            PackedConv tmp;
+            Allocs scratch;                                   // device copy of the k-major form is not needed
+            CHK(pack_conv(scratch, *w3, b3, &perm16, &tmp, &hp));
+            CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
+            std::vector<float> bperm(2 * C);
+            for (int r = 0; r < 2 * C; ++r) bperm[r] = b3->data[perm16[r]];
+            CHK(al.upload(bperm, &m->res[l].b3f));
+            scratch.release();
+        }
         GET(wc, p + "conditioner_projection.conv.weight", C, H, 1); GET(bc, p + "conditioner_projection.conv.bias", C);
         CHK(pack_conv(al, *wc, bc, nullptr, &m->res[l].cond));
         GET(wo, p + "output_projection.conv.weight", 2 * C, C, 1); GET(bo, p + "output_projection.conv.bias", 2 * C);
-        CHK(pack_conv(al, *wo, bo, nullptr, &m->res[l].outp));
+        CHK(pack_conv(al, *wo, bo, nullptr, &m->res[l].outp, &hp));
+        CHK(al.upload(to_fragment_order(hp, 1, C, 2 * C), &m->res[l].wof));
         GET(wd, p + "diffusion_projection.linear.weight", C, C);
         for (int n = 0; n < C; ++n)
             for (int k = 0; k < C; ++k) dproj[(size_t)k * NL * C + l * C + n] = wd->data[(size_t)n * C + k];
@@ -554,7 +592,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             ra.x_in = hcur; ra.cp = w.cp + (long)l * C * T; ra.cp_bstride = (long)NL * C * T;
             ra.dp = dp + (long)l * C; ra.d = w.dproj + (long)l * C;
             ra.x_out = halt; ra.skip = w.skip;
-            ra.W3 = R.conv3.w; ra.b3 = R.conv3.bias; ra.Wo = R.outp.w; ra.bo = R.outp.bias;
+            ra.W3f = R.w3f; ra.b3 = R.b3f; ra.Wof = R.wof; ra.bo = R.outp.bias;
             ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0;
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
             if (cmtts_launch_resblock(&ra, (void*)s) != 0) return fail(CMTTS_E_HIP, "fused residual block launch failed");
@@ -976,8 +1014,9 @@ int cmtts_set_fused_resblock(int on) {
     return prev;
 }
 
-int cmtts_set_stagger(int mode, int sleeps) {
-    cmtts_resblock_set_stagger(mode, sleeps);
+int cmtts_set_resblock_tile(int frames) {
+    if (frames != 0 && frames != 32 && frames != 64) return fail(CMTTS_E_INVALID, "cmtts_set_resblock_tile: 0, 32 or 64");
+    cmtts_resblock_set_tile(frames);
     return 0;
 }
 

@@ -8,15 +8,14 @@ struct ResArgs {
     const float* d;       // [B][vec_stride]: diffusion projection alone (residual = x + d)
     float* x_out;         // [B][256][T]  (must not alias x_in: neighbouring tiles read its halo)
     float* skip;          // [B][256][T]
-    const float *W3, *b3; // conv_layer              k-major [3][256][512], gate-permuted rows
-    const float *Wo, *bo; // output_projection       k-major [256][512]
+    const float *W3f, *b3; // conv_layer, MFMA A-fragment order [3][32 k-groups][16 m-tiles][64 lanes][4], gate-permuted rows
+    const float *Wof, *bo; // output_projection, fragment order [32][16][64][4]
     long cp_bstride;
     long vec_stride;
     int B, T;
     int accum_skip;       // skip += o[C:] (layers > 0) or skip = o[C:] (layer 0)
     int stagger_mode;     // 0 none; 1: second half of the grid; 2: odd workgroups — delayed start (experiment)
     int stagger_sleeps;
-    unsigned* cu_arrivals; // [2048] monotonically increasing per-CU arrival counters (stagger mode 3)
     long long* dbg;       // optional [grid][8] s_memtime stamps written by wave 0 (phase timing)   // number of s_sleep 127 (~3.4 us each) for the delayed workgroups
 };
 
@@ -24,7 +23,7 @@ struct ResArgs {
 extern "C" {
 #endif
 int cmtts_launch_resblock(const ResArgs* a, void* stream);
-void cmtts_resblock_set_stagger(int mode, int sleeps);
+void cmtts_resblock_set_tile(int frames);   // 0 = automatic, 32 or 64 = forced frames per workgroup
 void cmtts_resblock_set_debug(long long* dbg);
 #ifdef __cplusplus
 }

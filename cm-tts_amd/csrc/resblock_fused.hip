@@ -6,21 +6,29 @@
 //   y  = W3 (*) u + b3 ; z = sigmoid(y[:C]) * tanh(y[C:])      conv_layer k=3 pad 1 + gate   (phase B)
 //   o  = Wo * z + bo ; x' = (o[:C] + (x + d)) / sqrt(2) ; skip (+)= o[C:]                    (phase C)
 //
-// One workgroup (8 wave64) owns 32 frames of one utterance; u (with its +-1 frame Conv1D halo) and z
-// never leave LDS (z re-uses u's buffer): per layer HBM sees x, cp in and x', skip in/out only.
-// Both contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) in the same (8-channel chunk, tap, k)
-// order as an fmaf chain over k — identical to conv_mfma.hip's order, so the result is BITWISE equal
-// to the three-launch form (tests/test_gpu_parity.py::test_fused_resblock_bitwise).
+// One workgroup (16 wave64) owns FN = 64 frames of one utterance; u (with its +-1 frame Conv1D halo)
+// and z never leave LDS (z re-uses u's buffer): per layer HBM sees x, cp in and x', skip in/out.
+// Both contractions run on v_mfma_f32_32x32x2_f32 (exact fp32) in the same (16-channel chunk, tap, k)
+// order as conv_mfma.hip, so the result is BITWISE equal to the three-launch form
+// (tests/test_gpu_parity.py::test_fused_resblock_bitwise).
 //
-// Occupancy is the design point: 68 KB of LDS and <= 128 VGPRs per wave let TWO 8-wave workgroups share
-// a CU = 4 waves per SIMD.  A lone wave keeps the matrix pipe only ~65 % busy (its LDS stores, prefetch
-// loads and address arithmetic are not hidden), two reach ~90 %, and the staging / gate / epilogue
-// phases of one workgroup run under the MFMAs of the other; with one 4-wave workgroup per CU the pipe
-// idled 49 % of the time (measured, profiles/).  Wave w owns output rows [w*64, +64) (2 accumulator
-// tiles) over all 32 frames and streams ITS weight slice global -> registers -> a private 4 KB LDS
-// ring (double buffered; the tile consumed at iteration i+3 is requested at iteration i; operands of
-// k-step k+1 are read before the MFMAs of k-step k), so the main loops contain no workgroup barrier:
-// three s_barriers per workgroup in total (u staged, u dead, z complete).
+// Operand delivery (the part that decides the MFMA duty cycle):
+//  * WEIGHTS never touch LDS.  Wave w owns ONE 32-row MFMA tile of the output (rows [32w, +32)) over
+//    all 64 frames, and no other wave needs those rows, so they are streamed global/L2 -> VGPR already
+//    in MFMA A-fragment order: cmtts_finalize() re-packs each layer as [k-group of 8][m-tile][lane][4]
+//    so that ONE coalesced global_load_dwordx4 (1 KB per wave) delivers the A operands of four
+//    k-steps = 8 MFMAs.  The measured wall (tools/mfma_probe.hip, profiles/) is the per-CU L2->CU fill
+//    rate, ~12 B/clk: a 32-frame tile needs 256 B of weights per MFMA and caps the kernel at ~75 % of
+//    the MFMA peak whatever the schedule; 64 frames per workgroup halve that.  A 4-deep register ring
+//    keeps three groups in flight; there is no ds_write / wave barrier / LDS double buffering.
+//  * The gate needs sigmoid and tanh operands in the same lane: each 32-row tile is packed as
+//    [16 sigmoid rows | 16 tanh rows] of the same 16 channels, which the 32x32 C layout puts in
+//    registers r and r+8 of one lane.
+//  * ACTIVATIONS (u, then z) are read from LDS with conflict-free ds_read_b32 (32 consecutive frames
+//    per half-wave), one k-group ahead of the MFMAs that consume them.
+//  * 16 waves = 4 per SIMD keep the matrix pipe fed while other waves wait on loads (70 KB LDS,
+//    <= 128 VGPRs per wave).
+// Three s_barriers per workgroup in total (u staged, u dead, z complete).
 #include <hip/hip_runtime.h>
 #include "gate.h"
 #include "resblock_args.h"
@@ -31,21 +39,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 namespace {
 
 constexpr int C = 256;          // residual channels (= encoder hidden)
-constexpr int FN = 32;          // frames per workgroup
-constexpr int U_LD = 36;        // LDS row stride of u / z (34 columns used by u)
-constexpr int KC = 8;           // channels per K chunk
-constexpr int NW = 8;           // waves per workgroup
-constexpr int WROWS = 512 / NW; // output rows per wave (64)
-constexpr int MTW = WROWS / 32; // accumulator tiles per wave (2)
-constexpr int PRIV = 2 * KC * WROWS;   // floats of private LDS per wave (4 KB): [2][KC][WROWS]
+constexpr int NW = 16;          // waves per workgroup (one 32-row MFMA tile each)
+constexpr int RING = 4;         // register ring depth for the weight stream
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+template <int FN>
 __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArgs a) {
+    static_assert(64 * NW == 1024, "1024-thread workgroups");
+    constexpr int NT = FN / 32;         // 32-frame MFMA column tiles per wave
+    constexpr int U_LD = FN + 4;        // LDS row stride of u / z (FN + 2 columns used by u)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* u_lds = smem;                         // [C][U_LD]
+    float* u_lds = smem;                // [C][U_LD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* pw = smem + C * U_LD + w * PRIV;      // wave-private weight ring [2][KC][WROWS]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * FN;
     const int T = a.T;
@@ -60,51 +66,34 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
         if (a.dbg && tid == 0) a.dbg[(long)bid_dbg * 8 + slot] = (long long)__builtin_readcyclecounter();
     };
     stamp(0);
-    if (a.stagger_mode) {   // de-phase the two workgroups that share a CU (they are dispatched together)
-        const int bid = blockIdx.x + gridDim.x * blockIdx.y;
-        bool late;
-        if (a.stagger_mode == 3) {
-            // per-CU arrival parity: the hardware ids are read for SPEED only (placement is undefined by
-            // contract); any value gives correct results, a wrong guess merely forgoes the overlap
-            __shared__ int late_sh;
-            if (tid == 0) {
-                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
-                const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // HW_REG_XCC_ID[3:0]
-                const unsigned cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
-                const unsigned idx = ((xcc & 7) * 8 + se) * 32 + sh * 16 + cu;
-                late_sh = atomicAdd(a.cu_arrivals + (idx & 2047), 1u) & 1;
-            }
-            __syncthreads();
-            late = late_sh != 0;
-        } else {
-            late = a.stagger_mode == 1 ? bid >= (int)(gridDim.x * gridDim.y) / 2 : (bid & 1);
-        }
-        if (late)
-            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    // ---- stage u[m][j] = cp + (x + dp) for frames t0-1+j, j in [0,34); zero outside [0,T) (conv padding).
-    // Unconditional clamped loads, selects at LDS-store time.
+
+    // ---- stage u[m][j] = cp + (x + dp) for frames t0-1+j, j in [0, FN+2); zero outside [0,T) (conv padding).
+    // Unconditional clamped loads, selects at LDS-store time, 8 rows in flight per thread.
     {
-        const int t = t0 + l31;
+        constexpr int RPI = 64 / FN;                 // rows covered by one wave-wide access (2 or 1)
+        const int n = lane & (FN - 1);
+        const int rsub = RPI == 2 ? khalf : 0;
+        const int t = t0 + n;
         const int t_c = min(t, T - 1);
-#pragma unroll 2
-        for (int i = 0; i < C / (2 * NW); i += 4) {
-            float xv[4], cv[4], dq[4];
+        constexpr int ROWS_PER_WAVE = C / NW;        // 32 rows per wave
+#pragma unroll 1
+        for (int i = 0; i < ROWS_PER_WAVE / RPI; i += 8) {
+            float xv[8], cv[8], dq[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = 2 * NW * (i + q) + 2 * w + khalf;
+            for (int q = 0; q < 8; ++q) {
+                const int m = w * ROWS_PER_WAVE + (i + q) * RPI + rsub;
                 xv[q] = xin[(unsigned)(m * T + t_c)];
                 cv[q] = cp[(unsigned)(m * T + t_c)];
                 dq[q] = dp[m];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = 2 * NW * (i + q) + 2 * w + khalf;
+            for (int q = 0; q < 8; ++q) {
+                const int m = w * ROWS_PER_WAVE + (i + q) * RPI + rsub;
                 const float uv = cv[q] + (xv[q] + dq[q]);
-                u_lds[m * U_LD + 1 + l31] = t < T ? uv : 0.f;
+                u_lds[m * U_LD + 1 + n] = t < T ? uv : 0.f;
             }
         }
-        if (tid < 2 * C) {                       // halo columns: thread = (side, row)
+        if (tid < 2 * C) {                           // halo columns: thread = (side, row)
             const int m = tid & (C - 1);
             const bool right = tid >= C;
             const int th = right ? t0 + FN : t0 - 1;
@@ -116,102 +105,84 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
     __syncthreads();   // (1) u staged
     stamp(1);
 
-    f32x16 acc[MTW];
+    f32x16 acc[NT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     };
-    constexpr int WL = KC * WROWS / 256;         // f32x4 per lane per weight tile (2)
-    constexpr int LPR = WROWS / 4;               // lanes per tile row (16)
-    const int wrow = lane / LPR, wcol = (lane % LPR) * 4;
-    auto store_w = [&](int buf, const f32x4 (&wr)[WL]) {
-#pragma unroll
-        for (int i = 0; i < WL; ++i)
-            *reinterpret_cast<f32x4*>(pw + buf * (KC * WROWS) + ((64 / LPR) * i + wrow) * WROWS + wcol) = wr[i];
+    // A fragments of one k-group (8 input channels = 4 k-steps) for this wave's 32-row tile
+    auto load_a = [&](f32x4& dst, const float* wfrag, int group) {
+        dst = *reinterpret_cast<const f32x4*>(wfrag + ((long)group * (2 * C / 32) + w) * 256 + lane * 4);
     };
-    // KC/2 = 4 k-steps of 4 MFMAs; the A/B operands of k-step kk+1 are read before the MFMAs of kk
-    auto mma_chunk = [&](int buf, const float* bsrc) {
-        const float* ws = pw + buf * (KC * WROWS) + l31 + khalf * WROWS;
-        const float* bs = bsrc + khalf * U_LD;
-        float av[MTW], bv;
+    // B operands of one k-group: rows krow0 + 2kk + khalf of the LDS tile at column offset `col`
+    auto load_b = [&](float (&dst)[4][NT], int krow0, int col) {
+        const float* bs = u_lds + (krow0 + khalf) * U_LD + l31 + col;
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) av[i] = ws[i * 32];
-        bv = bs[0];
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            float nav[MTW], nbv = 0.f;
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
+    };
+    auto mma_group = [&](const f32x4& af, const float (&bv)[4][NT]) {
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) nav[i] = kk + 1 < KC / 2 ? ws[(kk + 1) * 2 * WROWS + i * 32] : 0.f;
-            if (kk + 1 < KC / 2) nbv = bs[(kk + 1) * 2 * U_LD];
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, MTW + 1, 0);   // DS reads of the next step
-            __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);       // MFMAs of this step
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) av[i] = nav[i];
-            bv = nbv;
-        }
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bv[kk][j], acc[j], 0, 0, 0);
     };
 
     // =============================================================== phase B: gated k=3 conv
     {
         zero_acc();
-        f32x4 wr[WL];
-        const long tap_stride = (long)C * 2 * C;
-        // iteration order (16-channel chunk, tap, 8-channel half) == conv_mfma.hip's (chunk, tap, k) order.
-        // Two register sets: the tile consumed at iteration i+3 is requested at iteration i and written
-        // to LDS at iteration i+2 — two MFMA blocks (>= 2048 cycles) cover the L2 latency.
-        constexpr int NIT = (C / KC) * 3;
-        auto load_it = [&](f32x4 (&r)[WL], int it) {
-            it = min(it, NIT - 1);
+        constexpr int NG = (C / 8) * 3;                       // 96 k-groups: (16-chunk, tap, 8-half)
+        auto kgrp = [&](int it, int& g8, int& tap) {           // iteration -> (k-group of 8 channels, tap)
+            it = min(it, NG - 1);
             const int q = it / 6, rr = it - q * 6;
-            const int tap = rr >> 1, c8 = 2 * q + (rr & 1);
+            tap = rr >> 1;
+            g8 = 2 * q + (rr & 1);
+        };
+        f32x4 A[RING];
+        float Bv[2][4][NT];
+        int g8, tap;
 #pragma unroll
-            for (int i = 0; i < WL; ++i)
-                r[i] = *reinterpret_cast<const f32x4*>(a.W3 + tap * tap_stride +
-                                                       (long)(c8 * KC + (64 / LPR) * i + wrow) * (2 * C) + w * WROWS + wcol);
-        };
-        auto bsrc_it = [&](int it) {
-            const int q = it / 6, rr = it - q * 6;
-            return u_lds + ((2 * q + (rr & 1)) * KC) * U_LD + l31 + (rr >> 1);
-        };
-        f32x4 wb[WL];
-        load_it(wr, 0);
-        store_w(0, wr);
-        load_it(wr, 1);
-        load_it(wb, 2);
-        __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < NIT; it += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            store_w(1, wr);                        // tile it+1
-            load_it(wr, it + 3);
-            mma_chunk(0, bsrc_it(it));
-            __builtin_amdgcn_sched_barrier(0);
-            store_w(0, wb);                        // tile it+2
-            load_it(wb, it + 4);
-            mma_chunk(1, bsrc_it(it + 1));
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < RING - 1; ++s) {
+            kgrp(s, g8, tap);
+            load_a(A[s], a.W3f, tap * (C / 8) + g8);
+        }
+        kgrp(0, g8, tap);
+        load_b(Bv[0], g8 * 8, tap);
+        for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                kgrp(it + s + RING - 1, g8, tap);
+                load_a(A[(s + RING - 1) % RING], a.W3f, tap * (C / 8) + g8);
+                kgrp(it + s + 1, g8, tap);
+                load_b(Bv[(s + 1) & 1], g8 * 8, tap);
+                mma_group(A[s], Bv[s & 1]);
+            }
         }
     }
     stamp(2);
     __syncthreads();   // (2) every wave is done reading u: its buffer becomes z
     stamp(3);
     {
-        // packed rows of this wave: [w*64, +64) = one 64-row group [32 gate | 32 filter] -> z rows [w*32, +32)
-        float bg[16], bf[16];
+        // this wave's tile = [16 sigmoid rows | 16 tanh rows] of channels [16w, +16): registers r (rows 0-15)
+        // and r+8 (rows 16-31) of the same lane pair up
+        float bg[8], bf[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mg = w * WROWS + acc_row(r, lane);
+        for (int r = 0; r < 8; ++r) {
+            const int mg = w * 32 + acc_row(r, lane);
             bg[r] = a.b3[mg];
-            bf[r] = a.b3[mg + 32];
+            bf[r] = a.b3[mg + 16];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float zv = cmtts_gate(acc[0][r] + bg[r], acc[1][r] + bf[r]);
-            u_lds[(w * 32 + acc_row(r, lane)) * U_LD + l31] = zv;
-        }
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float zv = cmtts_gate(acc[j][r] + bg[r], acc[j][r + 8] + bf[r]);
+                u_lds[(w * 16 + acc_row(r, lane)) * U_LD + j * 32 + l31] = zv;
+            }
     }
     __syncthreads();   // (3) z complete
     stamp(4);
@@ -219,30 +190,19 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
     // =============================================================== phase C: output projection
     {
         zero_acc();
-        f32x4 wr[WL];
-        constexpr int NIT = C / KC;
-        auto load_it = [&](f32x4 (&r)[WL], int it) {
-            it = min(it, NIT - 1);
+        constexpr int NG = C / 8;                              // 32 k-groups
+        f32x4 A[RING];
+        float Bv[2][4][NT];
 #pragma unroll
-            for (int i = 0; i < WL; ++i)
-                r[i] = *reinterpret_cast<const f32x4*>(a.Wo + (long)(it * KC + (64 / LPR) * i + wrow) * (2 * C) + w * WROWS + wcol);
-        };
-        f32x4 wb[WL];
-        load_it(wr, 0);
-        store_w(0, wr);
-        load_it(wr, 1);
-        load_it(wb, 2);
-        __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < NIT; it += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            store_w(1, wr);
-            load_it(wr, it + 3);
-            mma_chunk(0, u_lds + (it * KC) * U_LD + l31);
-            __builtin_amdgcn_sched_barrier(0);
-            store_w(0, wb);
-            load_it(wb, it + 4);
-            mma_chunk(1, u_lds + ((it + 1) * KC) * U_LD + l31);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.Wof, s);
+        load_b(Bv[0], 0, 0);
+        for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                load_a(A[(s + RING - 1) % RING], a.Wof, min(it + s + RING - 1, NG - 1));
+                load_b(Bv[(s + 1) & 1], min(it + s + 1, NG - 1) * 8, 0);
+                mma_group(A[s], Bv[s & 1]);
+            }
         }
         stamp(5);
         float* xout = a.x_out + (long)b * C * T;
@@ -251,23 +211,25 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
         const float* src = res_half ? xin : skip;
         float* dst = res_half ? xout : skip;
         const bool need_src = res_half || a.accum_skip;
-        const int t = t0 + l31;
-        const int t_c = min(t, T - 1);
+        const int mrow0 = (w % (NW / 2)) * 32;                   // row inside the half
+        float bo[16], dd[16];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int mrow0 = (w % (NW / 2)) * WROWS + i * 32;   // row inside the half
-            float sv[16], bo[16], dd[16];
+        for (int r = 0; r < 16; ++r) {
+            bo[r] = a.bo[w * 32 + acc_row(r, lane)];
+            dd[r] = res_half ? dv[mrow0 + acc_row(r, lane)] : 0.f;
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {                       // all gathers first: 48 loads in flight
-                const int mr = mrow0 + acc_row(r, lane);
-                sv[r] = need_src ? src[(unsigned)(mr * T + t_c)] : 0.f;
-                bo[r] = a.bo[w * WROWS + i * 32 + acc_row(r, lane)];
-                dd[r] = res_half ? dv[mr] : 0.f;
-            }
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + j * 32 + l31;
+            const int t_c = min(t, T - 1);
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)             // all gathers first: 16 loads in flight
+                sv[r] = need_src ? src[(unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mr = mrow0 + acc_row(r, lane);
-                const float o = acc[i][r] + bo[r];
+                const float o = acc[j][r] + bo[r];
                 float v;
                 if (res_half) v = (o + (sv[r] + dd[r])) / 1.41421356237309504880f;
                 else v = a.accum_skip ? o + sv[r] : o;
@@ -278,35 +240,36 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
     stamp(6);
 }
 
-}  // namespace
+long long* g_dbg = nullptr;
+int g_force_fn = 0;
 
-static int g_stagger_mode = 0, g_stagger_sleeps = 0;
-static long long* g_dbg = nullptr;
-static unsigned* g_cu_arrivals = nullptr;
-extern "C" void cmtts_resblock_set_debug(long long* dbg) { g_dbg = dbg; }
-extern "C" void cmtts_resblock_set_stagger(int mode, int sleeps) { g_stagger_mode = mode; g_stagger_sleeps = sleeps; }
-
-extern "C" int cmtts_launch_resblock(const ResArgs* a_in, void* stream) {
-    ResArgs a_copy = *a_in;
-    a_copy.stagger_mode = g_stagger_mode;
-    a_copy.stagger_sleeps = g_stagger_sleeps;
-    a_copy.dbg = g_dbg;
-    if (g_stagger_mode == 3 && !g_cu_arrivals) {
-        if (hipMalloc((void**)&g_cu_arrivals, 2048 * sizeof(unsigned)) != hipSuccess) return -3;
-        if (hipMemset(g_cu_arrivals, 0, 2048 * sizeof(unsigned)) != hipSuccess) return -3;
-    }
-    a_copy.cu_arrivals = g_cu_arrivals;
-    const ResArgs* a = &a_copy;
+template <int FN>
+int launch_fn(const ResArgs& a, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(C * U_LD + NW * PRIV) * sizeof(float);
+    const size_t lds = (size_t)(C * (FN + 4)) * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fused_kernel<FN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    if ((long)C * a->T >= (1L << 31)) return -2;
-    dim3 grid((a->T + FN - 1) / FN, a->B);
-    hipLaunchKernelGGL(resblock_fused_kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, *a);
+    dim3 grid((a.T + FN - 1) / FN, a.B);
+    hipLaunchKernelGGL(resblock_fused_kernel<FN>, grid, dim3(64 * NW), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+extern "C" void cmtts_resblock_set_debug(long long* dbg) { g_dbg = dbg; }
+extern "C" void cmtts_resblock_set_tile(int frames) { g_force_fn = frames; }
+
+extern "C" int cmtts_launch_resblock(const ResArgs* a_in, void* stream) {
+    ResArgs a = *a_in;
+    a.dbg = g_dbg;
+    if ((long)C * a.T >= (1L << 31)) return -2;
+    // 64-frame tiles halve the weight bytes per MFMA (the measured wall); 32-frame tiles only when 64-frame
+    // tiles could not even give every CU one workgroup
+    const long tiles64 = (long)((a.T + 63) / 64) * a.B;
+    const bool use32 = g_force_fn ? g_force_fn == 32 : tiles64 < 256;
+    return use32 ? launch_fn<32>(a, (hipStream_t)stream) : launch_fn<64>(a, (hipStream_t)stream);
 }

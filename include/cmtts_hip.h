@@ -130,10 +130,9 @@ int cmtts_profile_begin(int max_launches);
  * the denoiser; both are bitwise identical (tests) — the switch exists for A/B measurement.
  * Returns the previous setting. */
 int cmtts_set_fused_resblock(int on);
-/* Tuning knob of the fused residual block: delay the start of half of the workgroups (mode 1: second
- * half of the grid, 2: odd workgroups, 0: off) by `sleeps` x ~3.4 us so that the two workgroups sharing
- * a CU run out of phase.  Affects speed only, never results. */
-int cmtts_set_stagger(int mode, int sleeps);
+/* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still
+ * yields >= 512 workgroups, else 32).  Affects speed only, never results. */
+int cmtts_set_resblock_tile(int frames);
 /* Debug/tuning: when non-NULL, every workgroup of the fused residual block writes 8 int64 s_memtime
  * stamps (phase boundaries) to dev_buf[workgroup*8 ...]; NULL switches it off. */
 int cmtts_set_debug_stamps(void* dev_buf);

@@ -1,0 +1,75 @@
+// Micro-benchmark: what duty cycle can v_mfma_f32_32x32x2_f32 reach under the operand-delivery
+// patterns of resblock_fused.hip?  Variants: 0 = registers only; 1 = B operand from LDS (ds_read_b32,
+// one k-group ahead); 2 = variant 1 + A operand streamed from global memory (dwordx4 fragment order,
+// 4-deep register ring).  512-thread workgroups, NACC accumulators per wave, grid = 2 per CU.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o /tmp/mfma_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VAR, int NACC>
+__global__ __launch_bounds__(512, 4) void probe(const float* __restrict__ wfrag, float* out, int ngroups) {
+    __shared__ float u[256 * 36];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 256 * 36; i += 512) u[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    f32x4 A[4][2];
+    float B[2][4];
+    const float* wp = wfrag + (long)w * 512 + lane * 4;
+    auto load_a = [&](f32x4 (&d)[2], int g) {
+        if (VAR >= 2) { const float* p = wp + (long)(g & 255) * 4096; d[0] = *(const f32x4*)p; d[1] = *(const f32x4*)(p + 256); }
+        else { d[0] = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(lane + 1); d[1] = d[0]; }
+    };
+    auto load_b = [&](float (&d)[4], int g) {
+        if (VAR >= 1) { const float* bs = u + ((g & 31) * 8 + (lane >> 5)) * 36 + (lane & 31); for (int k = 0; k < 4; ++k) d[k] = bs[2 * k * 36]; }
+        else for (int k = 0; k < 4; ++k) d[k] = (float)(k + lane);
+    };
+    for (int s = 0; s < 3; ++s) load_a(A[s], s);
+    load_b(B[0], 0);
+    for (int g = 0; g < ngroups; g += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_a(A[(s + 3) & 3], g + s + 3);
+            load_b(B[(s + 1) & 1], g + s + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[(i + 2 * kk) % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i][kk], B[s & 1][kk], acc[(i + 2 * kk) % NACC], 0, 0, 0);
+        }
+    }
+    float sum = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) sum += acc[i][r];
+    out[blockIdx.x * 512 + tid] = sum;
+}
+
+template <int VAR, int NACC>
+void run(const float* w, float* out, int blocks) {
+    const int ng = 4096;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe<VAR, NACC>), dim3(blocks), dim3(512), 0, 0, w, out, ng);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe<VAR, NACC>), dim3(blocks), dim3(512), 0, 0, w, out, ng);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 8 /*waves*/ * ng * 8 /*mfma per group*/ * 4096.0;
+    printf("variant %d, %d accumulators, %d workgroups: %.3f ms  %.1f TFLOP/s (%.1f %% of 157.3)\n", VAR, NACC, blocks, ms,
+           flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+}
+
+int main() {
+    float *w, *out;
+    hipMalloc(&w, 256L * 4096 * 4 + 65536); hipMemset(w, 0, 256L * 4096 * 4 + 65536);
+    hipMalloc(&out, 2048L * 512 * 4);
+    for (int blocks : {256, 512}) {
+        run<0, 2>(w, out, blocks); run<0, 4>(w, out, blocks); run<0, 8>(w, out, blocks);
+        run<1, 2>(w, out, blocks); run<1, 8>(w, out, blocks);
+        run<2, 2>(w, out, blocks); run<2, 8>(w, out, blocks);
+    }
+    return 0;
+}

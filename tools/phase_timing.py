@@ -15,7 +15,7 @@ x = torch.randn(B, 1, T, 80, device="cuda"); cond = torch.randn(B, T, 256, devic
 lib = _lib.load()
 for _ in range(2):
     model.net(x, t, cond, None)
-nblk = (T // 32) * B
+nblk = (T // 64) * B        # 64-frame tiles (auto-selected at this size)
 buf = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
 lib.cmtts_set_debug_stamps(buf.data_ptr())
 model.net(x, t, cond, None)      # stamps of the LAST layer remain
