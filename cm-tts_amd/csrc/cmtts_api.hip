@@ -143,6 +143,21 @@ std::vector<float> omega_table(int C) {
     return w;
 }
 
+// Sinusoid table rows 0..rows-1 (row 0 = padding = zeros): fp32 argument p*w_j, sine/cosine in f64 rounded to
+// fp32 — the same recipe the kernels use on the fly beyond the table.
+constexpr int PE_ROWS = 4096;
+std::vector<float> pe_table(int C, int rows) {
+    const std::vector<float> w = omega_table(C);
+    const int half = C / 2;
+    std::vector<float> t((size_t)rows * C, 0.f);
+    for (int p = 1; p < rows; ++p)
+        for (int c = 0; c < C; ++c) {
+            const float arg = (float)p * w[c < half ? c : c - half];
+            t[(size_t)p * C + c] = c < half ? (float)sin((double)arg) : (float)cos((double)arg);
+        }
+    return t;
+}
+
 ConvArgs conv_args(const PackedConv& w, const float* X, int Tin, int ldx, long x_bs, float* Y, int ldy, long y_bs, int N) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -215,6 +230,7 @@ struct cmtts_model {
     bool finalized = false;
     Allocs al;
     float *embed = nullptr, *omega_h = nullptr, *omega_cwt = nullptr, *omega_res = nullptr;
+    float *pe_h = nullptr, *pe_cwt = nullptr;   // sinusoid tables [PE_ROWS][C]
     std::vector<EncLayer> enc;
     float *encln_g = nullptr, *encln_b = nullptr;
     float *spk_wt = nullptr, *spk_b = nullptr;
@@ -292,6 +308,8 @@ int finalize_model(cmtts_model* m) {
     CHK(al.upload(omega_table(H), &m->omega_h));
     CHK(al.upload(omega_table(c.cwt_hidden), &m->omega_cwt));
     CHK(al.upload(omega_table(C), &m->omega_res));
+    CHK(al.upload(pe_table(H, PE_ROWS), &m->pe_h));
+    CHK(al.upload(pe_table(c.cwt_hidden, PE_ROWS), &m->pe_cwt));
 
     const std::string enc = "duration_pitch_energy_net.text_encoder.";
     GET(emb, enc + "embed_tokens.weight", c.n_symbols, H);
@@ -558,8 +576,26 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
     return launch(a, EPI_PLAIN, B, s);
 }
 
+// DiffusionEmbedding -> mlp (Linear, Mish, Linear) -> the 20 stacked diffusion (+ speaker) projections
+// (model/blocks.py:633-640,669-674; model/modules.py:579-583,626-627).  Depends only on the timesteps and
+// the speaker vector, so the sampler re-uses it across evaluations at the same sigma (T = 2, 4: always 80).
+int step_embedding(cmtts_model* m, const DenWs& w, const float* timesteps, const float* spk, int B, hipStream_t s) {
+    const cmtts_config& c = m->cfg;
+    const int C = c.res_channels, NL = c.res_layers;
+    k_diff_embed(timesteps, m->omega_res, w.emb, B, C, s);
+    k_dense_small(w.emb, C, 1, m->mlp0_wt, nullptr, nullptr, w.e1, B, C, 4 * C, DENSE_MISH, s);
+    k_dense_small(w.e1, 4 * C, 1, m->mlp2_wt, nullptr, nullptr, w.e2, B, 4 * C, C, DENSE_NONE, s);
+    k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, nullptr, w.dproj, B, C, NL * C, DENSE_NONE, s);
+    if (c.multi_speaker) {
+        if (!spk) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
+        k_dense_small(spk, c.hidden, 1, m->sproj_wt, nullptr, nullptr, w.sproj, B, c.hidden, NL * C, DENSE_NONE, s);
+        k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, w.sproj, w.dp, B, C, NL * C, DENSE_NONE, s);
+    }
+    return 0;
+}
+
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
-                  const float* cond_ct, const float* spk, int B, int T, hipStream_t s) {
+                  const float* cond_ct, const float* spk, int B, int T, hipStream_t s, bool embed = true) {
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
@@ -569,17 +605,8 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         a.out[0].act = ACT_RELU;   // relu(relu(.)) == relu(.), model/modules.py:575-577,624
         CHK(launch(a, EPI_PLAIN, B, s));
     }
-    k_diff_embed(timesteps, m->omega_res, w.emb, B, C, s);
-    k_dense_small(w.emb, C, 1, m->mlp0_wt, nullptr, nullptr, w.e1, B, C, 4 * C, DENSE_MISH, s);
-    k_dense_small(w.e1, 4 * C, 1, m->mlp2_wt, nullptr, nullptr, w.e2, B, 4 * C, C, DENSE_NONE, s);
-    k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, nullptr, w.dproj, B, C, NL * C, DENSE_NONE, s);
-    const float* dp = w.dproj;
-    if (c.multi_speaker) {
-        if (!spk) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
-        k_dense_small(spk, c.hidden, 1, m->sproj_wt, nullptr, nullptr, w.sproj, B, c.hidden, NL * C, DENSE_NONE, s);
-        k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, w.sproj, w.dp, B, C, NL * C, DENSE_NONE, s);
-        dp = w.dp;
-    }
+    if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s));
+    const float* dp = m->cfg.multi_speaker ? w.dp : w.dproj;
     const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
     float* hcur = w.h;
     float* halt = w.u;
@@ -690,7 +717,7 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     if (!e_pred) e_pred = w.epred;
     if (!e_idx) e_idx = w.eidx;
 
-    k_embed_tokens(texts, src_lens, m->embed, m->omega_h, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
+    k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& E = m->enc[i];
         k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
@@ -765,7 +792,7 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     CHK(predictor_convs(m->dur, w.x, Lp, B, L, Lp, src_lens, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->dur.lin_w, m->dur.lin_b, log_d, src_lens, B, c.pred_filter, L, Lp, 1, s);
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
-    k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, B, H, L, Lp, s);
+    k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, s);
     CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, s);
     k_energy_embed(w.x, e_pred, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1, e_idx, B, H, L, Lp, s);
@@ -797,7 +824,7 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
         ConvArgs a = conv_args(m->cwt_in, w.xlr, T, T, (long)H * T, w.h128, T, (long)CH * T, T);
         CHK(launch(a, EPI_PLAIN, B, s));
     }
-    k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, B, CH, T, T, s);
+    k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
     CHK(predictor_convs(m->cwt, w.hp, T, B, T, T, nullptr, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->cwt.lin_w, m->cwt.lin_b, cwt_out, nullptr, B, c.pred_filter, T, T, O, s);
     // cwt_stats_layers on the first phoneme of output_1    (model/modules.py:212-215,279)
@@ -881,8 +908,9 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
         const float c_out = dm * c.sigma_data / rt;
         const float c_in = 1.0f / rt;
         const float t_resc = 250.0f * logf(sg + 1e-44f);
-        k_fill_float(w.tbuf, t_resc, B, s);
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, s));
+        const bool new_sigma = i == 0 || sigmas[i] != sigmas[i - 1];
+        if (new_sigma) k_fill_float(w.tbuf, t_resc, B, s);
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, s, new_sigma));
         const bool last = i + 1 == n_steps;
         const bool renoise = renoise_std[i] >= 0.0f;
         k_mel_post(w.hin, w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,

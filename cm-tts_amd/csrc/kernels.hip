@@ -13,8 +13,9 @@ __device__ __forceinline__ float cos_exact(float a) { return (float)cos((double)
 
 // Sinusoidal position embedding value (model/blocks.py:45-62): row p = [sin(p*w_j) | cos(p*w_j)],
 // row 0 (padding) is all zeros.  omega[j] = exp(-j*ln(1e4)/(C/2-1)) is precomputed on the host.
-__device__ __forceinline__ float pos_embed(int p, int c, int C, const float* omega) {
+__device__ __forceinline__ float pos_embed(int p, int c, int C, const float* omega, const float* tab, int tab_rows) {
     if (p == 0) return 0.f;
+    if (p < tab_rows) return tab[(long)p * C + c];      // host-built table (same fp32-arg / f64-sin recipe)
     const int half = C >> 1;
     const int j = c < half ? c : c - half;
     const float arg = (float)p * omega[j];
@@ -49,8 +50,8 @@ __device__ void block_positions(FlagFn flag, int T, int* pos, int* counts) {
 
 // ---- FastspeechEncoder.forward_embedding (model/modules.py:145-151) + first mask (:94)
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts, const int64_t* lens,
-                                                           const float* E, const float* omega, float* x,
-                                                           int L, int ld, int C, float scale) {
+                                                           const float* E, const float* omega, const float* tab,
+                                                           int tab_rows, float* x, int L, int ld, int C, float scale) {
     extern __shared__ int sh[];
     int* counts = sh;
     int* pos = sh + 256;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts,
     for (int idx = threadIdx.x; idx < C * L; idx += 256) {
         const int c = idx / L, l = idx - c * L;
         float v = 0.f;
-        if (l < len) v = scale * E[tok[l] * C + c] + pos_embed(pos[l], c, C, omega);
+        if (l < len) v = scale * E[tok[l] * C + c] + pos_embed(pos[l], c, C, omega, tab, tab_rows);
         x[((long)b * C + c) * ld + l] = v;
     }
 }
@@ -139,7 +140,8 @@ __global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int 
 // ---- PitchPredictor/EnergyPredictor input: xs + alpha * PE[positions(xs[...,0] != 0)]
 // (model/modules.py:548-549; the float-zero test on channel 0 is part of the semantics)
 __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, float* out, const float* alpha,
-                                                            const float* omega, int C, int T, int ld) {
+                                                            const float* omega, const float* tab, int tab_rows,
+                                                            int C, int T, int ld) {
     extern __shared__ int sh[];
     int* counts = sh;
     int* pos = sh + 256;
@@ -150,34 +152,50 @@ __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, floa
     for (long idx = threadIdx.x; idx < (long)C * T; idx += 256) {
         const int c = (int)(idx / T), t = (int)(idx - (long)c * T);
         const long off = ((long)b * C + c) * ld + t;
-        out[off] = x[off] + al * pos_embed(pos[t], c, C, omega);
+        out[off] = x[off] + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
     }
 }
 
 // ---- Linear(C -> O<=16) over channel-major input, output time-major [B][T][O]
-// (duration/energy/cwt predictor heads, model/modules.py:505-506,554)
+// (duration/energy/cwt predictor heads, model/modules.py:505-506,554).  Workgroup = 64 positions x 4
+// channel slices (one wave each, 8 independent loads in flight), partial sums meet in LDS.
 __global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const float* W, const float* bias,
                                                           float* out, const int64_t* lens, int C, int T, int ld, int O) {
-    extern __shared__ float wsh[];     // [O][C]
+    extern __shared__ float wsh[];     // [O][C] weights, then [3][16][64] partial sums
+    float* part = wsh + O * C;
     for (int i = threadIdx.x; i < O * C; i += 256) wsh[i] = W[i];
     __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int tl = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
     const int b = blockIdx.y;
-    if (t >= T) return;
+    const int tc = min(t, T - 1);
+    const int cq = C / 4, c0 = cs * cq;
     float acc[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-    const float* xb = x + (long)b * C * ld + t;
-    for (int c = 0; c < C; ++c) {
+    const float* xb = x + (long)b * C * ld + tc;
+#pragma unroll 8
+    for (int c = c0; c < c0 + cq; ++c) {
         const float xv = xb[(long)c * ld];
 #pragma unroll
         for (int o = 0; o < 16; ++o)
             if (o < O) acc[o] = fmaf(xv, wsh[o * C + c], acc[o]);
     }
-    const bool keep = !(lens && (int64_t)t >= lens[b]);
+    if (cs > 0) {
 #pragma unroll
-    for (int o = 0; o < 16; ++o)
-        if (o < O) out[((long)b * T + t) * O + o] = keep ? acc[o] + bias[o] : 0.f;
+        for (int o = 0; o < 16; ++o)
+            if (o < O) part[((cs - 1) * 16 + o) * 64 + tl] = acc[o];
+    }
+    __syncthreads();
+    if (cs == 0 && t < T) {
+        const bool keep = !(lens && (int64_t)t >= lens[b]);
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+            if (o < O) {
+                const float v = ((acc[o] + part[(0 * 16 + o) * 64 + tl]) + part[(1 * 16 + o) * 64 + tl]) + part[(2 * 16 + o) * 64 + tl];
+                out[((long)b * T + t) * O + o] = keep ? v + bias[o] : 0.f;
+            }
+    }
 }
 
 // ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
@@ -461,10 +479,10 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
-void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, const float* omega, float* x,
-                    int B, int L, int ld, int C, float scale, hipStream_t s) {
+void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, const float* omega, const float* tab,
+                    int tab_rows, float* x, int B, int L, int ld, int C, float scale, hipStream_t s) {
     hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), (256 + L) * sizeof(int), s, texts, lens, E, omega,
-                       x, L, ld, C, scale);
+                       tab, tab_rows, x, L, ld, C, scale);
 }
 void k_layernorm_ct(const float* in, float* out, const float* gamma, const float* beta, float eps,
                     const int64_t* lens, int B, int T, int ld, hipStream_t s) {
@@ -476,14 +494,15 @@ void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld
 void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s) {
     hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld);
 }
-void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, int B, int C, int T,
-                     int ld, hipStream_t s) {
-    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, C, T, ld);
+void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
+                     int tab_rows, int B, int C, int T, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, tab,
+                       tab_rows, C, T, ld);
 }
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens, int B,
                    int C, int T, int ld, int O, hipStream_t s) {
-    hipLaunchKernelGGL(chan_linear_kernel, dim3(cdiv(T, 256), B), dim3(256), (size_t)O * C * sizeof(float), s, x, W,
-                       bias, out, lens, C, T, ld, O);
+    hipLaunchKernelGGL(chan_linear_kernel, dim3(cdiv(T, 64), B), dim3(256), (size_t)(O * C + 3 * 16 * 64) * sizeof(float), s,
+                       x, W, bias, out, lens, C, T, ld, O);
 }
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias, const float* add,
                    float* out, int B, int K, int N, int act, hipStream_t s) {
