@@ -338,6 +338,82 @@ def test_full_path_vs_oracle_random_batch():
     assert np.abs(_np(mel) - ref).max() < 1e-3
 
 
+def test_bucketed_ragged_shard_vs_oracle():
+    """BASELINE configs[3] shape of ONE rank: LibriTTS model (multi-speaker, no uv), ragged phoneme lengths,
+    frames padded to the static 1024 bucket (the longest utterance is truncated by the bucket, as the
+    reference's pad() does with mels=x), T = 4.  Integer stages bit-exact, mel < 1e-3 vs the oracle."""
+    host = _host()
+    cfg = get_config("LibriTTS")
+    sd = synth_cmtts_state_dict(cfg, seed=21, dur_frames=6.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(3)
+    lens = np.asarray([171, 90, 133, 40], np.int64)
+    B, L, T = len(lens), 171, 1024
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)
+    st = O.duration_pitch_speaker_net(sd, cfg, texts, lens, spk, max_mel_len=T)
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens),
+                                          spker_embeds=torch.from_numpy(spk), max_mel_len=T)
+    torch.cuda.synchronize()
+    assert st["mel_len"].tolist() == [1026, 540, 798, 240]
+    assert np.array_equal(_np(out["mel_lens"]), st["mel_len"])
+    assert np.array_equal(_np(out["d_rounded"]), st["d_rounded"])
+    ref_m2p = O.dur_to_mel2ph(st["d_rounded"], st["src_mask"], T)
+    assert np.array_equal(_np(out["mel2ph"]), ref_m2p)
+    valid = np.arange(L)[None, :] < lens[:, None]
+    e_same = (_np(out["e_idx"]) == st["e_idx"]) | ~valid
+    p_same = _np(out["p_predictions"]["p_idx"]) == st["p_idx"]
+    assert e_same.mean() > 0.97 and p_same.mean() > 0.97
+    # frames fed by agreeing energy buckets and pitch buckets must match the oracle's conditioning
+    ph = np.clip(ref_m2p - 1, 0, L - 1)
+    ok = p_same & np.take_along_axis(e_same, ph, 1)
+    np.testing.assert_allclose(_np(out["cond"])[ok], st["cond"][ok], atol=1e-4)
+    noise = np.stack([rs.standard_normal(size=(B, 1, T, cfg.n_mels)).astype(np.float32) for _ in range(5)])
+    cond_ct = torch.from_numpy(np.ascontiguousarray(st["cond"].transpose(0, 2, 1))).to(DEV)
+    mel = host.sample_with_cond(model, cond_ct, torch.from_numpy(st["speaker_emb"]).to(DEV), 4,
+                                torch.from_numpy(noise).to(DEV))
+    torch.cuda.synchronize()
+    ref = O.karras_sample_tts_torch(sd, cfg, st["cond"], st["speaker_emb"], 4, list(noise))
+    assert np.abs(_np(mel) - ref).max() < 1e-3
+
+
+def test_end_to_end_wav_multispeaker_batch():
+    """BASELINE configs[2]/[4] shape in fp32: VCTK model, T = 2, universal-vocoder architecture, int16 out.
+    Every utterance of the batch must be bit-identical to synthesising it in a batch of its own padding."""
+    host = _host()
+    cfg = get_config("VCTK")
+    sd = synth_cmtts_state_dict(cfg, seed=8, dur_frames=5.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=8))
+    rs = np.random.RandomState(4)
+    B, L = 16, 24
+    lens = rs.randint(8, L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)
+    T = 5 * L
+    gen = torch.Generator().manual_seed(7)
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+
+    def run(idx):
+        out = model.duration_pitch_energy_net(None, torch.from_numpy(texts[idx]), torch.from_numpy(lens[idx]),
+                                              spker_embeds=torch.from_numpy(spk[idx]), max_mel_len=T)
+        mel = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], 2, noise[:, idx].contiguous())
+        pcm = host.vocoder_infer(mel.transpose(1, 2).contiguous(), voc, lengths=out["mel_lens"].cpu().numpy() * cfg.hop_length)
+        return mel, out["mel_lens"].cpu().numpy(), pcm
+
+    mel, mel_len, pcm = run(np.arange(B))
+    assert torch.isfinite(mel).all() and mel_len.tolist() == (lens * 5).tolist()
+    assert all(p.dtype == np.int16 and p.shape[0] == n * cfg.hop_length for p, n in zip(pcm, mel_len))
+    sub = np.asarray([0, 5, 11])
+    mel_s, _, pcm_s = run(sub)
+    assert torch.equal(mel_s, mel[sub])
+    assert all(np.array_equal(a, pcm[i]) for a, i in zip(pcm_s, sub))
+
+
 def test_denoiser_full_size_properties():
     """cfg2 size (B=32, T=512): no cross-utterance arithmetic exists on the path, so every
     utterance's output must be bit-identical to running it alone; outputs finite; and a sub-batch
