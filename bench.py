@@ -197,6 +197,20 @@ def main():
             d = timed(lambda: step(n), k, 2, 1)
             extras[f"frames_per_s_T{n}"] = round(frames_rank * k / d, 1)
             extras[f"rtf_mel_only_T{n}"] = round((d / k) / audio_s, 6)
+        # north-star shape: 80x1024 frames per utterance (BASELINE.json north_star), same batch of 32, T=4
+        L2, T2 = 171, 1024
+        rs2 = np.random.RandomState(99)
+        texts2 = torch.from_numpy(rs2.randint(1, cfg.n_symbols, size=(BATCH, L2)).astype(np.int64)).to(device)
+        lens2 = torch.full((BATCH,), L2, dtype=torch.int64, device=device)
+        noise2 = torch.randn(N_STEPS + 1, BATCH, 1, T2, cfg.n_mels, device=device)
+
+        def step1024():
+            o = model.duration_pitch_energy_net(None, texts2, lens2, max_mel_len=T2)
+            state["mel1024"] = host.sample_with_cond(model, o["cond_ct"], None, N_STEPS, noise2)
+        k = max(4, args.steps // 2)
+        d = timed(step1024, k, 2, 1)
+        extras["frames_per_s_T4_80x1024"] = round(BATCH * T2 * k / d, 1)      # frames truncated to the 1024 bucket
+        del noise2
         # end to end with the HiFi-GAN generator (fp32), T=4
         hcfg = HifiGanConfig()
         voc = host.Generator(hcfg, device).load_state_dict(synth_hifigan_state_dict(hcfg, seed=0))

@@ -309,6 +309,41 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
     return sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise)
 
 
+def sample_onestep(distiller, x, sigmas, generator=None, **kw):
+    """karras_diffusion.py:801-811 on the generic (unfused) denoise callable."""
+    return distiller(x, sigmas[0] * x.new_ones([x.shape[0]]))
+
+
+def our_multistep(distiller, x, sigmas, generator=None, T=4, **kw):
+    """karras_diffusion.py:814-826: T evaluations at sigma_max without re-noising."""
+    s_in = x.new_ones([x.shape[0]])
+    for _ in range(T):
+        x = distiller(x, sigmas[0] * s_in)
+    return x
+
+
+def stochastic_iterative_sampler(distiller, x, sigmas, generator, ts, t_min=0.002, t_max=80.0, rho=7.0, steps=40, **kw):
+    """karras_diffusion.py:830-854, any `ts` schedule, on the generic denoise callable (SURVEY.md §8f item 3:
+    host-side loops around the same denoiser kernels; the fused cmtts_sample covers synthesize.py's cases)."""
+    t_max_rho, t_min_rho = t_max ** (1 / rho), t_min ** (1 / rho)
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(ts) - 1):
+        t = (t_max_rho + ts[i] / (steps - 1) * (t_min_rho - t_max_rho)) ** rho
+        x0 = distiller(x, t * s_in)
+        next_t = (t_max_rho + ts[i + 1] / (steps - 1) * (t_min_rho - t_max_rho)) ** rho
+        next_t = float(np.clip(next_t, t_min, t_max))
+        x = x0 + generator.randn_like(x) * np.sqrt(next_t ** 2 - t_min ** 2) * 0.85
+    return x
+
+
+def make_distiller(diffusion: "KarrasDenoiser", model: CMTotalTTS, cond, speaker_emb):
+    """denoiser(x_t, sigma) closure of karras_sample_tts (karras_diffusion.py:561-566) over precomputed
+    conditioning: KarrasDenoiser.denoise around CMDenoiserTTS.forward."""
+    def distiller(x_t, sigma):
+        return diffusion.denoise(lambda xx, tt: model.net(xx, tt, cond, speaker_emb), x_t, sigma)[1]
+    return distiller
+
+
 class Generator(torch.nn.Module):
     """hifigan/models.py:112-174 — HiFi-GAN V1 generator; forward(x [B,80,T]) -> [B,1,256*T]."""
 

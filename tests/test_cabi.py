@@ -51,3 +51,26 @@ def test_config_struct_matches_header():
     cfg = cmtts_amd.get_config("VCTK")
     for n, _ in fields:
         assert hasattr(cfg, n), n
+
+
+def test_fold_weight_norm_matches_torch():
+    """Checkpoint importer: weight_g/weight_v pairs of a HiFi-GAN checkpoint fold to the
+    same tensors torch's remove_weight_norm produces (utils/model.py:175-181)."""
+    import numpy as np
+    import torch
+    from torch.nn.utils import weight_norm, remove_weight_norm
+    from cmtts_amd.weights import fold_weight_norm
+    torch.manual_seed(0)
+    conv = weight_norm(torch.nn.Conv1d(6, 4, 3))
+    tconv = weight_norm(torch.nn.ConvTranspose1d(6, 4, 4, 2))
+    with torch.no_grad():
+        conv.weight_g.mul_(1.7)
+        tconv.weight_g.mul_(0.6)
+    sd = {"a." + k: v.detach().numpy() for k, v in conv.state_dict().items()}
+    sd.update({"b." + k: v.detach().numpy() for k, v in tconv.state_dict().items()})
+    folded = fold_weight_norm(sd)
+    remove_weight_norm(conv)
+    remove_weight_norm(tconv)
+    np.testing.assert_allclose(folded["a.weight"], conv.weight.detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(folded["b.weight"], tconv.weight.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert set(folded) == {"a.weight", "a.bias", "b.weight", "b.bias"}

@@ -273,6 +273,36 @@ def test_generic_denoise_path_matches_fused_sampler(models):
     assert err[ok].max() < 1e-3, err[ok].max()
 
 
+def test_host_side_samplers_match_fused(models):
+    """§8(f) item 3: the reference's sampler loops run host-side over the same denoiser kernels; for the
+    schedules synthesize.py uses they must reproduce the fused cmtts_sample result."""
+    host = _host()
+    g, cfg, sd, model = models("VCTK")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    cond = torch.from_numpy(g["cond"]).to(DEV)
+    spk = torch.from_numpy(g["speaker_emb"]).to(DEV)
+    diffusion = host.KarrasDenoiser()
+    dist = host.make_distiller(diffusion, model, cond, spk)
+    x_T = torch.from_numpy(noise[0]).to(DEV) * cfg.sigma_max
+    sig = torch.tensor([cfg.sigma_max, 0.0], device=DEV)
+
+    class Gen:
+        i = 1
+
+        def randn_like(self, x):
+            t = torch.from_numpy(noise[Gen.i]).to(DEV)
+            Gen.i += 1
+            return t
+
+    one = host.sample_onestep(dist, x_T, sig)[:, 0]
+    assert np.abs(_np(one) - g["mel_T1"]).max() < 1e-3
+    multi = host.stochastic_iterative_sampler(dist, x_T, sig, Gen(), ts=(0, 0, 1), steps=2)[:, 0]
+    assert np.abs(_np(multi) - g["mel_T2"]).max() < 1e-3
+    twice = host.our_multistep(dist, x_T, sig, T=2)
+    assert torch.isfinite(twice).all() and tuple(twice.shape) == (B, 1, T, cfg.n_mels)
+
+
 def test_hifigan_golden(golden):
     host = _host()
     g = golden("hifigan")
