@@ -85,18 +85,24 @@ def cpu_baseline(cfg, sd):
     noise = [rs.standard_normal(size=(B, 1, FRAMES_PAD, cfg.n_mels)).astype(np.float32) for _ in range(N_STEPS + 1)]
     O.synthesize(sd, cfg, texts[:1, :8], np.asarray([8]), None, 1,
                  [rs.standard_normal(size=(1, 1, 48, cfg.n_mels)).astype(np.float32)])      # warm BLAS threads
-    best = None
-    for _ in range(3):                 # best of 3 passes (the first also pays one-off weight re-layouts)
-        t0 = time.perf_counter()
-        mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, N_STEPS, noise, max_mel_len=FRAMES_PAD, torch_sampler=True)
-        d = time.perf_counter() - t0
-        best = d if best is None else min(best, d)
-    dt = best
+    # torch-CPU scaling on a 128-thread host is not monotonic for tensors this small: try a few thread
+    # counts (bounded: each pass is ~1-3 s) and report the best one with the thread count it used
+    best, best_threads = None, threads
+    for nt in sorted({min(threads, n) for n in (16, 32, 64, threads)}):
+        torch.set_num_threads(nt)
+        for _ in range(2):
+            t0 = time.perf_counter()
+            mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, N_STEPS, noise, max_mel_len=FRAMES_PAD, torch_sampler=True)
+            d = time.perf_counter() - t0
+            if best is None or d < best:
+                best, best_threads = d, nt
+    torch.set_num_threads(threads)
+    dt, threads = best, best_threads
     O.set_backend("numpy")
     return {"value": round(float(mel_len.sum()) / dt, 1), "unit": "mel-frames/s", "cores": int(threads),
             "kind": "port",
             "sample": f"oracle graph in stock torch-CPU ops (oneDNN/MKL; sampler end-to-end in torch), text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
-                      f"T={N_STEPS}, best of 3 passes = {dt:.2f} s"}
+                      f"T={N_STEPS}, best pass over thread counts {{16,32,64,all}} = {dt:.2f} s"}
 
 
 def main():
