@@ -203,6 +203,13 @@ def main():
             d = timed(lambda: step(n), k, 2, 1)
             extras[f"frames_per_s_T{n}"] = round(frames_rank * k / d, 1)
             extras[f"rtf_mel_only_T{n}"] = round((d / k) / audio_s, 6)
+        # reduced-precision denoiser operands (BASELINE.json configs[2]/[4]); NOT the headline (fp32)
+        for dt in ("bf16", "fp16"):
+            model.set_precision(dt)
+            k = max(4, args.steps // 2)
+            d = timed(step, k, 2, 1)
+            extras[f"frames_per_s_T4_{dt}_resblocks"] = round(frames_rank * k / d, 1)
+        model.set_precision("fp32")
         # north-star shape: 80x1024 frames per utterance (BASELINE.json north_star), same batch of 32, T=4
         L2, T2 = 171, 1024
         rs2 = np.random.RandomState(99)

@@ -60,6 +60,14 @@ struct Allocs {
         *out = (float*)p;
         return 0;
     }
+    int upload_bytes(const void* h, size_t nbytes, void** out) {
+        void* p = nullptr;
+        HIPCHK(hipMalloc(&p, nbytes + 256));
+        HIPCHK(hipMemcpy(p, h, nbytes, hipMemcpyHostToDevice));
+        ptrs.push_back(p);
+        *out = p;
+        return 0;
+    }
     void release() {
         for (void* p : ptrs) (void)hipFree(p);
         ptrs.clear();
@@ -123,6 +131,33 @@ std::vector<float> to_fragment_order(const std::vector<float>& p, int taps, int 
                     for (int j = 0; j < 4; ++j)
                         f[((((size_t)tap * G + g) * MTn + mt) * 64 + lane) * 4 + j] =
                             p[((size_t)tap * K + 8 * g + 2 * j + (lane >> 5)) * M + 32 * mt + (lane & 31)];
+    return f;
+}
+
+inline unsigned short host_cvt16(float f, int mode) {   // mode 1 = bf16 (round to nearest even), 2 = fp16
+    if (mode == 1) {
+        unsigned u;
+        memcpy(&u, &f, 4);
+        return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    const _Float16 h = (_Float16)f;
+    unsigned short r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+// k-major packed weights [taps][K][M] -> 16-bit MFMA A-fragment order for v_mfma_f32_32x32x16_{bf16,f16}:
+// [taps][K/16][M/32][64 lanes][8]: element (lane, j) = P[tap][16g + 8 (lane >> 5) + j][32 mt + (lane & 31)].
+std::vector<unsigned short> to_fragment16(const std::vector<float>& p, int taps, int K, int M, int mode) {
+    std::vector<unsigned short> f((size_t)taps * K * M);
+    const int G = K / 16, MTn = M / 32;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int g = 0; g < G; ++g)
+            for (int mt = 0; mt < MTn; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        f[((((size_t)tap * G + g) * MTn + mt) * 64 + lane) * 8 + j] =
+                            host_cvt16(p[((size_t)tap * K + 16 * g + 8 * (lane >> 5) + j) * M + 32 * mt + (lane & 31)], mode);
     return f;
 }
 
@@ -220,6 +255,7 @@ struct ResLayer {
     PackedConv cond, conv3, outp;
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
+    void *w3f16[2] = {nullptr, nullptr}, *wof16[2] = {nullptr, nullptr};   // bf16 / fp16 fragment-order copies
 };
 
 }  // namespace
@@ -228,6 +264,7 @@ struct cmtts_model {
     cmtts_config cfg;
     std::map<std::string, HostTensor> host;
     bool finalized = false;
+    int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
     Allocs al;
     float *embed = nullptr, *omega_h = nullptr, *omega_cwt = nullptr, *omega_res = nullptr;
     float *pe_h = nullptr, *pe_cwt = nullptr;   // sinusoid tables [PE_ROWS][C]
@@ -415,6 +452,10 @@ int finalize_model(cmtts_model* m) {
             Allocs scratch;                                   // device copy of the k-major form is not needed
             CHK(pack_conv(scratch, *w3, b3, &perm16, &tmp, &hp));
             CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
+            for (int mode = 1; mode <= 2; ++mode) {
+                const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
+                CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].w3f16[mode - 1]));
+            }
             std::vector<float> bperm(2 * C);
             for (int r = 0; r < 2 * C; ++r) bperm[r] = b3->data[perm16[r]];
             CHK(al.upload(bperm, &m->res[l].b3f));
@@ -425,6 +466,10 @@ int finalize_model(cmtts_model* m) {
         GET(wo, p + "output_projection.conv.weight", 2 * C, C, 1); GET(bo, p + "output_projection.conv.bias", 2 * C);
         CHK(pack_conv(al, *wo, bo, nullptr, &m->res[l].outp, &hp));
         CHK(al.upload(to_fragment_order(hp, 1, C, 2 * C), &m->res[l].wof));
+        for (int mode = 1; mode <= 2; ++mode) {
+            const std::vector<unsigned short> f16 = to_fragment16(hp, 1, C, 2 * C, mode);
+            CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].wof16[mode - 1]));
+        }
         GET(wd, p + "diffusion_projection.linear.weight", C, C);
         for (int n = 0; n < C; ++n)
             for (int k = 0; k < C; ++k) dproj[(size_t)k * NL * C + l * C + n] = wd->data[(size_t)n * C + k];
@@ -622,7 +667,15 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             ra.W3f = R.w3f; ra.b3 = R.b3f; ra.Wof = R.wof; ra.bo = R.outp.bias;
             ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0;
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-            if (cmtts_launch_resblock(&ra, (void*)s) != 0) return fail(CMTTS_E_HIP, "fused residual block launch failed");
+            int lrc;
+            if (m->precision == 0) {
+                lrc = cmtts_launch_resblock(&ra, (void*)s);
+            } else {
+                ra.W3f = (const float*)R.w3f16[m->precision - 1];
+                ra.Wof = (const float*)R.wof16[m->precision - 1];
+                lrc = cmtts_launch_resblock_lp(&ra, m->precision, (void*)s);
+            }
+            if (lrc != 0) return fail(CMTTS_E_HIP, "fused residual block launch failed");
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
             float* t = hcur; hcur = halt; halt = t;
             continue;
@@ -1040,6 +1093,12 @@ int cmtts_set_fused_resblock(int on) {
     const int prev = g_fused_resblock ? 1 : 0;
     g_fused_resblock = on != 0;
     return prev;
+}
+
+int cmtts_set_precision(cmtts_model* m, int mode) {
+    if (!m || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
+    m->precision = mode;
+    return 0;
 }
 
 int cmtts_set_resblock_tile(int frames) {

@@ -23,6 +23,7 @@ struct ResArgs {
 extern "C" {
 #endif
 int cmtts_launch_resblock(const ResArgs* a, void* stream);
+int cmtts_launch_resblock_lp(const ResArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16 operands
 void cmtts_resblock_set_tile(int frames);   // 0 = automatic, 32 or 64 = forced frames per workgroup
 void cmtts_resblock_set_debug(long long* dbg);
 #ifdef __cplusplus

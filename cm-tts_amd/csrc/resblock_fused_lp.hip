@@ -1,0 +1,233 @@
+// Reduced-precision variant of the fused denoiser residual block (resblock_fused.hip): the two
+// contractions run on v_mfma_f32_32x32x16_{bf16,f16} (fp32 accumulate, 16x the fp32 MFMA rate); x, cp,
+// x', skip, biases, the gate and the residual arithmetic stay fp32 in HBM and registers.  This is the
+// denoiser of BASELINE.json configs[2] (bf16) and configs[4] (fp16); the reference has no reduced-
+// precision inference path, so parity is stated against the fp32 oracle with its own
+// tolerance (tests/test_gpu_parity.py::test_reduced_precision_denoiser).
+//
+// Layout differences from the fp32 kernel, all forced by the K=16 MFMA fragment (lane l supplies
+// 8 consecutive k of row/column l&31, k half = l>>5):
+//  * u and z live in LDS TRANSPOSED and converted: [frame][channel] 16-bit, row stride 520 B, so a
+//    B fragment is 16 contiguous bytes (two conflict-free ds_read_b64) and a tap is a row offset;
+//  * weights are re-packed per layer as [tap][k-group of 16][m-tile][lane][8 x 16-bit]: one
+//    global_load_dwordx4 per MFMA, streamed L2 -> VGPR through a 4-deep register ring.
+// At this MFMA rate the kernel is bound by the weight fill (1.05 MB per workgroup) and by the HBM
+// bursts, not by the matrix pipe.
+#include <hip/hip_runtime.h>
+#include "gate.h"
+#include "resblock_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int C = 256;
+constexpr int NW = 16;
+constexpr int FN = 64;
+constexpr int NT = FN / 32;
+constexpr int RS = 260;          // 16-bit elements per LDS row (520 B: 8-B aligned rows, bank stride 2 dwords)
+constexpr int RING = 4;
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int MODE>
+__device__ __forceinline__ unsigned cvt16(float f) {
+    if (MODE == 1) {   // bf16, round to nearest even
+        const unsigned u = __float_as_uint(f);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    } else {
+        const _Float16 h = (_Float16)f;
+        return (unsigned)__builtin_bit_cast(unsigned short, h);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if (MODE == 1)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short ut[];   // [FN + 2][RS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FN;
+    const int T = a.T;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* xin = a.x_in + (long)b * C * T;
+    const float* cp = a.cp + (long)b * a.cp_bstride;
+    const float* dp = a.dp + (long)b * a.vec_stride;
+    const float* dv = a.d + (long)b * a.vec_stride;
+
+    // ---- stage u^T[j][m] = cvt(cp + (x + dp)), j = frame - (t0 - 1); lane = frame, waves over channel pairs
+    {
+        const int t = t0 + lane;
+        const int t_c = min(t, T - 1);
+#pragma unroll 1
+        for (int i = 0; i < C / (2 * NW); i += 4) {
+            float x0[4], x1[4], c0[4], c1[4], d0[4], d1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 2 * (w + NW * (i + q));
+                x0[q] = xin[(unsigned)(m * T + t_c)];
+                x1[q] = xin[(unsigned)((m + 1) * T + t_c)];
+                c0[q] = cp[(unsigned)(m * T + t_c)];
+                c1[q] = cp[(unsigned)((m + 1) * T + t_c)];
+                d0[q] = dp[m];
+                d1[q] = dp[m + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 2 * (w + NW * (i + q));
+                const float u0 = c0[q] + (x0[q] + d0[q]);
+                const float u1 = c1[q] + (x1[q] + d1[q]);
+                const unsigned pk = t < T ? (cvt16<MODE>(u0) | (cvt16<MODE>(u1) << 16)) : 0u;
+                *reinterpret_cast<unsigned*>(ut + (1 + lane) * RS + m) = pk;
+            }
+        }
+        if (tid < 2 * C) {
+            const int m = tid & (C - 1);
+            const bool right = tid >= C;
+            const int th = right ? t0 + FN : t0 - 1;
+            const int thc = min(max(th, 0), T - 1);
+            const float uh = cp[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp[m]);
+            ut[(right ? FN + 1 : 0) * RS + m] = (th >= 0 && th < T) ? (unsigned short)cvt16<MODE>(uh) : (unsigned short)0;
+        }
+    }
+    __syncthreads();   // (1) u staged
+
+    f32x16 acc[NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    };
+    auto load_a = [&](u32x4& dst, const void* wfrag, int group) {   // group = tap * 16 + k-group
+        dst = *(reinterpret_cast<const u32x4*>(wfrag) + ((long)group * (2 * C / 32) + w) * 64 + lane);
+    };
+    auto load_b = [&](u32x4 (&dst)[NT], int kg, int row_off) {      // 16 bytes = 8 k-values of one frame
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const unsigned short* p = ut + (j * 32 + l31 + row_off) * RS + kg * 16 + khalf * 8;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
+            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+
+    // =============================================================== phase B: gated k=3 conv, 48 k-groups
+    {
+        zero_acc();
+        constexpr int NG = 3 * (C / 16);
+        u32x4 A[RING], Bv[2][NT];
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.W3f, s);
+        load_b(Bv[0], 0, 0);
+        for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                load_a(A[(s + RING - 1) % RING], a.W3f, min(it + s + RING - 1, NG - 1));
+                const int nx = min(it + s + 1, NG - 1);
+                load_b(Bv[(s + 1) & 1], nx & 15, nx >> 4);      // group = tap * 16 + kg
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[s], Bv[s & 1][j], acc[j]);
+            }
+        }
+    }
+    __syncthreads();   // (2) u dead: its buffer becomes z^T
+    {
+        float bg[8], bf[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int mg = w * 32 + acc_row(r, lane);
+            bg[r] = a.b3[mg];
+            bf[r] = a.b3[mg + 16];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {     // registers r, r+1 = adjacent channels (even first)
+                const float z0 = cmtts_gate(acc[j][r] + bg[r], acc[j][r + 8] + bf[r]);
+                const float z1 = cmtts_gate(acc[j][r + 1] + bg[r + 1], acc[j][r + 9] + bf[r + 1]);
+                const int ch = w * 16 + acc_row(r, lane);
+                *reinterpret_cast<unsigned*>(ut + (j * 32 + l31) * RS + ch) = cvt16<MODE>(z0) | (cvt16<MODE>(z1) << 16);
+            }
+    }
+    __syncthreads();   // (3) z complete
+
+    // =============================================================== phase C: output projection, 16 k-groups
+    {
+        zero_acc();
+        constexpr int NG = C / 16;
+        u32x4 A[RING], Bv[2][NT];
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.Wof, s);
+        load_b(Bv[0], 0, 0);
+        for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                load_a(A[(s + RING - 1) % RING], a.Wof, min(it + s + RING - 1, NG - 1));
+                load_b(Bv[(s + 1) & 1], min(it + s + 1, NG - 1), 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[s], Bv[s & 1][j], acc[j]);
+            }
+        }
+        float* xout = a.x_out + (long)b * C * T;
+        float* skip = a.skip + (long)b * C * T;
+        const bool res_half = w < NW / 2;
+        const float* src = res_half ? xin : skip;
+        float* dst = res_half ? xout : skip;
+        const bool need_src = res_half || a.accum_skip;
+        const int mrow0 = (w % (NW / 2)) * 32;
+        float bo[16], dd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bo[r] = a.bo[w * 32 + acc_row(r, lane)];
+            dd[r] = res_half ? dv[mrow0 + acc_row(r, lane)] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + j * 32 + l31;
+            const int t_c = min(t, T - 1);
+            float sv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sv[r] = need_src ? src[(unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = mrow0 + acc_row(r, lane);
+                const float o = acc[j][r] + bo[r];
+                float v;
+                if (res_half) v = (o + (sv[r] + dd[r])) / 1.41421356237309504880f;
+                else v = a.accum_skip ? o + sv[r] : o;
+                if (t < T) dst[(unsigned)(mr * T + t)] = v;
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_lp(const ResArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)(FN + 2) * RS * sizeof(unsigned short);
+    dim3 grid((a.T + FN - 1) / FN, a.B);
+    hipLaunchKernelGGL(resblock_fused_lp_kernel<MODE>, grid, dim3(64 * NW), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+// mode: 1 = bf16, 2 = fp16 operands.  a->W3f / a->Wof point to the 16-bit fragment-order weights.
+extern "C" int cmtts_launch_resblock_lp(const ResArgs* a, int mode, void* stream) {
+    if ((long)C * a->T >= (1L << 31)) return -2;
+    ResArgs c = *a;
+    c.dbg = nullptr;
+    return mode == 1 ? launch_lp<1>(c, (hipStream_t)stream) : launch_lp<2>(c, (hipStream_t)stream);
+}

@@ -109,6 +109,12 @@ class CMTotalTTS(torch.nn.Module):
     def eval(self):
         return self
 
+    def set_precision(self, dtype="fp32"):
+        """Operand precision of the denoiser residual blocks: "fp32" (reference), "bf16" or "fp16"."""
+        mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}[dtype]
+        _lib.check(self.lib.cmtts_set_precision(self._h, mode))
+        return self
+
     def _require(self):
         if not self._ready:
             raise RuntimeError("CMTotalTTS: load_state_dict() first")

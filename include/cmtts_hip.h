@@ -130,6 +130,11 @@ int cmtts_profile_begin(int max_launches);
  * the denoiser; both are bitwise identical (tests) — the switch exists for A/B measurement.
  * Returns the previous setting. */
 int cmtts_set_fused_resblock(int on);
+/* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
+ * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
+ * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4]. */
+int cmtts_set_precision(cmtts_model* m, int mode);
+
 /* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still
  * yields >= 512 workgroups, else 32).  Affects speed only, never results. */
 int cmtts_set_resblock_tile(int frames);
