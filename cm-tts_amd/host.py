@@ -425,6 +425,42 @@ def transpose_last2(x):
     return out
 
 
+class StreamPipelinedSynthesizer:
+    """Throughput mode for a stream of batches: the phoneme/frame-level conditioning of batch i+1 (many small,
+    latency-bound launches that cannot fill 256 CUs) runs on a second HIP stream underneath the MFMA-bound
+    sampler of batch i.  Same kernels, same results per batch; only the issue order across batches changes."""
+
+    def __init__(self, model: CMTotalTTS, n_steps=4):
+        self.model, self.n_steps = model, n_steps
+        self.side = torch.cuda.Stream(device=model.device)
+        self.ready = None          # (event, out_dict) of the batch whose conditioning is already computed
+        self._keep = []
+
+    def prepare(self, texts, src_lens, spker_embeds=None, max_mel_len=None):
+        main = torch.cuda.current_stream(self.model.device)
+        self.side.wait_stream(main)                       # inputs / workspaces written on main are visible
+        with torch.cuda.stream(self.side):
+            out = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spker_embeds,
+                                                       max_mel_len=max_mel_len)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.ready = (ev, out)
+
+    def sample_and_prepare_next(self, noise, next_batch):
+        """Sample the prepared batch on the current stream while `next_batch` = (texts, src_lens, spk,
+        max_mel_len) is conditioned on the side stream.  Returns (mel, mel_lens) of the prepared batch."""
+        ev, out = self.ready
+        torch.cuda.current_stream(self.model.device).wait_event(ev)
+        for v in (out["cond_ct"], out["speaker_emb"]):
+            if v is not None:
+                v.record_stream(torch.cuda.current_stream(self.model.device))
+        self._keep = [out]
+        if next_batch is not None:
+            self.prepare(*next_batch)
+        mel = sample_with_cond(self.model, out["cond_ct"], out["speaker_emb"], self.n_steps, noise)
+        return mel, out["mel_lens"]
+
+
 class CMTotalTTSSynthesize:
     """synthesize.py:35-153.  The reference reloads the checkpoint for every batch (:203-206); here
     the model object is built once and handed in."""
