@@ -51,6 +51,7 @@ SIGNATURES = {
     "cmtts_set_fused_resblock": (_i, [_i]),
     "cmtts_set_resblock_tile": (_i, [_i]),
     "cmtts_set_precision": (_i, [_vp, _i]),
+    "cmtts_vocoder_set_precision": (_i, [_vp, _i]),
     "cmtts_set_debug_stamps": (_i, [_vp]),
     "cmtts_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -292,6 +292,8 @@ struct cmtts_vocoder {
     int rb_kernel[3] = {3, 7, 11};
     int rb_dil[3] = {1, 3, 5};
     PackedConv c1[12][3], c2[12][3];
+    void *c1f[12][3][2] = {}, *c2f[12][3][2] = {};   // bf16 / fp16 fragment-order copies of the ResBlock convs
+    int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
     float *post_w = nullptr, *post_b = nullptr;
     int post_cin = 32, post_k = 7;
 };
@@ -1006,8 +1008,17 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 GETV(b1, p + ".convs1." + std::to_string(mi) + ".bias", co);
                 GETV(w2, p + ".convs2." + std::to_string(mi) + ".weight", co, co, v->rb_kernel[j]);
                 GETV(b2, p + ".convs2." + std::to_string(mi) + ".bias", co);
-                CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi]));
-                CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi]));
+                std::vector<float> hp;
+                CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
+                }
+                CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
+                }
             }
         }
         ch = co;
@@ -1070,13 +1081,23 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 const int dil = v->rb_dil[mi];
                 ConvArgs a = conv_args(v->c1[r][mi], xr, To, To, cs, bufT, To, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
-                CHK(launch(a, EPI_PLAIN, B, s));
+                if (v->precision) {
+                    if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
+                        return fail(CMTTS_E_HIP, "conv16 launch failed");
+                } else {
+                    CHK(launch(a, EPI_PLAIN, B, s));
+                }
                 const bool lastm = mi == 2;
                 ConvArgs b = conv_args(v->c2[r][mi], bufT, To, To, cs, lastm ? bufS : bufR, To, cs, To);
                 b.pre_slope = 0.1f;
                 b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = To;
                 b.out[0].accum = lastm && j > 0;
-                CHK(launch(b, EPI_PLAIN, B, s));
+                if (v->precision) {
+                    if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
+                        return fail(CMTTS_E_HIP, "conv16 launch failed");
+                } else {
+                    CHK(launch(b, EPI_PLAIN, B, s));
+                }
                 xr = bufR;
             }
         }
@@ -1098,6 +1119,12 @@ int cmtts_set_fused_resblock(int on) {
 int cmtts_set_precision(cmtts_model* m, int mode) {
     if (!m || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
     m->precision = mode;
+    return 0;
+}
+
+int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode) {
+    if (!v || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
+    v->precision = mode;
     return 0;
 }
 

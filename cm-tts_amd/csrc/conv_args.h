@@ -56,6 +56,8 @@ extern "C" {
 // Chooses the tile configuration from (M, N, taps*|dil|) and launches on `stream`.  epi = ConvEpi.
 // Returns 0 or a negative cmtts status.
 int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
+// 16-bit-operand variant (conv_mfma16.hip): wfrag = fragment-order weights, mode 1 = bf16, 2 = fp16.
+int cmtts_launch_conv16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
 #ifdef __cplusplus
 }
 #endif

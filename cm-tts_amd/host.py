@@ -95,9 +95,9 @@ class CMTotalTTS(torch.nn.Module):
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and C is not None:      # C is None during interpreter teardown
             self.lib.cmtts_destroy(h)
-            self._h = C.c_void_p()
+            self._h = None
 
     def load_state_dict(self, state_dict, strict=True):
         with torch.cuda.device(self.device):
@@ -365,9 +365,9 @@ class Generator(torch.nn.Module):
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and C is not None:
             self.lib.cmtts_vocoder_destroy(h)
-            self._h = C.c_void_p()
+            self._h = None
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts plain weights or weight_g/weight_v pairs (folded like remove_weight_norm)."""
@@ -382,6 +382,12 @@ class Generator(torch.nn.Module):
         return self
 
     def remove_weight_norm(self):
+        return self
+
+    def set_precision(self, dtype="fp32"):
+        """Operand precision of the ResBlock convs: "fp32" (reference), "bf16" or "fp16"."""
+        mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}[dtype]
+        _lib.check(self.lib.cmtts_vocoder_set_precision(self._h, mode))
         return self
 
     def eval(self):

@@ -134,6 +134,9 @@ int cmtts_set_fused_resblock(int on);
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
  * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4]. */
 int cmtts_set_precision(cmtts_model* m, int mode);
+/* Same switch for the HiFi-GAN ResBlock convs (94 % of the generator's FLOPs); conv_pre, the transposed
+ * convs, conv_post and all activations in HBM stay fp32. */
+int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode);
 
 /* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still
  * yields >= 512 workgroups, else 32).  Affects speed only, never results. */

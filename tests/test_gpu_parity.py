@@ -520,6 +520,27 @@ def test_reduced_precision_denoiser(models, dtype, tol):
     assert err.max() > 1e-6          # it really ran in reduced precision
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 5e-2), ("fp16", 6e-3)])
+def test_reduced_precision_vocoder(golden, dtype, tol):
+    """HiFi-GAN ResBlock convs with 16-bit MFMA operands (BASELINE configs[2]); stated tolerance on the wav in
+    (-1, 1) against the fp32 golden: bf16 5e-2, fp16 6e-3 (measured error printed)."""
+    host = _host()
+    g = golden("hifigan")
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=int(g["seed"])))
+    mel_ct = torch.from_numpy(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)))
+    ref = voc(mel_ct)
+    voc.set_precision(dtype)
+    lo = voc(mel_ct)
+    voc.set_precision("fp32")
+    again = voc(mel_ct)
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref)
+    err = np.abs(_np(lo) - g["wav"])
+    print(f"vocoder {dtype}: max |dwav| {err.max():.2e}, mean {err.mean():.2e}")
+    assert torch.isfinite(lo).all() and 1e-7 < err.max() < tol, err.max()
+
+
 def test_hifigan_vs_oracle_other_shape():
     host = _host()
     hcfg = HifiGanConfig()
