@@ -290,29 +290,129 @@ def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
 def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, progress=False, callback=None,
                       model_kwargs=None, device=None, sigma_min=0.002, sigma_max=80, rho=7.0, sampler="onestep",
                       generator=None, ts=None, **unused):
-    """karras_diffusion.py:480-577 for the samplers synthesize.py selects: "onestep", and
-    "multistep" with steps=2, ts=(0,)*T+(1,).  The duration net runs once (bit-identical to the
-    reference's per-step re-run) with max_mel_len = shape[2]."""
+    """karras_diffusion.py:480-577.  "onestep" and "multistep" with steps=2, ts=(0,)*T+(1,) (what
+    synthesize.py selects) run fused in cmtts_sample; "heun", "dpm", "euler", "ancestral" and
+    "our_multistep" run the reference's loops host-side around the denoiser kernels (s_churn, s_tmin,
+    s_tmax, s_noise, T as keywords).  The duration net runs once (bit-identical to the reference's
+    per-evaluation re-run) with max_mel_len = shape[2]."""
     if generator is None:
         generator = DummyGenerator()
     B, one, T, M = shape
+    ode = sampler in ("heun", "dpm", "euler", "ancestral", "our_multistep")
     if sampler == "onestep":
         n_steps = 1
     elif sampler == "multistep":
         if steps != 2 or ts is None or tuple(ts[:-1]) != (0,) * (len(ts) - 1) or ts[-1] != 1:
-            raise NotImplementedError("only the schedules synthesize.py:122-147 uses: steps=2, ts=(0,...,0,1)")
+            raise NotImplementedError("fused multistep covers the schedules synthesize.py:122-147 uses: steps=2, "
+                                      "ts=(0,...,0,1); use stochastic_iterative_sampler for other ts")
         n_steps = len(ts) - 1
-    else:
-        raise NotImplementedError(f"sampler {sampler!r} is never selected by synthesize.py")
+    elif not ode:
+        raise NotImplementedError(f"sampler {sampler!r}: progdist is a training-time schedule (SURVEY.md §2)")
     dev = model.device
     kw = dict(model_kwargs or {})
     out = model.duration_pitch_energy_net(kw.get("speakers"), kw["texts"], kw["src_lens"],
                                           spker_embeds=kw.get("spker_embeds"), max_mel_len=T)
+    if ode:
+        # the reference's other loops (karras_diffusion.py:538-577), host-side around the denoiser kernels
+        sigmas = get_sigmas_karras(steps, sigma_min, sigma_max, rho)
+        x_T = _f32(generator.randn(*shape, device=dev), dev) * sigma_max
+        dist = make_distiller(diffusion, model, out_cond(out), out["speaker_emb"])
+        fn = {"heun": sample_heun, "dpm": sample_dpm, "euler": sample_euler, "ancestral": sample_euler_ancestral,
+              "our_multistep": our_multistep}[sampler]
+        args = {}
+        if sampler in ("heun", "dpm"):
+            args = {k: unused[k] for k in ("s_churn", "s_tmin", "s_tmax", "s_noise") if k in unused}
+        elif sampler == "our_multistep":
+            args = {"T": unused.get("T", 4)}
+        return fn(dist, x_T, sigmas, generator, **args)[:, 0]
     draws = [generator.randn(*shape, device=dev)]
     for _ in range(n_steps if n_steps > 1 else 0):
         draws.append(generator.randn_like(draws[0]))
     noise = torch.stack([_f32(d, dev) for d in draws], 0)
     return sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise)
+
+
+def out_cond(out):
+    """[B,T,H] view of the duration net's channel-major conditioning (what CMDenoiserTTS.forward takes)."""
+    return out["cond_ct"].transpose(1, 2)
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0, device="cpu"):
+    """karras_diffusion.py:580-586 (fp32, trailing 0).  Kept on the host: the loops branch on its values."""
+    ramp = torch.linspace(0, 1, n)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return torch.cat([(hi + ramp * (lo - hi)) ** rho, torch.zeros(1)])
+
+
+def to_d(x, sigma, denoised):
+    """karras_diffusion.py:589-591."""
+    return (x - denoised) / float(sigma)
+
+
+def get_ancestral_step(sigma_from, sigma_to):
+    """karras_diffusion.py:594-601."""
+    sigma_up = (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def sample_euler(denoiser, x, sigmas, generator=None, **kw):
+    """karras_diffusion.py:743-771."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        d = to_d(x, sigmas[i], denoiser(x, float(sigmas[i]) * s_in))
+        x = x + d * float(sigmas[i + 1] - sigmas[i])
+    return x
+
+
+def sample_euler_ancestral(denoiser, x, sigmas, generator, **kw):
+    """karras_diffusion.py:605-632."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, float(sigmas[i]) * s_in)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1])
+        d = to_d(x, sigmas[i], denoised)
+        x = x + d * float(sigma_down - sigmas[i])
+        x = x + generator.randn_like(x) * float(sigma_up)
+    return x
+
+
+def _churn(x, sigmas, i, generator, s_churn, s_tmin, s_tmax, s_noise):
+    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+    eps = generator.randn_like(x) * s_noise          # drawn every iteration, like the reference
+    sigma_hat = sigmas[i] * (gamma + 1)
+    if gamma > 0:
+        x = x + eps * float((sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5)
+    return x, sigma_hat
+
+
+def sample_heun(denoiser, x, sigmas, generator, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, **kw):
+    """karras_diffusion.py:693-739 (Algorithm 2 of Karras et al. 2022)."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        x, sigma_hat = _churn(x, sigmas, i, generator, s_churn, s_tmin, s_tmax, s_noise)
+        d = to_d(x, sigma_hat, denoiser(x, float(sigma_hat) * s_in))
+        dt = float(sigmas[i + 1] - sigma_hat)
+        if sigmas[i + 1] == 0:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            d_2 = to_d(x_2, sigmas[i + 1], denoiser(x_2, float(sigmas[i + 1]) * s_in))
+            x = x + (d + d_2) / 2 * dt
+    return x
+
+
+def sample_dpm(denoiser, x, sigmas, generator, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, **kw):
+    """karras_diffusion.py:775-820 (midpoint on a rho=3 schedule)."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        x, sigma_hat = _churn(x, sigmas, i, generator, s_churn, s_tmin, s_tmax, s_noise)
+        d = to_d(x, sigma_hat, denoiser(x, float(sigma_hat) * s_in))
+        sigma_mid = ((sigma_hat ** (1 / 3) + sigmas[i + 1] ** (1 / 3)) / 2) ** 3
+        x_2 = x + d * float(sigma_mid - sigma_hat)
+        d_2 = to_d(x_2, sigma_mid, denoiser(x_2, float(sigma_mid) * s_in))
+        x = x + d_2 * float(sigmas[i + 1] - sigma_hat)
+    return x
 
 
 def sample_onestep(distiller, x, sigmas, generator=None, **kw):

@@ -461,6 +461,73 @@ def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise):
     return x[:, 0]
 
 
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
+    """karras_diffusion.py:580-586: the Karras et al. (2022) schedule, n sigmas + a trailing 0, fp32 like
+    th.linspace."""
+    ramp = np.linspace(0, 1, n, dtype=F32)
+    lo, hi = F32(sigma_min ** (1 / rho)), F32(sigma_max ** (1 / rho))
+    sig = ((hi + ramp * (lo - hi)).astype(F32) ** F32(rho)).astype(F32)
+    return np.concatenate([sig, np.zeros(1, F32)])
+
+
+def ode_samplers(denoiser, x, sigmas, noise, sampler, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0):
+    """The ODE/SDE sampler loops of karras_diffusion.py around any denoiser(x, sigma[B]) -> x0:
+    "euler" :743-771, "heun" :693-739, "dpm" :775-820, "ancestral" :605-632.  `noise` is the list of
+    N(0,1) draws handed out in call order (heun/dpm draw one per iteration even with s_churn = 0;
+    ancestral adds one per iteration).  fp32 throughout, like the reference's tensors."""
+    x = x.astype(F32)
+    s_in = np.ones((x.shape[0],), F32)
+    n = len(sigmas) - 1
+    draws = iter(noise)
+    to_d = lambda xx, sg, den: ((xx - den) / F32(sg)).astype(F32)
+    for i in range(n):
+        if sampler == "euler":
+            d = to_d(x, sigmas[i], denoiser(x, sigmas[i] * s_in))
+            x = (x + d * F32(sigmas[i + 1] - sigmas[i])).astype(F32)
+        elif sampler == "ancestral":
+            den = denoiser(x, sigmas[i] * s_in)
+            sf, st = F32(sigmas[i]), F32(sigmas[i + 1])
+            up = F32((st ** 2 * (sf ** 2 - st ** 2) / sf ** 2) ** F32(0.5))
+            down = F32((st ** 2 - up ** 2) ** F32(0.5))
+            d = to_d(x, sf, den)
+            x = (x + d * F32(down - sf)).astype(F32)
+            x = (x + next(draws).astype(F32) * up).astype(F32)
+        elif sampler in ("heun", "dpm"):
+            gamma = min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+            eps = (next(draws).astype(F32) * F32(s_noise)).astype(F32)
+            sigma_hat = F32(sigmas[i] * F32(gamma + 1))
+            if gamma > 0:
+                x = (x + eps * F32((sigma_hat ** 2 - sigmas[i] ** 2) ** F32(0.5))).astype(F32)
+            d = to_d(x, sigma_hat, denoiser(x, sigma_hat * s_in))
+            if sampler == "heun":
+                dt = F32(sigmas[i + 1] - sigma_hat)
+                if sigmas[i + 1] == 0:
+                    x = (x + d * dt).astype(F32)
+                else:
+                    x2 = (x + d * dt).astype(F32)
+                    d2 = to_d(x2, sigmas[i + 1], denoiser(x2, sigmas[i + 1] * s_in))
+                    x = (x + ((d + d2) / F32(2)).astype(F32) * dt).astype(F32)
+            else:
+                third = F32(1.0 / 3.0)
+                mid = F32(((sigma_hat ** third + F32(sigmas[i + 1]) ** third) / F32(2)) ** F32(3))
+                x2 = (x + d * F32(mid - sigma_hat)).astype(F32)
+                d2 = to_d(x2, mid, denoiser(x2, mid * s_in))
+                x = (x + d2 * F32(sigmas[i + 1] - sigma_hat)).astype(F32)
+        else:
+            raise ValueError(sampler)
+    return x
+
+
+def karras_sample_tts_ode(sd, cfg, cond, speaker_emb, sampler, steps, noise, **kw):
+    """karras_sample_tts (karras_diffusion.py:480-577) with sampler in {"euler", "heun", "dpm", "ancestral"}:
+    sigmas = get_sigmas_karras(steps), x_T = noise[0] * sigma_max, remaining draws feed the loop.
+    Returns mel [B,T,80]."""
+    sig = get_sigmas_karras(steps, cfg.sigma_min, cfg.sigma_max, cfg.rho)
+    den = lambda x, s: karras_denoise(sd, cfg, x, s, cond, speaker_emb)
+    x = (noise[0] * F32(cfg.sigma_max)).astype(F32)
+    return ode_samplers(den, x, sig, noise[1:], sampler, **kw)[:, 0]
+
+
 def karras_sample_tts_torch(sd, cfg, cond, speaker_emb, n_steps, noise):
     """Same computation as karras_sample_tts/denoiser_forward, written end-to-end in stock torch CPU ops
     (multi-threaded conv/GEMM *and* element-wise kernels) — the layer graph a PyTorch-CPU run of the

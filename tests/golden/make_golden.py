@@ -235,6 +235,37 @@ def golden_hifigan():
                         pcm0=pcm[0], pcm1=pcm[1], seed=np.int64(GOLDEN_SEED))
 
 
+def golden_samplers():
+    """The reference's other sampler loops (karras_diffusion.py: sample_euler :743, sample_heun :693,
+    sample_dpm :775, sample_euler_ancestral :605) run through karras_sample_tts on the LJSpeech golden
+    model and inputs (same seed, weights and noise draws as cmtts_LJSpeech.npz)."""
+    from model.cm_tool.karras_diffusion import karras_sample_tts
+    variant = "LJSpeech"
+    cfg = get_config(variant)
+    g = np.load(os.path.join(HERE, f"cmtts_{variant}.npz"))
+    seed = int(g["seed"])
+    model, diffusion = build_reference_model(variant, cfg)
+    sd = synth_cmtts_state_dict(cfg, seed=seed, dur_frames=4.0, dur_spread=0.03)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    t_texts, t_lens = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
+    speakers = torch.zeros(len(FIX_LENS), dtype=torch.long)
+    B, T, _ = g["cond"].shape
+    noise = draw_noise(seed, (B, 1, T, cfg.n_mels), 5)
+    kwargs = dict(speakers=speakers, texts=t_texts, src_lens=t_lens, spker_embeds=None)
+    out = {"seed": np.int64(seed)}
+    with torch.no_grad():
+        for sampler, steps in (("euler", 3), ("heun", 3), ("dpm", 2), ("ancestral", 3)):
+            gen = FixedNoise([torch.from_numpy(n) for n in noise])
+            mel = karras_sample_tts(diffusion=diffusion, model=model, shape=(B, 1, T, cfg.n_mels), steps=steps,
+                                    model_kwargs=kwargs, device="cpu", sigma_max=cfg.sigma_max,
+                                    sigma_min=cfg.sigma_min, rho=cfg.rho, sampler=sampler, generator=gen)
+            out[f"mel_{sampler}"] = mel.numpy()
+            out[f"steps_{sampler}"] = np.int64(steps)
+            out[f"draws_{sampler}"] = np.int64(gen.i)
+            print(f"[samplers] {sampler} steps={steps} draws={gen.i} |mel| {np.abs(out['mel_' + sampler]).mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, f"samplers_{variant}.npz"), **out)
+
+
 def golden_text():
     """Vocabulary table (360 symbols -> ids, text/symbols.py:21-29) and text_to_sequence outputs
     (text/__init__.py:15-41) for val.txt-style `{ARPAbet}` lines (dataset.py:271-283)."""
@@ -258,7 +289,13 @@ def golden_text():
 if __name__ == "__main__":
     torch.manual_seed(0)
     import_reference()
-    for v in ("LJSpeech", "VCTK", "LibriTTS"):
-        golden_cmtts(v)
-    golden_hifigan()
-    golden_text()
+    only = sys.argv[1:]          # e.g. `make_golden.py samplers` regenerates one fixture
+    if not only or "cmtts" in only:
+        for v in ("LJSpeech", "VCTK", "LibriTTS"):
+            golden_cmtts(v)
+    if not only or "hifigan" in only:
+        golden_hifigan()
+    if not only or "text" in only:
+        golden_text()
+    if not only or "samplers" in only:
+        golden_samplers()

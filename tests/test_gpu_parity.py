@@ -303,6 +303,41 @@ def test_host_side_samplers_match_fused(models):
     assert torch.isfinite(twice).all() and tuple(twice.shape) == (B, 1, T, cfg.n_mels)
 
 
+@pytest.mark.parametrize("sampler", ["euler", "heun", "dpm", "ancestral"])
+def test_ode_samplers_golden(models, golden, sampler):
+    """§8(f) item 3: karras_sample_tts(sampler=euler|heun|dpm|ancestral) — the reference's other loops run
+    host-side around the HIP denoiser — against the reference's own output for the same noise draws."""
+    host = _host()
+    g, cfg, sd, model = models("LJSpeech")
+    gs = golden("samplers_LJSpeech")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        def __init__(self):
+            self.i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[self.i]).to(DEV)
+            self.i += 1
+            assert tuple(t.shape) == tuple(shape)
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    gen = Gen()
+    kwargs = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]))
+    mel = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=int(gs["steps_" + sampler]),
+                                 model_kwargs=kwargs, sigma_min=cfg.sigma_min, sigma_max=cfg.sigma_max, rho=cfg.rho,
+                                 sampler=sampler, generator=gen)
+    torch.cuda.synchronize()
+    assert gen.i == int(gs["draws_" + sampler])          # same number of noise draws as the reference
+    ref = gs["mel_" + sampler]
+    # fp32; the ODE steps divide by sigma, so the bound scales with the output (|mel| up to ~13 for heun)
+    np.testing.assert_allclose(_np(mel), ref, atol=1e-3, rtol=2e-4)
+
+
 def test_hifigan_golden(golden):
     host = _host()
     g = golden("hifigan")

@@ -113,3 +113,28 @@ def test_torch_backend_agrees_with_numpy_backend(golden):
     np.testing.assert_allclose(mel, g["mel_T2"], atol=2e-4)
     np.testing.assert_array_equal(st["mel_len"], g["mel_len"])
     np.testing.assert_array_equal(st["mel2ph"], g["mel2ph"])
+
+
+@pytest.mark.parametrize("sampler", ["euler", "heun", "dpm", "ancestral"])
+def test_ode_samplers(golden, sampler):
+    """the reference's other sampler loops (sample_euler/heun/dpm/euler_ancestral)
+    around the same denoiser, against karras_sample_tts of the reference on the LJSpeech golden model."""
+    g, cfg, sd = _setup(golden, "LJSpeech")
+    gs = golden("samplers_LJSpeech")
+    assert int(gs["seed"]) == int(g["seed"])
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    mel = O.karras_sample_tts_ode(sd, cfg, g["cond"], None, sampler, int(gs["steps_" + sampler]), noise)
+    ref = gs["mel_" + sampler]
+    assert mel.shape == ref.shape
+    # the ODE steps divide by sigma down to 0.002-scale values: fp32 roundoff of the denoiser is amplified,
+    # so the bound is relative to the output scale (|mel| up to ~10)
+    np.testing.assert_allclose(mel, ref, atol=1e-3, rtol=1e-4)
+
+
+def test_sigmas_karras():
+    s = O.get_sigmas_karras(5, 0.002, 80.0, 7.0)
+    assert s.dtype == np.float32 and s.shape == (6,) and s[-1] == 0
+    np.testing.assert_allclose(s[0], 80.0, rtol=1e-6)
+    np.testing.assert_allclose(s[4], 0.002, rtol=1e-5)
+    assert np.all(np.diff(s) < 0)
