@@ -21,6 +21,12 @@ class CMTTSConfigStruct(C.Structure):
             "cwt_std_scale", "pitch_norm_eps", "sigma_min", "sigma_max", "sigma_data", "rho")]
 
 
+class VarianceControlsStruct(C.Structure):
+    """struct cmtts_variance_controls (include/cmtts_hip.h): device pointers as void*."""
+    _fields_ = [("p_control", C.c_float), ("e_control", C.c_float), ("d_target", C.c_void_p), ("e_target", C.c_void_p),
+                ("cwt_spec", C.c_void_p), ("f0_mean", C.c_void_p), ("f0_std", C.c_void_p), ("uv", C.c_void_p)]
+
+
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes); must list every symbol include/cmtts_hip.h declares
@@ -33,6 +39,7 @@ SIGNATURES = {
     "cmtts_destroy": (None, [_vp]),
     "cmtts_text_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_set_variance_controls": (_i, [_vp, C.POINTER(VarianceControlsStruct)]),
     "cmtts_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_frame_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_length_regulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

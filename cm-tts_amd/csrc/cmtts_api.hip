@@ -265,6 +265,7 @@ struct cmtts_model {
     std::map<std::string, HostTensor> host;
     bool finalized = false;
     int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
+    cmtts_variance_controls vc = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Allocs al;
     float *embed = nullptr, *omega_h = nullptr, *omega_cwt = nullptr, *omega_res = nullptr;
     float *pe_h = nullptr, *pe_cwt = nullptr;   // sinusoid tables [PE_ROWS][C]
@@ -850,8 +851,14 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, s);
     CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, s);
-    k_energy_embed(w.x, e_pred, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1, e_idx, B, H, L, Lp, s);
-    k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
+    k_energy_embed(w.x, e_pred, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1,
+                   e_idx, B, H, L, Lp, s);
+    if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
+        HIPCHK(hipMemcpyAsync(d_rounded, m->vc.d_target, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
+        k_cumsum_durations(m->vc.d_target, w.cum, mel_len, B, L, s);
+    } else {
+        k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -886,7 +893,14 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
     k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, s);
     k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, s);
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, s);
-    k_pitch_index(cwt_out, O, c.use_uv, f0_stats, c.cwt_std_scale, c.pitch_norm_eps, w.r, p_idx, f0_denorm, B, T, s);
+    if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
+    if (m->vc.cwt_spec) {   // teacher-forced pitch: target spectrogram, statistics and uv (:379-390)
+        k_pitch_index(m->vc.cwt_spec, 10, m->vc.f0_mean, m->vc.f0_std, 1, 1.0f, nullptr, 0, c.use_uv ? m->vc.uv : nullptr,
+                      c.pitch_norm_eps, w.r, p_idx, f0_denorm, B, T, s);
+    } else {
+        k_pitch_index(cwt_out, O, f0_stats, f0_stats + 1, 2, c.cwt_std_scale, c.use_uv ? cwt_out + (O - 1) : nullptr, O, nullptr,
+                      c.pitch_norm_eps, w.r, p_idx, f0_denorm, B, T, s);
+    }
     k_gather_add(w.xlr, p_idx, m->pitch_emb, cond_ct, B, H, T, s);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1125,6 +1139,18 @@ int cmtts_set_fused_resblock(int on) {
 int cmtts_set_precision(cmtts_model* m, int mode) {
     if (!m || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
     m->precision = mode;
+    return 0;
+}
+
+int cmtts_set_variance_controls(cmtts_model* m, const cmtts_variance_controls* vc) {
+    if (!m) return fail(CMTTS_E_INVALID, "cmtts_set_variance_controls: null model");
+    const cmtts_variance_controls off = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!vc) { m->vc = off; return 0; }
+    if (!(vc->p_control > 0.f) || !(vc->e_control == vc->e_control))
+        return fail(CMTTS_E_INVALID, "cmtts_set_variance_controls: p_control must be > 0 (it also scales the uv logit)");
+    if (vc->cwt_spec && (!vc->f0_mean || !vc->f0_std || (m->cfg.use_uv && !vc->uv)))
+        return fail(CMTTS_E_INVALID, "cmtts_set_variance_controls: a pitch target needs cwt_spec, f0_mean, f0_std (and uv)");
+    m->vc = *vc;
     return 0;
 }
 

@@ -19,16 +19,17 @@ void k_chan_linear(const float* x, const float* W, const float* bias, float* out
                    int B, int C, int T, int ld, int O, hipStream_t s);
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,
                    const float* add, float* out, int B, int K, int N, int act, hipStream_t s);
-void k_energy_embed(const float* x, const float* e_pred, const float* bins, int nbins, const float* E,
-                    float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s);
+void k_energy_embed(const float* x, float* e_pred, const float* e_target, float e_control, const float* bins,
+                    int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s);
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
                  int B, int L, hipStream_t s);
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);
 void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t s);
 void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl,
                        int T, hipStream_t s);
-void k_pitch_index(const float* cwt, int O, int use_uv, const float* stats, float std_scale, float eps,
-                   float* r_ws, int64_t* p_idx, float* f0_denorm, int B, int T, hipStream_t s);
+void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* std_p, int stat_ld, float std_scale,
+                   const float* uv_logit, int uv_ld, const uint8_t* uv_mask, float eps, float* r_ws, int64_t* p_idx,
+                   float* f0_denorm, int B, int T, hipStream_t s);
 void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T,
                   hipStream_t s);
 void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s);

@@ -250,12 +250,17 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long 
 
 // ---- energy bucketize + embedding add (model/modules.py:319-329,358-363); torch.bucketize
 // right=False = first i with bins[i] >= v
-__global__ void energy_embed_kernel(const float* x, const float* e_pred, const float* bins, int nbins,
-                                    const float* E, float* out1, int64_t* e_idx, int C, int L, int ld) {
+__global__ void energy_embed_kernel(const float* x, float* e_pred, const float* e_target, float e_control,
+                                    const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx,
+                                    int C, int L, int ld) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (l >= L) return;
-    const float v = e_pred[(long)b * L + l];
+    // get_energy_embedding (model/modules.py:318-328): the target is bucketized when given, else
+    // prediction * control (which is also what is returned as the prediction)
+    float v;
+    if (e_target) v = e_target[(long)b * L + l];
+    else { v = e_pred[(long)b * L + l] * e_control; e_pred[(long)b * L + l] = v; }
     int lo = 0, hi = nbins;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] >= v) hi = mid; else lo = mid + 1; }
     if (v != v) lo = nbins;   // NaN sorts last
@@ -323,9 +328,13 @@ __global__ void length_regulate_kernel(const float* out1, const int64_t* mel2ph,
 
 // ---- inverse CWT -> f0 -> coarse pitch bucket (model/modules.py:274-300; utils/pitch_tools.py
 // 244-250 inverse_cwt_torch, 261-279 cwt2f0/_norm, 38-47 norm_f0, 64-78 denorm_f0, 26-35 f0_to_coarse)
-__global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int O, int use_uv, const float* stats,
-                                                          float std_scale, float eps, float* r_ws, int64_t* p_idx,
-                                                          float* f0_denorm, int T) {
+// spec: [B][T][O] with the 10 wavelet scales first (predicted cwt, or the teacher-forced target with O = 10);
+// mean / stdv: [B] with strides (the stats head's [B,2] or separate target vectors); uv: predicted logit
+// column uv_logit[(b*T+t)*uv_ld] > 0 or target bytes uv_mask[b*T+t] != 0.
+__global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int O, const float* mean_p, const float* std_p,
+                                                          int stat_ld, float std_scale, const float* uv_logit, int uv_ld,
+                                                          const uint8_t* uv_mask, float eps, float* r_ws,
+                                                          int64_t* p_idx, float* f0_denorm, int T) {
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* cw = cwt + (long)b * T * O;
@@ -349,8 +358,8 @@ __global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int 
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
     const float std_r = (float)sqrt(red[0] / (double)(T - 1));       // torch.std: unbiased
-    const float mean = stats[b * 2 + 0];
-    const float stdv = stats[b * 2 + 1] * std_scale;
+    const float mean = mean_p[b * stat_ld];
+    const float stdv = std_p[b * stat_ld] * std_scale;
     const float mel_min = (float)(1127.0 * log(1.0 + 50.0 / 700.0));
     const float mel_rng = (float)(1127.0 * log(1.0 + 1100.0 / 700.0) - 1127.0 * log(1.0 + 50.0 / 700.0));
     for (int t = tid; t < T; t += 256) {
@@ -358,7 +367,8 @@ __global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int 
         const float f0 = expf(rn * stdv + mean);
         const float f0n = log2f(f0 + eps);
         float f0d = exp2f(f0n);
-        if (use_uv && cw[(long)t * O + (O - 1)] > 0.f) f0d = 0.f;
+        if (uv_logit && uv_logit[((long)b * T + t) * uv_ld] > 0.f) f0d = 0.f;
+        if (uv_mask && uv_mask[(long)b * T + t]) f0d = 0.f;
         f0_denorm[(long)b * T + t] = f0d;
         float mel = 1127.0f * logf(1.0f + f0d / 700.0f);
         if (mel > 0.f) mel = (mel - mel_min) * 254.0f / mel_rng + 1.0f;
@@ -509,10 +519,10 @@ void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, con
     hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias,
                        add, out, B, K, N, act);
 }
-void k_energy_embed(const float* x, const float* e_pred, const float* bins, int nbins, const float* E, float* out1,
-                    int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(energy_embed_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, s, x, e_pred, bins, nbins, E, out1,
-                       e_idx, C, L, ld);
+void k_energy_embed(const float* x, float* e_pred, const float* e_target, float e_control, const float* bins,
+                    int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(energy_embed_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, s, x, e_pred, e_target, e_control, bins,
+                       nbins, E, out1, e_idx, C, L, ld);
 }
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
                  hipStream_t s) {
@@ -528,10 +538,11 @@ void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int
                        hipStream_t s) {
     hipLaunchKernelGGL(length_regulate_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, out1, mel2ph, xlr, C, ldl, T);
 }
-void k_pitch_index(const float* cwt, int O, int use_uv, const float* stats, float std_scale, float eps,
-                   float* r_ws, int64_t* p_idx, float* f0_denorm, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(pitch_index_kernel, dim3(B), dim3(256), 0, s, cwt, O, use_uv, stats, std_scale, eps, r_ws,
-                       p_idx, f0_denorm, T);
+void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* std_p, int stat_ld, float std_scale,
+                   const float* uv_logit, int uv_ld, const uint8_t* uv_mask, float eps, float* r_ws, int64_t* p_idx,
+                   float* f0_denorm, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(pitch_index_kernel, dim3(B), dim3(256), 0, s, cwt, O, mean_p, std_p, stat_ld, std_scale, uv_logit,
+                       uv_ld, uv_mask, eps, r_ws, p_idx, f0_denorm, T);
 }
 void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T, hipStream_t s) {
     hipLaunchKernelGGL(gather_add_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, x, idx, E, out, C, T);

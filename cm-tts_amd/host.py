@@ -127,24 +127,42 @@ class CMTotalTTS(torch.nn.Module):
                 p_control=1.0, e_control=1.0, d_control=1.0, **kwargs):
         """tts_net.py:75-183: re-runs the duration net with max_mel_len = x.size(2), then the denoiser."""
         out = self.duration_pitch_energy_net(speakers, texts, src_lens, mels=x, spker_embeds=spker_embeds,
-                                             d_control=d_control)
+                                             p_control=p_control, e_control=e_control, d_control=d_control,
+                                             **{k: kwargs[k] for k in ("mel_lens", "p_targets", "e_targets", "d_targets",
+                                                                       "mel2phs") if k in kwargs})
         return self.net(x, timesteps, out["cond"], out["speaker_emb"], out["mel_masks"])
 
 
 class DurationPitchSpeakerNet(torch.nn.Module):
-    """model/cmtts.py:10-122, inference branch (all targets None)."""
+    """model/cmtts.py:10-122: the inference branch (targets None, controls 1) and the teacher-forced /
+    controlled branches of VarianceAdaptor.forward (model/modules.py:331-412)."""
 
     def __init__(self, owner: CMTotalTTS):
         super().__init__()
         self.__dict__["_owner"] = owner
 
-    def forward(self, speakers=None, texts=None, src_lens=None, mels=None, mel_lens=None, spker_embeds=None,
+    def forward(self, speakers=None, texts=None, src_lens=None, mels=None, mel_lens=None, p_targets=None,
+                e_targets=None, d_targets=None, mel2phs=None, spker_embeds=None,
                 p_control=1.0, e_control=1.0, d_control=1.0, max_mel_len=None, **kwargs):
+        """p_targets = {"cwt_spec" [B,T,10], "f0_mean" [B], "f0_std" [B], "uv" bool [B,T]}, e_targets [B,L],
+        d_targets [B,L] as in the reference.  `mel2phs` is accepted and ignored: mel2ph is recomputed from
+        d_targets (dur_to_mel2ph), which is what the reference's dataset stores."""
         o = self._owner
         o._require()
         cfg, lib, dev = o.config, o.lib, o.device
-        if p_control != 1.0 or e_control != 1.0:
-            raise NotImplementedError("p_control/e_control are never forwarded by synthesize.py:96-101")
+        vc, keep = None, []
+        if p_control != 1.0 or e_control != 1.0 or p_targets is not None or e_targets is not None or d_targets is not None:
+            vc = _lib.VarianceControlsStruct(p_control=float(p_control), e_control=float(e_control))
+            if d_targets is not None:
+                keep.append(_f32(d_targets, dev)); vc.d_target = _ptr(keep[-1])
+            if e_targets is not None:
+                keep.append(_f32(e_targets, dev)); vc.e_target = _ptr(keep[-1])
+            if p_targets is not None:
+                for k in ("cwt_spec", "f0_mean", "f0_std"):
+                    keep.append(_f32(p_targets[k], dev)); setattr(vc, k, _ptr(keep[-1]))
+                keep.append(p_targets["uv"].to(device=dev, dtype=torch.uint8).contiguous()); vc.uv = _ptr(keep[-1])
+                if mels is None and max_mel_len is None:
+                    max_mel_len = int(p_targets["cwt_spec"].shape[1])
         texts = _i64(texts, dev)
         src_lens = _i64(src_lens, dev)
         B, L = texts.shape
@@ -161,31 +179,38 @@ class DurationPitchSpeakerNet(torch.nn.Module):
             spk = f(B, H) if cfg.multi_speaker else None
             nb = lib.cmtts_text_workspace_bytes(o._h, B, L)
             tws = o._ws.get("text", nb, dev)
-            _lib.check(lib.cmtts_text_forward(o._h, _ptr(texts), _ptr(src_lens), _ptr(spk_in), B, L, float(d_control),
-                                              _ptr(log_d), _ptr(d_rounded), _ptr(mel_len), _ptr(e_pred), _ptr(e_idx),
-                                              _ptr(enc_ct), _ptr(spk), _ptr(tws), nb, _stream()))
-            if mels is not None:
-                T = int(mels.size(2))                       # model/cmtts.py:61-62
-            elif max_mel_len is not None:
-                T = int(max_mel_len)
-            else:
-                T = int(mel_len.max().item())               # the one host read-back (pad() batch max)
-            O = cfg.cwt_out
-            cond_ct = f(B, H, T)
-            mel2ph = torch.empty(B, T, dtype=torch.int64, device=dev)
-            cwt = f(B, T, O)
-            f0 = f(B, T)
-            p_idx = torch.empty(B, T, dtype=torch.int64, device=dev)
-            stats = f(B, 2)
-            nf = lib.cmtts_frame_workspace_bytes(o._h, B, T)
-            fws = o._ws.get("frame", nf, dev)
-            _lib.check(lib.cmtts_frame_forward(o._h, _ptr(tws), B, L, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
-                                               _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(fws), nf, _stream()))
+            if vc is not None:
+                _lib.check(lib.cmtts_set_variance_controls(o._h, C.byref(vc)))
+            try:
+                _lib.check(lib.cmtts_text_forward(o._h, _ptr(texts), _ptr(src_lens), _ptr(spk_in), B, L, float(d_control),
+                                                  _ptr(log_d), _ptr(d_rounded), _ptr(mel_len), _ptr(e_pred), _ptr(e_idx),
+                                                  _ptr(enc_ct), _ptr(spk), _ptr(tws), nb, _stream()))
+                if mels is not None:
+                    T = int(mels.size(2))                       # model/cmtts.py:61-62
+                elif max_mel_len is not None:
+                    T = int(max_mel_len)
+                else:
+                    T = int(mel_len.max().item())               # the one host read-back (pad() batch max)
+                O = cfg.cwt_out
+                cond_ct = f(B, H, T)
+                mel2ph = torch.empty(B, T, dtype=torch.int64, device=dev)
+                cwt = f(B, T, O)
+                f0 = f(B, T)
+                p_idx = torch.empty(B, T, dtype=torch.int64, device=dev)
+                stats = f(B, 2)
+                nf = lib.cmtts_frame_workspace_bytes(o._h, B, T)
+                fws = o._ws.get("frame", nf, dev)
+                _lib.check(lib.cmtts_frame_forward(o._h, _ptr(tws), B, L, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
+                                                   _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(fws), nf, _stream()))
+            finally:
+                if vc is not None:
+                    lib.cmtts_set_variance_controls(o._h, None)              # back to the inference defaults
+                    torch.cuda.current_stream(dev).synchronize()             # targets must outlive the kernels
         mel_masks = get_mask_from_lengths(mel_len, T)
         return {
             "cond": cond_ct.transpose(1, 2),               # [B,T,H] view of the channel-major buffer
             "cond_ct": cond_ct,
-            "p_targets": None,
+            "p_targets": p_targets,
             "p_predictions": {"pitch_pred": None, "f0_denorm": f0, "cwt": cwt,
                               "f0_mean": stats[:, 0], "f0_std": stats[:, 1], "p_idx": p_idx},
             "e_predictions": e_pred,

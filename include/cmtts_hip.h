@@ -70,6 +70,26 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
                        float* enc_out_ct, float* speaker_emb,
                        void* text_ws, size_t text_ws_bytes, void* stream);
 
+/* ---- VarianceAdaptor controls and teacher-forced targets (model/modules.py:331-343: p_control, e_control,
+ * pitch_target, energy_target, duration_target; d_control is an argument of cmtts_text_forward).  The
+ * settings stay on the model until replaced; NULL restores the inference defaults (controls 1, no
+ * targets).  All pointers are DEVICE pointers that must stay valid while the forward calls run.
+ *   d_target fp32 [B,L]: durations used instead of the predicted ones (:365-367)
+ *   e_target fp32 [B,L]: energies bucketized instead of prediction * e_control (:318-328)
+ *   cwt_spec fp32 [B,T,10] + f0_mean, f0_std fp32 [B] + uv u8 [B,T]: pitch target (:379-390; f0 from
+ *   cwt2f0_norm utils/pitch_tools.py:268-273 with the target statistics; uv only read when use_uv)
+ * The predictors still run and their outputs are returned, like the reference. */
+typedef struct cmtts_variance_controls {
+    float p_control, e_control;
+    const float* d_target;
+    const float* e_target;
+    const float* cwt_spec;
+    const float* f0_mean;
+    const float* f0_std;
+    const uint8_t* uv;
+} cmtts_variance_controls;
+int cmtts_set_variance_controls(cmtts_model* m, const cmtts_variance_controls* vc);
+
 /* ---- frame-level half (model/modules.py:373-412; LengthRegulator :415-448; dur_to_mel2ph
  * utils/tools.py:768-798; get_pitch_embedding cwt branch :259-317).  T = padded frame count chosen
  * by the host (max(mel_len) like the reference, or a static bucket).

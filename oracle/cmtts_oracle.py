@@ -318,28 +318,44 @@ def cwt_to_pitch_index(cwt_out, mean, std, cfg):
     return idx, f0d, mel
 
 
-def variance_adaptor(sd, cfg, enc_out, src_mask, speaker_emb=None, max_len=None):
-    """VarianceAdaptor.forward inference branch, model/modules.py:331-412 (all targets None,
-    controls 1.0).  Returns a dict of every intermediate the parity tests pin."""
+def variance_adaptor(sd, cfg, enc_out, src_mask, speaker_emb=None, max_len=None, p_control=1.0, e_control=1.0,
+                     d_control=1.0, d_target=None, e_target=None, pitch_target=None):
+    """VarianceAdaptor.forward, model/modules.py:331-412.  Defaults = the inference branch (targets None,
+    controls 1.0).  Teacher-forced branches: d_target [B,L] (:365-367), e_target [B,L] (get_energy_embedding
+    :318-328), pitch_target = dict(cwt_spec [B,T,10], f0_mean [B], f0_std [B], uv bool [B,T]) (:379-390 with
+    cwt2f0_norm utils/pitch_tools.py:268-273: target statistics, no cwt_std_scale; the predictors still run
+    and their outputs are returned).  Controls multiply the predictor outputs (:270,326,369).
+    Returns a dict of every intermediate the parity tests pin."""
     va = "duration_pitch_energy_net.variance_adaptor."
     x = enc_out
     if speaker_emb is not None:
         x = (x + speaker_emb[:, None, :]).astype(F32)
     log_d = duration_predictor(sd, cfg, x, src_mask)
     e_pred = pitch_style_predictor(sd, va + "energy_predictor.", cfg, x)[..., 0]
-    e_idx = bucketize(e_pred, sd[va + "energy_bins"])
+    if e_target is not None:
+        e_idx = bucketize(np.asarray(e_target, F32), sd[va + "energy_bins"])
+    else:
+        e_pred = (e_pred * F32(e_control)).astype(F32)
+        e_idx = bucketize(e_pred, sd[va + "energy_bins"])
     out1 = (x + sd[va + "energy_embedding.weight"][e_idx]).astype(F32)
-    d_rounded = durations_from_log(log_d)
+    d_rounded = durations_from_log(log_d, d_control) if d_target is None else np.asarray(d_target, F32)
     x_lr, mel_len = length_regulate(out1, d_rounded, max_len)
     T = x_lr.shape[1]
     mel2ph = dur_to_mel2ph(d_rounded, src_mask)
     h = linear(x_lr, sd[va + "cwt_predictor.0.weight"], sd[va + "cwt_predictor.0.bias"])
-    cwt_out = pitch_style_predictor(sd, va + "cwt_predictor.1.", cfg, h)
+    cwt_out = (pitch_style_predictor(sd, va + "cwt_predictor.1.", cfg, h) * F32(p_control)).astype(F32)
     s = np.maximum(linear(out1[:, 0, :], sd[va + "cwt_stats_layers.0.weight"], sd[va + "cwt_stats_layers.0.bias"]), 0)
     s = np.maximum(linear(s, sd[va + "cwt_stats_layers.2.weight"], sd[va + "cwt_stats_layers.2.bias"]), 0)
     s = linear(s, sd[va + "cwt_stats_layers.4.weight"], sd[va + "cwt_stats_layers.4.bias"])
     mean, std_raw = s[:, 0], s[:, 1]                                  # f0_mean / f0_std as returned
-    p_idx, f0d, f0_mel = cwt_to_pitch_index(cwt_out, mean, (std_raw * F32(cfg.cwt_std_scale)).astype(F32), cfg)
+    if pitch_target is None:
+        p_idx, f0d, f0_mel = cwt_to_pitch_index(cwt_out, mean, (std_raw * F32(cfg.cwt_std_scale)).astype(F32), cfg)
+    else:
+        spec = np.asarray(pitch_target["cwt_spec"], F32)
+        if cfg.use_uv:      # the target's uv mask replaces the predicted uv logit
+            spec = np.concatenate([spec, np.where(pitch_target["uv"], F32(1), F32(-1))[..., None].astype(F32)], -1)
+        p_idx, f0d, f0_mel = cwt_to_pitch_index(spec, np.asarray(pitch_target["f0_mean"], F32),
+                                                np.asarray(pitch_target["f0_std"], F32), cfg)
     cond = (x_lr + sd[va + "pitch_embed.weight"][p_idx]).astype(F32)
     return dict(cond=cond, log_d=log_d, d_rounded=d_rounded, mel_len=mel_len, mel2ph=mel2ph,
                 e_pred=e_pred, e_idx=e_idx, out1=out1, x_lr=x_lr, cwt_out=cwt_out,
@@ -347,8 +363,9 @@ def variance_adaptor(sd, cfg, enc_out, src_mask, speaker_emb=None, max_len=None)
                 mel_mask=get_mask_from_lengths(mel_len, T))
 
 
-def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_mel_len=None):
-    """DurationPitchSpeakerNet.forward model/cmtts.py:44-122."""
+def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_mel_len=None, **va_kwargs):
+    """DurationPitchSpeakerNet.forward model/cmtts.py:44-122 (va_kwargs: controls / targets of
+    variance_adaptor)."""
     B, L = texts.shape
     src_mask = get_mask_from_lengths(src_lens, L)
     enc = text_encoder(sd, cfg, texts, src_mask)
@@ -356,7 +373,7 @@ def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_
     if cfg.multi_speaker:
         spk = linear(spker_embeds, sd["duration_pitch_energy_net.speaker_emb.weight"],
                      sd["duration_pitch_energy_net.speaker_emb.bias"]).astype(F32)
-    out = variance_adaptor(sd, cfg, enc, src_mask, spk, max_mel_len)
+    out = variance_adaptor(sd, cfg, enc, src_mask, spk, max_mel_len, **va_kwargs)
     out.update(enc_out=enc, speaker_emb=spk, src_mask=src_mask)
     return out
 

@@ -266,6 +266,62 @@ def golden_samplers():
     np.savez_compressed(os.path.join(HERE, f"samplers_{variant}.npz"), **out)
 
 
+def golden_controls():
+    """DurationPitchSpeakerNet.forward (model/cmtts.py:44-122) off the plain inference branch, on the VCTK
+    golden model (uv + multi-speaker): (a) p/e/d controls, (b) teacher-forced duration, energy and pitch
+    targets (model/modules.py:318-328,365-367,379-390)."""
+    from utils.pitch_tools import f0_to_coarse
+    from utils.tools import dur_to_mel2ph
+    variant = "VCTK"
+    cfg = get_config(variant)
+    g = np.load(os.path.join(HERE, f"cmtts_{variant}.npz"))
+    seed = int(g["seed"])
+    model, _ = build_reference_model(variant, cfg)
+    sd = synth_cmtts_state_dict(cfg, seed=seed, dur_frames=4.0, dur_spread=0.03)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    net = model.duration_pitch_energy_net
+    t_texts, t_lens = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
+    t_spk = torch.from_numpy(g["spker_embeds"])
+    speakers = torch.zeros(len(FIX_LENS), dtype=torch.long)
+    B, L = g["texts"].shape
+    out = {"seed": np.int64(seed)}
+
+    def record(tag, d):
+        pp = d["p_predictions"]
+        out.update({f"{tag}_cond": d["cond"].numpy(), f"{tag}_d_rounded": d["d_rounded"].numpy(),
+                    f"{tag}_mel_len": d["mel_lens"].numpy(), f"{tag}_e_pred": d["e_predictions"].numpy(),
+                    f"{tag}_log_d": d["log_d_predictions"].numpy(), f"{tag}_cwt_out": pp["cwt"].numpy(),
+                    f"{tag}_f0_denorm": pp["f0_denorm"].numpy(),
+                    f"{tag}_p_idx": f0_to_coarse(pp["f0_denorm"].clone()).numpy()})
+
+    with torch.no_grad():
+        ctl = dict(p_control=1.25, e_control=0.8, d_control=2.0)
+        record("ctl", net(speakers, t_texts, t_lens, spker_embeds=t_spk, **ctl))
+        out.update({k: np.float32(v) for k, v in ctl.items()})
+        # teacher forcing: integer durations, energies and a cwt pitch target drawn from a seeded generator
+        rs = np.random.RandomState(seed + 77)
+        valid = np.arange(L)[None, :] < g["src_lens"][:, None]
+        d_t = (rs.randint(1, 7, size=(B, L)) * valid).astype(np.float32)
+        T = int(d_t.sum(1).max())
+        e_t = rs.uniform(cfg.energy_min, cfg.energy_max, size=(B, L)).astype(np.float32)
+        cwt_spec = rs.standard_normal(size=(B, T, 10)).astype(np.float32)
+        f0_mean = rs.uniform(4.8, 5.4, size=(B,)).astype(np.float32)
+        f0_std = rs.uniform(0.1, 0.3, size=(B,)).astype(np.float32)
+        uv = rs.uniform(size=(B, T)) < 0.3
+        mel_lens = torch.from_numpy(d_t.sum(1).astype(np.int64))
+        src_masks = torch.from_numpy(~valid)
+        mel2phs = dur_to_mel2ph(torch.from_numpy(d_t), src_masks)
+        p_t = dict(cwt_spec=torch.from_numpy(cwt_spec), f0_mean=torch.from_numpy(f0_mean),
+                   f0_std=torch.from_numpy(f0_std), uv=torch.from_numpy(uv))
+        d = net(speakers, t_texts, t_lens, mels=torch.zeros(B, 1, T, cfg.n_mels), mel_lens=mel_lens, p_targets=p_t,
+                e_targets=torch.from_numpy(e_t), d_targets=torch.from_numpy(d_t), mel2phs=mel2phs, spker_embeds=t_spk)
+        record("tf", d)
+        out.update(tf_d_target=d_t, tf_e_target=e_t, tf_cwt_spec=cwt_spec, tf_f0_mean=f0_mean, tf_f0_std=f0_std,
+                   tf_uv=uv)
+    print(f"[controls] ctl mel_len {out['ctl_mel_len']} tf mel_len {out['tf_mel_len']}")
+    np.savez_compressed(os.path.join(HERE, f"controls_{variant}.npz"), **out)
+
+
 def golden_text():
     """Vocabulary table (360 symbols -> ids, text/symbols.py:21-29) and text_to_sequence outputs
     (text/__init__.py:15-41) for val.txt-style `{ARPAbet}` lines (dataset.py:271-283)."""
@@ -299,3 +355,5 @@ if __name__ == "__main__":
         golden_text()
     if not only or "samplers" in only:
         golden_samplers()
+    if not only or "controls" in only:
+        golden_controls()

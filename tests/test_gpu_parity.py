@@ -338,6 +338,54 @@ def test_ode_samplers_golden(models, golden, sampler):
     np.testing.assert_allclose(_np(mel), ref, atol=1e-3, rtol=2e-4)
 
 
+def _check_variance_gpu(out, gc, tag):
+    np.testing.assert_allclose(_np(out["log_d_predictions"]), gc[tag + "_log_d"], atol=5e-5)
+    np.testing.assert_array_equal(_np(out["d_rounded"]), gc[tag + "_d_rounded"])            # bit-exact
+    np.testing.assert_array_equal(_np(out["mel_lens"]), gc[tag + "_mel_len"])
+    np.testing.assert_allclose(_np(out["e_predictions"]), gc[tag + "_e_pred"], atol=1e-4)
+    pp = out["p_predictions"]
+    np.testing.assert_allclose(_np(pp["cwt"]), gc[tag + "_cwt_out"], atol=3e-4)
+    np.testing.assert_allclose(_np(pp["f0_denorm"]), gc[tag + "_f0_denorm"], rtol=3e-4, atol=2e-3)
+    ok = pitch_margin_mask(gc[tag + "_f0_denorm"])
+    np.testing.assert_array_equal(_np(pp["p_idx"])[ok], gc[tag + "_p_idx"][ok])
+    same = _np(pp["p_idx"]) == gc[tag + "_p_idx"]
+    assert same.mean() > 0.95
+    err = np.abs(_np(out["cond"]) - gc[tag + "_cond"])[same].max()
+    assert err < 1e-3, err
+
+
+def test_variance_controls_golden(models, golden):
+    """p_control / e_control / d_control (model/modules.py:270,326,369) against the reference's output."""
+    g, cfg, sd, model = models("VCTK")
+    gc = golden("controls_VCTK")
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]),
+                                          spker_embeds=torch.from_numpy(g["spker_embeds"]),
+                                          p_control=float(gc["p_control"]), e_control=float(gc["e_control"]),
+                                          d_control=float(gc["d_control"]))
+    torch.cuda.synchronize()
+    _check_variance_gpu(out, gc, "ctl")
+    # the settings do not stick: the next plain call reproduces the inference golden
+    plain = model.duration_pitch_energy_net(None, torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]),
+                                            spker_embeds=torch.from_numpy(g["spker_embeds"]))
+    np.testing.assert_array_equal(_np(plain["d_rounded"]), g["d_rounded"])
+    np.testing.assert_array_equal(_np(plain["e_idx"]), g["e_idx"])
+
+
+def test_variance_teacher_forced_golden(models, golden):
+    """Teacher-forced duration / energy / pitch targets (model/modules.py:318-328,365-367,379-390)."""
+    g, cfg, sd, model = models("VCTK")
+    gc = golden("controls_VCTK")
+    T = gc["tf_cwt_spec"].shape[1]
+    pt = {k: torch.from_numpy(gc["tf_" + k]) for k in ("cwt_spec", "f0_mean", "f0_std", "uv")}
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]),
+                                          mels=torch.zeros(len(g["src_lens"]), 1, T, cfg.n_mels),
+                                          p_targets=pt, e_targets=torch.from_numpy(gc["tf_e_target"]),
+                                          d_targets=torch.from_numpy(gc["tf_d_target"]),
+                                          spker_embeds=torch.from_numpy(g["spker_embeds"]))
+    torch.cuda.synchronize()
+    _check_variance_gpu(out, gc, "tf")
+
+
 def test_hifigan_golden(golden):
     host = _host()
     g = golden("hifigan")

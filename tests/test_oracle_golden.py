@@ -138,3 +138,38 @@ def test_sigmas_karras():
     np.testing.assert_allclose(s[0], 80.0, rtol=1e-6)
     np.testing.assert_allclose(s[4], 0.002, rtol=1e-5)
     assert np.all(np.diff(s) < 0)
+
+
+def _check_variance(st, gc, tag, g, cfg):
+    np.testing.assert_allclose(st["log_d"], gc[tag + "_log_d"], atol=2e-5)
+    np.testing.assert_array_equal(st["d_rounded"], gc[tag + "_d_rounded"])
+    np.testing.assert_array_equal(st["mel_len"], gc[tag + "_mel_len"])
+    np.testing.assert_allclose(st["e_pred"], gc[tag + "_e_pred"], atol=5e-5)
+    np.testing.assert_allclose(st["cwt_out"], gc[tag + "_cwt_out"], atol=2e-4)
+    np.testing.assert_allclose(st["f0_denorm"], gc[tag + "_f0_denorm"], rtol=2e-4, atol=1e-3)
+    ok = pitch_margin_mask(gc[tag + "_f0_denorm"])
+    assert ok.mean() > 0.95
+    np.testing.assert_array_equal(st["p_idx"][ok], gc[tag + "_p_idx"][ok])
+    same = st["p_idx"] == gc[tag + "_p_idx"]
+    np.testing.assert_allclose(st["cond"][same], gc[tag + "_cond"][same], atol=3e-5)
+
+
+def test_variance_controls(golden):
+    """p/e/d controls (model/modules.py:270,326,369) against the reference on the VCTK golden model."""
+    g, cfg, sd = _setup(golden, "VCTK")
+    gc = golden("controls_VCTK")
+    st = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], g["spker_embeds"],
+                                      p_control=float(gc["p_control"]), e_control=float(gc["e_control"]),
+                                      d_control=float(gc["d_control"]))
+    _check_variance(st, gc, "ctl", g, cfg)
+
+
+def test_variance_teacher_forced(golden):
+    """Duration / energy / pitch targets (model/modules.py:318-328,365-367,379-390)."""
+    g, cfg, sd = _setup(golden, "VCTK")
+    gc = golden("controls_VCTK")
+    pt = dict(cwt_spec=gc["tf_cwt_spec"], f0_mean=gc["tf_f0_mean"], f0_std=gc["tf_f0_std"], uv=gc["tf_uv"])
+    st = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], g["spker_embeds"],
+                                      max_mel_len=gc["tf_cwt_spec"].shape[1], d_target=gc["tf_d_target"],
+                                      e_target=gc["tf_e_target"], pitch_target=pt)
+    _check_variance(st, gc, "tf", g, cfg)
