@@ -851,8 +851,10 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, s);
     CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, s);
-    k_energy_embed(w.x, e_pred, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1,
-                   e_idx, B, H, L, Lp, s);
+    k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
+                   w.out1, e_idx, B, H, L, Lp, s);
+    if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
+        HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
     if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
         HIPCHK(hipMemcpyAsync(d_rounded, m->vc.d_target, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
         k_cumsum_durations(m->vc.d_target, w.cum, mel_len, B, L, s);

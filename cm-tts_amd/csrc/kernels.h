@@ -19,8 +19,9 @@ void k_chan_linear(const float* x, const float* W, const float* bias, float* out
                    int B, int C, int T, int ld, int O, hipStream_t s);
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,
                    const float* add, float* out, int B, int K, int N, int act, hipStream_t s);
-void k_energy_embed(const float* x, float* e_pred, const float* e_target, float e_control, const float* bins,
-                    int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s);
+void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const float* e_target, float e_control,
+                    const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld,
+                    hipStream_t s);
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
                  int B, int L, hipStream_t s);
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);

@@ -49,6 +49,9 @@ __device__ void block_positions(FlagFn flag, int T, int* pos, int* counts) {
 }
 
 // ---- FastspeechEncoder.forward_embedding (model/modules.py:145-151) + first mask (:94)
+// grid (B, C / EMB_CG): every workgroup recomputes the utterance's positions (a T-element scan) and fills
+// EMB_CG channels, so a batch of 32 utterances is 256+ workgroups instead of 32.
+constexpr int EMB_CG = 32;
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts, const int64_t* lens,
                                                            const float* E, const float* omega, const float* tab,
                                                            int tab_rows, float* x, int L, int ld, int C, float scale) {
@@ -59,8 +62,10 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts,
     const int64_t* tok = texts + (long)b * L;
     block_positions([&](int t) { return tok[t] != 0; }, L, pos, counts);
     const int len = (int)lens[b];
-    for (int idx = threadIdx.x; idx < C * L; idx += 256) {
-        const int c = idx / L, l = idx - c * L;
+    const int c0 = blockIdx.y * EMB_CG;             // this workgroup's channel slice
+    for (int idx = threadIdx.x; idx < EMB_CG * L; idx += 256) {
+        const int cl = idx / L, l = idx - cl * L, c = c0 + cl;
+        if (c >= C) break;
         float v = 0.f;
         if (l < len) v = scale * E[tok[l] * C + c] + pos_embed(pos[l], c, C, omega, tab, tab_rows);
         x[((long)b * C + c) * ld + l] = v;
@@ -116,18 +121,28 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, floa
 
 // ---- softmax over keys for transposed scores ST[z][j][i] (F.multi_head_attention_forward via
 // model/blocks.py:303-312): column i = one query; keys j >= lens[b] are masked (-inf -> prob 0).
+// Workgroup = 64 queries x 4 key slices (keys j = slice, slice + 4, ...); the slice maxima / sums meet in LDS.
 __global__ __launch_bounds__(256) void softmax_cols_kernel(float* st, const int64_t* lens, int H, int L, int ld, long zs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     const int z = blockIdx.y;
-    if (i >= L) return;
     const int len = min((int)lens[z / H], L);
-    float* col = st + (long)z * zs + i;
+    float* col = st + (long)z * zs + min(i, L - 1);
     float mx = -INFINITY;
-    for (int j = 0; j < len; ++j) mx = fmaxf(mx, col[(long)j * ld]);
+    for (int j = sl; j < len; j += 4) mx = fmaxf(mx, col[(long)j * ld]);
+    red[sl][il] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][il], red[1][il]), fmaxf(red[2][il], red[3][il]));
+    __syncthreads();
     float sum = 0.f;
-    for (int j = 0; j < len; ++j) sum += expf(col[(long)j * ld] - mx);
-    for (int j = 0; j < len; ++j) col[(long)j * ld] = expf(col[(long)j * ld] - mx) / sum;
-    for (int j = len; j < L; ++j) col[(long)j * ld] = 0.f;
+    for (int j = sl; j < len; j += 4) sum += expf(col[(long)j * ld] - mx);
+    red[sl][il] = sum;
+    __syncthreads();
+    sum = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+    if (i >= L) return;
+    for (int j = sl; j < len; j += 4) col[(long)j * ld] = expf(col[(long)j * ld] - mx) / sum;
+    for (int j = len + sl; j < L; j += 4) col[(long)j * ld] = 0.f;
 }
 
 // ---- x[b][c][l] += vec[b][c] (speaker embedding broadcast, model/modules.py:349-352)
@@ -139,6 +154,8 @@ __global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int 
 
 // ---- PitchPredictor/EnergyPredictor input: xs + alpha * PE[positions(xs[...,0] != 0)]
 // (model/modules.py:548-549; the float-zero test on channel 0 is part of the semantics)
+// grid (B, C / POS_CG): positions recomputed per workgroup, POS_CG channels each.
+constexpr int POS_CG = 8;
 __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, float* out, const float* alpha,
                                                             const float* omega, const float* tab, int tab_rows,
                                                             int C, int T, int ld) {
@@ -149,10 +166,13 @@ __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, floa
     const float* x0 = x + (long)b * C * ld;
     block_positions([&](int t) { return x0[t] != 0.f; }, T, pos, counts);
     const float al = alpha[0];
-    for (long idx = threadIdx.x; idx < (long)C * T; idx += 256) {
-        const int c = (int)(idx / T), t = (int)(idx - (long)c * T);
-        const long off = ((long)b * C + c) * ld + t;
-        out[off] = x[off] + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
+    const int c0 = blockIdx.y * POS_CG;
+    for (int cl = 0; cl < POS_CG && c0 + cl < C; ++cl) {
+        const int c = c0 + cl;
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const long off = ((long)b * C + c) * ld + t;
+            out[off] = x[off] + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
+        }
     }
 }
 
@@ -250,9 +270,10 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long 
 
 // ---- energy bucketize + embedding add (model/modules.py:319-329,358-363); torch.bucketize
 // right=False = first i with bins[i] >= v
-__global__ void energy_embed_kernel(const float* x, float* e_pred, const float* e_target, float e_control,
-                                    const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx,
-                                    int C, int L, int ld) {
+constexpr int ENE_CG = 32;
+__global__ void energy_embed_kernel(const float* x, const float* e_pred, float* e_scaled, const float* e_target,
+                                    float e_control, const float* bins, int nbins, const float* E, float* out1,
+                                    int64_t* e_idx, int C, int L, int ld) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (l >= L) return;
@@ -260,13 +281,14 @@ __global__ void energy_embed_kernel(const float* x, float* e_pred, const float* 
     // prediction * control (which is also what is returned as the prediction)
     float v;
     if (e_target) v = e_target[(long)b * L + l];
-    else { v = e_pred[(long)b * L + l] * e_control; e_pred[(long)b * L + l] = v; }
+    else { v = e_pred[(long)b * L + l] * e_control; if (blockIdx.z == 0 && e_control != 1.0f) e_scaled[(long)b * L + l] = v; }
     int lo = 0, hi = nbins;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] >= v) hi = mid; else lo = mid + 1; }
     if (v != v) lo = nbins;   // NaN sorts last
-    e_idx[(long)b * L + l] = lo;
+    const int c0 = blockIdx.z * ENE_CG, c1 = min(C, c0 + ENE_CG);     // channel slice of this workgroup
+    if (c0 == 0) e_idx[(long)b * L + l] = lo;
     const float* e = E + (long)lo * C;
-    for (int c = 0; c < C; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const long off = ((long)b * C + c) * ld + l;
         out1[off] = x[off] + e[c];
     }
@@ -491,7 +513,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, const float* omega, const float* tab,
                     int tab_rows, float* x, int B, int L, int ld, int C, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B), dim3(256), (256 + L) * sizeof(int), s, texts, lens, E, omega,
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(B, cdiv(C, EMB_CG)), dim3(256), (256 + L) * sizeof(int), s, texts, lens, E, omega,
                        tab, tab_rows, x, L, ld, C, scale);
 }
 void k_layernorm_ct(const float* in, float* out, const float* gamma, const float* beta, float eps,
@@ -499,14 +521,14 @@ void k_layernorm_ct(const float* in, float* out, const float* gamma, const float
     hipLaunchKernelGGL(layernorm_ct_kernel, dim3(cdiv(T, 32), B), dim3(256), 0, s, in, out, gamma, beta, eps, lens, T, ld);
 }
 void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(L, 256), nz), dim3(256), 0, s, st, lens, H, L, ld, zs);
+    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(L, 64), nz), dim3(256), 0, s, st, lens, H, L, ld, zs);
 }
 void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s) {
     hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld);
 }
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
                      int tab_rows, int B, int C, int T, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, tab,
+    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B, cdiv(C, POS_CG)), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, tab,
                        tab_rows, C, T, ld);
 }
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens, int B,
@@ -519,10 +541,13 @@ void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, con
     hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias,
                        add, out, B, K, N, act);
 }
-void k_energy_embed(const float* x, float* e_pred, const float* e_target, float e_control, const float* bins,
-                    int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(energy_embed_kernel, dim3(cdiv(L, 64), B), dim3(64), 0, s, x, e_pred, e_target, e_control, bins,
-                       nbins, E, out1, e_idx, C, L, ld);
+void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const float* e_target, float e_control,
+                    const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld,
+                    hipStream_t s) {
+    // every channel slice reads the unscaled prediction; the scaled copy (returned as the prediction when a
+    // control is set) is written to a second buffer and copied back afterwards
+    hipLaunchKernelGGL(energy_embed_kernel, dim3(cdiv(L, 64), B, cdiv(C, ENE_CG)), dim3(64), 0, s, x, e_pred, e_scaled, e_target,
+                       e_control, bins, nbins, E, out1, e_idx, C, L, ld);
 }
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
                  hipStream_t s) {
