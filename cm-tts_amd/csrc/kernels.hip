@@ -219,19 +219,20 @@ __global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const 
 }
 
 // ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
-// Workgroup = 64 output columns x 4 K-slices (one wave per slice), DB batch rows per thread: Wt (up to
+// Workgroup = 64 output columns x KS K-slices (one wave per slice), DB batch rows per thread: Wt (up to
 // 5 MB for the stacked per-layer projections) is streamed once per DB rows, 8 independent loads in
 // flight per thread; in[b][k] is wave-uniform (scalar loads); the 4 partial sums meet in LDS.
 constexpr int DB = 8;
-__global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long in_bs, long in_ks, const float* Wt,
-                                                          const float* bias, const float* add, float* out,
-                                                          int B, int K, int N, int act) {
-    __shared__ float part[3][DB][64];
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void dense_small_kernel(const float* in, long in_bs, long in_ks, const float* Wt,
+                                                              const float* bias, const float* add, float* out,
+                                                              int B, int K, int N, int act) {
+    __shared__ float part[KS - 1][DB][64];
     const int nl = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + nl;
     const int nc = min(n, N - 1);
     const int b0 = blockIdx.y * DB;
-    const int kq = (K + 3) / 4;
+    const int kq = (K + KS - 1) / KS;
     const int k0 = ks * kq, k1 = min(K, k0 + kq);
     float acc[DB];
 #pragma unroll
@@ -255,7 +256,9 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* in, long 
         for (int j = 0; j < DB; ++j) {
             const int b = b0 + j;
             if (b >= B) break;
-            float v = ((acc[j] + part[0][j][nl]) + part[1][j][nl]) + part[2][j][nl];
+            float v = acc[j];
+#pragma unroll
+            for (int q = 0; q < KS - 1; ++q) v += part[q][j][nl];
             if (bias) v += bias[n];
             if (act == DENSE_RELU) v = v > 0.f ? v : 0.f;
             else if (act == DENSE_MISH) {
@@ -538,8 +541,14 @@ void k_chan_linear(const float* x, const float* W, const float* bias, float* out
 }
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias, const float* add,
                    float* out, int B, int K, int N, int act, hipStream_t s) {
-    hipLaunchKernelGGL(dense_small_kernel, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt, bias,
-                       add, out, B, K, N, act);
+    // few output columns and a long K (the step-embedding MLP: 1024 -> 256) would leave 16 workgroups looping
+    // 256 times: cut K into 16 slices there, 4 otherwise
+    if (K >= 512 && cdiv(N, 64) * cdiv(B, DB) < 128)
+        hipLaunchKernelGGL(dense_small_kernel<16>, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(1024), 0, s, in, in_bs, in_ks, Wt,
+                           bias, add, out, B, K, N, act);
+    else
+        hipLaunchKernelGGL(dense_small_kernel<4>, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt,
+                           bias, add, out, B, K, N, act);
 }
 void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const float* e_target, float e_control,
                     const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld,
