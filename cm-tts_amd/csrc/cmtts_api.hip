@@ -236,6 +236,8 @@ struct Profile {
     bool on = false;
     std::vector<hipEvent_t> ev;   // start/stop pairs
     size_t used = 0;
+    int stride = 1;               // every stride-th launch is bracketed (event records cost launch-queue time)
+    long seen = 0;
 } g_prof;
 
 bool g_fused_resblock = true;
@@ -660,7 +662,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
     float* halt = w.u;
     for (int l = 0; l < NL; ++l) {
         const ResLayer& R = m->res[l];
-        const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.seen++ % g_prof.stride) == 0;
         if (!unfused) {   // ResidualBlock.forward (model/blocks.py:667-686) as one kernel, x ping-pongs
             ResArgs ra;
             memset(&ra, 0, sizeof(ra));
@@ -1173,8 +1175,10 @@ int cmtts_set_debug_stamps(void* dev_buf) {
     return 0;
 }
 
-int cmtts_profile_begin(int max_launches) {
-    if (max_launches <= 0) return fail(CMTTS_E_INVALID, "cmtts_profile_begin: bad argument");
+int cmtts_profile_begin(int max_launches, int stride) {
+    if (max_launches <= 0 || stride <= 0) return fail(CMTTS_E_INVALID, "cmtts_profile_begin: bad argument");
+    g_prof.stride = stride;
+    g_prof.seen = 0;
     for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : g_prof.ev) HIPCHK(hipEventCreate(&e));

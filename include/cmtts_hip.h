@@ -143,9 +143,11 @@ int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_
 
 /* ---- measurement hook (no reference counterpart; the reference's only perf tooling is the
  * wall-clock Timer of p_rtf_cm.py:64-108): HIP events recorded on the launch stream around every
- * launch of the dominant kernel (gated k=3 Conv1D of the denoiser residual block) between
- * begin and end.  end() synchronises on the events and returns the summed duration. */
-int cmtts_profile_begin(int max_launches);
+ * stride-th launch of the dominant kernel (the fused residual block of the denoiser) between begin and
+ * end, at most max_launches of them.  end() synchronises on the events and returns the summed duration
+ * and the number of launches measured.  (Two event records per launch cost ~4 % of a cfg2 step when every
+ * launch is bracketed; bench.py samples one launch in seven, which visits every layer.) */
+int cmtts_profile_begin(int max_launches, int stride);
 /* Selects the fused one-kernel-per-layer residual block (default, 1) or the three-launch form (0) of
  * the denoiser; both are bitwise identical (tests) — the switch exists for A/B measurement.
  * Returns the previous setting. */

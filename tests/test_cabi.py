@@ -31,7 +31,7 @@ def test_loader_binds_and_reports_errors():
     # invalid-argument paths never touch the GPU
     assert lib.cmtts_create(None, None) == -1
     assert b"null" in lib.cmtts_last_error()
-    assert lib.cmtts_profile_begin(0) == -1
+    assert lib.cmtts_profile_begin(0, 1) == -1
 
 
 def test_config_struct_matches_header():
