@@ -159,7 +159,9 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
                 load_a(A[(s + RING - 1) % RING], a.W3f, tap * (C / 8) + g8);
                 kgrp(it + s + 1, g8, tap);
                 load_b(Bv[(s + 1) & 1], g8 * 8, tap);
+                __builtin_amdgcn_sched_barrier(0);
                 mma_group(A[s], Bv[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -201,7 +203,9 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_kernel(const ResArg
             for (int s = 0; s < RING; ++s) {
                 load_a(A[(s + RING - 1) % RING], a.Wof, min(it + s + RING - 1, NG - 1));
                 load_b(Bv[(s + 1) & 1], min(it + s + 1, NG - 1) * 8, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 mma_group(A[s], Bv[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         stamp(5);
