@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="three-launch residual block (A/B)")
+    ap.add_argument("--per-layer", action="store_true", help="one fused launch per residual layer instead of the persistent stack (A/B)")
     ap.add_argument("--tile", type=int, default=0, help="frames per workgroup of the fused residual block (tuning)")
     args = ap.parse_args()
 
@@ -138,6 +139,8 @@ def main():
     lib = _lib.load()
     if args.unfused:
         lib.cmtts_set_fused_resblock(0)
+    if args.per_layer:
+        lib.cmtts_set_persistent_denoiser(0)
     if args.tile:
         _lib.check(lib.cmtts_set_resblock_tile(args.tile))
     state = {}
@@ -157,8 +160,11 @@ def main():
     assert torch.isfinite(state["mel"]).all()
 
     # ---- headline: timed region with HIP events around the dominant kernel
+    # persistent mode: ONE launch runs all residual layers of a sampler step (4 launches per step: bracket them all)
+    persistent = (not args.unfused) and lib.cmtts_set_persistent_denoiser(-1) != 0 and BATCH * ((FRAMES_PAD + 63) // 64) * 4 >= 256 * 3
+    stride = 1 if persistent else PROFILE_STRIDE
     dt = timed(step, args.steps, args.warmup, world,
-               before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers, PROFILE_STRIDE)))
+               before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers, stride)))
     tot_ms, n_l = C.c_double(), C.c_int()
     _lib.check(lib.cmtts_profile_end(C.byref(tot_ms), C.byref(n_l)))
     frames_total = frames_rank * world * args.steps
@@ -169,12 +175,15 @@ def main():
     if args.unfused:   # the timed kernel is the gated k=3 conv alone
         kname = "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_) * BATCH * FRAMES_PAD
+    elif persistent:   # all residual layers of one sampler step in one launch
+        kname = f"denoiser_persist_kernel ({cfg.res_layers} residual layers: gated k=3 conv + output projection each, x / skip resident)"
+        flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD * cfg.res_layers
     else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
         kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD
     traffic = None
     try:   # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 pass of this workload
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["resblock_fused_kernel"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["denoiser_persist_kernel" if persistent else "resblock_fused_kernel"]
         if not args.unfused and pmc["B"] == BATCH and pmc["T"] == FRAMES_PAD:
             traffic = pmc["bytes_per_launch"]
     except Exception:
@@ -195,8 +204,10 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE (profiles/r01_run2_fused_resblock.md); "
-                                     "algorithmic 83.9 MB -> HBM fraction %.3f" % ((traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
+                     "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE in separate --pmc passes (profiles/pmc_traffic.json); "
+                                     "algorithmic %.1f MB -> HBM fraction %.3f" % (
+                                         (BATCH * FRAMES_PAD * 1024 * (cfg.res_layers + 2) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
+                                         (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                      "flops_per_launch": flops_launch},
     }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "cmtts_wav_to_int16": (_i, [_vp, _vp, _i64, _f, _vp]),
     "cmtts_profile_begin": (_i, [_i, _i]),
     "cmtts_set_fused_resblock": (_i, [_i]),
+    "cmtts_set_persistent_denoiser": (_i, [_i]),
     "cmtts_set_resblock_tile": (_i, [_i]),
     "cmtts_set_precision": (_i, [_vp, _i]),
     "cmtts_vocoder_set_precision": (_i, [_vp, _i]),

@@ -16,6 +16,7 @@
 #include "conv_args.h"
 #include "kernels.h"
 #include "resblock_args.h"
+#include "persist_args.h"
 
 namespace {
 
@@ -241,6 +242,14 @@ struct Profile {
 } g_prof;
 
 bool g_fused_resblock = true;
+int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
+unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
+
+int persist_blocks() {          // workgroups that are certainly co-resident: one 1024-thread workgroup per CU
+    static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
+                        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
+    return n;
+}
 
 struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -575,6 +584,7 @@ FrameWs carve_frame(const cmtts_config& c, int B, int T, void* base) {
 
 struct DenWs {
     float *hin, *h, *u, *zb, *skip, *emb, *e1, *e2, *dproj, *sproj, *dp, *tbuf, *xcur, *cp;
+    unsigned long long* halo;   // edge-column granules of the persistent denoiser kernel
     size_t bytes;
 };
 DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
@@ -596,6 +606,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
     w.tbuf = cv.take<float>((size_t)B);
     w.xcur = cv.take<float>((size_t)B * T * c.n_mels);
     w.cp = cv.take<float>((size_t)NL * n);       // conditioner projections of all layers [B][NL*C][T]
+    w.halo = cv.take<unsigned long long>(cmtts_persist_halo_bytes(B, T) / sizeof(unsigned long long));
     w.bytes = cv.off + 256;
     return w;
 }
@@ -646,6 +657,10 @@ int step_embedding(cmtts_model* m, const DenWs& w, const float* timesteps, const
 
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
                   const float* cond_ct, const float* spk, int B, int T, hipStream_t s, bool embed = true) {
+    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
+        *(volatile unsigned*)g_tmo_host = 0;
+        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
+    }
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
@@ -660,7 +675,28 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
     const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
     float* hcur = w.h;
     float* halt = w.u;
-    for (int l = 0; l < NL; ++l) {
+    bool layers_done = false;
+    if (!unfused && g_persist && m->precision == 0 && NL <= PERSIST_MAX_LAYERS) {
+        // Denoiser.forward's layer loop (model/modules.py:626-633) as ONE persistent launch per utterance chunk
+        PersistArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.x0 = w.h; pa.cp = w.cp; pa.cp_bstride = (long)NL * C * T;
+        pa.dp = dp; pa.d = w.dproj; pa.vec_stride = (long)NL * C;
+        pa.skip = w.skip; pa.halo = w.halo; pa.tmo = g_tmo_host;
+        pa.B = B; pa.T = T; pa.NL = NL;
+        for (int l = 0; l < NL; ++l) {
+            pa.W3f[l] = m->res[l].w3f; pa.b3[l] = m->res[l].b3f; pa.Wof[l] = m->res[l].wof; pa.bo[l] = m->res[l].outp.bias;
+        }
+        const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+        const int rc = cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
+        if (rc == -3) return fail(CMTTS_E_HIP, "persistent denoiser launch failed");
+        if (rc == 0) {
+            if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
+            layers_done = true;
+        }
+    }
+    for (int l = 0; l < NL && !layers_done; ++l) {
         const ResLayer& R = m->res[l];
         const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.seen++ % g_prof.stride) == 0;
         if (!unfused) {   // ResidualBlock.forward (model/blocks.py:667-686) as one kernel, x ping-pongs
@@ -743,6 +779,10 @@ int cmtts_finalize(cmtts_model* m) {
     if (!m || m->finalized) return fail(CMTTS_E_INVALID, "cmtts_finalize: model is null or already finalized");
     const int r = finalize_model(m);
     if (r != 0) m->al.release();
+    if (r == 0 && !g_tmo_host) {   // one pinned word for the whole process
+        if (hipHostMalloc((void**)&g_tmo_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) g_tmo_host = nullptr;
+        else *g_tmo_host = 0;
+    }
     return r;
 }
 
@@ -1134,6 +1174,12 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     return 0;
 }
 
+int cmtts_set_persistent_denoiser(int mode) {
+    const int prev = g_persist;
+    if (mode >= 0 && mode <= 2) g_persist = mode;
+    return prev;
+}
+
 int cmtts_set_fused_resblock(int on) {
     const int prev = g_fused_resblock ? 1 : 0;
     g_fused_resblock = on != 0;
@@ -1172,6 +1218,7 @@ int cmtts_set_resblock_tile(int frames) {
 
 int cmtts_set_debug_stamps(void* dev_buf) {
     cmtts_resblock_set_debug((long long*)dev_buf);
+    cmtts_persist_set_debug((long long*)dev_buf);
     return 0;
 }
 

@@ -1,0 +1,446 @@
+// Persistent denoiser stack for gfx950: ALL residual layers of Denoiser.forward (model/modules.py:626-633,
+// ResidualBlock model/blocks.py:667-686) in ONE launch.  A workgroup (8 wave64) keeps its 64-frame tile of
+// one utterance for the whole stack:
+//
+//   * x (the residual stream) lives in the MFMA accumulator layout in the registers of waves 0-3, the skip sum in
+//     those of waves 4-7: per layer HBM sees only cp (the precomputed conditioner projection) — x, x', skip are
+//     neither re-read nor re-written (resblock_fused.hip moves 5 KB/frame/layer, this kernel 1 KB);
+//   * LDS holds u and z in separate buffers, so a wave gates its rows as soon as ITS k=3 conv is done (two
+//     workgroup barriers per layer instead of three) and u of the NEXT layer is written in place by the x waves
+//     straight from registers after the projection (its cp tile was pulled into L2 during the conv);
+//   * the +-1 frame Conv1D halo is the only inter-workgroup traffic: the two edge columns of x' (2 x 256 values)
+//     go to the neighbouring tiles as 8-byte {layer tag, value} granules — write-through agent-scope stores, the
+//     consumer re-reads until every tag matches (cdna_hip_programming.md §6 Guideline 16, form R2: the data is
+//     the flag, no fences).  Granule slots alternate by layer parity: a workgroup can be at most one layer ahead
+//     of a neighbour, because finishing layer l+1 needs the neighbour's layer-l columns.
+//
+// Every workgroup must be resident: the launcher keeps the grid <= the CU count (one 1024-thread workgroup per CU)
+// and splits larger batches into utterance chunks; spins are bounded and report through a timeout word.
+// Arithmetic and accumulation order are those of resblock_fused.hip: BITWISE equal to the per-layer kernels
+// (tests/test_gpu_parity.py::test_persistent_denoiser_bitwise).
+#include <hip/hip_runtime.h>
+#include "gate.h"
+#include "persist_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+namespace {
+
+constexpr int C = 256;
+constexpr int NW = 8;           // waves per workgroup: 2 per SIMD, each owning 2 m-tiles x 2 n-tiles (4 accumulators)
+constexpr int MT = 2;           // 32-row MFMA tiles per wave
+constexpr int RING = 6;         // register ring depth of the weight stream (k-groups in flight)
+constexpr int FN = 64;
+constexpr int NT = FN / 32;
+constexpr int U_LD = FN + 4;
+constexpr unsigned SPIN_LIMIT = 1u << 22;     // bounded wait for a neighbour (~seconds); then the timeout word is set
+
+// An opaque copy of a lane-dependent value: address arithmetic derived from it cannot be hoisted out of the layer
+// loop (hoisted per-lane offsets of the staging / epilogue sections would push the resident tile into scratch).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ void store_granule(unsigned long long* g, unsigned tag, float v) {
+    __hip_atomic_store((gu64*)g, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int t0 = tile * FN;
+    const int T = a.T;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* cp_b = a.cp + (long)b * a.cp_bstride;
+    const float* dp_b = a.dp + (long)b * a.vec_stride;
+    const float* dv_b = a.d + (long)b * a.vec_stride;
+    const bool xw = w < NW / 2;                       // waves 0-3 hold x, waves 4-7 hold the skip sum
+    const int mrow0 = (w % (NW / 2)) * (32 * MT);     // first row of this wave's register tiles inside its half
+
+
+    // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
+    {
+        const float* xin = a.x0 + (long)b * C * T;
+        const int t = t0 + lane;
+        const int t_c = min(t, T - 1);
+        constexpr int ROWS_PER_WAVE = C / NW;
+#pragma unroll 1
+        for (int i = 0; i < ROWS_PER_WAVE; i += 8) {
+            float xv[8], cv[8], dq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = w * ROWS_PER_WAVE + i + q;
+                xv[q] = xin[(unsigned)(m * T + t_c)];
+                cv[q] = cp_b[(unsigned)(m * T + t_c)];
+                dq[q] = dp_b[m];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = w * ROWS_PER_WAVE + i + q;
+                const float uv = cv[q] + (xv[q] + dq[q]);
+                smem[m * U_LD + 1 + lane] = t < T ? uv : 0.f;
+            }
+        }
+        if (tid < 2 * C) {
+            const int m = tid & (C - 1);
+            const bool right = tid >= C;
+            const int th = right ? t0 + FN : t0 - 1;
+            const int thc = min(max(th, 0), T - 1);
+            const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
+            smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < T) ? uh : 0.f;
+        }
+    }
+    // resident state: x tile (waves 0-7) or skip sum (waves 8-15), MFMA C layout: [j][r] = row acc_row(r), frame j*32+l31
+    f32x16 st[MT][NT];
+    {
+        const float* xin = a.x0 + (long)b * C * T;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t_c = min(t0 + j * 32 + l31, T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[i][j][r] = xw ? xin[(unsigned)((mrow0 + i * 32 + acc_row(r, lane)) * T + t_c)] : 0.f;
+            }
+    }
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // A fragments of one k-group (8 input channels = 4 k-steps) for this wave's MT 32-row tiles
+    auto load_a = [&](f32x4 (&dst)[MT], const float* wfrag, int group) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            dst[i] = *reinterpret_cast<const f32x4*>(wfrag + ((long)group * (2 * C / 32) + w * MT + i) * 256 + lane * 4);
+    };
+    auto mma_group = [&](const f32x4 (&af)[MT], const float (&bv)[4][NT]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bv[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+    const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
+    auto stamp = [&](int l, int slot) {
+        if (a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    for (int l = 0; l < a.NL; ++l) {
+        float* u_lds = smem;                  // u of the current layer, then assembled in place for the next one
+        float* z_lds = smem + C * U_LD;       // gate output
+        const bool more = l + 1 < a.NL;
+        auto load_b = [&](float (&dst)[4][NT], const float* src, int krow0, int col) {
+            const float* bs = src + (krow0 + khalf) * U_LD + l31 + col;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
+        };
+        stamp(l, 0);
+        __syncthreads();   // (1) u of layer l complete (interior, halo columns)
+        stamp(l, 1);
+        if (more && tid < 2 * C) {
+            // pull the next layer's cp tile (256 rows x 256 B) towards this XCD's L2 now: one dword per 128-B line;
+            // the x waves read it in the accumulator layout after the output projection and would otherwise pay the
+            // HBM latency there
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int tl = opaque(tid);
+            const float warm = cpn[(unsigned)((tl >> 1) * T + min(t0 + (tl & 1) * 32, T - 1))];
+            asm volatile("" ::"v"(warm));
+        }
+
+        // =========================================================== phase B: gated k=3 conv
+        {
+            zero_acc();
+            constexpr int NG = (C / 8) * 3;
+            auto kgrp = [&](int it, int& g8, int& tap) {
+                it = min(it, NG - 1);
+                const int q = it / 6, rr = it - q * 6;
+                tap = rr >> 1;
+                g8 = 2 * q + (rr & 1);
+            };
+            const float* W3f = a.W3f[l];
+            f32x4 A[RING][MT];
+            float Bv[2][4][NT];
+            int g8, tap;
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) {
+                kgrp(s, g8, tap);
+                load_a(A[s], W3f, tap * (C / 8) + g8);
+            }
+            kgrp(0, g8, tap);
+            load_b(Bv[0], u_lds, g8 * 8, tap);
+#pragma unroll 1
+            for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+                for (int s = 0; s < RING; ++s) {
+                    kgrp(it + s + RING - 1, g8, tap);
+                    load_a(A[(s + RING - 1) % RING], W3f, tap * (C / 8) + g8);
+                    kgrp(it + s + 1, g8, tap);
+                    load_b(Bv[(s + 1) & 1], u_lds, g8 * 8, tap);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it + s < NG) mma_group(A[s], Bv[s & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        stamp(l, 2);
+        {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
+            // other waves' MFMAs); nobody reads z before barrier (3)
+            const float* b3 = a.b3[l];
+            const int ln = opaque(lane);
+            float bg[MT][8], bf[MT][8];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int mg = (w * MT + i) * 32 + acc_row(r, ln);
+                    bg[i][r] = b3[mg];
+                    bf[i][r] = b3[mg + 16];
+                }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float zv = cmtts_gate(acc[i][j][r] + bg[i][r], acc[i][j][r + 8] + bf[i][r]);
+                        z_lds[((w * MT + i) * 16 + acc_row(r, ln)) * U_LD + j * 32 + (ln & 31)] = zv;
+                    }
+        }
+        stamp(l, 3);
+        __syncthreads();   // (3) z complete, u of this layer dead
+        stamp(l, 4);
+
+        // =========================================================== phase C: output projection
+        {
+            zero_acc();
+            constexpr int NG = C / 8;
+            const float* Wof = a.Wof[l];
+            f32x4 A[RING][MT];
+            float Bv[2][4][NT];
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) load_a(A[s], Wof, min(s, NG - 1));
+            load_b(Bv[0], z_lds, 0, 0);
+#pragma unroll 1
+            for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+                for (int s = 0; s < RING; ++s) {
+                    load_a(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
+                    load_b(Bv[(s + 1) & 1], z_lds, min(it + s + 1, NG - 1) * 8, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it + s < NG) mma_group(A[s], Bv[s & 1]);       // NG need not be a multiple of the ring depth
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        stamp(l, 5);
+        // ---- epilogue in registers: x' = (o[:C] + (x + d)) / sqrt(2) (waves 0-7), skip (+)= o[C:] (waves 8-15)
+        {
+            const float* bo = a.bo[l];
+            const float* dl = dv_b + (long)l * C;
+            const int ln = opaque(lane);
+            float bor[MT][16], ddr[MT][16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {        // all loads in flight before the first use
+                    bor[i][r] = bo[(w * MT + i) * 32 + acc_row(r, ln)];
+                    ddr[i][r] = dl[(xw ? mrow0 : 0) + i * 32 + acc_row(r, ln)];
+                }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float o = acc[i][j][r] + bor[i][r];
+                        if (xw) st[i][j][r] = (o + (st[i][j][r] + ddr[i][r])) / 1.41421356237309504880f;
+                        else st[i][j][r] = l > 0 ? o + st[i][j][r] : o;
+                    }
+        }
+        if (!more) break;
+        stamp(l, 6);
+        // next layer's cp in the accumulator layout (L2-warm), issued once the accumulators are dead (with them live the allocator
+        // serialises these 32 loads through scratch)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 cpc[MT][NT];
+        if (more && xw) {
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int t_c = min(t0 + j * 32 + (ln & 31), T - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cpc[i][j][r] = cpn[(unsigned)((mrow0 + i * 32 + acc_row(r, ln)) * T + t_c)];
+                }
+        }
+
+        // ---- hand the edge columns of x' to the neighbouring tiles, add x' into the next layer's u
+        const float* dpn = dp_b + (long)(l + 1) * C;
+        const unsigned tag = (unsigned)l + 1;
+        unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;    // [parity][b][tile][side][C]
+        if (xw) {
+            const int ln = opaque(lane), c31 = ln & 31;
+            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1)
+            if (c31 == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + i * 32 + acc_row(r, ln), tag, st[i][0][r]);
+            }
+            if (c31 == 31) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + i * 32 + acc_row(r, ln), tag, st[i][NT - 1][r]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int t = t0 + j * 32 + c31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mrow0 + i * 32 + acc_row(r, ln);
+                        const float uv = cpc[i][j][r] + (st[i][j][r] + dpn[m]);
+                        u_lds[m * U_LD + 1 + j * 32 + c31] = t < T ? uv : 0.f;
+                    }
+                }
+        } else if (w < NW / 2 + 2) {
+            // the first two skip waves fetch the left / right halo column: x' of the neighbour's edge + dp + cp
+            const bool right = w == NW / 2 + 1;
+            const int th = right ? t0 + FN : t0 - 1;
+            const bool inside = th >= 0 && th < T;
+            const int thc = min(max(th, 0), T - 1);
+            const int ntile = right ? tile + 1 : tile - 1;
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane);
+            float cph[C / 64];
+#pragma unroll
+            for (int k = 0; k < C / 64; ++k) cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)];
+            float xv[C / 64];
+#pragma unroll
+            for (int k = 0; k < C / 64; ++k) xv[k] = 0.f;
+            if (inside) {   // wave-uniform
+                // neighbour's slot: its right edge (side 1) feeds our left halo, its left edge (side 0) our right halo
+                const unsigned long long* g = hbase + ((long)ntile * 2 + (right ? 0 : 1)) * C;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < C / 64; ++k) {
+                        const unsigned long long v = __hip_atomic_load((gu64*)(g + ln + 64 * k), __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT);
+                        xv[k] = __uint_as_float((unsigned)v);
+                        ok &= (unsigned)(v >> 32) == tag;
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > SPIN_LIMIT) {      // wave-uniform: a neighbour never arrived
+                        if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < C / 64; ++k) {
+                const int m = ln + 64 * k;
+                const float uh = cph[k] + (xv[k] + dpn[m]);
+                u_lds[m * U_LD + (right ? FN + 1 : 0)] = inside ? uh : 0.f;
+            }
+        }
+        stamp(l, 7);
+    }
+
+    // ---- the skip sum leaves the chip once
+    if (!xw) {
+        float* skip = a.skip + (long)b * C * T;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t < T) skip[(unsigned)((mrow0 + i * 32 + acc_row(r, lane)) * T + t)] = st[i][j][r];
+            }
+    }
+}
+
+long long* g_pdbg = nullptr;
+
+}  // namespace
+
+extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
+
+extern "C" int cmtts_persist_chunks(int B, int T, int max_blocks) {
+    const int tiles = (T + FN - 1) / FN;
+    if (tiles > max_blocks) return 0;
+    const int per_launch = max_blocks / tiles;
+    return (B + per_launch - 1) / per_launch;
+}
+
+extern "C" size_t cmtts_persist_halo_bytes(int B, int T) {
+    const long tiles = (T + FN - 1) / FN;
+    return (size_t)2 * B * tiles * 2 * C * sizeof(unsigned long long);
+}
+
+// Returns 0, -2 (shape not supported: use the per-layer kernels) or -3 (HIP error).
+extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_blocks, int force, void* stream_) {
+    PersistArgs a = *a_in;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles = (a.T + FN - 1) / FN;
+    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 31)) return -2;
+    // a workgroup walks the whole stack alone (~140 us per layer): with fewer workgroups than 3/4 of the CUs the
+    // per-layer kernels, which spread a small batch over 32-frame tiles, finish sooner (measured)
+    if (!force && (long)tiles * a.B * 4 < (long)max_blocks * 3) return -2;
+    a.tiles = tiles;
+    a.dbg = g_pdbg;
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    // every granule tag must be stale (0) when a launch starts
+    if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
+    // utterance chunks: all workgroups of a launch must be resident (one per CU); chunks are balanced so that the last
+    // one does not run on a sliver of the chip
+    const int B = a.B;
+    const int per_launch = max_blocks / tiles;
+    const int nchunks = (B + per_launch - 1) / per_launch;
+    const int bc = (B + nchunks - 1) / nchunks;
+    for (int b0 = 0; b0 < B; b0 += bc) {
+        PersistArgs c = a;
+        const int nb = B - b0 < bc ? B - b0 : bc;
+        c.x0 = a.x0 + (long)b0 * C * a.T;
+        c.cp = a.cp + (long)b0 * a.cp_bstride;
+        c.dp = a.dp + (long)b0 * a.vec_stride;
+        c.d = a.d + (long)b0 * a.vec_stride;
+        c.skip = a.skip + (long)b0 * C * a.T;
+        c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
+        hipLaunchKernelGGL(denoiser_persist_kernel, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        if (hipGetLastError() != hipSuccess) return -3;
+    }
+    return 0;
+}

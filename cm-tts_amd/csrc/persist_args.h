@@ -1,0 +1,37 @@
+// Arguments of the persistent denoiser-stack kernel (denoiser_persist.hip).
+#pragma once
+#include <stddef.h>
+
+#define PERSIST_MAX_LAYERS 32
+
+struct PersistArgs {
+    const float* x0;      // [B][256][T] input of layer 0 (input projection output)
+    const float* cp;      // [B][NL*256][T] conditioner projections of all layers (batch stride cp_bstride)
+    const float* dp;      // [B][vec_stride]: per layer diffusion (+ speaker) projection, layer l at + l*256
+    const float* d;       // [B][vec_stride]: diffusion projection alone (residual = x + d)
+    float* skip;          // [B][256][T] out: sum of the layers' skip halves
+    const float* W3f[PERSIST_MAX_LAYERS];   // per layer: conv_layer / output_projection in MFMA A-fragment order
+    const float* b3[PERSIST_MAX_LAYERS];    // (same packing as ResArgs, resblock_args.h)
+    const float* Wof[PERSIST_MAX_LAYERS];
+    const float* bo[PERSIST_MAX_LAYERS];
+    unsigned long long* halo;   // [2][B][tiles][2][256] {tag, value} granules, zeroed by the launcher
+    unsigned* tmo;              // set to 1 when a bounded neighbour wait expires
+    long cp_bstride;
+    long vec_stride;
+    int B, T, NL;
+    int tiles;            // filled by the launcher
+    long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+size_t cmtts_persist_halo_bytes(int B, int T);
+// max_blocks = workgroups that are certainly co-resident (the CU count).  0 = launched, -2 = shape not
+// supported or (unless force) too small to pay off: the caller uses the per-layer kernels, -3 = HIP error.
+int cmtts_launch_denoiser_persist(const PersistArgs* a, int max_blocks, int force, void* stream);
+int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
+void cmtts_persist_set_debug(long long* dbg);
+#ifdef __cplusplus
+}
+#endif

@@ -152,6 +152,13 @@ int cmtts_profile_begin(int max_launches, int stride);
  * the denoiser; both are bitwise identical (tests) — the switch exists for A/B measurement.
  * Returns the previous setting. */
 int cmtts_set_fused_resblock(int on);
+/* Residual layers of the denoiser as ONE persistent launch per utterance chunk (denoiser_persist.hip: the tile's
+ * residual stream and skip sum stay in registers for all layers, neighbouring tiles exchange their edge columns
+ * in-kernel) instead of one launch per layer.  mode 0 = never, 1 = when it pays (default: at least 3/4 of the CUs
+ * get a workgroup), 2 = whenever the shape is supported (an utterance has at most as many 64-frame tiles as the
+ * GPU has CUs).  Bitwise identical to the per-layer kernels (tests); fp32 operands only.  Any other value only
+ * queries.  Returns the previous mode. */
+int cmtts_set_persistent_denoiser(int mode);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
  * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4]. */

@@ -576,6 +576,40 @@ def test_fused_resblock_bitwise(variant, T):
     assert torch.equal(fused, unfused), float((fused - unfused).abs().max())
 
 
+@pytest.mark.parametrize("variant,B,T", [("LJSpeech", 2, 200), ("VCTK", 3, 64), ("VCTK", 1, 130), ("LJSpeech", 5, 1000),
+                                         ("VCTK", 32, 512), ("LJSpeech", 40, 300)])
+def test_persistent_denoiser_bitwise(variant, B, T):
+    """denoiser_persist.hip (all residual layers in one launch: x and skip resident in registers, edge columns
+    exchanged between neighbouring tiles through tagged granules) must agree BITWISE with the per-layer kernels:
+    multi-tile utterances exercise the in-kernel halo exchange, ragged T the masked tail, B=40 the utterance
+    chunking (320 workgroups > 256 CUs), and the sampler runs it back to back (stale tags from the last call)."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=5))
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
+    spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
+    t = torch.full((B,), 1095.5)
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    cond_ct = cond.transpose(1, 2).contiguous().to(DEV)
+    spk_d = spk.to(DEV) if spk is not None else None
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    try:
+        one = model.net(x, t, cond, spk)
+        mel_p = host.sample_with_cond(model, cond_ct, spk_d, 2, noise)
+        lib.cmtts_set_persistent_denoiser(0)
+        ref = model.net(x, t, cond, spk)
+        mel_r = host.sample_with_cond(model, cond_ct, spk_d, 2, noise)
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, ref), float((one - ref).abs().max())
+    assert torch.equal(mel_p, mel_r), float((mel_p - mel_r).abs().max())
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp16", 8e-3)])
 def test_reduced_precision_denoiser(models, dtype, tol):
     """BASELINE configs[2] (bf16) / configs[4] (fp16 denoiser): MFMA operands of the residual blocks in 16 bits,

@@ -47,6 +47,63 @@ __global__ __launch_bounds__(512, 4) void probe(const float* __restrict__ wfrag,
     out[blockIdx.x * 512 + tid] = sum;
 }
 
+// Variant 3: each wave owns 2 m-tiles x 2 n-tiles (4 accumulators): two streamed A fragments (2 KB) and eight LDS
+// B reads feed 16 MFMAs per k-group = 128 B of weights per MFMA, 256 registers available at 2 waves per SIMD.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES + 3) / 4) void probe22(const float* __restrict__ wfrag, float* out, int ngroups) {
+    __shared__ float u[256 * 68];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 256 * 68; i += 64 * WAVES) { unsigned h = (unsigned)i * 2654435761u; u[i] = wfrag[h & 0xffff]; }
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int RING = 6;
+    f32x4 A[RING][2];
+    float B[2][4][2];
+    const float* wp = wfrag + (long)w * 512 + lane * 4;
+    auto load_a = [&](f32x4 (&d)[2], int g) { const float* p = wp + (long)(g & 255) * 4096; d[0] = *(const f32x4*)p; d[1] = *(const f32x4*)(p + 256); };
+    auto load_b = [&](float (&d)[4][2], int g) {
+        const float* bs = u + ((g & 31) * 8 + (lane >> 5)) * 68 + (lane & 31);
+        for (int k = 0; k < 4; ++k) for (int j = 0; j < 2; ++j) d[k][j] = bs[2 * k * 68 + j * 32];
+    };
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+    load_b(B[0], 0);
+    for (int g = 0; g < ngroups; g += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            load_a(A[(s + RING - 1) % RING], g + s + RING - 1);
+            load_b(B[(s + 1) & 1], g + s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i][kk], B[s & 1][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    out[blockIdx.x * 64 * WAVES + tid] = sum;
+}
+
+template <int WAVES>
+void run22(const float* w, float* out, int blocks) {
+    const int ng = 4092;     // multiple of the ring depth
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe22<WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, w, out, ng);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe22<WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, w, out, ng);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * WAVES * ng * 16 * 4096.0;
+    printf("variant 3 (2x2 tiles per wave, 128 B/MFMA), %d waves/workgroup, %d workgroups: %.3f ms  %.1f TFLOP/s (%.1f %% of 157.3)\n", WAVES, blocks, ms,
+           flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
+}
+
 template <int VAR, int NACC>
 void run(const float* w, float* out, int blocks) {
     const int ng = 4096;
@@ -62,14 +119,22 @@ void run(const float* w, float* out, int blocks) {
            flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
 }
 
-int main() {
+int main(int argc, char** argv) {
     float *w, *out;
     hipMalloc(&w, 256L * 4096 * 4 + 65536); hipMemset(w, 0, 256L * 4096 * 4 + 65536);
+    if (argc > 1) {   // random operands (value-dependent power): N(0,1)-like uniform in [-1, 1)
+        std::vector<float> h(256L * 4096 + 16384);
+        unsigned st = 12345u;
+        for (auto& v : h) { st = st * 1664525u + 1013904223u; v = (float)(int)(st >> 8) * (1.0f / 8388608.0f) - 1.0f; }
+        hipMemcpy(w, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        printf("random operands\n");
+    }
     hipMalloc(&out, 2048L * 512 * 4);
     for (int blocks : {256, 512}) {
         run<0, 2>(w, out, blocks); run<0, 4>(w, out, blocks); run<0, 8>(w, out, blocks);
         run<1, 2>(w, out, blocks); run<1, 8>(w, out, blocks);
         run<2, 2>(w, out, blocks); run<2, 8>(w, out, blocks);
     }
+    run22<4>(w, out, 256); run22<8>(w, out, 256); run22<4>(w, out, 512);
     return 0;
 }

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase timing of the persistent denoiser kernel from in-kernel cycle stamps of the middle layer (GPU only)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cmtts_amd
+from cmtts_amd import _lib, host
+from cmtts_amd.config import get_config
+from cmtts_amd.weights import synth_cmtts_state_dict
+
+cfg = get_config("LJSpeech")
+model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cfg, seed=0))
+B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 512)
+x = torch.randn(B, 1, T, 80, device="cuda"); cond = torch.randn(B, T, 256, device="cuda"); t = torch.full((B,), 1095.5, device="cuda")
+lib = _lib.load()
+for _ in range(2):
+    model.net(x, t, cond, None)
+nblk = ((T + 63) // 64) * B
+NW = 8
+buf = torch.zeros(nblk * NW * 8, dtype=torch.int64, device="cuda")
+lib.cmtts_set_debug_stamps(buf.data_ptr())
+model.net(x, t, cond, None)
+torch.cuda.synchronize()
+lib.cmtts_set_debug_stamps(None)
+s = buf.cpu().numpy().reshape(nblk, NW, 8).astype(np.float64)
+names = ["wait barrier(1)", "phase B loop", "gate", "wait barrier(3)", "phase C loop", "epilogue regs", "publish/u/halo"]
+d = np.diff(s, axis=2)       # [blk][wave][7]
+print(f"B={B} T={T}: cycle-counter ticks per phase of layer {cfg.res_layers // 2} (mean over workgroups)")
+for grp, sl in (("x waves 0-3", slice(0, 4)), ("skip waves 6-7", slice(6, 8)), ("halo waves 4-5", slice(4, 6))):
+    print(" ", grp)
+    for i, n in enumerate(names):
+        v = d[:, sl, i]
+        print(f"    {n:18s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f}")
+tot = s[:, :, 7] - s[:, :, 0]
+print("  layer total per wave: mean %.0f max %.0f" % (tot.mean(), tot.max()))
