@@ -2,8 +2,8 @@
 // ResidualBlock model/blocks.py:667-686) in ONE launch.  A workgroup (8 wave64) keeps its 64-frame tile of
 // one utterance for the whole stack:
 //
-//   * x (the residual stream) lives in the MFMA accumulator layout in the registers of waves 0-3, the skip sum in
-//     those of waves 4-7: per layer HBM sees only cp (the precomputed conditioner projection) — x, x', skip are
+//   * every wave keeps 32 rows of x (the residual stream) and 32 rows of the skip sum in registers, in the MFMA
+//     accumulator layout: per layer HBM sees only cp (the precomputed conditioner projection) — x, x', skip are
 //     neither re-read nor re-written (resblock_fused.hip moves 5 KB/frame/layer, this kernel 1 KB);
 //   * LDS holds u and z in separate buffers, so a wave gates its rows as soon as ITS k=3 conv is done (two
 //     workgroup barriers per layer instead of three) and u of the NEXT layer is written in place by the x waves
@@ -41,6 +41,12 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;     // bounded wait for a neighbour (~
 // loop (hoisted per-lane offsets of the staging / epilogue sections would push the resident tile into scratch).
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// base[idx] with the byte offset formed in 32 bits, so the load takes the (SGPR base + 32-bit VGPR offset) form instead of
+// a 64-bit VGPR address per element (64 of those in flight would not fit the register file).  idx < 2^30.
+__device__ __forceinline__ float ldg(const float* base, unsigned idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u));
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned tag, float v) {
@@ -48,6 +54,7 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool DBG>     // DBG: cycle stamps of the middle layer (tools/persist_timing.py); the production instance has none
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -58,8 +65,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     const float* cp_b = a.cp + (long)b * a.cp_bstride;
     const float* dp_b = a.dp + (long)b * a.vec_stride;
     const float* dv_b = a.d + (long)b * a.vec_stride;
-    const bool xw = w < NW / 2;                       // waves 0-3 hold x, waves 4-7 hold the skip sum
-    const int mrow0 = (w % (NW / 2)) * (32 * MT);     // first row of this wave's register tiles inside its half
+    const int mrow0 = w * 32;                          // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
 
 
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 const int t_c = min(t0 + j * 32 + l31, T - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    st[i][j][r] = xw ? xin[(unsigned)((mrow0 + i * 32 + acc_row(r, lane)) * T + t_c)] : 0.f;
+                    st[i][j][r] = i == 0 ? ldg(xin, (unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)) : 0.f;
             }
     }
 
@@ -119,10 +125,17 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
     // A fragments of one k-group (8 input channels = 4 k-steps) for this wave's MT 32-row tiles
-    auto load_a = [&](f32x4 (&dst)[MT], const float* wfrag, int group) {
+    auto load_a = [&](f32x4 (&dst)[MT], const float* wfrag, int group) {        // k=3 conv: packed gate tiles 2w, 2w+1
 #pragma unroll
         for (int i = 0; i < MT; ++i)
             dst[i] = *reinterpret_cast<const f32x4*>(wfrag + ((long)group * (2 * C / 32) + w * MT + i) * 256 + lane * 4);
+    };
+    // output projection: tile w (rows 32w.. of the residual half) and tile NW + w (rows 32w.. of the skip half), so that
+    // every wave owns 32 rows of x AND 32 rows of the skip sum and the epilogue work is spread over all waves
+    auto load_ao = [&](f32x4 (&dst)[MT], const float* wfrag, int group) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            dst[i] = *reinterpret_cast<const f32x4*>(wfrag + ((long)group * (2 * C / 32) + i * NW + w) * 256 + lane * 4);
     };
     auto mma_group = [&](const f32x4 (&af)[MT], const float (&bv)[4][NT]) {
 #pragma unroll
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 
     const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
     auto stamp = [&](int l, int slot) {
-        if (a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+        if (DBG && a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
     };
     for (int l = 0; l < a.NL; ++l) {
         float* u_lds = smem;                  // u of the current layer, then assembled in place for the next one
@@ -149,6 +162,24 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
                 for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
         };
+        constexpr int NGB = (C / 8) * 3;         // k-groups of the k=3 conv: (16-channel chunk, tap, 8-half)
+        constexpr int NGC = C / 8;               // k-groups of the output projection
+        auto kgrp = [&](int it, int& g8, int& tap) {
+            it = min(it, NGB - 1);
+            const int q = it / 6, rr = it - q * 6;
+            tap = rr >> 1;
+            g8 = 2 * q + (rr & 1);
+        };
+        // the weight stream does not depend on u: its first RING-1 k-groups are requested before the barrier
+        f32x4 A[RING][MT];
+        {
+            int g8, tap;
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) {
+                kgrp(s, g8, tap);
+                load_a(A[s], a.W3f[l], tap * (C / 8) + g8);
+            }
+        }
         stamp(l, 0);
         __syncthreads();   // (1) u of layer l complete (interior, halo columns)
         stamp(l, 1);
@@ -165,22 +196,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // =========================================================== phase B: gated k=3 conv
         {
             zero_acc();
-            constexpr int NG = (C / 8) * 3;
-            auto kgrp = [&](int it, int& g8, int& tap) {
-                it = min(it, NG - 1);
-                const int q = it / 6, rr = it - q * 6;
-                tap = rr >> 1;
-                g8 = 2 * q + (rr & 1);
-            };
+            constexpr int NG = NGB;
             const float* W3f = a.W3f[l];
-            f32x4 A[RING][MT];
             float Bv[2][4][NT];
             int g8, tap;
-#pragma unroll
-            for (int s = 0; s < RING - 1; ++s) {
-                kgrp(s, g8, tap);
-                load_a(A[s], W3f, tap * (C / 8) + g8);
-            }
             kgrp(0, g8, tap);
             load_b(Bv[0], u_lds, g8 * 8, tap);
 #pragma unroll 1
@@ -198,6 +217,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             }
         }
         stamp(l, 2);
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));   // output projection: same, before the gate
         {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
             // other waves' MFMAs); nobody reads z before barrier (3)
             const float* b3 = a.b3[l];
@@ -208,8 +229,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int mg = (w * MT + i) * 32 + acc_row(r, ln);
-                    bg[i][r] = b3[mg];
-                    bf[i][r] = b3[mg + 16];
+                    bg[i][r] = ldg(b3, (unsigned)mg);
+                    bf[i][r] = ldg(b3, (unsigned)(mg + 16));
                 }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -228,18 +249,15 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // =========================================================== phase C: output projection
         {
             zero_acc();
-            constexpr int NG = C / 8;
+            constexpr int NG = NGC;
             const float* Wof = a.Wof[l];
-            f32x4 A[RING][MT];
             float Bv[2][4][NT];
-#pragma unroll
-            for (int s = 0; s < RING - 1; ++s) load_a(A[s], Wof, min(s, NG - 1));
             load_b(Bv[0], z_lds, 0, 0);
 #pragma unroll 1
             for (int it = 0; it < NG; it += RING) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
-                    load_a(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
+                    load_ao(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
                     load_b(Bv[(s + 1) & 1], z_lds, min(it + s + 1, NG - 1) * 8, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) mma_group(A[s], Bv[s & 1]);       // NG need not be a multiple of the ring depth
@@ -248,85 +266,72 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             }
         }
         stamp(l, 5);
-        // ---- epilogue in registers: x' = (o[:C] + (x + d)) / sqrt(2) (waves 0-7), skip (+)= o[C:] (waves 8-15)
+        // ---- epilogue in registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
         {
             const float* bo = a.bo[l];
             const float* dl = dv_b + (long)l * C;
             const int ln = opaque(lane);
-            float bor[MT][16], ddr[MT][16];
+            float bor[MT][16], ddr[16];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int r = 0; r < 16; ++r) {            // all loads in flight before the first use
+                bor[0][r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
+                bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
+                ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {        // all loads in flight before the first use
-                    bor[i][r] = bo[(w * MT + i) * 32 + acc_row(r, ln)];
-                    ddr[i][r] = dl[(xw ? mrow0 : 0) + i * 32 + acc_row(r, ln)];
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float o = acc[0][j][r] + bor[0][r];
+                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
+                    const float os = acc[1][j][r] + bor[1][r];
+                    st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float o = acc[i][j][r] + bor[i][r];
-                        if (xw) st[i][j][r] = (o + (st[i][j][r] + ddr[i][r])) / 1.41421356237309504880f;
-                        else st[i][j][r] = l > 0 ? o + st[i][j][r] : o;
-                    }
         }
         if (!more) break;
         stamp(l, 6);
-        // next layer's cp in the accumulator layout (L2-warm), issued once the accumulators are dead (with them live the allocator
-        // serialises these 32 loads through scratch)
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 cpc[MT][NT];
-        if (more && xw) {
-            const float* cpn = cp_b + (long)(l + 1) * C * T;
-            const int ln = opaque(lane);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int t_c = min(t0 + j * 32 + (ln & 31), T - 1);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cpc[i][j][r] = cpn[(unsigned)((mrow0 + i * 32 + acc_row(r, ln)) * T + t_c)];
-                }
-        }
-
-        // ---- hand the edge columns of x' to the neighbouring tiles, add x' into the next layer's u
+        // ---- hand the edge columns of x' to the neighbouring tiles first (their latency is what the neighbours wait for)
         const float* dpn = dp_b + (long)(l + 1) * C;
         const unsigned tag = (unsigned)l + 1;
         unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;    // [parity][b][tile][side][C]
-        if (xw) {
+        {
             const int ln = opaque(lane), c31 = ln & 31;
             // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1)
             if (c31 == 0) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + i * 32 + acc_row(r, ln), tag, st[i][0][r]);
+                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + acc_row(r, ln), tag, st[0][0][r]);
             }
             if (c31 == 31) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
+            }
+        }
+        // ---- next layer's u rows of this wave: cp (L2-warm, accumulator layout) + (x' + dp)
+        {
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane), c31 = ln & 31;
+            f32x16 cpc[NT];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + i * 32 + acc_row(r, ln), tag, st[i][NT - 1][r]);
+            for (int j = 0; j < NT; ++j) {
+                const int t_c = min(t0 + j * 32 + c31, T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + c31;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int t = t0 + j * 32 + c31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mrow0 + i * 32 + acc_row(r, ln);
-                        const float uv = cpc[i][j][r] + (st[i][j][r] + dpn[m]);
-                        u_lds[m * U_LD + 1 + j * 32 + c31] = t < T ? uv : 0.f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow0 + acc_row(r, ln);
+                    const float uv = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
+                    u_lds[m * U_LD + 1 + j * 32 + c31] = t < T ? uv : 0.f;
                 }
-        } else if (w < NW / 2 + 2) {
-            // the first two skip waves fetch the left / right halo column: x' of the neighbour's edge + dp + cp
-            const bool right = w == NW / 2 + 1;
+            }
+        }
+        if (w >= NW - 2) {
+            // the last two waves also fetch the left / right halo column: x' of the neighbour's edge + dp + cp
+            const bool right = w == NW - 1;
             const int th = right ? t0 + FN : t0 - 1;
             const bool inside = th >= 0 && th < T;
             const int thc = min(max(th, 0), T - 1);
@@ -371,17 +376,15 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     }
 
     // ---- the skip sum leaves the chip once
-    if (!xw) {
+    {
         float* skip = a.skip + (long)b * C * T;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + j * 32 + l31;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t < T) skip[(unsigned)((mrow0 + i * 32 + acc_row(r, lane)) * T + t)] = st[i][j][r];
-            }
+            for (int r = 0; r < 16; ++r)
+                if (t < T) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
+        }
     }
 }
 
@@ -408,7 +411,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     PersistArgs a = *a_in;
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles = (a.T + FN - 1) / FN;
-    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 31)) return -2;
+    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30)) return -2;
     // a workgroup walks the whole stack alone (~140 us per layer): with fewer workgroups than 3/4 of the CUs the
     // per-layer kernels, which spread a small batch over 32-frame tiles, finish sooner (measured)
     if (!force && (long)tiles * a.B * 4 < (long)max_blocks * 3) return -2;
@@ -417,7 +420,9 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
@@ -439,7 +444,8 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
-        hipLaunchKernelGGL(denoiser_persist_kernel, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        if (a.dbg) hipLaunchKernelGGL(denoiser_persist_kernel<true>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        else hipLaunchKernelGGL(denoiser_persist_kernel<false>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;
