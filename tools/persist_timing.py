@@ -26,7 +26,7 @@ s = buf.cpu().numpy().reshape(nblk, NW, 8).astype(np.float64)
 names = ["wait barrier(1)", "phase B loop", "gate", "wait barrier(3)", "phase C loop", "epilogue regs", "publish/u/halo"]
 d = np.diff(s, axis=2)       # [blk][wave][7]
 print(f"B={B} T={T}: cycle-counter ticks per phase of layer {cfg.res_layers // 2} (mean over workgroups)")
-for grp, sl in (("x waves 0-3", slice(0, 4)), ("skip waves 6-7", slice(6, 8)), ("halo waves 4-5", slice(4, 6))):
+for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-5", slice(4, 6)), ("waves 6-7 (also fetch the halo columns)", slice(6, 8))):
     print(" ", grp)
     for i, n in enumerate(names):
         v = d[:, sl, i]
