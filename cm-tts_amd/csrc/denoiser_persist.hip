@@ -35,7 +35,8 @@ constexpr int RING = 6;         // register ring depth of the weight stream (k-g
 constexpr int FN = 64;
 constexpr int NT = FN / 32;
 constexpr int U_LD = FN + 4;
-constexpr unsigned SPIN_LIMIT = 1u << 22;     // bounded wait for a neighbour (~seconds); then the timeout word is set
+constexpr unsigned SPIN_LIMIT = 1u << 20;     // bounded wait for a neighbour (~2 s); then the timeout word is set and
+                                              // this wave stops waiting for the rest of the launch (results invalid)
 
 // An opaque copy of a lane-dependent value: address arithmetic derived from it cannot be hoisted out of the layer
 // loop (hoisted per-lane offsets of the staging / epilogue sections would push the resident tile into scratch).
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     auto stamp = [&](int l, int slot) {
         if (DBG && a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
     };
+    bool gave_up = false;
     for (int l = 0; l < a.NL; ++l) {
         float* u_lds = smem;                  // u of the current layer, then assembled in place for the next one
         float* z_lds = smem + C * U_LD;       // gate output
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             float xv[C / 64];
 #pragma unroll
             for (int k = 0; k < C / 64; ++k) xv[k] = 0.f;
-            if (inside) {   // wave-uniform
+            if (inside && !gave_up) {   // wave-uniform
                 // neighbour's slot: its right edge (side 1) feeds our left halo, its left edge (side 0) our right halo
                 const unsigned long long* g = hbase + ((long)ntile * 2 + (right ? 0 : 1)) * C;
                 unsigned spins = 0;
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     if (__all(ok)) break;
                     if (++spins > SPIN_LIMIT) {      // wave-uniform: a neighbour never arrived
                         if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                        gave_up = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(8);
