@@ -676,7 +676,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
     float* hcur = w.h;
     float* halt = w.u;
     bool layers_done = false;
-    if (!unfused && g_persist && m->precision == 0 && NL <= PERSIST_MAX_LAYERS) {
+    if (!unfused && g_persist && NL <= PERSIST_MAX_LAYERS) {
         // Denoiser.forward's layer loop (model/modules.py:626-633) as ONE persistent launch per utterance chunk
         PersistArgs pa;
         memset(&pa, 0, sizeof(pa));
@@ -684,12 +684,16 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         pa.dp = dp; pa.d = w.dproj; pa.vec_stride = (long)NL * C;
         pa.skip = w.skip; pa.halo = w.halo; pa.tmo = g_tmo_host;
         pa.B = B; pa.T = T; pa.NL = NL;
+        const int prec = m->precision;
         for (int l = 0; l < NL; ++l) {
-            pa.W3f[l] = m->res[l].w3f; pa.b3[l] = m->res[l].b3f; pa.Wof[l] = m->res[l].wof; pa.bo[l] = m->res[l].outp.bias;
+            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : m->res[l].w3f;
+            pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
+            pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
         const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
         if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-        const int rc = cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
+        const int rc = prec ? cmtts_launch_denoiser_persist_lp(&pa, prec, persist_blocks(), g_persist == 2, (void*)s)
+                            : cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
         if (rc == -3) return fail(CMTTS_E_HIP, "persistent denoiser launch failed");
         if (rc == 0) {
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }

@@ -1,0 +1,384 @@
+// Persistent denoiser stack with 16-bit MFMA operands (bf16 / fp16, fp32 accumulate): denoiser_persist.hip's
+// structure (all residual layers in one launch, x and the skip sum resident in fp32 registers, edge columns exchanged
+// between tiles as tagged granules, two barriers per layer) around resblock_fused_lp.hip's contractions
+// (v_mfma_f32_32x32x16_{bf16,f16}; u and z transposed and converted in LDS, weights in 16-bit fragment order).
+// BASELINE.json configs[2] (bf16) and configs[4] (fp16 denoiser).  Per layer HBM sees cp only (1 KB/frame instead of
+// 5 KB); at this MFMA rate the layer time is set by the weight fill (1.05 MB per workgroup per layer).
+// Same arithmetic and (tap, k-group) accumulation order as resblock_fused_lp.hip: BITWISE equal to the per-layer
+// 16-bit kernels (tests/test_gpu_parity.py::test_persistent_denoiser_lp_bitwise).
+#include <hip/hip_runtime.h>
+#include "cvt16.h"
+#include "gate.h"
+#include "persist_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+namespace {
+
+constexpr int C = 256;
+constexpr int NW = 8;           // waves per workgroup, each owning 2 m-tiles x 2 n-tiles
+constexpr int MT = 2;
+constexpr int RING = 6;         // 16-channel k-groups of weights in flight
+constexpr int FN = 64;
+constexpr int NT = FN / 32;
+constexpr int RS = 260;         // 16-bit elements per LDS row (520 B)
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float ldg(const float* base, unsigned idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u));
+}
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ void store_granule(unsigned long long* g, unsigned tag, float v) {
+    __hip_atomic_store((gu64*)g, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int MODE>
+__device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if (MODE == 1)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short* ut = lds16;                       // u^T [FN + 2][RS], row j = frame t0 - 1 + j
+    unsigned short* zt = lds16 + (FN + 2) * RS;       // z^T [FN][RS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int t0 = tile * FN;
+    const int T = a.T;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* cp_b = a.cp + (long)b * a.cp_bstride;
+    const float* dp_b = a.dp + (long)b * a.vec_stride;
+    const float* dv_b = a.d + (long)b * a.vec_stride;
+    const int mrow0 = w * 32;                         // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
+
+    // ---- layer-0 staging (as resblock_fused_lp.hip): u^T[j][m] = cvt(cp + (x + dp)); lane = frame, waves over channel pairs
+    {
+        const float* xin = a.x0 + (long)b * C * T;
+        const int t = t0 + lane;
+        const int t_c = min(t, T - 1);
+#pragma unroll 1
+        for (int i = 0; i < C / (2 * NW); i += 4) {
+            float x0[4], x1[4], c0[4], c1[4], d0[4], d1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 2 * (w + NW * (i + q));
+                x0[q] = xin[(unsigned)(m * T + t_c)];
+                x1[q] = xin[(unsigned)((m + 1) * T + t_c)];
+                c0[q] = cp_b[(unsigned)(m * T + t_c)];
+                c1[q] = cp_b[(unsigned)((m + 1) * T + t_c)];
+                d0[q] = dp_b[m];
+                d1[q] = dp_b[m + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 2 * (w + NW * (i + q));
+                const float u0 = c0[q] + (x0[q] + d0[q]);
+                const float u1 = c1[q] + (x1[q] + d1[q]);
+                *reinterpret_cast<unsigned*>(ut + (1 + lane) * RS + m) = t < T ? pack16<MODE>(u0, u1) : 0u;
+            }
+        }
+        {
+            const int m = tid & (C - 1);
+            const bool right = tid >= C;
+            const int th = right ? t0 + FN : t0 - 1;
+            const int thc = min(max(th, 0), T - 1);
+            const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
+            ut[(right ? FN + 1 : 0) * RS + m] = (th >= 0 && th < T) ? (unsigned short)pack16<MODE>(uh, 0.f) : (unsigned short)0;
+        }
+    }
+    f32x16 st[MT][NT];
+    {
+        const float* xin = a.x0 + (long)b * C * T;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t_c = min(t0 + j * 32 + l31, T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[i][j][r] = i == 0 ? ldg(xin, (unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)) : 0.f;
+            }
+    }
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // weights [group][m-tile (16)][lane][8 x 16-bit]: k=3 conv tiles 2w, 2w+1; projection tiles w (residual half), NW+w (skip half)
+    auto load_a = [&](u32x4 (&dst)[MT], const void* wfrag, int group) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            dst[i] = *(reinterpret_cast<const u32x4*>(wfrag) + ((long)group * (2 * C / 32) + w * MT + i) * 64 + lane);
+    };
+    auto load_ao = [&](u32x4 (&dst)[MT], const void* wfrag, int group) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            dst[i] = *(reinterpret_cast<const u32x4*>(wfrag) + ((long)group * (2 * C / 32) + i * NW + w) * 64 + lane);
+    };
+    auto load_b = [&](u32x4 (&dst)[NT], const unsigned short* src, int kg, int row_off) {      // 16 bytes = 8 k-values of one frame
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const unsigned short* p = src + (j * 32 + l31 + row_off) * RS + kg * 16 + khalf * 8;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
+            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    auto mma_group = [&](const u32x4 (&af)[MT], const u32x4 (&bv)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma16<MODE>(af[i], bv[j], acc[i][j]);
+    };
+
+    bool gave_up = false;
+    for (int l = 0; l < a.NL; ++l) {
+        const bool more = l + 1 < a.NL;
+        constexpr int NGB = 3 * (C / 16);        // k=3 conv: group = tap * 16 + k-group
+        constexpr int NGC = C / 16;
+        u32x4 A[RING][MT];
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.W3f[l], s);          // the weight stream does not depend on u
+        __syncthreads();   // (1) u^T of layer l complete
+        if (more) {        // pull the next layer's cp tile towards L2: one dword per 128-B line
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int tl = opaque(tid);
+            const float warm = cpn[(unsigned)((tl >> 1) * T + min(t0 + (tl & 1) * 32, T - 1))];
+            asm volatile("" ::"v"(warm));
+        }
+
+        // =========================================================== phase B: gated k=3 conv, 48 k-groups
+        {
+            zero_acc();
+            u32x4 Bv[2][NT];
+            load_b(Bv[0], ut, 0, 0);
+#pragma unroll 1
+            for (int it = 0; it < NGB; it += RING) {
+#pragma unroll
+                for (int s = 0; s < RING; ++s) {
+                    load_a(A[(s + RING - 1) % RING], a.W3f[l], min(it + s + RING - 1, NGB - 1));
+                    const int nx = min(it + s + 1, NGB - 1);
+                    load_b(Bv[(s + 1) & 1], ut, nx & 15, nx >> 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it + s < NGB) mma_group(A[s], Bv[s & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
+        {   // gate -> z^T (own buffer: no barrier between the conv and the gate)
+            const float* b3 = a.b3[l];
+            const int ln = opaque(lane);
+            float bg[MT][8], bf[MT][8];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int mg = (w * MT + i) * 32 + acc_row(r, ln);
+                    bg[i][r] = ldg(b3, (unsigned)mg);
+                    bf[i][r] = ldg(b3, (unsigned)(mg + 16));
+                }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {      // registers r, r+1 = adjacent channels (even first)
+                        const float z0 = cmtts_gate(acc[i][j][r] + bg[i][r], acc[i][j][r + 8] + bf[i][r]);
+                        const float z1 = cmtts_gate(acc[i][j][r + 1] + bg[i][r + 1], acc[i][j][r + 9] + bf[i][r + 1]);
+                        const int ch = (w * MT + i) * 16 + acc_row(r, ln);
+                        *reinterpret_cast<unsigned*>(zt + (j * 32 + (ln & 31)) * RS + ch) = pack16<MODE>(z0, z1);
+                    }
+        }
+        __syncthreads();   // (3) z^T complete, u^T of this layer dead
+
+        // =========================================================== phase C: output projection, 16 k-groups
+        {
+            zero_acc();
+            u32x4 Bv[2][NT];
+            load_b(Bv[0], zt, 0, 0);
+#pragma unroll 1
+            for (int it = 0; it < NGC; it += RING) {
+#pragma unroll
+                for (int s = 0; s < RING; ++s) {
+                    load_ao(A[(s + RING - 1) % RING], a.Wof[l], min(it + s + RING - 1, NGC - 1));
+                    load_b(Bv[(s + 1) & 1], zt, min(it + s + 1, NGC - 1), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (it + s < NGC) mma_group(A[s], Bv[s & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // ---- epilogue in fp32 registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
+        {
+            const float* bo = a.bo[l];
+            const float* dl = dv_b + (long)l * C;
+            const int ln = opaque(lane);
+            float bor[MT][16], ddr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bor[0][r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
+                bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
+                ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float o = acc[0][j][r] + bor[0][r];
+                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
+                    const float os = acc[1][j][r] + bor[1][r];
+                    st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
+                }
+        }
+        if (!more) break;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* dpn = dp_b + (long)(l + 1) * C;
+        const unsigned tag = (unsigned)l + 1;
+        unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;
+        {   // edge columns of x' (fp32) to the neighbouring tiles
+            const int ln = opaque(lane), c31 = ln & 31;
+            if (c31 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + acc_row(r, ln), tag, st[0][0][r]);
+            }
+            if (c31 == 31) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
+            }
+        }
+        {   // next layer's u^T, this wave's 32 channels: cvt(cp + (x' + dp)), channel pairs packed
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane), c31 = ln & 31;
+            f32x16 cpc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t_c = min(t0 + j * 32 + c31, T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + c31;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int m = mrow0 + acc_row(r, ln);
+                    const float u0 = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
+                    const float u1 = cpc[j][r + 1] + (st[0][j][r + 1] + ldg(dpn, (unsigned)(m + 1)));
+                    *reinterpret_cast<unsigned*>(ut + (1 + j * 32 + c31) * RS + m) = t < T ? pack16<MODE>(u0, u1) : 0u;
+                }
+            }
+        }
+        if (w >= NW - 2) {   // the last two waves also fetch the left / right halo frame
+            const bool right = w == NW - 1;
+            const int th = right ? t0 + FN : t0 - 1;
+            const bool inside = th >= 0 && th < T;
+            const int thc = min(max(th, 0), T - 1);
+            const int ntile = right ? tile + 1 : tile - 1;
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane);
+            float cph[C / 64], xv[C / 64];
+#pragma unroll
+            for (int k = 0; k < C / 64; ++k) { cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)]; xv[k] = 0.f; }
+            if (inside && !gave_up) {
+                const unsigned long long* g = hbase + ((long)ntile * 2 + (right ? 0 : 1)) * C;
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < C / 64; ++k) {
+                        const unsigned long long v = __hip_atomic_load((gu64*)(g + ln + 64 * k), __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT);
+                        xv[k] = __uint_as_float((unsigned)v);
+                        ok &= (unsigned)(v >> 32) == tag;
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > SPIN_LIMIT) {
+                        if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                        gave_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < C / 64; ++k) {
+                const int m = ln + 64 * k;
+                const float uh = cph[k] + (xv[k] + dpn[m]);
+                ut[(right ? FN + 1 : 0) * RS + m] = inside ? (unsigned short)pack16<MODE>(uh, 0.f) : (unsigned short)0;
+            }
+        }
+    }
+
+    {   // the skip sum leaves the chip once
+        float* skip = a.skip + (long)b * C * T;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t < T) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
+        }
+    }
+}
+
+template <int MODE>
+int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * FN + 2) * RS * sizeof(unsigned short);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    const int B = a.B;
+    const int per_launch = max_blocks / tiles;
+    const int nchunks = (B + per_launch - 1) / per_launch;
+    const int bc = (B + nchunks - 1) / nchunks;
+    for (int b0 = 0; b0 < B; b0 += bc) {
+        PersistArgs c = a;
+        const int nb = B - b0 < bc ? B - b0 : bc;
+        c.x0 = a.x0 + (long)b0 * C * a.T;
+        c.cp = a.cp + (long)b0 * a.cp_bstride;
+        c.dp = a.dp + (long)b0 * a.vec_stride;
+        c.d = a.d + (long)b0 * a.vec_stride;
+        c.skip = a.skip + (long)b0 * C * a.T;
+        c.halo = a.halo + (long)b0 * tiles * 2 * C;
+        hipLaunchKernelGGL(denoiser_persist_lp_kernel<MODE>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        if (hipGetLastError() != hipSuccess) return -3;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// mode 1 = bf16, 2 = fp16; a->W3f / a->Wof point to the 16-bit fragment-order weights of each layer.  Return
+// codes and the residency rule are those of cmtts_launch_denoiser_persist.
+extern "C" int cmtts_launch_denoiser_persist_lp(const PersistArgs* a_in, int mode, int max_blocks, int force, void* stream_) {
+    PersistArgs a = *a_in;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles = (a.T + FN - 1) / FN;
+    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30) || (mode != 1 && mode != 2)) return -2;
+    if (!force && (long)tiles * a.B * 4 < (long)max_blocks * 3) return -2;
+    a.tiles = tiles;
+    a.dbg = nullptr;
+    if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
+    return mode == 1 ? launch_mode<1>(a, tiles, max_blocks, stream) : launch_mode<2>(a, tiles, max_blocks, stream);
+}

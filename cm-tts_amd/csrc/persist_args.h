@@ -30,6 +30,8 @@ size_t cmtts_persist_halo_bytes(int B, int T);
 // max_blocks = workgroups that are certainly co-resident (the CU count).  0 = launched, -2 = shape not
 // supported or (unless force) too small to pay off: the caller uses the per-layer kernels, -3 = HIP error.
 int cmtts_launch_denoiser_persist(const PersistArgs* a, int max_blocks, int force, void* stream);
+// 16-bit operand variant (denoiser_persist_lp.hip): mode 1 = bf16, 2 = fp16; W3f / Wof = 16-bit fragment-order weights.
+int cmtts_launch_denoiser_persist_lp(const PersistArgs* a, int mode, int max_blocks, int force, void* stream);
 int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
 void cmtts_persist_set_debug(long long* dbg);
 #ifdef __cplusplus

@@ -14,9 +14,7 @@ struct ResArgs {
     long vec_stride;
     int B, T;
     int accum_skip;       // skip += o[C:] (layers > 0) or skip = o[C:] (layer 0)
-    int stagger_mode;     // 0 none; 1: second half of the grid; 2: odd workgroups — delayed start (experiment)
-    int stagger_sleeps;
-    long long* dbg;       // optional [grid][8] s_memtime stamps written by wave 0 (phase timing)   // number of s_sleep 127 (~3.4 us each) for the delayed workgroups
+    long long* dbg;       // optional [grid][8] cycle stamps written by wave 0 (phase timing, tools/phase_timing.py)
 };
 
 #ifdef __cplusplus

@@ -610,6 +610,34 @@ def test_persistent_denoiser_bitwise(variant, B, T):
     assert torch.equal(mel_p, mel_r), float((mel_p - mel_r).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("variant,B,T", [("VCTK", 2, 200), ("LJSpeech", 32, 512), ("VCTK", 40, 300)])
+def test_persistent_denoiser_lp_bitwise(variant, B, T, dtype):
+    """denoiser_persist_lp.hip (16-bit MFMA operands, persistent stack) must agree BITWISE with the per-layer 16-bit
+    kernels (resblock_fused_lp.hip): same conversions, same (tap, k-group) accumulation order."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=6))
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
+    spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
+    t = torch.full((B,), 1095.5)
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    model.set_precision(dtype)
+    try:
+        one = model.net(x, t, cond, spk)
+        lib.cmtts_set_persistent_denoiser(0)
+        ref = model.net(x, t, cond, spk)
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+        model.set_precision("fp32")
+    torch.cuda.synchronize()
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, ref), float((one - ref).abs().max())
+
+
 @pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp16", 8e-3)])
 def test_reduced_precision_denoiser(models, dtype, tol):
     """BASELINE configs[2] (bf16) / configs[4] (fp16 denoiser): MFMA operands of the residual blocks in 16 bits,
