@@ -28,8 +28,11 @@ namespace {
 // KC = input channels per K chunk (template parameter): 16 for the large launches, 64 for the small
 // latency-bound ones (4x fewer barrier-separated iterations, 4x the bytes in flight per iteration)
 
-template <int BM, int BN, int WM, int WN, int EPI, int KC>
-__global__ __launch_bounds__(256, KC > 16 ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
+// TB = taps staged (and multiplied) per barrier-separated iteration: 1 for the large launches; 5 for the small k>1
+// launches (text-side FFN / predictors), whose 8 MFMAs per wave per tap cannot hide a barrier.  The (chunk, tap, k)
+// accumulation order is the same for every TB.
+template <int BM, int BN, int WM, int WN, int EPI, int KC, int TB>
+__global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
     constexpr int MT = BM / (WM * 32);
     constexpr int NT = BN / (WN * 32);
     constexpr int XJ = (BN + 64 + 63) / 64;         // columns per lane of an X row (halo <= 64)
@@ -53,16 +56,17 @@ __global__ __launch_bounds__(256, KC > 16 ? 2 : 3) void conv1d_mfma_kernel(const
     const int tap_min = a.dil < 0 ? (a.taps - 1) * a.dil : 0;
     const int tbase = n0 - a.pad + tap_min;
 
-    float* Ws = smem;                    // [2][KC][BM]
-    float* Xs = smem + 2 * KC * BM;      // [2][KC][XW]
+    float* Ws = smem;                         // [2][TB][KC][BM]
+    float* Xs = smem + 2 * TB * KC * BM;      // [2][KC][XW]
 
     const float* Ab = a.A + zq * a.a_zs0 + zr * a.a_zs1;
     const float* Xb = a.X + zq * a.x_zs0 + zr * a.x_zs1;
 
     const int nchunks = (a.K + KC - 1) / KC;
-    const int niter = nchunks * a.taps;
+    const int tgroups = (a.taps + TB - 1) / TB;      // iterations per chunk
+    const int niter = nchunks * tgroups;
 
-    float4 wreg[WV];
+    float4 wreg[TB][WV];
     constexpr int XR = KC / 4;                      // X rows staged per wave
     float xreg[XR][XJ];
 
@@ -72,25 +76,31 @@ __global__ __launch_bounds__(256, KC > 16 ? 2 : 3) void conv1d_mfma_kernel(const
     // The raw loaded values stay untouched in registers until store time (after the MFMAs): the
     // zero-fill selects and the pre-activation are applied in store_*, so nothing waits on vmcnt
     // between issuing the prefetch and the MFMA block.
-    auto load_w = [&](int chunk, int tap) {
+    auto load_w = [&](int chunk, int tap0) {
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int i = min(tid + v * 256, KC * WQ - 1);
-            const int row = i / WQ, c4 = i - row * WQ;
-            const int krow_c = min(chunk * KC + row, a.K - 1), m_c = min(m0 + c4 * 4, a.a_cols - 4);
-            wreg[v] = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow_c * a.a_ld + m_c);
+        for (int tb = 0; tb < TB; ++tb) {
+            const int tap = min(tap0 + tb, a.taps - 1);          // taps beyond the kernel are loaded again and never used
+#pragma unroll
+            for (int v = 0; v < WV; ++v) {
+                const int i = min(tid + v * 256, KC * WQ - 1);
+                const int row = i / WQ, c4 = i - row * WQ;
+                const int krow_c = min(chunk * KC + row, a.K - 1), m_c = min(m0 + c4 * 4, a.a_cols - 4);
+                wreg[tb][v] = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow_c * a.a_ld + m_c);
+            }
         }
     };
     auto store_w = [&](int buf, int chunk) {
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int i = tid + v * 256;
-            const int row = i / WQ, c4 = i - row * WQ;
-            const bool ok = chunk * KC + row < a.K && m0 + c4 * 4 < a.a_cols;
-            float4 w = wreg[v];
-            if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + buf * KC * BM + i * 4) = w;
-        }
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int v = 0; v < WV; ++v) {
+                const int i = tid + v * 256;
+                const int row = i / WQ, c4 = i - row * WQ;
+                const bool ok = chunk * KC + row < a.K && m0 + c4 * 4 < a.a_cols;
+                float4 w = wreg[tb][v];
+                if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + (buf * TB + tb) * KC * BM + i * 4) = w;
+            }
     };
     auto load_x = [&](int chunk) {
 #pragma unroll
@@ -143,43 +153,45 @@ __global__ __launch_bounds__(256, KC > 16 ? 2 : 3) void conv1d_mfma_kernel(const
     const int khalf = lane >> 5;
 
     for (int it = 0; it < niter; ++it) {
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
+        int ntap = tap + TB, nchunk = chunk;                  // tap = first tap of this iteration's group
+        if (ntap >= a.taps) { ntap = 0; nchunk = chunk + 1; }
         const bool has_next = it + 1 < niter;
         const bool next_x = has_next && ntap == 0;
         if (has_next) load_w(nchunk, ntap);
         if (next_x) load_x(nchunk);
-
-        const float* wsc = Ws + (it & 1) * KC * BM + a_off;
-        const float* xsc = Xs + (chunk & 1) * KC * XW + b_off + (tap * a.dil - tap_min);
         __builtin_amdgcn_sched_barrier(0);           // prefetch loads stay above the MFMA block
-        {
-            // operands of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued
-            const float* wk = wsc + khalf * BM;
-            const float* xk = xsc + khalf * XW;
-            float av[MT], bv[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = wk[i * 32];
+        for (int tb = 0; tb < TB; ++tb) {
+            if (tap + tb < a.taps) {                 // wave-uniform
+                const float* wsc = Ws + ((it & 1) * TB + tb) * KC * BM + a_off;
+                const float* xsc = Xs + (chunk & 1) * KC * XW + b_off + ((tap + tb) * a.dil - tap_min);
+                // operands of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued
+                const float* wk = wsc + khalf * BM;
+                const float* xk = xsc + khalf * XW;
+                float av[MT], bv[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = xk[j * 32];
+                for (int i = 0; i < MT; ++i) av[i] = wk[i * 32];
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float nav[MT], nbv[NT];
+                for (int j = 0; j < NT; ++j) bv[j] = xk[j * 32];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) nav[i] = kk + 1 < KC / 2 ? wk[(kk + 1) * 2 * BM + i * 32] : 0.f;
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    float nav[MT], nbv[NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) nbv[j] = kk + 1 < KC / 2 ? xk[(kk + 1) * 2 * XW + j * 32] : 0.f;
+                    for (int i = 0; i < MT; ++i) nav[i] = kk + 1 < KC / 2 ? wk[(kk + 1) * 2 * BM + i * 32] : 0.f;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int j = 0; j < NT; ++j) nbv[j] = kk + 1 < KC / 2 ? xk[(kk + 1) * 2 * XW + j * 32] : 0.f;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) av[i] = nav[i];
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = nbv[j];
+                    for (int i = 0; i < MT; ++i) av[i] = nav[i];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[j] = nbv[j];
+                }
             }
         }
 
@@ -226,15 +238,15 @@ __global__ __launch_bounds__(256, KC > 16 ? 2 : 3) void conv1d_mfma_kernel(const
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int KC = 16>
+template <int BM, int BN, int WM, int WN, int EPI, int KC = 16, int TB = 1>
 int launch_cfg(const ConvArgs& a, int nbatch, hipStream_t stream) {
     const int adil = a.dil < 0 ? -a.dil : a.dil;
     const int halo = (a.taps - 1) * adil;
     if (halo > 64) return -2;
     const int XW = BN + halo;
-    const size_t lds = (size_t)(2 * KC * BM + 2 * KC * XW) * sizeof(float);
+    const size_t lds = (size_t)(2 * TB * KC * BM + 2 * KC * XW) * sizeof(float);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch);
-    hipLaunchKernelGGL((conv1d_mfma_kernel<BM, BN, WM, WN, EPI, KC>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<BM, BN, WM, WN, EPI, KC, TB>), grid, dim3(256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -260,6 +272,8 @@ extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* 
             // chunks, so an utterance's result does not depend on which configuration its batch size selects
             // (tests: every utterance bit-identical to synthesising it alone)
             if (a.taps == 1 && a.K >= 128) return launch_cfg<64, 64, 2, 2, EPI_PLAIN, 64>(a, nbatch, stream);
+            // k > 1: up to five taps per barrier (same accumulation order)
+            if (a.taps > 1) return launch_cfg<64, 64, 2, 2, EPI_PLAIN, 16, 5>(a, nbatch, stream);
             return launch_cfg<64, 64, 2, 2, EPI_PLAIN>(a, nbatch, stream);
         }
         return launch_cfg<128, 128, 2, 2, EPI_PLAIN>(a, nbatch, stream);
