@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "resblock_args.h"
 #include "persist_args.h"
+#include "cond_gemm.h"
 
 namespace {
 
@@ -242,6 +243,7 @@ struct Profile {
 } g_prof;
 
 bool g_fused_resblock = true;
+bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hip (false: generic kernel, A/B and tests)
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
 
@@ -289,6 +291,7 @@ struct cmtts_model {
     float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
     PackedConv in_proj, skip_proj, out_proj;
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
+    float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
 };
@@ -506,7 +509,10 @@ int finalize_model(cmtts_model* m) {
             std::copy(wc.data.begin(), wc.data.end(), W.data.begin() + (size_t)l * C * H);
             std::copy(bc.data.begin(), bc.data.end(), Bv.data.begin() + (size_t)l * C);
         }
-        CHK(pack_conv(al, W, &Bv, nullptr, &m->cond_all));
+        std::vector<float> hp;
+        CHK(pack_conv(al, W, &Bv, nullptr, &m->cond_all, &hp));
+        if (H % 8 == 0 && (NL * C) % 32 == 0 && m->cond_all.ld == NL * C)
+            CHK(al.upload(to_fragment_order(hp, 1, H, NL * C), &m->cond_all_f));
     }
     CHK(al.upload(dproj, &m->dproj_wt));
     if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
@@ -633,6 +639,14 @@ int predictor_convs(const Predictor& P, const float* in, int ld_in, int B, int T
 // cp[b][l*C + m][t] = conditioner_projection_l(cond)[m][t] + bias: one stacked GEMM, reused by every step
 int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B, int T, hipStream_t s) {
     const cmtts_config& c = m->cfg;
+    if (m->cond_all_f) {   // X tile resident in LDS, one walk over all 20 x 256 rows (bitwise equal to the generic kernel)
+        CondGemmArgs g;
+        g.X = cond_ct; g.Wf = m->cond_all_f; g.bias = m->cond_all.bias; g.Y = w.cp;
+        g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden;
+        const int r = g_cond_gemm ? cmtts_launch_cond_gemm(&g, (void*)s) : -2;
+        if (r == 0) return 0;
+        if (r != -2) return fail(CMTTS_E_HIP, "cond_gemm launch failed");
+    }
     ConvArgs a = conv_args(m->cond_all, cond_ct, T, T, (long)c.hidden * T, w.cp, T, (long)c.res_layers * c.res_channels * T, T);
     return launch(a, EPI_PLAIN, B, s);
 }
@@ -1176,6 +1190,16 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     k_conv_post(bufA, v->post_w, v->post_b, 3.0f, 0.01f, wav, B, ch, Ti, Ti + P, v->post_k, s);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int cmtts_set_option(const char* name, int value) {
+    if (!name) return fail(CMTTS_E_INVALID, "cmtts_set_option: null name");
+    if (!strcmp(name, "cond_gemm")) {
+        const int prev = g_cond_gemm ? 1 : 0;
+        if (value == 0 || value == 1) g_cond_gemm = value != 0;
+        return prev;
+    }
+    return fail(CMTTS_E_INVALID, "cmtts_set_option: unknown option");
 }
 
 int cmtts_set_persistent_denoiser(int mode) {

@@ -1,0 +1,18 @@
+// Arguments of the X-resident stacked GEMM (cond_gemm.hip).
+#pragma once
+
+struct CondGemmArgs {
+    const float* X;       // [B][K = 256][T]
+    const float* Wf;      // fragment-order weights [K/8][M/32][64][4] (k-major [K][M] re-packed by cmtts_finalize)
+    const float* bias;    // [M]
+    float* Y;             // [B][M][T]
+    int B, T, M, K;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int cmtts_launch_cond_gemm(const CondGemmArgs* a, void* stream);   // 0, -2 (unsupported shape), -3 (HIP error)
+#ifdef __cplusplus
+}
+#endif

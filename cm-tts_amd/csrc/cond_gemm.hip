@@ -1,0 +1,138 @@
+// Stacked conditioner projections for gfx950: cp[b][l*256 + m][t] = sum_k Wc_l[m][k] * cond[b][k][t] + bc_l[m] for ALL
+// residual layers at once (ResidualBlock.conditioner_projection, model/blocks.py:663,676) — a k=1 "convolution" with
+// M = 20 * 256 output rows and only K = 256 input channels.  The generic kernel (conv_mfma.hip) re-stages the same
+// X tile for each of the 40 m-tiles and pays a prologue and an epilogue per 128x128 tile for 16 short iterations
+// (71 TFLOP/s).  Here the X tile of a workgroup ([256 channels][64 frames]) is staged in LDS ONCE and the workgroup
+// walks over all M: 8 waves, each 2x2 MFMA tiles per pass (512 rows per pass), weights streamed L2 -> VGPR in
+// A-fragment order through a register ring exactly as in denoiser_persist.hip; stores of pass p overlap the MFMAs of
+// pass p+1.  Same (16-channel chunk, k) accumulation order as the generic kernel: BITWISE equal
+// (tests/test_gpu_parity.py::test_cond_gemm_bitwise).
+#include <hip/hip_runtime.h>
+#include "cond_gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int K = 256;          // input channels (encoder hidden)
+constexpr int NW = 8;
+constexpr int MT = 2;
+constexpr int FN = 64;
+constexpr int NT = FN / 32;
+constexpr int X_LD = FN + 4;
+constexpr int RING = 4;
+constexpr int NG = K / 8;       // k-groups of 8 channels
+
+__device__ __forceinline__ float ldg(const float* base, unsigned idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u));
+}
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FN;
+    const int T = a.T;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* xin = a.X + (long)b * K * T;
+    float* yb = a.Y + (long)b * a.M * T;
+
+    {   // stage X[k][t0 .. t0+63] (zero beyond T): lane = frame, 32 rows per wave, 8 in flight
+        const int t = t0 + lane;
+        const int t_c = min(t, T - 1);
+#pragma unroll 1
+        for (int i = 0; i < K / NW; i += 8) {
+            float xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = xin[(unsigned)((w * (K / NW) + i + q) * T + t_c)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xs[(w * (K / NW) + i + q) * X_LD + lane] = t < T ? xv[q] : 0.f;
+        }
+    }
+    const int MTn = a.M / 32;
+    auto load_a = [&](f32x4 (&dst)[MT], int mt0, int g) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            dst[i] = *reinterpret_cast<const f32x4*>(a.Wf + (((long)g * MTn + mt0 + i) * 64 + lane) * 4);
+    };
+    auto load_b = [&](float (&dst)[4][NT], int g) {
+        const float* bs = xs + (g * 8 + khalf) * X_LD + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * X_LD + j * 32];
+    };
+    const int npass = a.M / (32 * MT * NW);          // 512 rows per pass
+    f32x4 A[RING][MT];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], w * MT, s);
+    __syncthreads();
+
+    for (int p = 0; p < npass; ++p) {
+        const int mt0 = (p * NW + w) * MT;           // this wave's first m-tile in this pass
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float Bv[2][4][NT];
+        load_b(Bv[0], 0);
+        const int mt_next = (min(p + 1, npass - 1) * NW + w) * MT;
+#pragma unroll 1
+        for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                const int nx = it + s + RING - 1;    // prefetch runs into the next pass's first k-groups
+                if (nx < NG) load_a(A[(s + RING - 1) % RING], mt0, nx);
+                else load_a(A[(s + RING - 1) % RING], mt_next, nx - NG);
+                load_b(Bv[(s + 1) & 1], min(it + s + 1, NG - 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][i][kk], Bv[s & 1][kk][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // bias + store (the stores drain under the next pass)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m0 = (mt0 + i) * 32;
+            float bi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bi[r] = ldg(a.bias, (unsigned)(m0 + acc_row(r, lane)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t < T) yb[(unsigned)((m0 + acc_row(r, lane)) * T + t)] = acc[i][j][r] + bi[r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Returns 0, -2 (shape not supported: use the generic kernel) or -3.
+extern "C" int cmtts_launch_cond_gemm(const CondGemmArgs* ap, void* stream_) {
+    const CondGemmArgs& a = *ap;
+    if (a.K != K || a.M % (32 * MT * NW) != 0 || (long)a.M * a.T >= (1L << 30) || a.B <= 0 || a.T <= 0) return -2;
+    static bool attr_set = false;
+    const size_t lds = (size_t)K * X_LD * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(cond_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cond_gemm_kernel, dim3((a.T + FN - 1) / FN, a.B), dim3(64 * NW), lds, (hipStream_t)stream_, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -159,6 +159,10 @@ int cmtts_set_fused_resblock(int on);
  * GPU has CUs).  Bitwise identical to the per-layer kernels (tests); fp32 operands only.  Any other value only
  * queries.  Returns the previous mode. */
 int cmtts_set_persistent_denoiser(int mode);
+/* A/B switches that do not change results (bitwise, tested).  "cond_gemm": 1 (default) = the stacked conditioner
+ * projections of all residual layers through the X-resident kernel (cond_gemm.hip), 0 = through the generic conv
+ * kernel.  Returns the previous value (any other value only queries), or a negative status for an unknown name. */
+int cmtts_set_option(const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
  * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4]. */

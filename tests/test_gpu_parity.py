@@ -610,6 +610,32 @@ def test_persistent_denoiser_bitwise(variant, B, T):
     assert torch.equal(mel_p, mel_r), float((mel_p - mel_r).abs().max())
 
 
+@pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
+def test_cond_gemm_bitwise(variant, B, T):
+    """cond_gemm.hip (conditioner projections of all layers, X tile resident in LDS) keeps the generic kernel's
+    accumulation order: the denoiser output must not change by a bit."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=7))
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
+    spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
+    t = torch.full((B,), 1095.5)
+    prev = lib.cmtts_set_option(b"cond_gemm", 1)
+    try:
+        one = model.net(x, t, cond, spk)
+        lib.cmtts_set_option(b"cond_gemm", 0)
+        ref = model.net(x, t, cond, spk)
+    finally:
+        lib.cmtts_set_option(b"cond_gemm", prev)
+    torch.cuda.synchronize()
+    assert lib.cmtts_set_option(b"no_such_option", 0) < 0
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, ref), float((one - ref).abs().max())
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("variant,B,T", [("VCTK", 2, 200), ("LJSpeech", 32, 512), ("VCTK", 40, 300)])
 def test_persistent_denoiser_lp_bitwise(variant, B, T, dtype):
