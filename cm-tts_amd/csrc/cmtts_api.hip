@@ -243,6 +243,7 @@ struct Profile {
 } g_prof;
 
 bool g_fused_resblock = true;
+bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hip (false: generic kernel, A/B and tests)
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
@@ -256,6 +257,7 @@ int persist_blocks() {          // workgroups that are certainly co-resident: on
 struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     PackedConv qk, wo, ffn1, ffn2;
+    float* ffn1_f = nullptr;   // ffn1 in MFMA A-fragment order (conv_xres.hip)
     float* wvT;  // [256 c][256 d]
 };
 struct Predictor {
@@ -384,7 +386,12 @@ int finalize_model(cmtts_model* m) {
         HostTensor ow3 = *ow; ow3.shape = {H, H, 1};
         CHK(pack_conv(al, ow3, nullptr, nullptr, &L.wo));
         GET(f1w, p + "ffn.ffn_1.weight", 4 * H, H, c.ffn_kernel); GET(f1b, p + "ffn.ffn_1.bias", 4 * H);
-        CHK(pack_conv(al, *f1w, f1b, nullptr, &L.ffn1));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, *f1w, f1b, nullptr, &L.ffn1, &hp));
+            if (L.ffn1.cin % 8 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
+                CHK(al.upload(to_fragment_order(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_f));
+        }
         GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
         HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
         CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2));
@@ -886,7 +893,13 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
             ConvArgs a = conv_args(E.ffn1, w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
             a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
             a.out[0].act = ACT_GELU_ERF;
-            CHK(launch(a, EPI_PLAIN, B, s));
+            // X-resident kernel when it fills the chip and its 96-column tiles pad no more than the 64-column ones
+            const int t96 = (L + 95) / 96, t64 = (L + 63) / 64;
+            int rc = -2;
+            if (g_ffn_xres && E.ffn1_f && t96 * 96 <= t64 * 64 && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128)
+                rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
+            if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+            if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
         }
         {   // x = (x + ffn_2(.)) * nonpad          (:551, :616-617)
             ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.x, Lp, hs, L);
@@ -1197,6 +1210,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cond_gemm")) {
         const int prev = g_cond_gemm ? 1 : 0;
         if (value == 0 || value == 1) g_cond_gemm = value != 0;
+        return prev;
+    }
+    if (!strcmp(name, "ffn_xres")) {
+        const int prev = g_ffn_xres ? 1 : 0;
+        if (value == 0 || value == 1) g_ffn_xres = value != 0;
         return prev;
     }
     return fail(CMTTS_E_INVALID, "cmtts_set_option: unknown option");

@@ -58,6 +58,8 @@ extern "C" {
 int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
 // 16-bit-operand variant (conv_mfma16.hip): wfrag = fragment-order weights, mode 1 = bf16, 2 = fp16.
 int cmtts_launch_conv16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
+// X-resident variant for short sequences (conv_xres.hip): wfrag = fp32 fragment-order weights; -2 = unsupported.
+int cmtts_launch_conv_xres(const ConvArgs* a, const float* wfrag, int nbatch, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+// X-resident Conv1D for short sequences on gfx950: the k=9 FFN conv of the FFT blocks (model/blocks.py:539-546,
+// Conv1d(256 -> 1024, k=9) + scale + GELU over L <= ~100 phonemes).  The generic kernel (conv_mfma.hip) runs an
+// 85-phoneme utterance as two 64-column tiles (a third of the MFMAs multiply padding) and re-stages X per m-tile.
+// Here a workgroup (4 waves) stages the whole X tile [K <= 256][96 + halo] of one utterance in LDS once, each wave
+// owns one 32-row m-tile over three 32-column n-tiles, and the weights stream L2 -> VGPR in MFMA A-fragment order
+// ([tap][k-group of 8][m-tile][lane][4], one dwordx4 per 12 MFMAs) through a register ring — no weight staging,
+// no barrier in the K loop.  Same (16-channel chunk, tap, k) accumulation order and the same epilogue arithmetic as
+// the generic kernel: BITWISE equal (tests/test_gpu_parity.py::test_xres_conv_bitwise).
+#include <hip/hip_runtime.h>
+#include "conv_args.h"
+#include "conv_epilogue.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KMAX = 256;
+constexpr int BN = 96;          // columns per workgroup (3 MFMA n-tiles)
+constexpr int NT = 3;
+constexpr int HALO = 8;         // (taps - 1) * dil <= 8
+constexpr int X_LD = BN + HALO; // 104
+constexpr int RING = 4;
+
+__global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.x * BN;
+    const int mt = blockIdx.y * 4 + w;             // this wave's m-tile
+    const int z = blockIdx.z;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const float* Xb = a.X + z * a.x_zs0;
+    const int MTn = (a.M + 31) / 32;
+    const int G8 = a.K / 8;
+    const int nq = a.taps * 2;                      // k-groups per 16-channel chunk: (tap, 8-half)
+    const int total = (a.K / 16) * nq;
+
+    // weights of linear k-group index it = chunk * nq + tap * 2 + half (clamped m-tile: idle waves load valid memory)
+    const int mtc = min(mt, MTn - 1);
+    auto load_a = [&](f32x4& dst, int it) {
+        it = min(it, total - 1);
+        const int chunk = it / nq, q = it - chunk * nq;
+        const int g = (q >> 1) * G8 + chunk * 2 + (q & 1);
+        dst = *reinterpret_cast<const f32x4*>(wfrag + (((long)g * MTn + mtc) * 64 + lane) * 4);
+    };
+    f32x4 A[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+
+    {   // stage X[k][n0 - pad + c], c in [0, X_LD): zero outside [0, Tin); 4 rows per thread-row group
+        const int xw = BN + (a.taps - 1) * a.dil;
+        for (int idx = tid; idx < a.K * X_LD; idx += 256) {
+            const int k = idx / X_LD, c = idx - k * X_LD;
+            const int t = n0 - a.pad + c;
+            float v = 0.f;
+            if (c < xw && t >= 0 && t < a.Tin) v = Xb[(long)k * a.ldx + t];
+            xs[idx] = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    auto load_b = [&](float (&dst)[4][NT], int it) {
+        it = min(it, total - 1);
+        const int chunk = it / nq, q = it - chunk * nq;
+        const float* bs = xs + (chunk * 16 + (q & 1) * 8 + khalf) * X_LD + l31 + (q >> 1) * a.dil;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * X_LD + j * 32];
+    };
+    float Bv[2][4][NT];
+    load_b(Bv[0], 0);
+#pragma unroll 1
+    for (int it = 0; it < total; it += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+            load_b(Bv[(s + 1) & 1], it + s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + s < total) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (mt >= MTn) return;
+    const ConvOut& o = a.out[0];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) epi_tile(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z, 0);
+}
+
+}  // namespace
+
+// Conv1d with fragment-order fp32 weights [taps][K/8][ceil(M/32)][64][4]; zdiv == 1, split == INT_MAX, dil > 0,
+// K % 16 == 0, K <= 256, (taps-1)*dil <= 8, no pre-activation.  Meant for short sequences (N of a few 96-column tiles)
+// with many output rows.  Returns 0, -2 (unsupported: use cmtts_launch_conv) or -3.
+extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, int nbatch, void* stream_) {
+    const ConvArgs& a = *ap;
+    if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
+    if (!wfrag || a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || a.K % 16 != 0 || a.K > KMAX || (a.taps - 1) * a.dil > HALO ||
+        a.pre_div != 1.0f || a.pre_slope != 1.0f)
+        return -2;
+    static bool attr_set = false;
+    const size_t lds = (size_t)a.K * X_LD * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)KMAX * X_LD * sizeof(float))) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.N + BN - 1) / BN, ((a.M + 31) / 32 + 3) / 4, nbatch);
+    hipLaunchKernelGGL(conv_xres_kernel, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

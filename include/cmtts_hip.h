@@ -161,7 +161,9 @@ int cmtts_set_fused_resblock(int on);
 int cmtts_set_persistent_denoiser(int mode);
 /* A/B switches that do not change results (bitwise, tested).  "cond_gemm": 1 (default) = the stacked conditioner
  * projections of all residual layers through the X-resident kernel (cond_gemm.hip), 0 = through the generic conv
- * kernel.  Returns the previous value (any other value only queries), or a negative status for an unknown name. */
+ * kernel.  "ffn_xres": 1 (default) = the k=9 FFN conv of the FFT blocks through the X-resident kernel
+ * (conv_xres.hip) when the batch fills the chip, 0 = always the generic kernel.  Returns the previous value (any
+ * other value only queries), or a negative status for an unknown name. */
 int cmtts_set_option(const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;

@@ -610,6 +610,31 @@ def test_persistent_denoiser_bitwise(variant, B, T):
     assert torch.equal(mel_p, mel_r), float((mel_p - mel_r).abs().max())
 
 
+def test_xres_conv_bitwise(models):
+    """conv_xres.hip (k=9 FFN conv with the utterance's X tile resident in LDS, 96-column tiles) keeps the generic
+    kernel's accumulation order and epilogue: the text encoder output must not change by a bit (B=32 x L=85 takes the
+    X-resident path, the ragged golden batch the generic one)."""
+    host = _host()
+    lib = _lib.load()
+    g, cfg, sd, model = models("LJSpeech")
+    rs = np.random.RandomState(11)
+    B, L = 32, 85
+    lens = rs.randint(40, L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    prev = lib.cmtts_set_option(b"ffn_xres", 1)
+    try:
+        one = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        lib.cmtts_set_option(b"ffn_xres", 0)
+        ref = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+    finally:
+        lib.cmtts_set_option(b"ffn_xres", prev)
+    torch.cuda.synchronize()
+    for k in ("enc_out", "log_d_predictions", "cond"):
+        assert torch.equal(one[k], ref[k]), (k, float((one[k] - ref[k]).abs().max()))
+
+
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
 def test_cond_gemm_bitwise(variant, B, T):
     """cond_gemm.hip (conditioner projections of all layers, X tile resident in LDS) keeps the generic kernel's
