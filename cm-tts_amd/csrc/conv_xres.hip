@@ -46,14 +46,27 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
 
-    {   // stage X[k][n0 - pad + c], c in [0, X_LD): zero outside [0, Tin); 4 rows per thread-row group
+    {   // stage X[k][n0 - pad + c], c in [0, X_LD): zero outside [0, Tin); lane = column (two passes), a quarter of the
+        // rows per wave, 8 unconditional clamped loads in flight
         const int xw = BN + (a.taps - 1) * a.dil;
-        for (int idx = tid; idx < a.K * X_LD; idx += 256) {
-            const int k = idx / X_LD, c = idx - k * X_LD;
+        const int rows = a.K / 4;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const int c = lane + 64 * cp;
             const int t = n0 - a.pad + c;
-            float v = 0.f;
-            if (c < xw && t >= 0 && t < a.Tin) v = Xb[(long)k * a.ldx + t];
-            xs[idx] = v;
+            const bool ok = c < xw && t >= 0 && t < a.Tin;
+            const int tc = min(max(t, 0), a.Tin - 1);
+            if (c < X_LD) {
+#pragma unroll 1
+                for (int k0 = w * rows; k0 < (w + 1) * rows; k0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = Xb[(long)min(k0 + q, a.K - 1) * a.ldx + tc];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (k0 + q < (w + 1) * rows) xs[(k0 + q) * X_LD + c] = ok ? v[q] : 0.f;
+                }
+            }
         }
     }
     __syncthreads();
