@@ -188,8 +188,9 @@ def main():
         kname = "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_) * BATCH * FRAMES_PAD
     elif persistent:   # all residual layers of one sampler step in one launch
-        kname = f"denoiser_persist_kernel ({cfg.res_layers} residual layers: gated k=3 conv + output projection each, x / skip resident)"
-        flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD * cfg.res_layers
+        kname = (f"denoiser_persist_kernel ({cfg.res_layers} residual layers: gated k=3 conv + output projection each, x / skip "
+                 "resident; skip head in the tail)")
+        flops_launch = (2.0 * (2 * C_) * (3 * C_ + C_) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
     else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
         kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD

@@ -243,6 +243,7 @@ struct Profile {
 } g_prof;
 
 bool g_fused_resblock = true;
+bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hip (false: generic kernel, A/B and tests)
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
@@ -292,6 +293,7 @@ struct cmtts_model {
     float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
     float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
     PackedConv in_proj, skip_proj, out_proj;
+    float *skip_f = nullptr, *outp_f = nullptr;   // skip / output projection in fragment order (persistent kernel's tail)
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
@@ -525,9 +527,18 @@ int finalize_model(cmtts_model* m) {
     if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
     {
         GET(w, "net.skip_projection.conv.weight", C, C, 1); GET(b, "net.skip_projection.conv.bias", C);
-        CHK(pack_conv(al, *w, b, nullptr, &m->skip_proj));
+        std::vector<float> hp;
+        CHK(pack_conv(al, *w, b, nullptr, &m->skip_proj, &hp));
+        if (C % 32 == 0 && m->skip_proj.ld == C) CHK(al.upload(to_fragment_order(hp, 1, C, C), &m->skip_f));
         GET(w2, "net.output_projection.conv.weight", c.n_mels, C, 1); GET(b2, "net.output_projection.conv.bias", c.n_mels);
-        CHK(pack_conv(al, *w2, b2, nullptr, &m->out_proj));
+        CHK(pack_conv(al, *w2, b2, nullptr, &m->out_proj, &hp));
+        {   // rows padded to a multiple of 32 with zeros for the MFMA tiles of the fused tail
+            const int ld = m->out_proj.ld, Mp = round_up(c.n_mels, 32);
+            std::vector<float> padded((size_t)C * Mp, 0.f);
+            for (int k = 0; k < C; ++k)
+                for (int n = 0; n < c.n_mels; ++n) padded[(size_t)k * Mp + n] = hp[(size_t)k * ld + n];
+            CHK(al.upload(to_fragment_order(padded, 1, C, Mp), &m->outp_f));
+        }
     }
 #undef GET
 #undef UP
@@ -676,8 +687,16 @@ int step_embedding(cmtts_model* m, const DenWs& w, const float* timesteps, const
     return 0;
 }
 
+// The sampler's post-scaling of the denoiser output (karras_diffusion.py:406,852): out = c_out*F + c_skip*xold (+ noise*nstd*0.85)
+struct MelPost {
+    const float* xold;
+    const float* noise;
+    float c_out, c_skip, nstd;
+    float* out;
+};
+
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
-                  const float* cond_ct, const float* spk, int B, int T, hipStream_t s, bool embed = true) {
+                  const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true) {
     if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
@@ -706,6 +725,13 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         pa.skip = w.skip; pa.halo = w.halo; pa.tmo = g_tmo_host;
         pa.B = B; pa.T = T; pa.NL = NL;
         const int prec = m->precision;
+        if (g_persist_tail && prec == 0 && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
+            pa.tail = 1;
+            pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
+            pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;
+            pa.xold = post.xold; pa.noise = post.noise; pa.c_out = post.c_out; pa.c_skip = post.c_skip; pa.nstd = post.nstd;
+            pa.out = post.out;
+        }
         for (int l = 0; l < NL; ++l) {
             pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : m->res[l].w3f;
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
@@ -719,6 +745,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         if (rc == 0) {
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
             layers_done = true;
+            if (pa.tail) return 0;
         }
     }
     for (int l = 0; l < NL && !layers_done; ++l) {
@@ -776,6 +803,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         ConvArgs b = conv_args(m->out_proj, halt, T, T, cs, w.hin, T, (long)M * T, T);
         CHK(launch(b, EPI_PLAIN, B, s));
     }
+    k_mel_post(w.hin, post.xold, post.noise, post.c_out, post.c_skip, post.nstd, post.out, B, T, M, s);
     return 0;
 }
 
@@ -1002,8 +1030,8 @@ int cmtts_denoiser_forward(cmtts_model* m, const float* x, const float* timestep
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, s));
-    CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, s));
-    k_mel_post(w.hin, nullptr, nullptr, 1.0f, 0.0f, 0.0f, out, B, T, m->cfg.n_mels, s);
+    const MelPost post = {nullptr, nullptr, 1.0f, 0.0f, 0.0f, out};
+    CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, post, s));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1054,11 +1082,11 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
         const float t_resc = 250.0f * logf(sg + 1e-44f);
         const bool new_sigma = i == 0 || sigmas[i] != sigmas[i - 1];
         if (new_sigma) k_fill_float(w.tbuf, t_resc, B, s);
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, s, new_sigma));
         const bool last = i + 1 == n_steps;
         const bool renoise = renoise_std[i] >= 0.0f;
-        k_mel_post(w.hin, w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
-                   renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur, B, T, c.n_mels, s);
+        const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
+                              renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1210,6 +1238,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cond_gemm")) {
         const int prev = g_cond_gemm ? 1 : 0;
         if (value == 0 || value == 1) g_cond_gemm = value != 0;
+        return prev;
+    }
+    if (!strcmp(name, "persist_tail")) {
+        const int prev = g_persist_tail ? 1 : 0;
+        if (value == 0 || value == 1) g_persist_tail = value != 0;
         return prev;
     }
     if (!strcmp(name, "ffn_xres")) {

@@ -20,6 +20,19 @@ struct PersistArgs {
     long vec_stride;
     int B, T, NL;
     int tiles;            // filled by the launcher
+    // optional in-kernel tail (fp32 kernel): skip head of Denoiser.forward (model/modules.py:634-637) + the sampler's
+    // post-scaling (karras_diffusion.py:406,852); when tail != 0 the skip sum is not written to `skip`
+    int tail;
+    const float* Wsf;     // skip_projection, fragment order [32][8][64][4]
+    const float* bs;      // [256]
+    const float* Wpf;     // output_projection, fragment order [32][3][64][4] (rows >= n_mels zero)
+    const float* bp;      // [n_mels]
+    float skip_div;       // sqrt(NL)
+    int n_mels;
+    const float* xold;    // [B][T][n_mels] or null
+    const float* noise;   // [B][T][n_mels] or null
+    float c_out, c_skip, nstd;
+    float* out;           // [B][T][n_mels]
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
 };
 

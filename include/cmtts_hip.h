@@ -162,7 +162,9 @@ int cmtts_set_persistent_denoiser(int mode);
 /* A/B switches that do not change results (bitwise, tested).  "cond_gemm": 1 (default) = the stacked conditioner
  * projections of all residual layers through the X-resident kernel (cond_gemm.hip), 0 = through the generic conv
  * kernel.  "ffn_xres": 1 (default) = the k=9 FFN conv of the FFT blocks through the X-resident kernel
- * (conv_xres.hip) when the batch fills the chip, 0 = always the generic kernel.  Returns the previous value (any
+ * (conv_xres.hip) when the batch fills the chip, 0 = always the generic kernel.  "persist_tail": 1 (default) = the
+ * skip head (skip_projection, ReLU, output_projection) and the sampler's post-scaling run inside the persistent
+ * denoiser launch, 0 = as separate launches.  Returns the previous value (any
  * other value only queries), or a negative status for an unknown name. */
 int cmtts_set_option(const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
