@@ -725,7 +725,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         pa.skip = w.skip; pa.halo = w.halo; pa.tmo = g_tmo_host;
         pa.B = B; pa.T = T; pa.NL = NL;
         const int prec = m->precision;
-        if (g_persist_tail && prec == 0 && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
+        if (g_persist_tail && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
             pa.tail = 1;
             pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
             pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;

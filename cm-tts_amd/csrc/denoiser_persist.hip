@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include "gate.h"
 #include "persist_args.h"
+#include "persist_tail.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -378,98 +379,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         stamp(l, 7);
     }
 
-    if (a.tail) {
-        // ---- skip head in-kernel: sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection -> c_out*F + c_skip*x
-        // (+ re-noising), the arithmetic of the generic conv epilogues and of mel_post_kernel, in the same order.
-        float* u_lds = smem;                  // free since barrier (3) of the last layer
-        float* z_lds = smem + C * U_LD;
-        {
-            const int ln = opaque(lane), c31 = ln & 31;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u_lds[(mrow0 + acc_row(r, ln)) * U_LD + j * 32 + c31] = st[1][j][r] / a.skip_div;
-        }
-        __syncthreads();   // (A) skip tile staged; every wave has left the last output projection (z is free)
-        constexpr int NGC = C / 8;
-        auto load_bt = [&](float (&dst)[4][NT], const float* src, int g) {
-            const float* bs = src + (g * 8 + khalf) * U_LD + l31;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
-        };
-        f32x16 h[NT];
-        auto gemm_tile = [&](const float* wfrag, int mtiles, int mt, const float* src) {   // h = W[mt] * src, K = 256
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[j][r] = 0.f;
-            f32x4 Af[RING];
-            float Bt[2][4][NT];
-#pragma unroll
-            for (int s = 0; s < RING - 1; ++s)
-                Af[s] = *reinterpret_cast<const f32x4*>(wfrag + (((long)min(s, NGC - 1) * mtiles + mt) * 64 + lane) * 4);
-            load_bt(Bt[0], src, 0);
-#pragma unroll 1
-            for (int it = 0; it < NGC; it += RING) {
-#pragma unroll
-                for (int s = 0; s < RING; ++s) {
-                    Af[(s + RING - 1) % RING] =
-                        *reinterpret_cast<const f32x4*>(wfrag + (((long)min(it + s + RING - 1, NGC - 1) * mtiles + mt) * 64 + lane) * 4);
-                    load_bt(Bt[(s + 1) & 1], src, min(it + s + 1, NGC - 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (it + s < NGC) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j)
-                                h[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[s][kk], Bt[s & 1][kk][j], h[j], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        gemm_tile(a.Wsf, C / 32, w, u_lds);          // skip_projection rows [32w, +32)
-        {
-            const int ln = opaque(lane), c31 = ln & 31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + acc_row(r, ln);
-                const float bi = ldg(a.bs, (unsigned)m);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float v = h[j][r] + bi;
-                    v *= 1.0f;
-                    v = v > 0.f ? v : 0.f;
-                    z_lds[m * U_LD + j * 32 + c31] = v;
-                }
-            }
-        }
-        __syncthreads();   // (B) relu(skip_projection) complete
-        const int otiles = (a.n_mels + 31) / 32;
-        if (w < otiles) {
-            gemm_tile(a.Wpf, otiles, w, z_lds);      // output_projection rows [32w, +32) of n_mels
-            const int ln = opaque(lane), c31 = ln & 31;
-            const int M = a.n_mels;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + acc_row(r, ln);
-                const float bi = m < M ? ldg(a.bp, (unsigned)m) : 0.f;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int t = t0 + j * 32 + c31;
-                    if (m < M && t < T) {
-                        const long o = ((long)b * T + t) * M + m;
-                        const float F = h[j][r] + bi;
-                        float v = a.c_out * F;
-                        if (a.xold) v = __builtin_fmaf(a.c_skip, a.xold[o], v);
-                        if (a.noise) v = __builtin_fmaf(a.noise[o] * a.nstd, 0.85f, v);
-                        a.out[o] = v;
-                    }
-                }
-            }
-        }
+    if (a.tail) {   // skip head + post-scaling in-kernel (persist_tail.h); the u buffer is free since barrier (3), z after barrier (A) inside
+        persist_tail::run(a, smem, smem + C * U_LD, st[1], w, lane, b, t0, T);
     } else {   // ---- the skip sum leaves the chip once
         float* skip = a.skip + (long)b * C * T;
 #pragma unroll

@@ -10,6 +10,7 @@
 #include "cvt16.h"
 #include "gate.h"
 #include "persist_args.h"
+#include "persist_tail.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -326,7 +327,13 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         }
     }
 
-    {   // the skip sum leaves the chip once
+    if (a.tail) {
+        // skip head + post-scaling in fp32 (persist_tail.h).  Its two fp32 buffers overlay u^T / z^T: wait until every
+        // wave has left the last output projection.
+        __syncthreads();
+        float* f32lds = reinterpret_cast<float*>(lds16);
+        persist_tail::run(a, f32lds, f32lds + C * persist_tail::PT_LD, st[1], w, lane, b, t0, T);
+    } else {   // the skip sum leaves the chip once
         float* skip = a.skip + (long)b * C * T;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -341,10 +348,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
 template <int MODE>
 int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * FN + 2) * RS * sizeof(unsigned short);
+    // the fp32 tail overlays two [256][68] float buffers on the 16-bit u^T / z^T images
+    const size_t lds16b = (size_t)(2 * FN + 2) * RS * sizeof(unsigned short), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
+    const size_t lds = a.tail && ldstail > lds16b ? ldstail : lds16b;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ldstail > lds16b ? ldstail : lds16b)) != hipSuccess)
             return -3;
         attr_set = true;
     }
@@ -361,6 +370,12 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
         c.halo = a.halo + (long)b0 * tiles * 2 * C;
+        if (a.tail) {
+            const long off = (long)b0 * a.T * a.n_mels;
+            c.xold = a.xold ? a.xold + off : nullptr;
+            c.noise = a.noise ? a.noise + off : nullptr;
+            c.out = a.out + off;
+        }
         hipLaunchKernelGGL(denoiser_persist_lp_kernel<MODE>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }

@@ -1,0 +1,122 @@
+// Tail of the persistent denoiser kernels (denoiser_persist.hip, denoiser_persist_lp.hip): the skip head of
+// Denoiser.forward (model/modules.py:634-637: sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection) and
+// the sampler's post-scaling (karras_diffusion.py:406,852), in fp32, with the arithmetic of the generic conv epilogues
+// and of mel_post_kernel in the same order (bitwise equal to the separate launches).  Every wave passes its 32 rows x
+// 64 frames of the skip sum (MFMA accumulator layout); u_lds / z_lds are two [256][PT_LD] fp32 LDS buffers that no
+// wave reads any more.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "persist_args.h"
+
+namespace persist_tail {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PT_C = 256, PT_NT = 2, PT_LD = 68, PT_RING = 6;
+
+__device__ __forceinline__ int pt_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float pt_ldg(const float* base, unsigned idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u));
+}
+__device__ __forceinline__ int pt_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z_lds, const f32x16 (&skip)[PT_NT], int w, int lane,
+                                    int b, int t0, int T) {
+    constexpr int C = PT_C, NT = PT_NT, U_LD = PT_LD, RING = PT_RING;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int mrow0 = w * 32;
+    auto opaque = [](int v) { return pt_opaque(v); };
+    auto acc_row = [](int r, int ln) { return pt_row(r, ln); };
+    auto ldg = [](const float* p, unsigned i) { return pt_ldg(p, i); };
+    // ---- skip head in-kernel: sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection -> c_out*F + c_skip*x
+    // (+ re-noising), the arithmetic of the generic conv epilogues and of mel_post_kernel, in the same order.
+    {
+        const int ln = opaque(lane), c31 = ln & 31;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u_lds[(mrow0 + acc_row(r, ln)) * U_LD + j * 32 + c31] = skip[j][r] / a.skip_div;
+    }
+    __syncthreads();   // (A) skip tile staged; every wave has left the last output projection (z is free)
+    constexpr int NGC = C / 8;
+    auto load_bt = [&](float (&dst)[4][NT], const float* src, int g) {
+        const float* bs = src + (g * 8 + khalf) * U_LD + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
+    };
+    f32x16 h[NT];
+    auto gemm_tile = [&](const float* wfrag, int mtiles, int mt, const float* src) {   // h = W[mt] * src, K = 256
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[j][r] = 0.f;
+        f32x4 Af[RING];
+        float Bt[2][4][NT];
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s)
+            Af[s] = *reinterpret_cast<const f32x4*>(wfrag + (((long)min(s, NGC - 1) * mtiles + mt) * 64 + lane) * 4);
+        load_bt(Bt[0], src, 0);
+#pragma unroll 1
+        for (int it = 0; it < NGC; it += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                Af[(s + RING - 1) % RING] =
+                    *reinterpret_cast<const f32x4*>(wfrag + (((long)min(it + s + RING - 1, NGC - 1) * mtiles + mt) * 64 + lane) * 4);
+                load_bt(Bt[(s + 1) & 1], src, min(it + s + 1, NGC - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + s < NGC) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            h[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[s][kk], Bt[s & 1][kk][j], h[j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    gemm_tile(a.Wsf, C / 32, w, u_lds);          // skip_projection rows [32w, +32)
+    {
+        const int ln = opaque(lane), c31 = ln & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + acc_row(r, ln);
+            const float bi = ldg(a.bs, (unsigned)m);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v = h[j][r] + bi;
+                v *= 1.0f;
+                v = v > 0.f ? v : 0.f;
+                z_lds[m * U_LD + j * 32 + c31] = v;
+            }
+        }
+    }
+    __syncthreads();   // (B) relu(skip_projection) complete
+    const int otiles = (a.n_mels + 31) / 32;
+    if (w < otiles) {
+        gemm_tile(a.Wpf, otiles, w, z_lds);      // output_projection rows [32w, +32) of n_mels
+        const int ln = opaque(lane), c31 = ln & 31;
+        const int M = a.n_mels;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + acc_row(r, ln);
+            const float bi = m < M ? ldg(a.bp, (unsigned)m) : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + c31;
+                if (m < M && t < T) {
+                    const long o = ((long)b * T + t) * M + m;
+                    const float F = h[j][r] + bi;
+                    float v = a.c_out * F;
+                    if (a.xold) v = __builtin_fmaf(a.c_skip, a.xold[o], v);
+                    if (a.noise) v = __builtin_fmaf(a.noise[o] * a.nstd, 0.85f, v);
+                    a.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace persist_tail
