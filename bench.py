@@ -219,7 +219,7 @@ def main():
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE in separate --pmc passes (profiles/pmc_traffic.json); "
                                      "algorithmic %.1f MB -> HBM fraction %.3f" % (
-                                         (BATCH * FRAMES_PAD * 1024 * (cfg.res_layers + 2) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
+                                         (BATCH * FRAMES_PAD * (1024 * (cfg.res_layers + 1) + 8 * cfg.n_mels) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
                                          (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                      "flops_per_launch": flops_launch},
