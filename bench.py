@@ -279,6 +279,14 @@ def main():
         assert torch.isfinite(state["wav"]).all()
         extras["frames_per_s_end_to_end_wav_T4"] = round(frames_rank * k / d, 1)
         extras["rtf_end_to_end_T4"] = round((d / k) / audio_s, 6)
+        # BASELINE.json configs[2] shape: bf16 residual blocks + bf16 HiFi-GAN ResBlock convs (fp32 accumulate)
+        model.set_precision("bf16")
+        voc.set_precision("bf16")
+        d = timed(e2e, k, 1, 1)
+        model.set_precision("fp32")
+        voc.set_precision("fp32")
+        assert torch.isfinite(state["wav"]).all()
+        extras["frames_per_s_end_to_end_wav_T4_bf16"] = round(frames_rank * k / d, 1)
         result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd)

@@ -13,6 +13,7 @@ model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cf
 B, T = 32, 512
 x = torch.randn(B, 1, T, 80, device="cuda"); cond = torch.randn(B, T, 256, device="cuda"); t = torch.full((B,), 1095.5, device="cuda")
 lib = _lib.load()
+lib.cmtts_set_persistent_denoiser(0)      # this tool times the per-layer kernel (tools/persist_timing.py: the persistent one)
 for _ in range(2):
     model.net(x, t, cond, None)
 nblk = (T // 64) * B        # 64-frame tiles (auto-selected at this size)
