@@ -13,6 +13,15 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a fresh checkout has no libcmtts_hip.so (build artefacts are git-ignored): build it once (hipcc cross-compiles
+    # gfx950 without a GPU; the GPU box only ever sees the prebuilt file)
+    lib = os.path.join(ROOT, "cm-tts_amd", "libcmtts_hip.so")
+    if not os.path.exists(lib):
+        import shutil
+        import subprocess
+        if shutil.which("hipcc"):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "cm-tts_amd", "csrc"), "-j4"], check=True,
+                           stdout=subprocess.DEVNULL)
 
 
 def load_golden(name):
