@@ -661,6 +661,39 @@ def test_cond_gemm_bitwise(variant, B, T):
     assert torch.equal(one, ref), float((one - ref).abs().max())
 
 
+def test_persistent_denoiser_under_uneven_load():
+    """The in-kernel edge-column hand-off must not depend on the workgroups starting together: run the persistent stack
+    while other streams keep part of the GPU busy (its workgroups then become resident at different times and wait for
+    each other through the tagged granules), several times, and compare bitwise with the per-layer result."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("LJSpeech")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=9))
+    B, T = 32, 512
+    gen = torch.Generator(device="cpu").manual_seed(99)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen).to(DEV)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    t = torch.full((B,), 1095.5, device=DEV)
+    prev = lib.cmtts_set_persistent_denoiser(0)
+    try:
+        ref = model.net(x, t, cond, None)
+        torch.cuda.synchronize()
+        lib.cmtts_set_persistent_denoiser(2)
+        side = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+        a = torch.randn(4096, 4096, device=DEV)
+        for rep in range(4):
+            for i, s in enumerate(side):            # long GEMMs / elementwise chains on other streams
+                with torch.cuda.stream(s):
+                    for _ in range(3 + 2 * rep + i):
+                        b = a @ a
+                        b = torch.tanh(b * 1e-3)
+            out = model.net(x, t, cond, None)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("variant,B,T", [("VCTK", 2, 200), ("LJSpeech", 32, 512), ("VCTK", 40, 300)])
 def test_persistent_denoiser_lp_bitwise(variant, B, T, dtype):
