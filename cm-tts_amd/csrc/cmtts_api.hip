@@ -1205,6 +1205,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bufT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
                 if (v->precision) {
+                    a.y16 = 1; a.y16_slope = 0.1f;        // xt crosses HBM as convert(leaky_relu(xt)) in 16 bits
                     if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
@@ -1216,6 +1217,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = ld;
                 b.out[0].accum = lastm && j > 0;
                 if (v->precision) {
+                    b.x16 = 1;
                     if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {

@@ -48,6 +48,10 @@ struct ConvArgs {
     float pre_slope;      // then leaky_relu with this slope (1 = identity)
     int split;            // rows m >= split use out[1]
     ConvOut out[2];
+    // 16-bit kernel only (conv_mfma16.hip): activations exchanged between two convs of a ResBlock in 16 bits
+    int x16;              // X holds 16-bit values that are already activated (no pre_div / pre_slope applied)
+    int y16;              // Y is written as 16-bit leaky_relu(v, y16_slope) instead of fp32 v
+    float y16_slope;
 };
 
 #ifdef __cplusplus

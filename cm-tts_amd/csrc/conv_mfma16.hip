@@ -36,7 +36,10 @@ __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f3
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// IO: 0 = fp32 in / fp32 out, 1 = fp32 in / 16-bit activated out (conv1 of a ResBlock pair), 2 = 16-bit activated in /
+// fp32 out (conv2): the intermediate xt of a pair crosses HBM in 16 bits, with exactly the value conv2's staging would
+// have produced from an fp32 xt (convert(leaky_relu(xt))), so results do not change.
+template <int BM, int BN, int WM, int WN, int MODE, int IO>
 __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(const ConvArgs a, const u32x4* __restrict__ wfrag) {
     constexpr int MT = BM / (WM * 32);
     constexpr int NT = BN / (WN * 32);
@@ -71,15 +74,22 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
         // columns beyond the tile's halo are never read: point them at one line instead of fetching them
         tcl[j] = min(max(min(t, tbase + BN + (a.taps - 1) * a.dil - 1), 0), a.Tin - 1);
     }
-    float xr[4][2][XJ];
+    float xr[4][2][XJ];                 // IO == 2: the 16-bit values, zero-extended, in the same registers
     auto load_x = [&](int chunk) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float* xrow = Xb + (long)(chunk * KC + (wid * 4 + p) * 2 + h) * a.ldx;
+                const long row = (long)(chunk * KC + (wid * 4 + p) * 2 + h) * a.ldx;
+                if (IO == 2) {
+                    const unsigned short* xrow = reinterpret_cast<const unsigned short*>(a.X) + z * a.x_zs0 + row;
 #pragma unroll
-                for (int j = 0; j < XJ; ++j) xr[p][h][j] = xrow[tcl[j]];
+                    for (int j = 0; j < XJ; ++j) xr[p][h][j] = __uint_as_float((unsigned)xrow[tcl[j]]);
+                } else {
+                    const float* xrow = Xb + row;
+#pragma unroll
+                    for (int j = 0; j < XJ; ++j) xr[p][h][j] = xrow[tcl[j]];
+                }
             }
     };
     auto store_x = [&](int buf) {
@@ -88,9 +98,14 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int j = 0; j < XJ; ++j) {
-                const float v0 = xr[p][0][j], v1 = xr[p][1][j];
-                *reinterpret_cast<unsigned*>(xb + (lane + 64 * j) * RSX + (wid * 4 + p) * 2) =
-                    pack16<MODE>(v0 * (v0 > 0.f ? fpos[j] : fneg[j]), v1 * (v1 > 0.f ? fpos[j] : fneg[j]));
+                unsigned pk;
+                if (IO == 2) {
+                    pk = fpos[j] != 0.f ? (__float_as_uint(xr[p][0][j]) | (__float_as_uint(xr[p][1][j]) << 16)) : 0u;
+                } else {
+                    const float v0 = xr[p][0][j], v1 = xr[p][1][j];
+                    pk = pack16<MODE>(v0 * (v0 > 0.f ? fpos[j] : fneg[j]), v1 * (v1 > 0.f ? fpos[j] : fneg[j]));
+                }
+                *reinterpret_cast<unsigned*>(xb + (lane + 64 * j) * RSX + (wid * 4 + p) * 2) = pk;
             }
     };
 
@@ -178,7 +193,16 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
                 rv[r] = rb ? rb[mrow[r] * (unsigned)o.ldr + nc] : 0.f;
                 yv[r] = o.accum ? yb[mrow[r] * (unsigned)o.ldy + nc] : 0.f;
             }
-            if (full_m) {
+            if (IO == 1) {      // conv1 of a pair: xt leaves as convert(leaky_relu(xt)), what conv2's staging would compute
+                unsigned short* y16 = reinterpret_cast<unsigned short*>(o.Y) + z * o.y_zs0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    float v = acc[i][j][r] + bi[r];
+                    v = v * (v > 0.f ? 1.f : a.y16_slope);
+                    if (n < a.N && m < a.M) y16[(unsigned)m * (unsigned)o.ldy + (unsigned)n] = (unsigned short)pack16<MODE>(v, 0.f);
+                }
+            } else if (full_m) {
                 if (n < a.N) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) yb[mrow[r] * (unsigned)o.ldy + (unsigned)n] = ((acc[i][j][r] + bi[r]) + rv[r]) + yv[r];
@@ -201,10 +225,11 @@ int launch16(const ConvArgs& a, const void* wfrag, int mode, int nbatch, hipStre
     if (halo > 64) return -2;
     const size_t lds = (size_t)2 * (BN + 64) * RSX * sizeof(unsigned short);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch);
-    if (mode == 1)
-        hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag);
-    else
-        hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag);
+    const int io = a.y16 ? 1 : (a.x16 ? 2 : 0);
+#define CMTTS_L16(M_, IO_) hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, M_, IO_>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag)
+    if (mode == 1) { if (io == 1) CMTTS_L16(1, 1); else if (io == 2) CMTTS_L16(1, 2); else CMTTS_L16(1, 0); }
+    else { if (io == 1) CMTTS_L16(2, 1); else if (io == 2) CMTTS_L16(2, 2); else CMTTS_L16(2, 0); }
+#undef CMTTS_L16
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -220,6 +245,7 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
     if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
     const ConvOut& o = a.out[0];
     if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || (mode != 1 && mode != 2) || a.K % KC != 0) return -2;
+    if ((a.x16 && a.y16) || (a.y16 && (o.res || o.accum)) || (a.x16 && (a.pre_div != 1.f))) return -2;
     if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||
         o.row_off != 0 || o.Tout != a.N)
         return -2;
