@@ -6,16 +6,19 @@
 //     accumulator layout: per layer HBM sees only cp (the precomputed conditioner projection) — x, x', skip are
 //     neither re-read nor re-written (resblock_fused.hip moves 5 KB/frame/layer, this kernel 1 KB);
 //   * LDS holds u and z in separate buffers, so a wave gates its rows as soon as ITS k=3 conv is done (two
-//     workgroup barriers per layer instead of three) and u of the NEXT layer is written in place by the x waves
-//     straight from registers after the projection (its cp tile was pulled into L2 during the conv);
+//     workgroup barriers per layer instead of three) and every wave writes its 32 rows of the NEXT layer's u in place,
+//     straight from registers, after the projection (the cp tile was pulled into L2 during the conv);
 //   * the +-1 frame Conv1D halo is the only inter-workgroup traffic: the two edge columns of x' (2 x 256 values)
 //     go to the neighbouring tiles as 8-byte {layer tag, value} granules — write-through agent-scope stores, the
 //     consumer re-reads until every tag matches (cdna_hip_programming.md §6 Guideline 16, form R2: the data is
 //     the flag, no fences).  Granule slots alternate by layer parity: a workgroup can be at most one layer ahead
 //     of a neighbour, because finishing layer l+1 needs the neighbour's layer-l columns.
 //
-// Every workgroup must be resident: the launcher keeps the grid <= the CU count (one 1024-thread workgroup per CU)
-// and splits larger batches into utterance chunks; spins are bounded and report through a timeout word.
+//   * after the last layer the skip head (skip_projection, ReLU, output_projection) and the sampler's post-scaling run
+//     in the same launch (persist_tail.h): the skip sum never leaves the chip.
+//
+// Every workgroup must be resident: the launcher keeps the grid <= the CU count (one 512-thread, 139-KB-LDS workgroup
+// per CU) and splits larger batches into balanced utterance chunks; spins are bounded and report through a timeout word.
 // Arithmetic and accumulation order are those of resblock_fused.hip: BITWISE equal to the per-layer kernels
 // (tests/test_gpu_parity.py::test_persistent_denoiser_bitwise).
 #include <hip/hip_runtime.h>
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < T) ? uh : 0.f;
         }
     }
-    // resident state: x tile (waves 0-7) or skip sum (waves 8-15), MFMA C layout: [j][r] = row acc_row(r), frame j*32+l31
+    // resident state: st[0] = this wave's 32 rows of x, st[1] = its 32 rows of the skip sum; MFMA C layout: [j][r] = row
+    // acc_row(r), frame j*32 + l31
     f32x16 st[MT][NT];
     {
         const float* xin = a.x0 + (long)b * C * T;
