@@ -173,7 +173,7 @@ def main():
 
     # ---- headline: timed region with HIP events around the dominant kernel
     # persistent mode: ONE launch runs all residual layers of a sampler step (4 launches per step: bracket them all)
-    persistent = (not args.unfused) and lib.cmtts_set_persistent_denoiser(-1) != 0 and BATCH * ((FRAMES_PAD + 63) // 64) * 4 >= 256 * 3
+    persistent = (not args.unfused) and lib.cmtts_set_persistent_denoiser(-1) != 0 and BATCH * ((FRAMES_PAD + 63) // 64) * 2 > 256
     stride = 1 if persistent else PROFILE_STRIDE
     dt = timed(step, args.steps, args.warmup, world,
                before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers, stride)))

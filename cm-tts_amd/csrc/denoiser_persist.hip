@@ -421,9 +421,10 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles = (a.T + FN - 1) / FN;
     if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30)) return -2;
-    // a workgroup walks the whole stack alone (~140 us per layer): with fewer workgroups than 3/4 of the CUs the
-    // per-layer kernels, which spread a small batch over 32-frame tiles, finish sooner (measured)
-    if (!force && (long)tiles * a.B * 4 < (long)max_blocks * 3) return -2;
+    // a workgroup walks the whole stack alone (~128 us per layer): while the per-layer kernels can still spread the batch
+    // over the chip in ONE round of 32-frame tiles (tiles <= CUs / 2) they finish sooner (2.4 vs 3.2 ms per evaluation);
+    // above that they need two rounds (4.0 ms) and the persistent stack wins (measured, tools/mid_bench.py)
+    if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
     static bool attr_set = false;

@@ -391,7 +391,7 @@ extern "C" int cmtts_launch_denoiser_persist_lp(const PersistArgs* a_in, int mod
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles = (a.T + FN - 1) / FN;
     if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30) || (mode != 1 && mode != 2)) return -2;
-    if (!force && (long)tiles * a.B * 4 < (long)max_blocks * 3) return -2;
+    if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = nullptr;
     if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;

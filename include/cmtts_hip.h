@@ -154,8 +154,8 @@ int cmtts_profile_begin(int max_launches, int stride);
 int cmtts_set_fused_resblock(int on);
 /* Residual layers of the denoiser as ONE persistent launch per utterance chunk (denoiser_persist.hip: the tile's
  * residual stream and skip sum stay in registers for all layers, neighbouring tiles exchange their edge columns
- * in-kernel) instead of one launch per layer.  mode 0 = never, 1 = when it pays (default: at least 3/4 of the CUs
- * get a workgroup), 2 = whenever the shape is supported (an utterance has at most as many 64-frame tiles as the
+ * in-kernel) instead of one launch per layer.  mode 0 = never, 1 = when it pays (default: more 64-frame
+ * tiles than half the CUs, i.e. the per-layer kernels would need a second round of 32-frame tiles), 2 = whenever the shape is supported (an utterance has at most as many 64-frame tiles as the
  * GPU has CUs).  Bitwise identical to the per-layer kernels (tests); fp32 operands only.  Any other value only
  * queries.  Returns the previous mode. */
 int cmtts_set_persistent_denoiser(int mode);
