@@ -267,6 +267,39 @@ def main():
         d = timed(step1024, k, 2, 1)
         extras["frames_per_s_T4_80x1024"] = round(BATCH * T2 * k / d, 1)      # frames truncated to the 1024 bucket
         del noise2
+        # BASELINE.json configs[3] shape on one rank: LibriTTS (multi-speaker) model, a 32-utterance shard of ragged
+        # lengths dealt into static frame buckets (256 / 512 / 768 / 1024, 8 utterances each), T=4, fp32
+        lcfg = get_config("LibriTTS")
+        lmodel = host.CMTotalTTS(lcfg, device).load_state_dict(synth_cmtts_state_dict(lcfg, seed=1, dur_frames=float(DUR), dur_spread=0.0))
+        rs4 = np.random.RandomState(4)
+        groups = []
+        for bucket in shard.FRAME_BUCKETS:
+            n = 8
+            Lmax = bucket // DUR
+            ln = np.maximum((rs4.uniform(0.5, 1.0, size=n) * Lmax).astype(np.int64), 1)
+            ln[0] = Lmax
+            tx = rs4.randint(1, lcfg.n_symbols, size=(n, Lmax)).astype(np.int64)
+            tx[np.arange(Lmax)[None, :] >= ln[:, None]] = 0
+            gen4 = torch.Generator(device="cpu").manual_seed(bucket)
+            groups.append((torch.from_numpy(tx).to(device), torch.from_numpy(ln).to(device),
+                           torch.randn(n, lcfg.external_speaker_dim, generator=gen4).to(device),
+                           torch.randn(N_STEPS + 1, n, 1, bucket, lcfg.n_mels, generator=gen4).to(device), bucket, int(ln.sum()) * DUR))
+
+        def step_bucketed():
+            for tx, ln, spk, nz, bucket, _ in groups:
+                o = lmodel.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
+                state["mel_b"] = host.sample_with_cond(lmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz)
+        k = max(4, args.steps // 2)
+        d = timed(step_bucketed, k, 2, 1)
+        extras["frames_per_s_T4_libritts_bucketed_shard"] = round(sum(g[5] for g in groups) * k / d, 1)   # valid frames only
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4)      # one HIP stream per bucket group
+
+        def step_bucketed_streams():
+            state["mel_b"] = bsyn.run([g[:5] for g in groups])
+        d = timed(step_bucketed_streams, k, 2, 1)
+        extras["frames_per_s_T4_libritts_bucketed_shard_4_streams"] = round(sum(g[5] for g in groups) * k / d, 1)
+        del bsyn
+        del groups, lmodel
         # end to end with the HiFi-GAN generator (fp32), T=4
         hcfg = HifiGanConfig()
         voc = host.Generator(hcfg, device).load_state_dict(synth_hifigan_state_dict(hcfg, seed=0))

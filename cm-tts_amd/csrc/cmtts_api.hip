@@ -249,6 +249,13 @@ bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hi
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
 
+// Two persistent launches must never be in flight together: each needs ALL of its workgroups resident, and two grids
+// that split the CUs between them would wait for each other's missing neighbours.  Launches on different streams of
+// this process are therefore chained through an event.
+hipEvent_t g_persist_evt = nullptr;
+hipStream_t g_persist_last = nullptr;
+bool g_persist_any = false;
+
 int persist_blocks() {          // workgroups that are certainly co-resident: one 1024-thread workgroup per CU
     static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
                         (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
@@ -738,11 +745,15 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
         const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        if (!g_persist_evt) HIPCHK(hipEventCreateWithFlags(&g_persist_evt, hipEventDisableTiming));
+        if (g_persist_any && g_persist_last != s) HIPCHK(hipStreamWaitEvent(s, g_persist_evt, 0));
         if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
         const int rc = prec ? cmtts_launch_denoiser_persist_lp(&pa, prec, persist_blocks(), g_persist == 2, (void*)s)
                             : cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
         if (rc == -3) return fail(CMTTS_E_HIP, "persistent denoiser launch failed");
         if (rc == 0) {
+            HIPCHK(hipEventRecord(g_persist_evt, s));
+            g_persist_last = s; g_persist_any = true;
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
             layers_done = true;
             if (pa.tail) return 0;

@@ -56,6 +56,8 @@ class _Workspace:
         self._bufs = {}
 
     def get(self, key, nbytes, device):
+        # one set of buffers per HIP stream: groups running concurrently on different streams must not share scratch
+        key = (key, torch.cuda.current_stream(device).cuda_stream)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes or buf.device != device:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -590,6 +592,34 @@ class StreamPipelinedSynthesizer:
             self.prepare(*next_batch)
         mel = sample_with_cond(self.model, out["cond_ct"], out["speaker_emb"], self.n_steps, noise)
         return mel, out["mel_lens"]
+
+
+class BucketedSynthesizer:
+    """BASELINE.json configs[3] on one rank: a shard of ragged utterances dealt into static frame buckets
+    (cmtts_amd.shard.frame_bucket).  A bucket group alone cannot fill 256 CUs, so every group runs on its own HIP
+    stream (own workspaces) and the groups overlap on the chip.  Same kernels and the same results per group as running
+    them one after the other; only the issue order across groups changes."""
+
+    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4):
+        self.model, self.n_steps = model, n_steps
+        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(n_streams)]
+
+    def run(self, groups):
+        """groups: iterable of (texts, src_lens, spker_embeds | None, noise [n_steps+1,n,1,bucket,80], bucket).
+        Returns [(mel [n,bucket,80], mel_lens [n])] in the same order."""
+        dev = self.model.device
+        main = torch.cuda.current_stream(dev)
+        out = []
+        for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
+            st = self.streams[i % len(self.streams)]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
+                mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
+            out.append((mel, o["mel_lens"]))
+        for st in self.streams:
+            main.wait_stream(st)
+        return out
 
 
 class CMTotalTTSSynthesize:

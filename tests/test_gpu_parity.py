@@ -661,6 +661,66 @@ def test_cond_gemm_bitwise(variant, B, T):
     assert torch.equal(one, ref), float((one - ref).abs().max())
 
 
+def test_bucketed_synthesizer_streams_match_sequential():
+    """configs[3] shape: bucket groups on separate HIP streams (own workspaces) must give exactly the results of running
+    the groups one after the other."""
+    host = _host()
+    cfg = get_config("LibriTTS")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=12, dur_frames=4.0, dur_spread=0.0))
+    rs = np.random.RandomState(5)
+    groups = []
+    for bucket in (64, 128, 256, 192):
+        n, Lmax = 3, bucket // 4
+        ln = np.maximum((rs.uniform(0.5, 1.0, size=n) * Lmax).astype(np.int64), 1)
+        ln[0] = Lmax
+        tx = rs.randint(1, cfg.n_symbols, size=(n, Lmax)).astype(np.int64)
+        tx[np.arange(Lmax)[None, :] >= ln[:, None]] = 0
+        gen = torch.Generator().manual_seed(bucket)
+        groups.append((torch.from_numpy(tx).to(DEV), torch.from_numpy(ln).to(DEV),
+                       torch.randn(n, cfg.external_speaker_dim, generator=gen).to(DEV),
+                       torch.randn(3, n, 1, bucket, cfg.n_mels, generator=gen).to(DEV), bucket))
+    seq = []
+    for tx, ln, spk, nz, bucket in groups:
+        o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
+        seq.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], 2, nz), o["mel_lens"]))
+    torch.cuda.synchronize()
+    par = host.BucketedSynthesizer(model, n_steps=2, n_streams=3).run(groups)
+    torch.cuda.synchronize()
+    for (m0, l0), (m1, l1) in zip(seq, par):
+        assert torch.equal(l0, l1) and torch.equal(m0, m1)
+
+
+def test_two_persistent_launches_on_two_streams():
+    """Two persistent denoiser launches issued on different streams are chained by the library (each needs all of its
+    workgroups resident): both finish, nothing times out, results are those of the per-layer kernels."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("LJSpeech")
+    m1 = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=13))
+    m2 = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=14))
+    B, T = 24, 512
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen).to(DEV)
+    t = torch.full((B,), 1095.5, device=DEV)
+    prev = lib.cmtts_set_persistent_denoiser(0)
+    try:
+        r1, r2 = m1.net(x, t, cond, None), m2.net(x, t, cond, None)
+        torch.cuda.synchronize()
+        lib.cmtts_set_persistent_denoiser(2)
+        s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                o1 = m1.net(x, t, cond, None)
+            with torch.cuda.stream(s2):
+                o2 = m2.net(x, t, cond, None)
+        torch.cuda.synchronize()
+        assert torch.equal(o1, r1) and torch.equal(o2, r2)
+        m1.net(x, t, cond, None)          # would raise if a neighbour wait had timed out
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+
+
 def test_persistent_denoiser_under_uneven_load():
     """The in-kernel edge-column hand-off must not depend on the workgroups starting together: run the persistent stack
     while other streams keep part of the GPU busy (its workgroups then become resident at different times and wait for
