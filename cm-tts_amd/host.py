@@ -268,6 +268,13 @@ class KarrasDenoiser:
         self.sigma_data, self.sigma_max, self.sigma_min, self.rho = sigma_data, sigma_max, sigma_min, rho
         self.distillation = distillation
 
+    def get_scalings(self, sigma):
+        """karras_diffusion.py:81-85 (distillation=False)."""
+        c_skip = self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2)
+        c_out = sigma * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
     def get_scalings_for_boundary_condition(self, sigma):
         c_skip = self.sigma_data ** 2 / ((sigma - self.sigma_min) ** 2 + self.sigma_data ** 2)
         c_out = (sigma - self.sigma_min) * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
@@ -277,8 +284,8 @@ class KarrasDenoiser:
     def denoise(self, model, x_t, sigmas, **model_kwargs):
         """Generic (unfused) form: host-side scalings around any model callable.  The fused
         path used by karras_sample_tts is cmtts_sample."""
-        c_skip, c_out, c_in = [v[(...,) + (None,) * (x_t.ndim - v.ndim)]
-                               for v in self.get_scalings_for_boundary_condition(sigmas)]
+        scal = self.get_scalings_for_boundary_condition if self.distillation else self.get_scalings
+        c_skip, c_out, c_in = [v[(...,) + (None,) * (x_t.ndim - v.ndim)] for v in scal(sigmas)]
         rescaled_t = 1000 * 0.25 * torch.log(sigmas + 1e-44)
         model_output = model(c_in * x_t, rescaled_t, **model_kwargs)
         return model_output, c_out * model_output + c_skip * x_t
@@ -318,21 +325,23 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
                       model_kwargs=None, device=None, sigma_min=0.002, sigma_max=80, rho=7.0, sampler="onestep",
                       generator=None, ts=None, **unused):
     """karras_diffusion.py:480-577.  "onestep" and "multistep" with steps=2, ts=(0,)*T+(1,) (what
-    synthesize.py selects) run fused in cmtts_sample; "heun", "dpm", "euler", "ancestral" and
-    "our_multistep" run the reference's loops host-side around the denoiser kernels (s_churn, s_tmin,
-    s_tmax, s_noise, T as keywords).  The duration net runs once (bit-identical to the reference's
+    synthesize.py selects) run fused in cmtts_sample; "heun", "dpm", "euler", "ancestral", "our_multistep", any
+    other multistep `ts` schedule, and everything under a diffusion with distillation=False (get_scalings instead of
+    the boundary-condition scalings) run the reference's loops host-side around the denoiser kernels (s_churn,
+    s_tmin, s_tmax, s_noise, T as keywords).  The duration net runs once (bit-identical to the reference's
     per-evaluation re-run) with max_mel_len = shape[2]."""
     if generator is None:
         generator = DummyGenerator()
     B, one, T, M = shape
     ode = sampler in ("heun", "dpm", "euler", "ancestral", "our_multistep")
+    distilled = getattr(diffusion, "distillation", True)
     if sampler == "onestep":
         n_steps = 1
+        ode = not distilled            # cmtts_sample fuses the boundary-condition scalings only
     elif sampler == "multistep":
-        if steps != 2 or ts is None or tuple(ts[:-1]) != (0,) * (len(ts) - 1) or ts[-1] != 1:
-            raise NotImplementedError("fused multistep covers the schedules synthesize.py:122-147 uses: steps=2, "
-                                      "ts=(0,...,0,1); use stochastic_iterative_sampler for other ts")
-        n_steps = len(ts) - 1
+        fused = distilled and steps == 2 and ts is not None and tuple(ts[:-1]) == (0,) * (len(ts) - 1) and ts[-1] == 1
+        n_steps = len(ts) - 1 if fused else 0
+        ode = not fused                # any other `ts` schedule: the reference's loop, host-side
     elif not ode:
         raise NotImplementedError(f"sampler {sampler!r}: progdist is a training-time schedule (SURVEY.md §2)")
     dev = model.device
@@ -345,12 +354,14 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
         x_T = _f32(generator.randn(*shape, device=dev), dev) * sigma_max
         dist = make_distiller(diffusion, model, out_cond(out), out["speaker_emb"])
         fn = {"heun": sample_heun, "dpm": sample_dpm, "euler": sample_euler, "ancestral": sample_euler_ancestral,
-              "our_multistep": our_multistep}[sampler]
+              "our_multistep": our_multistep, "onestep": sample_onestep, "multistep": stochastic_iterative_sampler}[sampler]
         args = {}
         if sampler in ("heun", "dpm"):
             args = {k: unused[k] for k in ("s_churn", "s_tmin", "s_tmax", "s_noise") if k in unused}
         elif sampler == "our_multistep":
             args = {"T": unused.get("T", 4)}
+        elif sampler == "multistep":
+            args = dict(ts=ts, t_min=sigma_min, t_max=sigma_max, rho=diffusion.rho, steps=steps)
         return fn(dist, x_T, sigmas, generator, **args)[:, 0]
     draws = [generator.randn(*shape, device=dev)]
     for _ in range(n_steps if n_steps > 1 else 0):

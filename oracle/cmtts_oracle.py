@@ -429,26 +429,39 @@ def boundary_scalings(sigma, cfg):
     return c_skip, c_out, c_in
 
 
-def karras_denoise(sd, cfg, x_t, sigma, cond, speaker_emb):
-    """KarrasDenoiser.denoise karras_diffusion.py:392-407 with distillation=True.
+def edm_scalings(sigma, cfg):
+    """KarrasDenoiser.get_scalings, karras_diffusion.py:81-85 (distillation=False: no sigma_min shift)."""
+    sd2 = cfg.sigma_data ** 2
+    c_skip = sd2 / (sigma ** 2 + sd2)
+    c_out = sigma * cfg.sigma_data / (sigma ** 2 + sd2) ** 0.5
+    c_in = 1 / (sigma ** 2 + sd2) ** 0.5
+    return c_skip, c_out, c_in
+
+
+def karras_denoise(sd, cfg, x_t, sigma, cond, speaker_emb, distillation=True):
+    """KarrasDenoiser.denoise karras_diffusion.py:392-407: boundary-condition scalings when distillation (what
+    synthesize.py:59-64 selects for consistency models), get_scalings otherwise (progdist teachers).
     sigma: fp32 [B].  Returns the denoised sample [B,1,T,80]."""
     sigma = np.asarray(sigma, F32)
-    c_skip, c_out, c_in = [np.asarray(v, F32)[:, None, None, None] for v in boundary_scalings(sigma, cfg)]
+    scal = boundary_scalings if distillation else edm_scalings
+    c_skip, c_out, c_in = [np.asarray(v, F32)[:, None, None, None] for v in scal(sigma, cfg)]
     t = (F32(1000 * 0.25) * np.log(sigma + F32(1e-44))).astype(F32)
     f = denoiser_forward(sd, cfg, (c_in * x_t).astype(F32), t, cond, speaker_emb)
     return (c_out * f + c_skip * x_t).astype(F32)
 
 
-def multistep_schedule(n_steps, cfg):
+def multistep_schedule(n_steps, cfg, ts=None, steps=2):
     """synthesize.py:111-147 + stochastic_iterative_sampler karras_diffusion.py:830-854.
     T=1 -> onestep at sigma_max.  T=2/4 -> ts=(0,)*T+(1,), steps=2: every evaluation happens at
     sigma_max; the re-noising std after evaluation i is sqrt(next_t^2 - sigma_min^2)*0.85 with
     next_t = sigma_max except after the last evaluation, where next_t = sigma_min -> std 0.
+    An explicit `ts` (with its `steps`) gives the general stochastic_iterative_sampler schedule instead.
     Returns (eval_sigmas float64[n], renoise_std float64[n]); onestep has renoise None."""
-    if n_steps == 1:
-        return [cfg.sigma_max], [None]
-    ts = (0,) * n_steps + (1,)
-    steps = 2
+    if ts is None:
+        if n_steps == 1:
+            return [cfg.sigma_max], [None]
+        ts = (0,) * n_steps + (1,)
+        steps = 2
     tmax, tmin = cfg.sigma_max ** (1 / cfg.rho), cfg.sigma_min ** (1 / cfg.rho)
     sig, std = [], []
     for i in range(len(ts) - 1):
@@ -460,13 +473,13 @@ def multistep_schedule(n_steps, cfg):
     return sig, std
 
 
-def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise):
+def karras_sample_tts(sd, cfg, cond, speaker_emb, n_steps, noise, ts=None, steps=2):
     """karras_sample_tts karras_diffusion.py:480-577 with explicit noise (the reference draws
     x_T then one randn_like per multistep iteration, random_util.py:17-25).
     noise: list of [B,1,T,80] N(0,1) arrays — noise[0] -> x_T, noise[1+i] -> re-noise after eval i.
     Returns mel [B,T,80]."""
     B = cond.shape[0]
-    sig, std = multistep_schedule(n_steps, cfg)
+    sig, std = multistep_schedule(n_steps, cfg, ts, steps)
     x = (noise[0] * F32(cfg.sigma_max)).astype(F32)
     for i, s in enumerate(sig):
         x0 = karras_denoise(sd, cfg, x, np.full((B,), s, F32), cond, speaker_emb)
@@ -539,8 +552,9 @@ def karras_sample_tts_ode(sd, cfg, cond, speaker_emb, sampler, steps, noise, **k
     """karras_sample_tts (karras_diffusion.py:480-577) with sampler in {"euler", "heun", "dpm", "ancestral"}:
     sigmas = get_sigmas_karras(steps), x_T = noise[0] * sigma_max, remaining draws feed the loop.
     Returns mel [B,T,80]."""
+    distillation = kw.pop("distillation", True)
     sig = get_sigmas_karras(steps, cfg.sigma_min, cfg.sigma_max, cfg.rho)
-    den = lambda x, s: karras_denoise(sd, cfg, x, s, cond, speaker_emb)
+    den = lambda x, s: karras_denoise(sd, cfg, x, s, cond, speaker_emb, distillation)
     x = (noise[0] * F32(cfg.sigma_max)).astype(F32)
     return ode_samplers(den, x, sig, noise[1:], sampler, **kw)[:, 0]
 

@@ -263,6 +263,24 @@ def golden_samplers():
             out[f"steps_{sampler}"] = np.int64(steps)
             out[f"draws_{sampler}"] = np.int64(gen.i)
             print(f"[samplers] {sampler} steps={steps} draws={gen.i} |mel| {np.abs(out['mel_' + sampler]).mean():.3f}")
+        # stochastic_iterative_sampler (karras_diffusion.py:830-854) on a schedule with interior points
+        gen = FixedNoise([torch.from_numpy(n) for n in noise])
+        mel = karras_sample_tts(diffusion=diffusion, model=model, shape=(B, 1, T, cfg.n_mels), steps=4,
+                                model_kwargs=kwargs, device="cpu", sigma_max=cfg.sigma_max, sigma_min=cfg.sigma_min,
+                                rho=cfg.rho, sampler="multistep", ts=(0, 1, 3), generator=gen)
+        out["mel_multistep_ts013"] = mel.numpy()
+        out["draws_multistep_ts013"] = np.int64(gen.i)
+        print(f"[samplers] multistep steps=4 ts=(0,1,3) draws={gen.i} |mel| {np.abs(mel.numpy()).mean():.3f}")
+        # distillation=False (synthesize.py:61-62, training_mode "progdist"): KarrasDenoiser.get_scalings without the
+        # sigma_min shift (karras_diffusion.py:81-85,395-398), heun sampler
+        diffusion.distillation = False
+        gen = FixedNoise([torch.from_numpy(n) for n in noise])
+        mel = karras_sample_tts(diffusion=diffusion, model=model, shape=(B, 1, T, cfg.n_mels), steps=3,
+                                model_kwargs=kwargs, device="cpu", sigma_max=cfg.sigma_max, sigma_min=cfg.sigma_min,
+                                rho=cfg.rho, sampler="heun", generator=gen)
+        diffusion.distillation = True
+        out["mel_heun_edm"] = mel.numpy()
+        print(f"[samplers] heun (distillation=False) |mel| {np.abs(out['mel_heun_edm']).mean():.3f}")
     np.savez_compressed(os.path.join(HERE, f"samplers_{variant}.npz"), **out)
 
 

@@ -338,6 +338,51 @@ def test_ode_samplers_golden(models, golden, sampler):
     np.testing.assert_allclose(_np(mel), ref, atol=1e-3, rtol=2e-4)
 
 
+def test_non_distilled_diffusion_routes(models, golden):
+    """KarrasDenoiser(distillation=False): denoise uses get_scalings (karras_diffusion.py:81-85,395-398).  heun is
+    checked against the reference run that way; onestep/multistep must then leave the fused cmtts_sample path
+    (which bakes the boundary-condition scalings in) and differ from the distilled result."""
+    host = _host()
+    g, cfg, sd, model = models("LJSpeech")
+    gs = golden("samplers_LJSpeech")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        def __init__(self):
+            self.i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[self.i]).to(DEV)
+            self.i += 1
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    kwargs = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]))
+    common = dict(model_kwargs=kwargs, sigma_min=cfg.sigma_min, sigma_max=cfg.sigma_max, rho=cfg.rho)
+    edm = host.KarrasDenoiser(distillation=False)
+    mel = host.karras_sample_tts(edm, model, (B, 1, T, cfg.n_mels), steps=int(gs["steps_heun"]), sampler="heun",
+                                 generator=Gen(), **common)
+    np.testing.assert_allclose(_np(mel), gs["mel_heun_edm"], atol=3e-3, rtol=2e-4)
+    # onestep at sigma_max: c_skip/c_out of the two scalings differ by O(sigma_min/sigma_max) only, but they differ
+    one_edm = host.karras_sample_tts(edm, model, (B, 1, T, cfg.n_mels), steps=2, sampler="onestep", generator=Gen(), **common)
+    one_cm = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=2, sampler="onestep",
+                                    generator=Gen(), **common)
+    torch.cuda.synchronize()
+    assert np.abs(_np(one_cm) - g["mel_T1"]).max() < 1e-3
+    d = np.abs(_np(one_edm) - _np(one_cm)).max()
+    assert 0 < d < 1e-2, d
+    # a multistep schedule the fused path does not cover runs through the host loop instead of raising
+    gen = Gen()
+    ms = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=4, sampler="multistep",
+                                ts=(0, 1, 3), generator=gen, **common)
+    torch.cuda.synchronize()
+    assert gen.i == int(gs["draws_multistep_ts013"])
+    assert np.abs(_np(ms) - gs["mel_multistep_ts013"]).max() < 1e-3
+
+
 def _check_variance_gpu(out, gc, tag):
     np.testing.assert_allclose(_np(out["log_d_predictions"]), gc[tag + "_log_d"], atol=5e-5)
     np.testing.assert_array_equal(_np(out["d_rounded"]), gc[tag + "_d_rounded"])            # bit-exact

@@ -132,6 +132,32 @@ def test_ode_samplers(golden, sampler):
     np.testing.assert_allclose(mel, ref, atol=1e-3, rtol=1e-4)
 
 
+def test_ode_sampler_edm_scalings(golden):
+    """KarrasDenoiser.denoise with distillation=False (karras_diffusion.py:81-85,395-398: get_scalings instead of
+    the boundary-condition scalings), heun, against the reference run that way."""
+    g, cfg, sd = _setup(golden, "LJSpeech")
+    gs = golden("samplers_LJSpeech")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    mel = O.karras_sample_tts_ode(sd, cfg, g["cond"], None, "heun", int(gs["steps_heun"]), noise, distillation=False)
+    # without the boundary shift c_out(sigma_min) != 0, so the last 1/sigma division amplifies the denoiser's fp32
+    # roundoff a little more than in test_ode_samplers: 6 of 25920 elements sit at 1.0-1.4e-3
+    np.testing.assert_allclose(mel, gs["mel_heun_edm"], atol=3e-3, rtol=1e-4)
+    assert np.abs(gs["mel_heun_edm"] - gs["mel_heun"]).max() > 1e-2     # the flag changes the result
+
+
+def test_multistep_general_ts(golden):
+    """stochastic_iterative_sampler (karras_diffusion.py:830-854) on a schedule with interior points,
+    steps=4, ts=(0,1,3), against the reference."""
+    g, cfg, sd = _setup(golden, "LJSpeech")
+    gs = golden("samplers_LJSpeech")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    mel = O.karras_sample_tts(sd, cfg, g["cond"], None, None, noise, ts=(0, 1, 3), steps=4)
+    assert int(gs["draws_multistep_ts013"]) == 3
+    np.testing.assert_allclose(mel, gs["mel_multistep_ts013"], atol=1e-3)
+
+
 def test_sigmas_karras():
     s = O.get_sigmas_karras(5, 0.002, 80.0, 7.0)
     assert s.dtype == np.float32 and s.shape == (6,) and s[-1] == 0
