@@ -54,9 +54,13 @@ def make_inputs(cfg, seed, device):
 PROFILE_STRIDE = 7
 
 
-def timed(fn, steps, warmup, world, before=None):
+def timed(fn, steps, warmup, world, before=None, flush=None):
+    """`flush` completes whatever the last fn() left in flight (the async all-gather): it runs INSIDE the timed
+    region, before the closing synchronize + barrier, so all K steps' work is counted."""
     for _ in range(warmup):
         fn()
+    if flush is not None:
+        flush()
     if before is not None:
         torch.cuda.synchronize()
         before()
@@ -66,6 +70,8 @@ def timed(fn, steps, warmup, world, before=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if flush is not None:
+        flush()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -157,15 +163,34 @@ def main():
         _lib.check(lib.cmtts_set_resblock_tile(args.tile))
     state = {}
 
+    gather = world > 1 or os.environ.get("CMTTS_FORCE_COLLECTIVE") == "1"
+    if gather and world == 1:          # single-GPU check of the RCCL call sequence (tools / tests, not the default run)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+
+    def flush():
+        """Complete the all-gather still in flight: the collated block of the previous batch."""
+        pend = state.pop("pending", None)
+        if pend is not None:
+            state["gathered"], state["gathered_len"] = pend.wait()
+
     def step(n_steps=N_STEPS):
+        # the text side of this batch runs while RCCL collates the previous batch's mels over xGMI
         out = model.duration_pitch_energy_net(None, texts, lens, max_mel_len=FRAMES_PAD)
+        flush()       # the persistent denoiser needs every CU: RCCL's kernels must be off the GPU before it starts
         mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, noise)
-        if world > 1:
-            mel, mlen = shard.allgather_mels(mel, out["mel_lens"])
+        if gather:
+            state["pending"] = shard.allgather_mels_async(mel, out["mel_lens"], force=True)
         state["mel"], state["mel_len"] = mel, out["mel_lens"]
 
     step()
+    flush()
     torch.cuda.synchronize()
+    if gather:     # rank order, every rank's block present
+        G = state["gathered"]
+        assert G.shape[0] == world * BATCH and torch.equal(G[rank * BATCH:(rank + 1) * BATCH], state["mel"])
+        assert (state["gathered_len"] == PHONEMES * DUR).all()
     mel_len = state["mel_len"].cpu().numpy()
     assert (mel_len == PHONEMES * DUR).all(), mel_len
     frames_rank = int(mel_len.sum())
@@ -175,7 +200,7 @@ def main():
     # persistent mode: ONE launch runs all residual layers of a sampler step (4 launches per step: bracket them all)
     persistent = (not args.unfused) and lib.cmtts_set_persistent_denoiser(-1) != 0 and BATCH * ((FRAMES_PAD + 63) // 64) * 2 > 256
     stride = 1 if persistent else PROFILE_STRIDE
-    dt = timed(step, args.steps, args.warmup, world,
+    dt = timed(step, args.steps, args.warmup, world, flush=flush,
                before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers, stride)))
     tot_ms, n_l = C.c_double(), C.c_int()
     _lib.check(lib.cmtts_profile_end(C.byref(tot_ms), C.byref(n_l)))
@@ -323,10 +348,13 @@ def main():
         result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    # RCCL writes a banner ("Librccl path : ...") through C stdio, which is fully buffered on a pipe and would land
+    # AFTER the result at exit: drain it first so the JSON line is the last line of stdout
+    C.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

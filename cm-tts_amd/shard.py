@@ -68,3 +68,38 @@ def allgather_mels(mel: torch.Tensor, mel_len: torch.Tensor, group=None) -> Tupl
     else:
         dist.all_gather_into_tensor(out, buf, group=group)
     return unpack_mels(out, T, M)
+
+
+class PendingGather:
+    """An all-gather of one batch's mels in flight (RCCL runs it on its own stream).  ``wait()`` orders the caller's
+    current stream after it and returns (mel [world*Bl,T,M], mel_len [world*Bl]).  The packed send / receive buffers
+    are owned by this object, so the producer may overwrite its ``mel`` workspace as soon as the call returns."""
+
+    def __init__(self, work, out, T, M, keep):
+        self._work, self._out, self._T, self._M, self._keep = work, out, T, M, keep
+
+    def wait(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        return unpack_mels(self._out, self._T, self._M)
+
+
+def allgather_mels_async(mel: torch.Tensor, mel_len: torch.Tensor, group=None, force: bool = False) -> PendingGather:
+    """``allgather_mels`` issued asynchronously: the collective of batch i overlaps the text-side kernels of batch
+    i+1 (the xGMI links are idle otherwise).  Callers ``wait()`` before they launch the next persistent denoiser
+    stack — that kernel needs every CU, so it must not share the GPU with RCCL's kernels — and before they read the
+    result.  ``force`` runs the collective on a 1-rank group too (single-GPU test of the RCCL call sequence)."""
+    Bl, T, M = mel.shape
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return PendingGather(None, pack_mels(mel, mel_len), T, M, None)
+    world = dist.get_world_size(group)
+    buf = pack_mels(mel, mel_len)
+    out = torch.empty(world * Bl, buf.shape[1], dtype=buf.dtype, device=buf.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.chunk(world, 0))
+        work = dist.all_gather(parts, buf, group=group, async_op=True)
+        return PendingGather(work, out, T, M, (buf, parts))
+    work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
+    return PendingGather(work, out, T, M, buf)
