@@ -496,6 +496,36 @@ def test_full_path_vs_oracle_random_batch():
     assert np.abs(_np(mel) - ref).max() < 1e-3
 
 
+def test_smallest_inputs_vs_oracle():
+    """One utterance of ONE phoneme (a handful of frames: every conv is all halo, every tile is ragged, attention is
+    1x1) and a 2-utterance batch of lengths (1, 2), end to end against the oracle, T = 1 and 4."""
+    host = _host()
+    cfg = get_config("LJSpeech")
+    sd = synth_cmtts_state_dict(cfg, seed=4, dur_frames=3.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(8)
+    for lens in ([1], [1, 2]):
+        lens = np.asarray(lens, np.int64)
+        B, L = len(lens), int(lens.max())
+        texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+        texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+        st = O.duration_pitch_speaker_net(sd, cfg, texts, lens, None)
+        out = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens))
+        torch.cuda.synchronize()
+        assert np.array_equal(_np(out["d_rounded"]), st["d_rounded"])
+        assert np.array_equal(_np(out["mel_lens"]), st["mel_len"]) and st["mel_len"].min() >= 1
+        assert np.array_equal(_np(out["mel2ph"]), st["mel2ph"])
+        T = st["cond"].shape[1]
+        assert T <= 8
+        noise = np.stack([rs.standard_normal(size=(B, 1, T, cfg.n_mels)).astype(np.float32) for _ in range(5)])
+        for n_steps in (1, 4):
+            mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, torch.from_numpy(noise).to(DEV))
+            torch.cuda.synchronize()
+            ref = O.karras_sample_tts(sd, cfg, _np(out["cond"]), None, n_steps, list(noise))
+            assert np.abs(_np(mel) - ref).max() < 1e-3
+        np.testing.assert_allclose(_np(out["cond"]), st["cond"], atol=1e-4)
+
+
 def test_bucketed_ragged_shard_vs_oracle():
     """BASELINE configs[3] shape of ONE rank: LibriTTS model (multi-speaker, no uv), ragged phoneme lengths,
     frames padded to the static 1024 bucket (the longest utterance is truncated by the bucket, as the
