@@ -1350,6 +1350,14 @@ int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_
     return 0;
 }
 
+int cmtts_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, void* stream) {
+    if (!lens || !mask || B <= 0 || W < 0) return fail(CMTTS_E_INVALID, "cmtts_length_mask: bad argument");
+    if (W == 0) return 0;
+    k_length_mask(lens, mask, B, W, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int cmtts_transpose(const float* in, float* out, int B, int R, int C, void* stream) {
     if (!in || !out || B <= 0 || R <= 0 || C <= 0) return fail(CMTTS_E_INVALID, "cmtts_transpose: bad argument");
     k_transpose(in, out, B, R, C, (hipStream_t)stream);

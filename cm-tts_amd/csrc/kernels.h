@@ -40,6 +40,7 @@ void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, 
 void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,
                  int C, int T, int ld, int KW, hipStream_t s);
 void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s);
+void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t s);    // mask[b][t] = t >= lens[b]
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s);   // [B][R][Cn] -> [B][Cn][R]
 void k_fill_lens(int64_t* lens, int64_t v, int B, hipStream_t s);
 void k_scale(const float* in, float* out, long n, float sc, hipStream_t s);

@@ -602,6 +602,15 @@ void k_conv_post(const float* x, const float* w, const float* bias, float pre_di
 void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s) {
     hipLaunchKernelGGL(wav_to_int16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, wav, pcm, n, max_wav);
 }
+__global__ void length_mask_kernel(const int64_t* __restrict__ lens, uint8_t* __restrict__ mask, int B, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * W) return;
+    const int b = (int)(i / W), t = (int)(i - (long)b * W);
+    mask[i] = t >= lens[b] ? 1 : 0;
+}
+void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t s) {
+    hipLaunchKernelGGL(length_mask_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, s, lens, mask, B, W);
+}
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s) {
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), B), dim3(256), 0, s, in, out, R, Cn);
 }

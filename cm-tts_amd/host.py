@@ -69,6 +69,12 @@ def get_mask_from_lengths(lengths, max_len=None):
     """utils/tools.py:275-283 — True = padding."""
     if max_len is None:
         max_len = int(lengths.max().item())
+    if lengths.is_cuda and lengths.dtype == torch.int64:     # one small launch instead of arange + compare
+        lengths = lengths.contiguous()
+        mask = torch.empty(lengths.shape[0], int(max_len), dtype=torch.bool, device=lengths.device)
+        with torch.cuda.device(lengths.device):
+            _lib.check(_lib.load().cmtts_length_mask(_ptr(lengths), _ptr(mask), lengths.shape[0], int(max_len), _stream()))
+        return mask
     ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0)
     return ids >= lengths.unsqueeze(1)
 

@@ -183,6 +183,10 @@ int cmtts_set_resblock_tile(int frames);
 int cmtts_set_debug_stamps(void* dev_buf);
 int cmtts_profile_end(double* total_ms, int* n_launches);
 
+/* ---- get_mask_from_lengths (utils/tools.py:275-283): mask[b][t] = (t >= lens[b]) as one byte per element
+ * (True = padding), lens int64 [B], mask [B,W]. */
+int cmtts_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, void* stream);
+
 /* ---- layout helper: in [B,R,C] -> out [B,C,R] */
 int cmtts_transpose(const float* in, float* out, int B, int R, int C, void* stream);
 

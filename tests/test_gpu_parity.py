@@ -449,6 +449,18 @@ def test_hifigan_golden(golden):
         assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
 
 
+def test_length_mask_kernel():
+    """get_mask_from_lengths utils/tools.py:275-283 (True = padding): bit-exact against arange >= len."""
+    host = _host()
+    for lens, W in (([3, 0, 7], 7), ([1], 1), ([1026, 540, 798, 240], 1024), (list(range(1, 258)), 300)):
+        l = torch.tensor(lens, dtype=torch.int64, device=DEV)
+        m = host.get_mask_from_lengths(l, W)
+        ref = torch.arange(W, device=DEV)[None, :] >= l[:, None]
+        assert m.dtype == torch.bool and torch.equal(m, ref)
+    assert torch.equal(host.get_mask_from_lengths(torch.tensor([2, 5], device=DEV)),
+                       torch.tensor([[0, 0, 1, 1, 1], [0, 0, 0, 0, 0]], dtype=torch.bool, device=DEV))
+
+
 def test_wav_to_int16_wraps_like_numpy():
     lib = _lib.load()
     w = np.float32([1.0, -1.0, 0.99999, -0.00002, 0.5, -0.5])
