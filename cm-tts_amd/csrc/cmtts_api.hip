@@ -249,12 +249,55 @@ bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hi
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
 
-// Two persistent launches must never be in flight together: each needs ALL of its workgroups resident, and two grids
-// that split the CUs between them would wait for each other's missing neighbours.  Launches on different streams of
-// this process are therefore chained through an event.
-hipEvent_t g_persist_evt = nullptr;
-hipStream_t g_persist_last = nullptr;
-bool g_persist_any = false;
+// Persistent launches need ALL of their workgroups resident (one per CU): two grids that together exceed the CU count
+// would split the chip and wait for each other's missing neighbours.  Launches of this process on different streams
+// are therefore admitted by capacity: a launch waits (stream-side, through events) for the oldest launches in flight on
+// OTHER streams until the workgroups still possibly running plus its own fit the chip.  Small grids (bucket groups of a
+// ragged shard on separate streams) then run side by side; full-chip launches still run one after the other.
+struct PersistInFlight { hipEvent_t ev; hipStream_t stream; int blocks; };
+std::vector<PersistInFlight> g_persist_inflight;    // oldest first
+std::vector<hipEvent_t> g_persist_free_events;
+
+int persist_admit(hipStream_t s, int blocks, int capacity) {
+    // drop launches that have certainly finished
+    for (size_t i = 0; i < g_persist_inflight.size();) {
+        if (hipEventQuery(g_persist_inflight[i].ev) == hipSuccess) {
+            g_persist_free_events.push_back(g_persist_inflight[i].ev);
+            g_persist_inflight.erase(g_persist_inflight.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    (void)hipGetLastError();          // hipErrorNotReady from the queries is not an error
+    // launches of one stream run one after the other: a stream holds at most its largest launch in flight, and it is
+    // certainly idle once its NEWEST launch has finished
+    struct PerStream { hipStream_t stream; int blocks; hipEvent_t newest; };
+    std::vector<PerStream> per;          // in order of each stream's first launch in flight (oldest first)
+    for (const auto& f : g_persist_inflight) {
+        if (f.stream == s) continue;     // launches on `s` itself are ordered before this one by the stream
+        size_t i = 0;
+        while (i < per.size() && per[i].stream != f.stream) ++i;
+        if (i == per.size()) per.push_back({f.stream, 0, f.ev});
+        per[i].blocks = std::max(per[i].blocks, f.blocks);
+        per[i].newest = f.ev;
+    }
+    int others = 0;
+    for (const auto& q : per) others += q.blocks;
+    for (const auto& q : per) {
+        if (others + blocks <= capacity) break;
+        HIPCHK(hipStreamWaitEvent(s, q.newest, 0));
+        others -= q.blocks;
+    }
+    return 0;
+}
+int persist_launched(hipStream_t s, int blocks) {
+    hipEvent_t ev;
+    if (!g_persist_free_events.empty()) { ev = g_persist_free_events.back(); g_persist_free_events.pop_back(); }
+    else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, s));
+    g_persist_inflight.push_back({ev, s, blocks});
+    return 0;
+}
 
 int persist_blocks() {          // workgroups that are certainly co-resident: one 1024-thread workgroup per CU
     static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
@@ -745,15 +788,14 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
         const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-        if (!g_persist_evt) HIPCHK(hipEventCreateWithFlags(&g_persist_evt, hipEventDisableTiming));
-        if (g_persist_any && g_persist_last != s) HIPCHK(hipStreamWaitEvent(s, g_persist_evt, 0));
+        const int need = cmtts_persist_plan(B, T, NL, persist_blocks(), g_persist == 2);
+        if (need) CHK(persist_admit(s, need, persist_blocks()));
         if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
         const int rc = prec ? cmtts_launch_denoiser_persist_lp(&pa, prec, persist_blocks(), g_persist == 2, (void*)s)
                             : cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
         if (rc == -3) return fail(CMTTS_E_HIP, "persistent denoiser launch failed");
         if (rc == 0) {
-            HIPCHK(hipEventRecord(g_persist_evt, s));
-            g_persist_last = s; g_persist_any = true;
+            CHK(persist_launched(s, need));
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
             layers_done = true;
             if (pa.tail) return 0;

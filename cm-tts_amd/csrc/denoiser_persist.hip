@@ -410,6 +410,18 @@ extern "C" int cmtts_persist_chunks(int B, int T, int max_blocks) {
     return (B + per_launch - 1) / per_launch;
 }
 
+// Workgroups the largest launch of one call keeps resident (0 = the call would not take the persistent path): what the
+// caller's cross-stream guard has to reserve.  Mirrors the decisions of cmtts_launch_denoiser_persist(_lp).
+extern "C" int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int force) {
+    const int tiles = (T + FN - 1) / FN;
+    if (B < 1 || NL < 1 || NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * T >= (1L << 30)) return 0;
+    if (!force && (long)tiles * B * 2 <= (long)max_blocks) return 0;
+    const int per_launch = max_blocks / tiles;
+    const int nchunks = (B + per_launch - 1) / per_launch;
+    const int bc = (B + nchunks - 1) / nchunks;
+    return tiles * (bc < B ? bc : B);
+}
+
 extern "C" size_t cmtts_persist_halo_bytes(int B, int T) {
     const long tiles = (T + FN - 1) / FN;
     return (size_t)2 * B * tiles * 2 * C * sizeof(unsigned long long);

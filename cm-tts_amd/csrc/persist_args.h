@@ -45,6 +45,7 @@ size_t cmtts_persist_halo_bytes(int B, int T);
 int cmtts_launch_denoiser_persist(const PersistArgs* a, int max_blocks, int force, void* stream);
 // 16-bit operand variant (denoiser_persist_lp.hip): mode 1 = bf16, 2 = fp16; W3f / Wof = 16-bit fragment-order weights.
 int cmtts_launch_denoiser_persist_lp(const PersistArgs* a, int mode, int max_blocks, int force, void* stream);
+int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int force);   // resident workgroups of the largest launch (0 = path not taken)
 int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
 void cmtts_persist_set_debug(long long* dbg);
 #ifdef __cplusplus

@@ -617,8 +617,14 @@ class BucketedSynthesizer:
     stream (own workspaces) and the groups overlap on the chip.  Same kernels and the same results per group as running
     them one after the other; only the issue order across groups changes."""
 
-    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4):
-        self.model, self.n_steps = model, n_steps
+    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None):
+        """persistent: denoiser mode while the groups run (cmtts_set_persistent_denoiser; None = leave the process
+        setting alone, the default: a group takes the persistent stack when it alone has more than 128 tiles).
+        2 = every group takes it (the library admits persistent launches of different streams side by side while their
+        workgroups fit the chip) — measured slower for the 4 x 8-utterance shard of tools/bucketed_bench.py (41 vs 27
+        ms): each group then pays 20 x 128 us per evaluation whatever its size, and HIP maps the streams onto 3-4
+        hardware queues."""
+        self.model, self.n_steps, self.persistent = model, n_steps, persistent
         self.streams = [torch.cuda.Stream(device=model.device) for _ in range(n_streams)]
 
     def run(self, groups):
@@ -627,13 +633,19 @@ class BucketedSynthesizer:
         dev = self.model.device
         main = torch.cuda.current_stream(dev)
         out = []
-        for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
-            st = self.streams[i % len(self.streams)]
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
-                mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
-            out.append((mel, o["mel_lens"]))
+        lib = self.model.lib
+        prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None else None
+        try:
+            for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
+                st = self.streams[i % len(self.streams)]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
+                    mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
+                out.append((mel, o["mel_lens"]))
+        finally:
+            if prev is not None:
+                lib.cmtts_set_persistent_denoiser(prev)
         for st in self.streams:
             main.wait_stream(st)
         return out

@@ -808,6 +808,37 @@ def test_two_persistent_launches_on_two_streams():
         lib.cmtts_set_persistent_denoiser(prev)
 
 
+def test_small_persistent_launches_share_the_chip():
+    """Persistent launches are admitted by capacity: grids of different streams that fit the CU count together run
+    side by side (here 3 models x 48 workgroups, then a 4th stream with 192 that must wait for some of them);
+    every result equals the per-layer kernels' and nothing times out."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("LJSpeech")
+    shapes = [(6, 512), (6, 512), (6, 500), (12, 1024)]
+    models = [host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=30 + i)) for i in range(4)]
+    gen = torch.Generator().manual_seed(5)
+    data = [(torch.randn(B, 1, T, cfg.n_mels, generator=gen).to(DEV), torch.randn(B, T, cfg.hidden, generator=gen).to(DEV),
+             torch.full((B,), 1095.5, device=DEV)) for B, T in shapes]
+    prev = lib.cmtts_set_persistent_denoiser(0)
+    try:
+        ref = [m.net(x, t, c, None) for m, (x, c, t) in zip(models, data)]
+        torch.cuda.synchronize()
+        lib.cmtts_set_persistent_denoiser(2)
+        streams = [torch.cuda.Stream(device=DEV) for _ in range(4)]
+        out = [None] * 4
+        for _ in range(3):
+            for i, (m, (x, c, t)) in enumerate(zip(models, data)):
+                with torch.cuda.stream(streams[i]):
+                    out[i] = m.net(x, t, c, None)
+        torch.cuda.synchronize()
+        for o, r in zip(out, ref):
+            assert torch.equal(o, r)
+        models[0].net(*[data[0][j] for j in (0, 2, 1)], None)          # would raise if a neighbour wait had timed out
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+
+
 def test_persistent_denoiser_under_uneven_load():
     """The in-kernel edge-column hand-off must not depend on the workgroups starting together: run the persistent stack
     while other streams keep part of the GPU busy (its workgroups then become resident at different times and wait for
