@@ -243,7 +243,8 @@ def main():
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE in separate --pmc passes (profiles/pmc_traffic.json); "
-                                     "algorithmic %.1f MB -> HBM fraction %.3f" % (
+                                     "algorithmic %.1f MB (the excess is each layer's 2.1 MB weight set missing once in each of the 8 per-XCD L2s "
+                                     "+ the polled 8-byte granules) -> HBM fraction %.3f" % (
                                          (BATCH * FRAMES_PAD * (1024 * (cfg.res_layers + 1) + 8 * cfg.n_mels) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
                                          (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
