@@ -63,6 +63,8 @@ SIGNATURES = {
     "cmtts_vocoder_set_precision": (_i, [_vp, _i]),
     "cmtts_set_debug_stamps": (_i, [_vp]),
     "cmtts_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "cmtts_decoder_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "cmtts_decoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_length_mask": (_i, [_vp, _vp, _i, _i, _vp]),
     "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cmtts_pack_conv_weight": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i)]),

@@ -337,6 +337,9 @@ struct cmtts_model {
     float *pe_h = nullptr, *pe_cwt = nullptr;   // sinusoid tables [PE_ROWS][C]
     std::vector<EncLayer> enc;
     float *encln_g = nullptr, *encln_b = nullptr;
+    // FastspeechDecoder (model/modules.py:154-165): optional, present when the state dict holds "decoder.*"
+    std::vector<EncLayer> dec;
+    float *decln_g = nullptr, *decln_b = nullptr, *dec_alpha = nullptr;
     float *spk_wt = nullptr, *spk_b = nullptr;
     Predictor dur, energy, cwt;
     PackedConv cwt_in;
@@ -422,10 +425,8 @@ int finalize_model(cmtts_model* m) {
     const std::string enc = "duration_pitch_energy_net.text_encoder.";
     GET(emb, enc + "embed_tokens.weight", c.n_symbols, H);
     UP(m->embed, emb);
-    m->enc.resize(c.enc_layers);
-    for (int i = 0; i < c.enc_layers; ++i) {
-        const std::string p = enc + "layers." + std::to_string(i) + ".op.";
-        EncLayer& L = m->enc[i];
+    // one EncSALayer (model/blocks.py:560-618): shared by the text encoder and the optional FastspeechDecoder
+    auto load_fft_layer = [&](const std::string& p, EncLayer& L) -> int {
         GET(l1g, p + "layer_norm1.weight", H); GET(l1b, p + "layer_norm1.bias", H);
         GET(l2g, p + "layer_norm2.weight", H); GET(l2b, p + "layer_norm2.bias", H);
         UP(L.ln1_g, l1g); UP(L.ln1_b, l1b); UP(L.ln2_g, l2g); UP(L.ln2_b, l2b);
@@ -447,9 +448,24 @@ int finalize_model(cmtts_model* m) {
         GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
         HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
         CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2));
-    }
+        return 0;
+    };
+    m->enc.resize(c.enc_layers);
+    for (int i = 0; i < c.enc_layers; ++i) CHK(load_fft_layer(enc + "layers." + std::to_string(i) + ".op.", m->enc[i]));
     GET(eg, enc + "layer_norm.weight", H); GET(eb, enc + "layer_norm.bias", H);
     UP(m->encln_g, eg); UP(m->encln_b, eb);
+    {   // optional FastspeechDecoder: as many layers as the state dict holds under "decoder.layers.N.op."
+        int nd = 0;
+        while (m->host.count("decoder.layers." + std::to_string(nd) + ".op.layer_norm1.weight")) ++nd;
+        if (nd > 0) {
+            m->dec.resize(nd);
+            for (int i = 0; i < nd; ++i) CHK(load_fft_layer("decoder.layers." + std::to_string(i) + ".op.", m->dec[i]));
+            GET(dg, "decoder.layer_norm.weight", H); GET(db, "decoder.layer_norm.bias", H);
+            UP(m->decln_g, dg); UP(m->decln_b, db);
+            GET(da, "decoder.pos_embed_alpha", 1);
+            UP(m->dec_alpha, da);
+        }
+    }
 
     if (c.multi_speaker) {
         GET(sw, "duration_pitch_energy_net.speaker_emb.weight", H, c.external_speaker_dim);
@@ -902,28 +918,15 @@ size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L) { return c
 size_t cmtts_frame_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_frame(m->cfg, B, T, nullptr).bytes; }
 size_t cmtts_denoiser_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_den(m->cfg, B, T, nullptr).bytes; }
 
-int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
-                       int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
-                       float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
-                       void* text_ws, size_t text_ws_bytes, void* stream) {
-    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
-    if (!texts || !src_lens || !text_ws || B <= 0 || L <= 0) return fail(CMTTS_E_INVALID, "cmtts_text_forward: bad argument");
+// FFTBlocks.forward's layer loop (model/modules.py:97-99): pre-LN self-attention + Conv1D FFN blocks over channel-major
+// x = w.x [B][H][Lp], masked by `lens`.  Shared by the text encoder (L = phonemes) and the FastspeechDecoder (L = frames).
+int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs& w, const int64_t* src_lens, int B, int L,
+              hipStream_t s) {
     const cmtts_config& c = m->cfg;
-    if (c.multi_speaker && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
-    TextWs w = carve_text(c, B, L, text_ws);
-    if (text_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "text workspace too small");
-    hipStream_t s = (hipStream_t)stream;
     const int H = c.hidden, Lp = round_up(L, 4), NH = c.enc_heads, dh = H / NH;
     const long hs = (long)H * Lp;
-    if (!log_d) log_d = w.logd;
-    if (!d_rounded) d_rounded = w.dround;
-    if (!mel_len) mel_len = w.mlen;
-    if (!e_pred) e_pred = w.epred;
-    if (!e_idx) e_idx = w.eidx;
-
-    k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
-    for (int i = 0; i < c.enc_layers; ++i) {
-        const EncLayer& E = m->enc[i];
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const EncLayer& E = layers[i];
         k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
         {   // Q,K = h * W[0:2H]^T, channel-major [B][2H][Lp]
             ConvArgs a = conv_args(E.qk, w.h, L, Lp, hs, w.qk, Lp, 2 * hs, L);
@@ -988,6 +991,29 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
             CHK(launch(a, EPI_PLAIN, B, s));
         }
     }
+    return 0;
+}
+
+int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
+                       int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
+                       float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
+                       void* text_ws, size_t text_ws_bytes, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!texts || !src_lens || !text_ws || B <= 0 || L <= 0) return fail(CMTTS_E_INVALID, "cmtts_text_forward: bad argument");
+    const cmtts_config& c = m->cfg;
+    if (c.multi_speaker && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
+    TextWs w = carve_text(c, B, L, text_ws);
+    if (text_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "text workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c.hidden, Lp = round_up(L, 4);
+    if (!log_d) log_d = w.logd;
+    if (!d_rounded) d_rounded = w.dround;
+    if (!mel_len) mel_len = w.mlen;
+    if (!e_pred) e_pred = w.epred;
+    if (!e_idx) e_idx = w.eidx;
+
+    k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
+    CHK(fft_stack(m, m->enc, w, src_lens, B, L, s));
     k_layernorm_ct(w.x, w.x, m->encln_g, m->encln_b, 1e-5f, src_lens, B, L, Lp, s);
     if (enc_out_ct)
         HIPCHK(hipMemcpy2DAsync(enc_out_ct, (size_t)L * 4, w.x, (size_t)Lp * 4, (size_t)L * 4, (size_t)B * H,
@@ -1388,6 +1414,30 @@ int cmtts_profile_end(double* total_ms, int* n_launches) {
 int cmtts_wav_to_int16(const float* wav, int16_t* pcm, int64_t n, float max_wav_value, void* stream) {
     if (!wav || !pcm || n < 0) return fail(CMTTS_E_INVALID, "cmtts_wav_to_int16: bad argument");
     if (n) k_wav_to_int16(wav, pcm, (long)n, max_wav_value, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+size_t cmtts_decoder_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_text(m->cfg, B, T, nullptr).bytes; }
+
+// FastspeechDecoder.forward (model/modules.py:154-165 -> FFTBlocks.forward :80-105 with use_pos_embed=True):
+// x + alpha * PE[positions(x[..., 0] != 0)], masked, 4 FFT blocks, final LayerNorm (eps 1e-5), masked.
+int cmtts_decoder_forward(cmtts_model* m, const float* x_ct, const int64_t* lens, int B, int T, float* out_ct, void* ws,
+                          size_t ws_bytes, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (m->dec.empty()) return fail(CMTTS_E_INVALID, "cmtts_decoder_forward: the state dict held no decoder.* tensors");
+    if (!x_ct || !lens || !out_ct || !ws || B <= 0 || T <= 0) return fail(CMTTS_E_INVALID, "cmtts_decoder_forward: bad argument");
+    if (T + 1 >= PE_ROWS) return fail(CMTTS_E_UNSUPPORTED, "cmtts_decoder_forward: T exceeds the position table");
+    const cmtts_config& c = m->cfg;
+    TextWs w = carve_text(c, B, T, ws);
+    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "decoder workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c.hidden, Tp = round_up(T, 4);
+    HIPCHK(hipMemcpy2DAsync(w.f, (size_t)Tp * 4, x_ct, (size_t)T * 4, (size_t)T * 4, (size_t)B * H, hipMemcpyDeviceToDevice, s));
+    k_pos_embed_add(w.f, w.x, m->dec_alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, T, Tp, s, lens);
+    CHK(fft_stack(m, m->dec, w, lens, B, T, s));
+    k_layernorm_ct(w.x, w.x, m->decln_g, m->decln_b, 1e-5f, lens, B, T, Tp, s);
+    HIPCHK(hipMemcpy2DAsync(out_ct, (size_t)T * 4, w.x, (size_t)Tp * 4, (size_t)T * 4, (size_t)B * H, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     return 0;
 }

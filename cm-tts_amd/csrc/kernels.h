@@ -14,7 +14,8 @@ void k_layernorm_ct(const float* in, float* out, const float* gamma, const float
 void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s);
 void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s);
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
-                     int tab_rows, int B, int C, int T, int ld, hipStream_t s);
+                     int tab_rows, int B, int C, int T, int ld, hipStream_t s,
+                     const int64_t* lens = nullptr);      // lens: columns t >= lens[b] are written as 0
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens,
                    int B, int C, int T, int ld, int O, hipStream_t s);
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,

@@ -158,7 +158,7 @@ __global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int 
 constexpr int POS_CG = 8;
 __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, float* out, const float* alpha,
                                                             const float* omega, const float* tab, int tab_rows,
-                                                            int C, int T, int ld) {
+                                                            int C, int T, int ld, const int64_t* lens) {
     extern __shared__ int sh[];
     int* counts = sh;
     int* pos = sh + 256;
@@ -167,11 +167,13 @@ __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, floa
     block_positions([&](int t) { return x0[t] != 0.f; }, T, pos, counts);
     const float al = alpha[0];
     const int c0 = blockIdx.y * POS_CG;
+    const int valid = lens ? (int)min((int64_t)T, lens[b]) : T;       // x * nonpadding (FFTBlocks.forward, modules.py:95)
     for (int cl = 0; cl < POS_CG && c0 + cl < C; ++cl) {
         const int c = c0 + cl;
         for (int t = threadIdx.x; t < T; t += 256) {
             const long off = ((long)b * C + c) * ld + t;
-            out[off] = x[off] + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
+            const float v = x[off] + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
+            out[off] = t < valid ? v : 0.f;
         }
     }
 }
@@ -530,9 +532,9 @@ void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipSt
     hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld);
 }
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
-                     int tab_rows, int B, int C, int T, int ld, hipStream_t s) {
+                     int tab_rows, int B, int C, int T, int ld, hipStream_t s, const int64_t* lens) {
     hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B, cdiv(C, POS_CG)), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, tab,
-                       tab_rows, C, T, ld);
+                       tab_rows, C, T, ld, lens);
 }
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens, int B,
                    int C, int T, int ld, int O, hipStream_t s) {

@@ -100,6 +100,7 @@ class CMTotalTTS(torch.nn.Module):
         self._ws = _Workspace()
         self.duration_pitch_energy_net = DurationPitchSpeakerNet(self)
         self.net = CMDenoiserTTS(self)
+        self.decoder = FastspeechDecoder(self)      # usable when the loaded state dict carries decoder.* (else it raises)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -239,6 +240,39 @@ def _as_cond_ct(conditioner, dev):
     """[B,T,H] reference layout -> channel-major [B,H,T]; free when it is a view of a _ct buffer."""
     c = conditioner.to(device=dev, dtype=torch.float32).transpose(1, 2)
     return c if c.is_contiguous() else c.contiguous()
+
+
+class FastspeechDecoder(torch.nn.Module):
+    """model/modules.py:154-165 (FFTBlocks.forward :80-105 with the learnable pos_embed_alpha).  The reference defines
+    this module and never instantiates it; it is served here from the same FFT-block kernels as
+    the text encoder, over the frame axis, for checkpoints whose state dict carries `decoder.*`
+    (cmtts_amd.weights.synth_decoder_state_dict lists the keys).  forward(x [B,T,256], padding_mask [B,T] | None)."""
+
+    def __init__(self, owner: CMTotalTTS):
+        super().__init__()
+        self._owner = owner
+
+    def forward(self, x, padding_mask=None, attn_mask=None, return_hiddens=False):
+        if attn_mask is not None or return_hiddens:
+            raise NotImplementedError("FastspeechDecoder: attn_mask / return_hiddens are not used on the inference path")
+        o = self._owner
+        o._require()
+        dev, lib = o.device, o.lib
+        x = _f32(x, dev)
+        B, T, H = x.shape
+        if padding_mask is None:
+            padding_mask = x.abs().sum(-1).eq(0)            # modules.py:86
+        padding_mask = padding_mask.to(device=dev, dtype=torch.bool)
+        lens = (~padding_mask).sum(1).to(torch.int64)
+        if not torch.equal(padding_mask, get_mask_from_lengths(lens, T)):
+            raise NotImplementedError("FastspeechDecoder: the padding mask must mark a suffix of every row (a length mask)")
+        x_ct = transpose_last2(x)
+        with torch.cuda.device(dev):
+            out_ct = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+            nb = lib.cmtts_decoder_workspace_bytes(o._h, B, T)
+            ws = o._ws.get("dec", nb, dev)
+            _lib.check(lib.cmtts_decoder_forward(o._h, _ptr(x_ct), _ptr(lens), B, T, _ptr(out_ct), _ptr(ws), nb, _stream()))
+        return transpose_last2(out_ct)
 
 
 class CMDenoiserTTS(torch.nn.Module):

@@ -29,6 +29,35 @@ def _normal(name, seed, shape, std, mean=0.0):
     return (_rs(name, seed).standard_normal(size=shape) * std + mean).astype(np.float32)
 
 
+def synth_decoder_state_dict(cfg: CMTTSConfig, seed: int = 0, n_layers: int = 4) -> "OrderedDict[str, np.ndarray]":
+    """State dict of a FastspeechDecoder (model/modules.py:154-165) registered as `decoder` — the keys
+    `self.decoder = FastspeechDecoder(model_config)` would add to a CMTotalTTS checkpoint (CM-TTS defines the class but
+    never instantiates it): decoder.layers.N.op.*, decoder.layer_norm.*, decoder.pos_embed_alpha (a learnable scalar;
+    set away from its init value 1 here so that tests see it)."""
+    H = cfg.hidden
+    sd = OrderedDict()
+
+    def N(name, shape, std, mean=0.0):
+        sd[name] = _normal(name, seed, shape, std, mean)
+
+    for i in range(n_layers):
+        p = f"decoder.layers.{i}.op."
+        for l in ("layer_norm1", "layer_norm2"):
+            N(p + l + ".weight", (H,), 0.1, 1.0)
+            N(p + l + ".bias", (H,), 0.1)
+        N(p + "self_attn.in_proj_weight", (3 * H, H), 1.0 / math.sqrt(H))
+        N(p + "self_attn.out_proj.weight", (H, H), 1.0 / math.sqrt(H))
+        N(p + "ffn.ffn_1.weight", (4 * H, H, cfg.ffn_kernel), 1.5 / math.sqrt(H * cfg.ffn_kernel))
+        N(p + "ffn.ffn_1.bias", (4 * H,), 0.1)
+        N(p + "ffn.ffn_2.weight", (H, 4 * H), 1.0 / math.sqrt(4 * H))
+        N(p + "ffn.ffn_2.bias", (H,), 0.1)
+    N("decoder.layer_norm.weight", (H,), 0.1, 1.0)
+    N("decoder.layer_norm.bias", (H,), 0.1)
+    sd["decoder.pos_embed_alpha"] = np.asarray([0.7], np.float32)
+    sd["decoder.embed_positions._float_tensor"] = np.zeros((1,), np.float32)
+    return sd
+
+
 def synth_cmtts_state_dict(cfg: CMTTSConfig, seed: int = 0, dur_frames: float = 6.0,
                            dur_spread: float = 0.02) -> "OrderedDict[str, np.ndarray]":
     """State dict of CMTotalTTS for one dataset variant.

@@ -183,6 +183,14 @@ int cmtts_set_resblock_tile(int frames);
 int cmtts_set_debug_stamps(void* dev_buf);
 int cmtts_profile_end(double* total_ms, int* n_launches);
 
+/* ---- FastspeechDecoder.forward (model/modules.py:154-165 = FFTBlocks.forward :80-105 with use_pos_embed=True,
+ * learnable pos_embed_alpha): available when the state dict held "decoder.layers.N.op.*", "decoder.layer_norm.*" and
+ * "decoder.pos_embed_alpha" (what `self.decoder = FastspeechDecoder(model_config)` registers; CM-TTS defines the class
+ * but never instantiates it).  x_ct, out_ct fp32 [B,hidden,T] channel-major; the padding mask is `t >= lens[b]`. */
+size_t cmtts_decoder_workspace_bytes(const cmtts_model* m, int B, int T);
+int cmtts_decoder_forward(cmtts_model* m, const float* x_ct, const int64_t* lens, int B, int T, float* out_ct,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- get_mask_from_lengths (utils/tools.py:275-283): mask[b][t] = (t >= lens[b]) as one byte per element
  * (True = padding), lens int64 [B], mask [B,W]. */
 int cmtts_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, void* stream);

@@ -217,6 +217,21 @@ def text_encoder(sd, cfg, texts, src_mask):
     return x.astype(F32)
 
 
+def fastspeech_decoder(sd, cfg, x, pad_mask=None, prefix="decoder.", n_layers=4):
+    """FastspeechDecoder.forward = FFTBlocks.forward with use_pos_embed=True, model/modules.py:80-105,154-165:
+    pad = all-zero rows unless given; x + alpha*PE[positions(x[..., 0] != 0)]; masked; FFT blocks; LayerNorm 1e-5."""
+    x = np.asarray(x, F32)
+    if pad_mask is None:
+        pad_mask = np.abs(x).sum(-1) == 0
+    keep = (~pad_mask).astype(F32)[:, :, None]
+    x = (x + sd[prefix + "pos_embed_alpha"].astype(F32) * positional_embedding(x[..., 0], x.shape[-1])).astype(F32)
+    x = x * keep
+    for i in range(n_layers):
+        x = enc_sa_layer(sd, f"{prefix}layers.{i}.op.", x, pad_mask, cfg.enc_heads, cfg.ffn_kernel) * keep
+    x = layer_norm(x, sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], 1e-5) * keep
+    return x.astype(F32)
+
+
 # ----------------------------------------------------------------------------- variance adaptor
 
 def _pred_convs(sd, prefix, xs, n_layers, kernel, mask=None):

@@ -284,6 +284,34 @@ def golden_samplers():
     np.savez_compressed(os.path.join(HERE, f"samplers_{variant}.npz"), **out)
 
 
+def golden_decoder():
+    """FastspeechDecoder (model/modules.py:154-165; defined by the reference, never instantiated by CMTotalTTS):
+    built from the LJSpeech model config, synthetic weights, a ragged [3, 37, 256] input whose padded rows are zero;
+    once with the mask derived from the zero rows (padding_mask=None) and once with an explicit mask over non-zero
+    padding."""
+    from model.modules import FastspeechDecoder
+    from cmtts_amd.weights import synth_decoder_state_dict
+    variant = "LJSpeech"
+    cfg = get_config(variant)
+    mod = yaml.load(open(f"{REF}/config/{variant}/model.yaml"), Loader=yaml.FullLoader)
+    dec = FastspeechDecoder(mod).eval()
+    seed = 5
+    sd = synth_decoder_state_dict(cfg, seed=seed)
+    dec.load_state_dict({k[len("decoder."):]: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    rs = np.random.RandomState(seed)
+    B, T = 3, 37
+    lens = np.asarray([37, 22, 9], np.int64)
+    x = rs.standard_normal(size=(B, T, cfg.hidden)).astype(np.float32)
+    pad = np.arange(T)[None, :] >= lens[:, None]
+    x_zero = x.copy()
+    x_zero[pad] = 0
+    with torch.no_grad():
+        y_auto = dec(torch.from_numpy(x_zero)).numpy()
+        y_mask = dec(torch.from_numpy(x), torch.from_numpy(pad)).numpy()
+    print(f"[decoder] |y| {np.abs(y_auto).mean():.3f}; auto-mask vs explicit-mask max diff {np.abs(y_auto - y_mask).max():.2e}")
+    np.savez_compressed(os.path.join(HERE, "decoder_LJSpeech.npz"), seed=np.int64(seed), x=x, lens=lens, y_auto=y_auto, y_mask=y_mask)
+
+
 def golden_controls():
     """DurationPitchSpeakerNet.forward (model/cmtts.py:44-122) off the plain inference branch, on the VCTK
     golden model (uv + multi-speaker): (a) p/e/d controls, (b) teacher-forced duration, energy and pitch
@@ -375,3 +403,5 @@ if __name__ == "__main__":
         golden_samplers()
     if not only or "controls" in only:
         golden_controls()
+    if not only or "decoder" in only:
+        golden_decoder()

@@ -449,6 +449,44 @@ def test_hifigan_golden(golden):
         assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
 
 
+def test_fastspeech_decoder_golden_and_long(golden):
+    """FastspeechDecoder over the frame axis on the encoder's FFT-block kernels: the reference module's output for
+    the golden input (both mask forms), then T = 700 ragged frames against the oracle (attention over 700 keys)."""
+    from cmtts_amd.weights import synth_decoder_state_dict
+    host = _host()
+    g = golden("decoder_LJSpeech")
+    cfg = get_config("LJSpeech")
+    sd = synth_cmtts_state_dict(cfg, seed=2)
+    dsd = synth_decoder_state_dict(cfg, seed=int(g["seed"]))
+    sd.update(dsd)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    x, lens = g["x"], g["lens"]
+    pad = np.arange(x.shape[1])[None, :] >= lens[:, None]
+    xz = x.copy()
+    xz[pad] = 0
+    y = model.decoder(torch.from_numpy(xz))
+    np.testing.assert_allclose(_np(y), g["y_auto"], atol=5e-5)
+    y = model.decoder(torch.from_numpy(x), torch.from_numpy(pad))
+    np.testing.assert_allclose(_np(y), g["y_mask"], atol=5e-5)
+    rs = np.random.RandomState(1)
+    B, T = 2, 700
+    lens = np.asarray([700, 431])
+    xl = rs.standard_normal(size=(B, T, cfg.hidden)).astype(np.float32)
+    padl = np.arange(T)[None, :] >= lens[:, None]
+    xl[padl] = 0
+    xl[0, 5, 0] = 0.0          # a valid frame whose channel 0 is exactly zero: position 0 there, later positions shift
+    ref = O.fastspeech_decoder(dsd, cfg, xl, padl)
+    y = model.decoder(torch.from_numpy(xl), torch.from_numpy(padl))
+    np.testing.assert_allclose(_np(y), ref, atol=1e-4)
+    # a model without decoder.* tensors refuses loudly
+    plain = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=2))
+    with pytest.raises(RuntimeError):
+        plain.decoder(torch.from_numpy(xz))
+    with pytest.raises(NotImplementedError):
+        holes = pad.copy(); holes[0, 3] = True
+        model.decoder(torch.from_numpy(x), torch.from_numpy(holes))
+
+
 def test_length_mask_kernel():
     """get_mask_from_lengths utils/tools.py:275-283 (True = padding): bit-exact against arange >= len."""
     host = _host()

@@ -158,6 +158,22 @@ def test_multistep_general_ts(golden):
     np.testing.assert_allclose(mel, gs["mel_multistep_ts013"], atol=1e-3)
 
 
+def test_fastspeech_decoder(golden):
+    """FastspeechDecoder (model/modules.py:154-165) restated in the oracle against the reference module's output:
+    mask derived from zero rows, and an explicit mask over non-zero padding."""
+    from cmtts_amd.weights import synth_decoder_state_dict
+    g = golden("decoder_LJSpeech")
+    cfg = get_config("LJSpeech")
+    sd = synth_decoder_state_dict(cfg, seed=int(g["seed"]))
+    x, lens = g["x"], g["lens"]
+    pad = np.arange(x.shape[1])[None, :] >= lens[:, None]
+    xz = x.copy()
+    xz[pad] = 0
+    np.testing.assert_allclose(O.fastspeech_decoder(sd, cfg, xz), g["y_auto"], atol=2e-5)
+    np.testing.assert_allclose(O.fastspeech_decoder(sd, cfg, x, pad), g["y_mask"], atol=2e-5)
+    assert np.abs(g["y_auto"][pad]).max() == 0
+
+
 def test_sigmas_karras():
     s = O.get_sigmas_karras(5, 0.002, 80.0, 7.0)
     assert s.dtype == np.float32 and s.shape == (6,) and s[-1] == 0
