@@ -85,6 +85,10 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C cm-tts_amd/csrc). "
             "cmtts_amd has no CPU or PyTorch fallback.")
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and must bring them in FIRST: the library then binds to
+    # that HIP runtime (same SONAME) and shares torch's device context and streams.  Loaded the other way round, the
+    # process ends up with /opt/rocm's runtime under torch and "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks the symbol
