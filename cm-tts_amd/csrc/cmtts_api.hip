@@ -299,6 +299,38 @@ int persist_launched(hipStream_t s, int blocks) {
     return 0;
 }
 
+// Independent branches of the text side (duration / energy predictors, ...) are short launches that cannot fill the chip:
+// a branch runs on a side stream forked from and joined back into the caller's stream with events, so the two overlap.
+// One side stream per caller stream (callers that run bucket groups on several streams keep their concurrency).
+bool g_branch_streams = true;
+struct SideStream { hipStream_t user, side; hipEvent_t fork, join; };
+std::vector<SideStream> g_sides;
+SideStream* side_for(hipStream_t s) {
+    if (!g_branch_streams) return nullptr;
+    for (auto& x : g_sides)
+        if (x.user == s) return &x;
+    if (g_sides.size() >= 16) return nullptr;          // more caller streams than that: branches run in line
+    SideStream x{s, nullptr, nullptr, nullptr};
+    if (hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    g_sides.push_back(x);
+    return &g_sides.back();
+}
+int branch_fork(SideStream* ss) {       // work queued on ss->side after this sees everything queued on ss->user so far
+    HIPCHK(hipEventRecord(ss->fork, ss->user));
+    HIPCHK(hipStreamWaitEvent(ss->side, ss->fork, 0));
+    return 0;
+}
+int branch_join(SideStream* ss) {       // work queued on ss->user after this sees everything queued on ss->side so far
+    HIPCHK(hipEventRecord(ss->join, ss->side));
+    HIPCHK(hipStreamWaitEvent(ss->user, ss->join, 0));
+    return 0;
+}
+
 int persist_blocks() {          // workgroups that are certainly co-resident: one 1024-thread workgroup per CU
     static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
                         (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v; }();
@@ -762,7 +794,8 @@ struct MelPost {
 };
 
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
-                  const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true) {
+                  const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
+                  SideStream* pending = nullptr) {   // pending: a side branch (the conditioner GEMM) to join before the layers
     if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
@@ -777,6 +810,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         CHK(launch(a, EPI_PLAIN, B, s));
     }
     if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s));
+    if (pending) CHK(branch_join(pending));
     const float* dp = m->cfg.multi_speaker ? w.dp : w.dproj;
     const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
     float* hcur = w.h;
@@ -928,6 +962,10 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
     for (size_t i = 0; i < layers.size(); ++i) {
         const EncLayer& E = layers[i];
         k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+        // the V projection is needed only by the PV product: side stream, joined after the softmax
+        SideStream* ss = side_for(s);
+        hipStream_t sv = ss ? ss->side : s;
+        if (ss) CHK(branch_fork(ss));
         {   // Q,K = h * W[0:2H]^T, channel-major [B][2H][Lp]
             ConvArgs a = conv_args(E.qk, w.h, L, Lp, hs, w.qk, Lp, 2 * hs, L);
             CHK(launch(a, EPI_PLAIN, B, s));
@@ -941,7 +979,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             a.pre_div = 1.f; a.pre_slope = 1.f; a.split = INT_MAX;
             ConvOut& o = a.out[0];
             o.Y = w.vt; o.y_zs0 = (long)Lp * H; o.ldy = H; o.Tout = H; o.ostride = 1; o.alpha = 1.f; o.div = 1.f;
-            CHK(launch(a, EPI_PLAIN, B, s));
+            CHK(launch(a, EPI_PLAIN, B, sv));
         }
         {   // S^T[b,h][j][i] = sum_d K[d][j] Q[d][i] / sqrt(dh)
             ConvArgs a;
@@ -956,6 +994,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             CHK(launch(a, EPI_PLAIN, B * NH, s));
         }
         k_softmax_cols(w.st, src_lens, B * NH, NH, L, Lp, (long)Lp * Lp, s);
+        if (ss) CHK(branch_join(ss));
         {   // O[b,h][d][i] = sum_j V^T[j][d] P^T[j][i]
             ConvArgs a;
             memset(&a, 0, sizeof(a));
@@ -1024,13 +1063,21 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
         k_add_rowvec(w.x, w.spk, B, H, L, Lp, s);
         if (speaker_emb) HIPCHK(hipMemcpyAsync(speaker_emb, w.spk, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     }
+    // The duration and the energy predictor both read x and nothing of each other: the energy branch runs on the side
+    // stream with its own scratch (the encoder's q/k buffer is free by now)
+    SideStream* ss = side_for(s);
+    hipStream_t se = ss ? ss->side : s;
+    float* ec1 = ss ? w.qk : w.c1;
+    float* ec2 = ss ? w.qk + (size_t)B * H * Lp : w.c2;
+    if (ss) CHK(branch_fork(ss));
     // duration predictor (masked) -> log_d
     CHK(predictor_convs(m->dur, w.x, Lp, B, L, Lp, src_lens, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->dur.lin_w, m->dur.lin_b, log_d, src_lens, B, c.pred_filter, L, Lp, 1, s);
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
-    k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, s);
-    CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, w.c1, w.c2, s));
-    k_chan_linear(w.c2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, s);
+    k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
+    CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, ec1, ec2, se));
+    k_chan_linear(ec2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, se);
+    if (ss) CHK(branch_join(ss));
     k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
                    w.out1, e_idx, B, H, L, Lp, s);
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
@@ -1062,6 +1109,14 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
     if (!p_idx) p_idx = w.pidx;
     if (!f0_stats) f0_stats = w.stats;
 
+    // cwt_stats_layers on the first phoneme of output_1 (model/modules.py:212-215,279) read nothing of the frame-level
+    // chain below: side stream, joined before pitch_index
+    SideStream* ss = side_for(s);
+    hipStream_t sst = ss ? ss->side : s;
+    if (ss) CHK(branch_fork(ss));
+    k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
+    k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
+    k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
     k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
     {   // cwt_predictor[0]: Linear(H -> cwt_hidden)        (model/modules.py:204-205)
@@ -1071,10 +1126,7 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
     k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
     CHK(predictor_convs(m->cwt, w.hp, T, B, T, T, nullptr, w.c1, w.c2, s));
     k_chan_linear(w.c2, m->cwt.lin_w, m->cwt.lin_b, cwt_out, nullptr, B, c.pred_filter, T, T, O, s);
-    // cwt_stats_layers on the first phoneme of output_1    (model/modules.py:212-215,279)
-    k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, s);
-    k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, s);
-    k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, s);
+    if (ss) CHK(branch_join(ss));
     if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
     if (m->vc.cwt_spec) {   // teacher-forced pitch: target spectrogram, statistics and uv (:379-390)
         k_pitch_index(m->vc.cwt_spec, 10, m->vc.f0_mean, m->vc.f0_std, 1, 1.0f, nullptr, 0, c.use_uv ? m->vc.uv : nullptr,
@@ -1108,9 +1160,13 @@ int cmtts_denoiser_forward(cmtts_model* m, const float* x, const float* timestep
     DenWs w = carve_den(m->cfg, B, T, ws);
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, s));
+    // the conditioner GEMM (all layers' projections of cond) and the input projection + step-embedding MLP are
+    // independent: the GEMM runs on the side stream and is joined before the first residual layer
+    SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
+    if (ss) CHK(branch_fork(ss));
+    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
     const MelPost post = {nullptr, nullptr, 1.0f, 0.0f, 0.0f, out};
-    CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, post, s));
+    CHK(denoiser_core(m, w, x, 1.0f, timesteps, cond_ct, speaker_emb, B, T, post, s, true, ss));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1147,8 +1203,11 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const long nel = (long)B * T * c.n_mels;
+    // once for all n_steps evaluations, on the side stream: joined before the first residual layer of the first evaluation
+    SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
+    if (ss) CHK(branch_fork(ss));
+    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
     k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
-    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, s));   // once for all n_steps evaluations
     const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
     for (int i = 0; i < n_steps; ++i) {
         // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
@@ -1165,7 +1224,7 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
         const bool renoise = renoise_std[i] >= 0.0f;
         const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
                               renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma));
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1319,6 +1378,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cond_gemm")) {
         const int prev = g_cond_gemm ? 1 : 0;
         if (value == 0 || value == 1) g_cond_gemm = value != 0;
+        return prev;
+    }
+    if (!strcmp(name, "branch_streams")) {
+        const int prev = g_branch_streams ? 1 : 0;
+        if (value == 0 || value == 1) g_branch_streams = value != 0;
         return prev;
     }
     if (!strcmp(name, "persist_tail")) {

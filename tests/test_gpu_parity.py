@@ -487,6 +487,44 @@ def test_fastspeech_decoder_golden_and_long(golden):
         model.decoder(torch.from_numpy(x), torch.from_numpy(holes))
 
 
+@pytest.mark.parametrize("variant,B,L", [("VCTK", 3, 40), ("LJSpeech", 32, 85)])
+def test_branch_streams_bitwise(variant, B, L):
+    """Independent branches (energy predictor, V projection, cwt statistics MLP, conditioner GEMM) run on a side stream
+    forked from / joined into the caller's stream: the same kernels, so every output must be bit-identical to the
+    in-line order, call after call (a missing dependency would show up as a race)."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=9, dur_frames=5.0, dur_spread=0.02)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(B)
+    lens = np.maximum((rs.uniform(0.4, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    T = 6 * L
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run():
+        out = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=T)
+        mel = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], 2, noise)
+        torch.cuda.synchronize()
+        return [out[k].clone() for k in ("cond_ct", "log_d_predictions", "e_predictions", "mel_lens", "mel2ph")] + \
+               [out["p_predictions"]["cwt"].clone(), out["p_predictions"]["f0_mean"].clone(), mel.clone()]
+
+    prev = lib.cmtts_set_option(b"branch_streams", 0)
+    try:
+        ref = run()
+        lib.cmtts_set_option(b"branch_streams", 1)
+        for _ in range(4):
+            got = run()
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+    finally:
+        lib.cmtts_set_option(b"branch_streams", prev)
+
+
 def test_length_mask_kernel():
     """get_mask_from_lengths utils/tools.py:275-283 (True = padding): bit-exact against arange >= len."""
     host = _host()

@@ -22,3 +22,13 @@ for i in range(6):
     mel = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], 1, noise)
     torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"B={B} L={L}: text side {1e3*(t1-t0):.3f} ms, one denoiser evaluation {1e3*(t2-t1):.3f} ms")
+from cmtts_amd import _lib
+lib = _lib.load()
+for flag in (0, 1):
+    lib.cmtts_set_option(b"branch_streams", flag)
+    ts = []
+    for i in range(12):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=L * 6)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"branch_streams={flag}: text side median {1e3*sorted(ts)[len(ts)//2]:.3f} ms")
