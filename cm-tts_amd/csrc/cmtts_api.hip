@@ -303,7 +303,12 @@ int persist_launched(hipStream_t s, int blocks) {
 // a branch runs on a side stream forked from and joined back into the caller's stream with events, so the two overlap.
 // One side stream per caller stream (callers that run bucket groups on several streams keep their concurrency).
 bool g_branch_streams = true;
-struct SideStream { hipStream_t user, side; hipEvent_t fork, join; };
+struct SideStream {
+    hipStream_t user, side;
+    hipEvent_t fork, join;
+    hipStream_t side2 = nullptr;                      // second side stream + chain events: the three ResBlocks of an MRF stage
+    hipEvent_t join2 = nullptr, done0 = nullptr, done1 = nullptr;
+};
 std::vector<SideStream> g_sides;
 SideStream* side_for(hipStream_t s) {
     if (!g_branch_streams) return nullptr;
@@ -319,6 +324,20 @@ SideStream* side_for(hipStream_t s) {
     }
     g_sides.push_back(x);
     return &g_sides.back();
+}
+// The vocoder's third stream and chain events, created on first use only: HIP maps streams onto a handful of hardware
+// queues in creation order, and idle extra streams made four caller streams (bucket groups) collide (25 -> 39 ms).
+bool side2_ready(SideStream* ss) {
+    if (ss->side2) return true;
+    if (hipStreamCreateWithFlags(&ss->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ss->join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss->done0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss->done1, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        ss->side2 = nullptr;
+        return false;
+    }
+    return true;
 }
 int branch_fork(SideStream* ss) {       // work queued on ss->side after this sees everything queued on ss->user so far
     HIPCHK(hipEventRecord(ss->fork, ss->user));
@@ -1295,11 +1314,20 @@ void cmtts_vocoder_destroy(cmtts_vocoder* v) {
 // Row padding of the stage buffers (floats).  Power-of-two row strides were suspected of HBM channel
 // camping; padding by 256 B or 4 KB + 128 B changed the vocoder time by < 2 %, so rows stay dense.
 static int voc_row_pad() { return 0; }
+// The three ResBlocks of an MRF stage are independent until their sum: they run on three streams (own xt / residual
+// buffers, + 4 stage buffers of workspace).  Small batches, whose convs cannot fill the chip (stage 2 has B*T/2
+// workgroups), gain most — one 150-frame utterance 4.1 -> 2.7 ms — and 32 x 512 frames still 1 % (tails of one ResBlock's
+// launches under the next one's).  Above this many mel frames per call the extra workspace (4 x 32 KB per frame) is not
+// spent and the ResBlocks run in line.
+constexpr long VOC_PAR_FRAMES = 65536;
 size_t cmtts_vocoder_workspace_bytes(const cmtts_vocoder* v, int B, int T) {
     (void)v;
     // five stage buffers of B * max_i(C_i * T_i) floats: C_i*T_i = T * {512, 2048, 8192, 8192, 8192}
     // (rows are padded by VOC_ROW_PAD floats; at most 512 rows per utterance)
-    return (size_t)5 * (((size_t)B * T * 8192 + (size_t)B * 512 * voc_row_pad()) * sizeof(float) + 256) + 256;
+    // + four more (xt / running residual of the second and third ResBlock) when the batch is small enough for the three
+    // ResBlocks of a stage to run side by side (VOC_PAR_FRAMES)
+    const int nb = (long)B * T <= VOC_PAR_FRAMES ? 9 : 5;
+    return (size_t)nb * (((size_t)B * T * 8192 + (size_t)B * 512 * voc_row_pad()) * sizeof(float) + 256) + 256;
 }
 int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, float* wav, void* ws, size_t ws_bytes,
                           void* stream) {
@@ -1315,6 +1343,14 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     float* bufT = cv.take<float>(nbuf);   // xt
     float* bufR = cv.take<float>(nbuf);   // running residual inside a ResBlock
     float* bufS = cv.take<float>(nbuf);   // MRF sum
+    SideStream* ss = (long)B * T <= VOC_PAR_FRAMES ? side_for(s) : nullptr;
+    if (ss && !side2_ready(ss)) ss = nullptr;
+    float *bufTj[3] = {bufT, bufT, bufT}, *bufRj[3] = {bufR, bufR, bufR};
+    hipStream_t sj[3] = {s, s, s};
+    if (ss) {   // own xt / residual buffers and streams for the second and third ResBlock
+        for (int j = 1; j < 3; ++j) { bufTj[j] = cv.take<float>(nbuf); bufRj[j] = cv.take<float>(nbuf); }
+        sj[1] = ss->side; sj[2] = ss->side2;
+    }
     {   // conv_pre (hifigan/models.py:150)
         ConvArgs a = conv_args(v->conv_pre, mel_ct, T, T, (long)80 * T, bufA, T + P, (long)512 * (T + P), T);
         CHK(launch(a, EPI_PLAIN, B, s));
@@ -1335,34 +1371,52 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         }
         const int ld = To + P;               // row stride: not a power of two (HBM channel spread)
         const long cs = (long)co * ld;
+        if (ss) {   // the three chains see the upsampled input
+            HIPCHK(hipEventRecord(ss->fork, s));
+            HIPCHK(hipStreamWaitEvent(ss->side, ss->fork, 0));
+            HIPCHK(hipStreamWaitEvent(ss->side2, ss->fork, 0));
+        }
         for (int j = 0; j < 3; ++j) {          // MRF: three ResBlocks on the same input (:154-159)
             const int r = i * 3 + j, rk = v->rb_kernel[j];
+            hipStream_t q = sj[j];
+            float *bT = bufTj[j], *bR = bufRj[j];
             const float* xr = bufU;
             for (int mi = 0; mi < 3; ++mi) {   // ResBlock.forward (:96-103)
                 const int dil = v->rb_dil[mi];
-                ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bufT, ld, cs, To);
+                ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
                 if (v->precision) {
                     a.y16 = 1; a.y16_slope = 0.1f;        // xt crosses HBM as convert(leaky_relu(xt)) in 16 bits
-                    if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
+                    if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
-                    CHK(launch(a, EPI_PLAIN, B, s));
+                    CHK(launch(a, EPI_PLAIN, B, q));
                 }
                 const bool lastm = mi == 2;
-                ConvArgs b = conv_args(v->c2[r][mi], bufT, To, ld, cs, lastm ? bufS : bufR, ld, cs, To);
+                // the MRF sum accumulates in ResBlock order (bit-identical to the in-line order): the last conv of
+                // chain j waits for the last conv of chain j-1
+                if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                ConvArgs b = conv_args(v->c2[r][mi], bT, To, ld, cs, lastm ? bufS : bR, ld, cs, To);
                 b.pre_slope = 0.1f;
                 b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = ld;
                 b.out[0].accum = lastm && j > 0;
                 if (v->precision) {
                     b.x16 = 1;
-                    if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)s) != 0)
+                    if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
-                    CHK(launch(b, EPI_PLAIN, B, s));
+                    CHK(launch(b, EPI_PLAIN, B, q));
                 }
-                xr = bufR;
+                if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                xr = bR;
             }
+        }
+        if (ss) {   // the next stage (and conv_post) read the sum: chain 2's last conv is the last writer; chain 1 is
+                    // ordered before it, but its stream must also be idle before its buffers are reused
+            HIPCHK(hipEventRecord(ss->join, ss->side));
+            HIPCHK(hipEventRecord(ss->join2, ss->side2));
+            HIPCHK(hipStreamWaitEvent(s, ss->join, 0));
+            HIPCHK(hipStreamWaitEvent(s, ss->join2, 0));
         }
         float* t = bufA; bufA = bufS; bufS = t;
         Ti = To; ch = co;

@@ -669,6 +669,9 @@ class BucketedSynthesizer:
         out = []
         lib = self.model.lib
         prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None else None
+        # the groups already overlap across streams; the library's own side streams (independent branches of one group)
+        # would only add streams competing for the few hardware queues HIP maps them onto (25 -> 31-39 ms measured)
+        prev_branch = lib.cmtts_set_option(b"branch_streams", 0)
         try:
             for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
                 st = self.streams[i % len(self.streams)]
@@ -678,6 +681,7 @@ class BucketedSynthesizer:
                     mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
                 out.append((mel, o["mel_lens"]))
         finally:
+            lib.cmtts_set_option(b"branch_streams", prev_branch)
             if prev is not None:
                 lib.cmtts_set_persistent_denoiser(prev)
         for st in self.streams:

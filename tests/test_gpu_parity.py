@@ -1024,6 +1024,28 @@ def test_reduced_precision_vocoder(golden, dtype, tol):
     assert torch.isfinite(lo).all() and 1e-7 < err.max() < tol, err.max()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_vocoder_mrf_streams_bitwise(dtype):
+    """Small batches: the three ResBlocks of an MRF stage run on three streams, their sum still accumulates in ResBlock
+    order -> bit-identical to the in-line order, call after call."""
+    host = _host()
+    lib = _lib.load()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=5))
+    voc.set_precision(dtype)
+    mel = (torch.randn(2, 80, 61, generator=torch.Generator().manual_seed(2)) * 1.5 - 4).to(DEV)
+    prev = lib.cmtts_set_option(b"branch_streams", 0)
+    try:
+        ref = voc(mel).clone()
+        lib.cmtts_set_option(b"branch_streams", 1)
+        for _ in range(4):
+            got = voc(mel)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+    finally:
+        lib.cmtts_set_option(b"branch_streams", prev)
+
+
 def test_hifigan_vs_oracle_other_shape():
     host = _host()
     hcfg = HifiGanConfig()
