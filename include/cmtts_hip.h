@@ -7,7 +7,12 @@
  *     the parameter is documented as host;
  *   - caller-allocated outputs, caller-provided workspaces (size queries below), no hidden
  *     allocation and no host synchronisation on the hot path;
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - `stream` is a hipStream_t passed as void*; the result is ordered on it.  Independent branches of a call may run
+ *     on library-owned side streams that are forked from and joined back into `stream` with events before the call
+ *     returns control of the data (cmtts_set_option("branch_streams", 0) keeps everything on `stream`);
+ *   - like the reference (one Python thread, synthesize.py), the library is NOT thread-safe: process-wide options,
+ *     the error string and the persistent-launch admission table are unsynchronised — one host thread per process
+ *     (one process per GPU), any number of streams;
  *   - return 0 on success, negative on error (CMTTS_E_*), message via cmtts_last_error();
  *   - integer tensors are int64 (torch.long) like the reference's; activations fp32;
  *   - frame-level activations cross the boundary channel-major ("_ct": [B, C, T], T contiguous) —
