@@ -245,7 +245,7 @@ struct Profile {
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
-bool g_cond_gemm = true;        // stacked conditioner GEMM through cond_gemm.hip (false: generic kernel, A/B and tests)
+int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
 
@@ -777,7 +777,7 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
     if (m->cond_all_f) {   // X tile resident in LDS, one walk over all 20 x 256 rows (bitwise equal to the generic kernel)
         CondGemmArgs g;
         g.X = cond_ct; g.Wf = m->cond_all_f; g.bias = m->cond_all.bias; g.Y = w.cp;
-        g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden;
+        g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = g_cond_gemm == 2;
         const int r = g_cond_gemm ? cmtts_launch_cond_gemm(&g, (void*)s) : -2;
         if (r == 0) return 0;
         if (r != -2) return fail(CMTTS_E_HIP, "cond_gemm launch failed");
@@ -1429,9 +1429,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
 
 int cmtts_set_option(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_set_option: null name");
-    if (!strcmp(name, "cond_gemm")) {
-        const int prev = g_cond_gemm ? 1 : 0;
-        if (value == 0 || value == 1) g_cond_gemm = value != 0;
+    if (!strcmp(name, "cond_gemm")) {       // 0 never, 1 when it pays (>= 128 frame tiles), 2 whenever supported
+        const int prev = g_cond_gemm;
+        if (value >= 0 && value <= 2) g_cond_gemm = value;
         return prev;
     }
     if (!strcmp(name, "branch_streams")) {

@@ -7,6 +7,7 @@ struct CondGemmArgs {
     const float* bias;    // [M]
     float* Y;             // [B][M][T]
     int B, T, M, K;
+    int force;            // take the kernel even where the generic one would finish sooner (tests)
 };
 
 #ifdef __cplusplus

@@ -125,6 +125,10 @@ __global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArg
 extern "C" int cmtts_launch_cond_gemm(const CondGemmArgs* ap, void* stream_) {
     const CondGemmArgs& a = *ap;
     if (a.K != K || a.M % (32 * MT * NW) != 0 || (long)a.M * a.T >= (1L << 30) || a.B <= 0 || a.T <= 0) return -2;
+    // a workgroup walks all M rows of its 64 frames alone (~350 us whatever the batch): below ~half a chip of frame tiles
+    // the generic kernel, which spreads M over workgroups, finishes sooner (one 150-frame utterance: 347 -> ~40 us).
+    // Both are bitwise equal (tests), so the choice never changes a result.
+    if (!a.force && (long)((a.T + FN - 1) / FN) * a.B < 128) return -2;
     static bool attr_set = false;
     const size_t lds = (size_t)K * X_LD * sizeof(float);
     if (!attr_set) {
