@@ -279,6 +279,10 @@ extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* 
         return launch_cfg<128, 128, 2, 2, EPI_PLAIN>(a, nbatch, stream);
     }
     if (a.split != INT_MAX) return -2;
+    // few rows AND few columns (attention products of short utterances: V^T = h^T Wv^T and K^T Q with M = phonemes <= 64):
+    // the 256-column tiles would stage mostly padding; 64x64 tiles with 64-channel chunks, same accumulation order
+    if (a.taps == 1 && a.K >= 128 && (long)((a.N + 255) / 256) * nbatch < 256)
+        return launch_cfg<64, 64, 2, 2, EPI_PLAIN, 64>(a, nbatch, stream);
     if (a.M > 32) return launch_cfg<64, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
     return launch_cfg<32, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
 }
