@@ -245,6 +245,7 @@ struct Profile {
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
+int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
@@ -349,6 +350,8 @@ int branch_join(SideStream* ss) {       // work queued on ss->user after this se
     HIPCHK(hipStreamWaitEvent(ss->user, ss->join, 0));
     return 0;
 }
+
+constexpr long SPLIT_MAX_TILES = 176;    // 32-frame tiles up to which the two-launch residual block wins (tools/split_crossover.py: 0.88 vs 1.86 ms per evaluation up to 64 tiles, 1.46 vs 2.08 at 128, 2.00 vs 2.19 at 192, 2.65 vs 2.39 at 256)
 
 int persist_blocks() {          // workgroups that are certainly co-resident: one 1024-thread workgroup per CU
     static int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev);
@@ -884,7 +887,12 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
             int lrc;
             if (m->precision == 0) {
-                lrc = cmtts_launch_resblock(&ra, (void*)s);
+                // few 32-frame tiles: one workgroup per tile leaves most of the chip idle for 83 us per layer; four
+                // workgroups per tile in two launches finish sooner (measured crossover, tools/latency_bench.py)
+                const long tiles32 = (long)((T + 31) / 32) * B;
+                ra.z = w.zb;
+                if (g_split_resblock == 2 || (g_split_resblock == 1 && tiles32 <= SPLIT_MAX_TILES)) lrc = cmtts_launch_resblock_split(&ra, (void*)s);
+                else lrc = cmtts_launch_resblock(&ra, (void*)s);
             } else {
                 ra.W3f = (const float*)R.w3f16[m->precision - 1];
                 ra.Wof = (const float*)R.wof16[m->precision - 1];
@@ -1432,6 +1440,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cond_gemm")) {       // 0 never, 1 when it pays (>= 128 frame tiles), 2 whenever supported
         const int prev = g_cond_gemm;
         if (value >= 0 && value <= 2) g_cond_gemm = value;
+        return prev;
+    }
+    if (!strcmp(name, "resblock_split")) {   // 0 never, 1 small batches, 2 always (fp32 per-layer path)
+        const int prev = g_split_resblock;
+        if (value >= 0 && value <= 2) g_split_resblock = value;
         return prev;
     }
     if (!strcmp(name, "branch_streams")) {

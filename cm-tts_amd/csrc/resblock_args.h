@@ -14,6 +14,7 @@ struct ResArgs {
     long vec_stride;
     int B, T;
     int accum_skip;       // skip += o[C:] (layers > 0) or skip = o[C:] (layer 0)
+    float* z;             // split form only (resblock_split.hip): scratch [B][256][T] for the gated activations
     long long* dbg;       // optional [grid][8] cycle stamps written by wave 0 (phase timing, tools/phase_timing.py)
 };
 
@@ -21,6 +22,7 @@ struct ResArgs {
 extern "C" {
 #endif
 int cmtts_launch_resblock(const ResArgs* a, void* stream);
+int cmtts_launch_resblock_split(const ResArgs* a, void* stream);         // fp32, two launches, small batches (needs a->z)
 int cmtts_launch_resblock_lp(const ResArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16 operands
 void cmtts_resblock_set_tile(int frames);   // 0 = automatic, 32 or 64 = forced frames per workgroup
 void cmtts_resblock_set_debug(long long* dbg);

@@ -773,6 +773,36 @@ def test_persistent_denoiser_bitwise(variant, B, T):
     assert torch.equal(mel_p, mel_r), float((mel_p - mel_r).abs().max())
 
 
+@pytest.mark.parametrize("variant,B,T", [("LJSpeech", 1, 150), ("VCTK", 3, 33), ("VCTK", 2, 257), ("LJSpeech", 5, 64)])
+def test_split_resblock_bitwise(variant, B, T):
+    """Small batches: the residual block as two launches over four workgroups per 32-frame tile (resblock_split.hip)
+    must give bit for bit what the one-workgroup kernel and the three-launch form give."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=17))
+    gen = torch.Generator().manual_seed(T)
+    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    cond = torch.randn(B, T, cfg.hidden, generator=gen).to(DEV)
+    spk = torch.randn(B, cfg.hidden, generator=gen).to(DEV) if cfg.multi_speaker else None
+    t = torch.full((B,), 1095.5, device=DEV)
+    prev_p = lib.cmtts_set_persistent_denoiser(0)
+    prev_s = lib.cmtts_set_option(b"resblock_split", 0)
+    try:
+        one = model.net(x, t, cond, spk).clone()
+        lib.cmtts_set_option(b"resblock_split", 2)
+        two = model.net(x, t, cond, spk).clone()
+        lib.cmtts_set_fused_resblock(0)
+        three = model.net(x, t, cond, spk)
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_fused_resblock(1)
+        lib.cmtts_set_option(b"resblock_split", prev_s)
+        lib.cmtts_set_persistent_denoiser(prev_p)
+    assert torch.isfinite(two).all()
+    assert torch.equal(two, one) and torch.equal(two, three)
+
+
 def test_xres_conv_bitwise(models):
     """conv_xres.hip (k=9 FFN conv with the utterance's X tile resident in LDS, 96-column tiles) keeps the generic
     kernel's accumulation order and epilogue: the text encoder output must not change by a bit (B=32 x L=85 takes the
