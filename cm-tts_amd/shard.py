@@ -40,6 +40,38 @@ def frame_bucket(n_frames: int, buckets: Sequence[int] = FRAME_BUCKETS) -> int:
     raise ValueError(f"{n_frames} frames exceed the largest bucket {buckets[-1]}")
 
 
+def plan_shards(n_frames: Sequence[int], world: int, buckets: Sequence[int] = FRAME_BUCKETS):
+    """BASELINE.json configs[3] recipe: utterances go to the smallest static frame bucket that holds them; inside a
+    bucket they are dealt round-robin by length over the ranks; every rank gets the SAME count per bucket (the all-gather
+    needs equal blocks), short ranks are padded with -1 (the caller feeds any real utterance there and the restored list
+    ignores it).  Returns {bucket: [[utterance index or -1] * per_rank for each rank]} — identical on every rank, no
+    communication needed to agree on it."""
+    plan = {}
+    for b in buckets:
+        ids = [i for i, t in enumerate(n_frames) if frame_bucket(int(t), buckets) == b]
+        if not ids:
+            continue
+        deal = deal_by_length([n_frames[i] for i in ids], world)
+        per_rank = max(len(d) for d in deal)
+        plan[int(b)] = [[ids[j] for j in d] + [-1] * (per_rank - len(d)) for d in deal]
+    return plan
+
+
+def restore_order(gathered, plan, n_items: int):
+    """gathered: {bucket: (mel [world*per_rank, bucket, M], mel_len [world*per_rank])} as returned by allgather_mels for
+    every bucket of `plan`.  Returns the per-utterance mels [mel_len_i, M] in the ORIGINAL utterance order."""
+    out = [None] * n_items
+    for b, ranks in plan.items():
+        mel, mel_len = gathered[b]
+        flat = [i for r in ranks for i in r]
+        assert mel.shape[0] == len(flat), (mel.shape, len(flat))
+        for row, i in enumerate(flat):
+            if i >= 0:
+                out[i] = mel[row, : int(mel_len[row])]
+    assert all(o is not None for o in out)
+    return out
+
+
 def pack_mels(mel: torch.Tensor, mel_len: torch.Tensor) -> torch.Tensor:
     """[Bl,T,M] fp32 + int64 [Bl] -> one fp32 buffer [Bl, T*M + 1] (mel_len < 2**24 is exact in fp32)."""
     Bl = mel.shape[0]

@@ -75,3 +75,52 @@ def test_shard_arithmetic():
     mel = torch.arange(2 * 4 * 80, dtype=torch.float32).reshape(2, 4, 80)
     m2, l2 = shard.unpack_mels(shard.pack_mels(mel, torch.tensor([4, 3])), 4, 80)
     assert torch.equal(m2, mel) and l2.tolist() == [4, 3]
+
+
+FRAMES = [900, 100, 500, 510, 20, 1000, 30, 700, 255, 257, 600]     # 11 utterances: 3 / 3 / 2 / 3 per bucket
+
+
+def _fake_synth(idx, bucket):
+    """Stand-in for text -> mel on one rank: mel[t, m] = 1000 * utterance + t + m / 100 for t < n_frames, 0 after."""
+    n = FRAMES[idx]
+    mel = torch.zeros(bucket, 80)
+    mel[:n] = 1000.0 * idx + torch.arange(n, dtype=torch.float32)[:, None] + torch.arange(80, dtype=torch.float32)[None, :] / 100
+    return mel, n
+
+
+def _worker_plan(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = shard.plan_shards(FRAMES, world)
+    gathered = {}
+    for bucket, ranks in plan.items():
+        mine = ranks[rank]
+        mels, lens = zip(*[_fake_synth(i if i >= 0 else ranks[rank][0], bucket) for i in mine])
+        gathered[bucket] = shard.allgather_mels_async(torch.stack(mels), torch.tensor(lens, dtype=torch.int64)).wait()
+    out = shard.restore_order(gathered, plan, len(FRAMES))
+    q.put((rank, [o.numpy() for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_shard_plan_world2():
+    """The configs[3] flow on 2 ranks: bucket, deal, synthesize the local share per bucket, one all-gather per bucket,
+    restore the original order — every rank ends with every utterance's mel, trimmed to its length."""
+    world, port = 2, _free_port()
+    plan = shard.plan_shards(FRAMES, world)
+    assert sorted(plan) == [256, 512, 768, 1024]
+    assert sorted(i for ranks in plan.values() for r in ranks for i in r if i >= 0) == list(range(len(FRAMES)))
+    assert all(len({len(r) for r in ranks}) == 1 for ranks in plan.values())          # equal blocks per rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_plan, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, mels in res:
+        for i, m in enumerate(mels):
+            ref, n = _fake_synth(i, shard.frame_bucket(FRAMES[i]))
+            assert m.shape == (n, 80) and np.array_equal(m, ref[:n].numpy())
