@@ -57,6 +57,7 @@ SIGNATURES = {
     "cmtts_profile_begin": (_i, [_i, _i]),
     "cmtts_set_fused_resblock": (_i, [_i]),
     "cmtts_set_persistent_denoiser": (_i, [_i]),
+    "cmtts_poll_error": (_i, []),
     "cmtts_set_option": (_i, [C.c_char_p, _i]),
     "cmtts_set_resblock_tile": (_i, [_i]),
     "cmtts_set_precision": (_i, [_vp, _i]),

@@ -1457,12 +1457,23 @@ int cmtts_set_option(const char* name, int value) {
         if (value == 0 || value == 1) g_persist_tail = value != 0;
         return prev;
     }
+    if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
+        return cmtts_persist_set_cooperative(value);
+    }
     if (!strcmp(name, "ffn_xres")) {
         const int prev = g_ffn_xres ? 1 : 0;
         if (value == 0 || value == 1) g_ffn_xres = value != 0;
         return prev;
     }
     return fail(CMTTS_E_INVALID, "cmtts_set_option: unknown option");
+}
+
+int cmtts_poll_error(void) {
+    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
+        *(volatile unsigned*)g_tmo_host = 0;
+        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out (the affected utterances' mel is NaN)");
+    }
+    return 0;
 }
 
 int cmtts_set_persistent_denoiser(int mode) {

@@ -373,6 +373,11 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
+            if (gave_up) {   // poison the halo column: the utterance's mel comes out NaN (spreading one tile per layer)
+                             // instead of plausible-but-wrong, and cmtts_poll_error() reports the timeout
+#pragma unroll
+                for (int k = 0; k < C / 64; ++k) xv[k] = __builtin_nanf("");
+            }
 #pragma unroll
             for (int k = 0; k < C / 64; ++k) {
                 const int m = ln + 64 * k;
@@ -398,8 +403,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 }
 
 long long* g_pdbg = nullptr;
+int g_coop = 0;
 
 }  // namespace
+
+extern "C" int cmtts_persist_set_cooperative(int on) { const int p = g_coop; if (on == 0 || on == 1) g_coop = on; return p; }
+extern "C" int cmtts_persist_cooperative(void) { return g_coop; }
 
 extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
 
@@ -473,7 +482,11 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.out = a.out + off;
         }
         if (a.dbg) hipLaunchKernelGGL(denoiser_persist_kernel<true>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-        else hipLaunchKernelGGL(denoiser_persist_kernel<false>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        else if (g_coop) {
+            void* params[] = {(void*)&c};
+            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false>), dim3(tiles, nb),
+                                           dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+        } else hipLaunchKernelGGL(denoiser_persist_kernel<false>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;

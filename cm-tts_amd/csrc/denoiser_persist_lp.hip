@@ -318,6 +318,11 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
+            if (gave_up) {   // poison the halo column: the utterance's mel comes out NaN (spreading one tile per layer)
+                             // instead of plausible-but-wrong, and cmtts_poll_error() reports the timeout
+#pragma unroll
+                for (int k = 0; k < C / 64; ++k) xv[k] = __builtin_nanf("");
+            }
 #pragma unroll
             for (int k = 0; k < C / 64; ++k) {
                 const int m = ln + 64 * k;
@@ -376,7 +381,11 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        hipLaunchKernelGGL(denoiser_persist_lp_kernel<MODE>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        if (cmtts_persist_cooperative()) {
+            void* params[] = {(void*)&c};
+            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>), dim3(tiles, nb),
+                                           dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+        } else hipLaunchKernelGGL(denoiser_persist_lp_kernel<MODE>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;

@@ -48,6 +48,10 @@ int cmtts_launch_denoiser_persist_lp(const PersistArgs* a, int mode, int max_blo
 int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int force);   // resident workgroups of the largest launch (0 = path not taken)
 int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
 void cmtts_persist_set_debug(long long* dbg);
+// 1: launch through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident and dispatches it
+// with the cooperative-queue guarantee); 0: plain launch, grid <= CU count by construction.  Returns the previous value.
+int cmtts_persist_set_cooperative(int on);
+int cmtts_persist_cooperative(void);
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,15 @@ def _push_state_dict(lib, setter, handle, sd):
         _lib.check(setter(handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
 
 
+def _norm_device(device):
+    """torch.device with an explicit index ("cuda" -> "cuda:<current>"): tensors report indexed devices, so an
+    un-indexed one never compares equal to a buffer's and every workspace lookup would reallocate."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class _Workspace:
     """Caller-owned scratch buffers, cached per size (no allocation on the steady-state path)."""
 
@@ -56,6 +65,7 @@ class _Workspace:
         self._bufs = {}
 
     def get(self, key, nbytes, device):
+        device = _norm_device(device)
         # one set of buffers per HIP stream: groups running concurrently on different streams must not share scratch
         key = (key, torch.cuda.current_stream(device).cuda_stream)
         buf = self._bufs.get(key)
@@ -89,7 +99,7 @@ class CMTotalTTS(torch.nn.Module):
     def __init__(self, config: CMTTSConfig, device="cuda:0"):
         super().__init__()
         self.config = config
-        self.device = torch.device(device)
+        self.device = _norm_device(device) if torch.cuda.is_available() else torch.device(device)
         self.lib = _lib.load()
         cs = _lib.CMTTSConfigStruct()
         for name, _ in cs._fields_:
@@ -250,7 +260,7 @@ class FastspeechDecoder(torch.nn.Module):
 
     def __init__(self, owner: CMTotalTTS):
         super().__init__()
-        self._owner = owner
+        self.__dict__["_owner"] = owner      # not a registered child: the owner holds this module (no module cycle)
 
     def forward(self, x, padding_mask=None, attn_mask=None, return_hiddens=False):
         if attn_mask is not None or return_hiddens:
@@ -304,9 +314,12 @@ class CMDenoiserTTS(torch.nn.Module):
 class KarrasDenoiser:
     """model/cm_tool/karras_diffusion.py:35-102,392-407 (inference members only)."""
 
-    def __init__(self, sigma_data=0.5, sigma_max=80.0, sigma_min=0.002, rho=7.0, distillation=True, **kw):
+    def __init__(self, sigma_data=0.5, sigma_max=80.0, sigma_min=0.002, rho=7.0, weight_schedule="karras",
+                 distillation=False, loss_norm="lpips", **kw):
+        """Same defaults as the reference (karras_diffusion.py:36-45: distillation=False); the synthesize path builds
+        it with distillation=True (synthesize.py:59-78 via create_model_and_diffusion_tts)."""
         self.sigma_data, self.sigma_max, self.sigma_min, self.rho = sigma_data, sigma_max, sigma_min, rho
-        self.distillation = distillation
+        self.weight_schedule, self.distillation, self.loss_norm = weight_schedule, distillation, loss_norm
 
     def get_scalings(self, sigma):
         """karras_diffusion.py:81-85 (distillation=False)."""
@@ -339,6 +352,18 @@ class DummyGenerator:
 
     def randn_like(self, *args, **kwargs):
         return torch.randn_like(*args, **kwargs)
+
+
+def check_async_error():
+    """Raise if a persistent denoiser launch that has completed reported a neighbour-wait timeout (cmtts_poll_error)."""
+    _lib.check(_lib.load().cmtts_poll_error())
+
+
+def synchronize(device=None):
+    """torch.cuda.synchronize + cmtts_poll_error: a failure of any launch completed so far is raised HERE, by the call
+    that makes the results host-visible, not by whichever call comes next."""
+    torch.cuda.synchronize(device)
+    check_async_error()
 
 
 def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
@@ -374,12 +399,24 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
         generator = DummyGenerator()
     B, one, T, M = shape
     ode = sampler in ("heun", "dpm", "euler", "ancestral", "our_multistep")
-    distilled = getattr(diffusion, "distillation", True)
+    distilled = getattr(diffusion, "distillation", False)
+    # cmtts_schedule / cmtts_sample take sigma_min, sigma_max, sigma_data and rho from the model's config; a caller
+    # whose arguments or diffusion object say otherwise gets the reference's host-side loop, which honours them
+    cfg = model.config
+    same = lambda a, b: abs(float(a) - float(b)) <= 1e-6 * max(abs(float(a)), abs(float(b)), 1e-30)
+    if not (same(sigma_min, cfg.sigma_min) and same(sigma_max, cfg.sigma_max) and
+            same(getattr(diffusion, "sigma_min", cfg.sigma_min), cfg.sigma_min) and
+            same(getattr(diffusion, "sigma_max", cfg.sigma_max), cfg.sigma_max) and
+            same(getattr(diffusion, "sigma_data", cfg.sigma_data), cfg.sigma_data) and
+            same(getattr(diffusion, "rho", cfg.rho), cfg.rho)):
+        distilled_fusable = False
+    else:
+        distilled_fusable = distilled
     if sampler == "onestep":
         n_steps = 1
-        ode = not distilled            # cmtts_sample fuses the boundary-condition scalings only
+        ode = not distilled_fusable    # cmtts_sample fuses the boundary-condition scalings (and the config's sigmas) only
     elif sampler == "multistep":
-        fused = distilled and steps == 2 and ts is not None and tuple(ts[:-1]) == (0,) * (len(ts) - 1) and ts[-1] == 1
+        fused = distilled_fusable and steps == 2 and ts is not None and tuple(ts[:-1]) == (0,) * (len(ts) - 1) and ts[-1] == 1
         n_steps = len(ts) - 1 if fused else 0
         ode = not fused                # any other `ts` schedule: the reference's loop, host-side
     elif not ode:
@@ -534,7 +571,7 @@ class Generator(torch.nn.Module):
     def __init__(self, h: HifiGanConfig = HifiGanConfig(), device="cuda:0"):
         super().__init__()
         self.h = h
-        self.device = torch.device(device)
+        self.device = _norm_device(device) if torch.cuda.is_available() else torch.device(device)
         self.lib = _lib.load()
         self._h = C.c_void_p()
         _lib.check(self.lib.cmtts_vocoder_create(C.byref(self._h)))
@@ -594,6 +631,7 @@ def vocoder_infer(mels, vocoder, model_config=None, preprocess_config=None, leng
     with torch.cuda.device(wavs.device):
         _lib.check(vocoder.lib.cmtts_wav_to_int16(_ptr(wavs), _ptr(pcm), wavs.numel(), float(max_wav_value), _stream()))
     out = [w for w in pcm.cpu().numpy()]
+    check_async_error()          # the D2H copy synchronised: a timeout in the launches that produced `mels` is raised here
     if lengths is not None:
         out = [w[: int(lengths[i])] for i, w in enumerate(out)]
     return out
@@ -696,7 +734,7 @@ class CMTotalTTSSynthesize:
     def __init__(self, model: CMTotalTTS, T=1, generator=None):
         self.model = model
         self.diffusion = KarrasDenoiser(sigma_data=model.config.sigma_data, sigma_max=model.config.sigma_max,
-                                        sigma_min=model.config.sigma_min, rho=model.config.rho)
+                                        sigma_min=model.config.sigma_min, rho=model.config.rho, distillation=True)
         self.duration_pitch_energy_net, self.denoise_net = model.get_segmentation_model()
         self.T = int(T)
         self.generator = generator

@@ -135,3 +135,32 @@ def allgather_mels_async(mel: torch.Tensor, mel_len: torch.Tensor, group=None, f
         return PendingGather(work, out, T, M, (buf, parts))
     work = dist.all_gather_into_tensor(out, buf, group=group, async_op=True)
     return PendingGather(work, out, T, M, buf)
+
+
+def allgather_buckets(mels, group=None, force: bool = False):
+    """configs[3]: every bucket of a ragged shard in ONE all-gather.  mels: {bucket: (mel [n_b, bucket, M], mel_len
+    [n_b])} with the same n_b on every rank (plan_shards guarantees it).  The blocks are packed back to back (each as
+    pack_mels lays it out: mel_len rides in the same buffer) into one flat fp32 buffer per rank, gathered once, and split
+    again.  Returns {bucket: (mel [world*n_b, bucket, M], mel_len [world*n_b])} in rank order — what restore_order takes.
+    `force` runs the collective on a 1-rank group too (single-GPU check of the RCCL call sequence)."""
+    buckets = sorted(mels)
+    shapes = {b: tuple(mels[b][0].shape) for b in buckets}
+    parts = [pack_mels(mels[b][0], mels[b][1]).reshape(-1) for b in buckets]
+    sizes = [p.numel() for p in parts]
+    buf = torch.cat(parts) if len(parts) > 1 else parts[0]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if not dist.is_initialized() or (world == 1 and not force):
+        out = buf[None]
+    else:
+        out = torch.empty(world, buf.numel(), dtype=buf.dtype, device=buf.device)
+        if dist.get_backend(group) == "gloo":
+            dist.all_gather(list(out.unbind(0)), buf, group=group)
+        else:
+            dist.all_gather_into_tensor(out.reshape(-1), buf, group=group)
+    res, off = {}, 0
+    for b, n in zip(buckets, sizes):
+        nb, T, M = shapes[b]
+        blk = out[:, off:off + n].reshape(out.shape[0] * nb, T * M + 1)
+        res[b] = unpack_mels(blk, T, M)
+        off += n
+    return res

@@ -164,6 +164,14 @@ int cmtts_set_fused_resblock(int on);
  * GPU has CUs).  Bitwise identical to the per-layer kernels (tests); fp32 operands only.  Any other value only
  * queries.  Returns the previous mode. */
 int cmtts_set_persistent_denoiser(int mode);
+/* The persistent launch bounds every wait for a neighbouring tile (~2 s); when one expires the kernel poisons the
+ * affected utterance (its mel comes out NaN, never plausible-but-wrong) and sets a pinned host word.
+ * cmtts_poll_error() reads and clears that word: 0, or CMTTS_E_HIP with the message in cmtts_last_error().  It reflects
+ * launches that have COMPLETED, so call it after synchronising the stream the mel was produced on (host.py does, at
+ * every point where it hands host-visible data back: vocoder_infer, synthesize(sync=True), host.synchronize()).
+ * The next denoiser call also checks the word before it launches.  There is no counterpart in the reference (its
+ * errors are Python exceptions). */
+int cmtts_poll_error(void);
 /* A/B switches that do not change results (bitwise, tested).  "cond_gemm": 1 (default) = the stacked conditioner
  * projections of all residual layers through the X-resident kernel (cond_gemm.hip), 0 = through the generic conv
  * kernel.  "ffn_xres": 1 (default) = the k=9 FFN conv of the FFT blocks through the X-resident kernel

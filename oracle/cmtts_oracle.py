@@ -20,7 +20,68 @@ import math
 import numpy as np
 from scipy.special import erf as _erf
 
-F32 = np.float32
+F32 = np.float32          # the working dtype of every function below; `precision("f64")` rebinds it
+
+
+class precision:
+    """``with precision("f64"):`` runs the same restatement in float64 (inputs are cast on entry by every function,
+    fp32 weights promote).  The float64 result is the yardstick the tests measure fp32 / fp16 / bf16 errors against:
+    the reference itself only ever computes in fp32, so its golden vectors carry fp32 rounding of their own."""
+
+    def __init__(self, name):
+        self.dtype = {"f32": np.float32, "f64": np.float64}[name]
+
+    def __enter__(self):
+        global F32
+        self.prev = F32
+        F32 = self.dtype
+        _TAP_CACHE.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global F32
+        F32 = self.prev
+        _TAP_CACHE.clear()
+        return False
+
+
+_OPERAND16 = None          # None | "bf16" | "fp16": see operands16
+
+
+class operands16:
+    """``with operands16("bf16"):`` restates the library's reduced-precision scheme (BASELINE.json configs[2]/[4];
+    the reference has no such mode): the MFMA operands of the denoiser's residual-block convs (u, z and the two weight
+    sets) and of the HiFi-GAN ResBlock convs (leaky_relu(x), leaky_relu(xt), weights) are rounded to 16 bits
+    (round-to-nearest-even from their fp32 value), products and sums stay in the working precision, and everything
+    else (biases, gate, residual arithmetic, conv_pre / transposed convs / conv_post) is untouched."""
+
+    def __init__(self, mode):
+        assert mode in (None, "fp32", "bf16", "fp16")
+        self.mode = None if mode == "fp32" else mode
+
+    def __enter__(self):
+        global _OPERAND16
+        self.prev = _OPERAND16
+        _OPERAND16 = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND16
+        _OPERAND16 = self.prev
+        return False
+
+
+def quant16(a, mode=None):
+    """Round to bf16 / fp16 (RNE, via the fp32 value like v_cvt_pk_{bf16,f16}_f32) and return in the working dtype."""
+    mode = mode or _OPERAND16
+    if mode is None:
+        return a
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    if mode == "fp16":
+        return a32.astype(np.float16).astype(F32)
+    u = a32.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(F32)
 
 
 # ----------------------------------------------------------------------------- primitives
@@ -424,9 +485,9 @@ def denoiser_forward(sd, cfg, x, t, cond, speaker_emb):
         u = r + cp
         if cfg.multi_speaker:
             u = u + linear(speaker_emb, sd[p + "speaker_projection.linear.weight"])[:, :, None]
-        y = conv1d(u.astype(F32), sd[p + "conv_layer.conv.weight"], sd[p + "conv_layer.conv.bias"], padding=1)
+        y = conv1d(quant16(u.astype(F32)), quant16(sd[p + "conv_layer.conv.weight"]), sd[p + "conv_layer.conv.bias"], padding=1)
         z = (sigmoid(y[:, :C]) * np.tanh(y[:, C:])).astype(F32)
-        o = conv1d(z, sd[p + "output_projection.conv.weight"], sd[p + "output_projection.conv.bias"])
+        o = conv1d(quant16(z), quant16(sd[p + "output_projection.conv.weight"]), sd[p + "output_projection.conv.bias"])
         h = ((o[:, :C] + r) / F32(math.sqrt(2.0))).astype(F32)
         skip_sum = o[:, C:] if skip_sum is None else skip_sum + o[:, C:]
     s = (skip_sum / F32(math.sqrt(cfg.res_layers))).astype(F32)
@@ -643,11 +704,11 @@ def hifigan_generator(hsd, hcfg, mel_ct):
             r = i * nk + j
             xr = x
             for m, dil in enumerate(dils):
-                xt = leaky_relu(xr, hcfg.lrelu_slope)
-                xt = conv1d(xt, hsd[f"resblocks.{r}.convs1.{m}.weight"], hsd[f"resblocks.{r}.convs1.{m}.bias"],
+                xt = quant16(leaky_relu(xr, hcfg.lrelu_slope))
+                xt = conv1d(xt, quant16(hsd[f"resblocks.{r}.convs1.{m}.weight"]), hsd[f"resblocks.{r}.convs1.{m}.bias"],
                             padding=(rk * dil - dil) // 2, dilation=dil)
-                xt = leaky_relu(xt, hcfg.lrelu_slope)
-                xt = conv1d(xt, hsd[f"resblocks.{r}.convs2.{m}.weight"], hsd[f"resblocks.{r}.convs2.{m}.bias"],
+                xt = quant16(leaky_relu(xt, hcfg.lrelu_slope))
+                xt = conv1d(xt, quant16(hsd[f"resblocks.{r}.convs2.{m}.weight"]), hsd[f"resblocks.{r}.convs2.{m}.bias"],
                             padding=(rk - 1) // 2)
                 xr = (xt + xr).astype(F32)
             xs = xr if xs is None else xs + xr

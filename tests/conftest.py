@@ -24,6 +24,23 @@ def pytest_configure(config):
                            stdout=subprocess.DEVNULL)
 
 
+# Lines the GPU tests want in the run's summary even under `-q` without `-s` (flip counts, dtype error ladders):
+# collected here, printed by pytest_terminal_summary.
+REPORT = []
+
+
+def report(line):
+    REPORT.append(line)
+    print(line)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if REPORT:
+        terminalreporter.write_sep("-", "parity report")
+        for line in REPORT:
+            terminalreporter.write_line(line)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
 
@@ -44,6 +61,41 @@ def pitch_margin_mask(f0_denorm, thr=2e-3):
     sc = np.clip(sc, 1, 255)
     frac = sc + 0.5 - np.floor(sc + 0.5)
     return np.minimum(frac, 1 - frac) > thr
+
+
+# Pitch-bucket flips: `(mel + 0.5).long()` (utils/pitch_tools.py:26-35) is discontinuous, and the value it rounds is
+# computed from the cwt predictor's fp32 output, which differs from the reference's CPU result in the last bits
+# (different accumulation order).  A frame whose pre-rounding value sits within that drift of a bucket boundary may land
+# in the neighbouring bucket.  The tests COUNT those frames exactly, require every one of them to sit on a boundary
+# (golden margin < FLIP_MARGIN of a bucket), and pin the count per golden: a change of the count is a change of the
+# kernels' numerics and must be looked at.  Measured on MI355X (round 2); 0 everywhere means no masking takes place.
+FLIP_MARGIN = 2e-3
+KNOWN_PITCH_FLIPS = {
+    "cmtts_LJSpeech": 0, "cmtts_VCTK": 0, "cmtts_LibriTTS": 0,
+    "controls_VCTK:ctl": 0, "controls_VCTK:tf": 0,
+}
+
+
+def pitch_flips(p_idx, golden_p_idx, golden_f0_denorm, tag):
+    """Exact flip accounting.  Returns the boolean map of agreeing frames; prints `PITCH_FLIPS <tag> n/N`."""
+    same = np.asarray(p_idx) == np.asarray(golden_p_idx)
+    n = int((~same).sum())
+    line = f"PITCH_FLIPS {tag}: {n} of {same.size} frames (pinned: {KNOWN_PITCH_FLIPS[tag]})"
+    if line not in REPORT:
+        report(line)
+    on_boundary = ~pitch_margin_mask(golden_f0_denorm, FLIP_MARGIN)
+    assert not (~same & ~on_boundary).any(), f"{tag}: a pitch bucket differs away from a rounding boundary"
+    assert (np.abs(np.asarray(p_idx) - np.asarray(golden_p_idx)) <= 1).all(), f"{tag}: a pitch bucket is off by more than one"
+    assert n <= KNOWN_PITCH_FLIPS[tag], f"{tag}: {n} pitch-bucket flips, {KNOWN_PITCH_FLIPS[tag]} known"
+    return same
+
+
+def near_flip_mask(same, reach=24):
+    """Frames farther than the denoiser's receptive field (+-20 frames) from any flipped frame."""
+    near = np.zeros_like(same)
+    for b, t in zip(*np.nonzero(~same)):
+        near[b, max(0, t - reach): t + reach + 1] = True
+    return ~near
 
 
 @pytest.fixture(scope="session")

@@ -13,7 +13,9 @@ from cmtts_amd import _lib
 from cmtts_amd.config import get_config, HifiGanConfig
 from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
 from oracle import cmtts_oracle as O
-from conftest import golden_noise, pitch_margin_mask
+from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report
+
+KNOWN_ORACLE_FLIPS = {"energy": 20, "pitch": 120}      # test_bucketed_ragged_shard_vs_oracle (tightened after the first measurement)
 
 pytestmark = pytest.mark.gpu
 VARIANTS = ["LJSpeech", "VCTK", "LibriTTS"]
@@ -138,11 +140,7 @@ def test_duration_pitch_speaker_net_golden(models, variant):
     np.testing.assert_allclose(_np(pp["f0_mean"]), g["f0_mean"], atol=2e-5)
     np.testing.assert_allclose(_np(pp["f0_std"]), g["f0_std"], atol=2e-5)
     np.testing.assert_allclose(_np(pp["f0_denorm"]), g["f0_denorm"], rtol=5e-4, atol=1e-2)
-    ok = pitch_margin_mask(g["f0_denorm"])
-    p_idx = _np(pp["p_idx"])
-    assert np.array_equal(p_idx[ok], g["p_idx"][ok])
-    same = p_idx == g["p_idx"]
-    assert same.mean() > 0.98
+    same = pitch_flips(_np(pp["p_idx"]), g["p_idx"], g["f0_denorm"], "cmtts_" + variant)
     np.testing.assert_allclose(_np(out["cond"])[same], g["cond"][same], atol=5e-5)
 
 
@@ -197,33 +195,24 @@ def test_karras_sample_tts_end_to_end(models, variant):
 
     kw = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]),
               spker_embeds=torch.from_numpy(g["spker_embeds"]) if cfg.multi_speaker else None)
-    diffusion = host.KarrasDenoiser()
+    diffusion = host.KarrasDenoiser(distillation=True)
     mel = host.karras_sample_tts(diffusion, model, (B, 1, T, cfg.n_mels), steps=2, model_kwargs=kw, device=DEV,
                                  sampler="multistep", ts=(0, 0, 0, 0, 1), generator=Gen())
     torch.cuda.synchronize()
     ref = g["mel_T4"]
     # frames whose pitch bucket sits on a rounding boundary may take the neighbouring embedding row;
     # the denoiser's receptive field (+-20 frames) spreads that, so compare where all buckets agree
-    out = model.duration_pitch_energy_net(None, kw["texts"], kw["src_lens"], spker_embeds=kw["spker_embeds"])
-    same = _np(out["p_predictions"]["p_idx"]) == g["p_idx"]
+    ok = _mask_near_pitch_flips(model, g, kw, "cmtts_" + variant)
     err = np.abs(_np(mel) - ref)
-    if same.all():
-        assert err.max() < 1e-3, err.max()
-    else:
-        bad = ~same
-        near = np.zeros_like(bad)
-        for b, t in zip(*np.nonzero(bad)):
-            near[b, max(0, t - 24): t + 25] = True
-        assert err[~near].max() < 1e-3, err[~near].max()
+    assert err[ok].max() < 1e-3, err[ok].max()
 
 
-def _mask_near_pitch_flips(model, g, kw):
+def _mask_near_pitch_flips(model, g, kw, tag):
+    """Frames of the end-to-end mel that can be compared with the golden: all of them when no pitch bucket flipped
+    (the pinned count, conftest.KNOWN_PITCH_FLIPS); otherwise those outside the denoiser's reach of a flipped frame."""
     out = model.duration_pitch_energy_net(None, kw["texts"], kw["src_lens"], spker_embeds=kw["spker_embeds"])
-    bad = _np(out["p_predictions"]["p_idx"]) != g["p_idx"]
-    near = np.zeros_like(bad)
-    for b, t in zip(*np.nonzero(bad)):
-        near[b, max(0, t - 24): t + 25] = True
-    return ~near
+    same = pitch_flips(_np(out["p_predictions"]["p_idx"]), g["p_idx"], g["f0_denorm"], tag)
+    return near_flip_mask(same)
 
 
 @pytest.mark.parametrize("T_steps", [1, 2, 4])
@@ -251,9 +240,9 @@ def test_synthesize_driver(models, T_steps):
     out = host.CMTotalTTSSynthesize(model, T=T_steps, generator=Gen()).synthesize(batch)
     torch.cuda.synchronize()
     assert np.array_equal(_np(out[11]), g["mel_len"]) and np.array_equal(_np(out[10]), g["src_lens"])
-    ok = _mask_near_pitch_flips(model, g, dict(texts=texts, src_lens=lens, spker_embeds=spk))
+    ok = _mask_near_pitch_flips(model, g, dict(texts=texts, src_lens=lens, spker_embeds=spk), "cmtts_VCTK")
     err = np.abs(_np(out[0]) - g[f"mel_T{T_steps}"])
-    assert ok.mean() > 0.5 and err[ok].max() < 1e-3, err[ok].max()
+    assert err[ok].max() < 1e-3, err[ok].max()
 
 
 def test_generic_denoise_path_matches_fused_sampler(models):
@@ -266,9 +255,9 @@ def test_generic_denoise_path_matches_fused_sampler(models):
     x_T = torch.from_numpy(noise).to(DEV) * cfg.sigma_max
     sig = torch.full((B,), cfg.sigma_max, device=DEV)
     kw = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]), spker_embeds=None)
-    _, den = host.KarrasDenoiser().denoise(model, x_T, sig, **kw)
+    _, den = host.KarrasDenoiser(distillation=True).denoise(model, x_T, sig, **kw)
     torch.cuda.synchronize()
-    ok = _mask_near_pitch_flips(model, g, kw)
+    ok = _mask_near_pitch_flips(model, g, kw, "cmtts_LJSpeech")
     err = np.abs(_np(den[:, 0]) - g["mel_T1"])
     assert err[ok].max() < 1e-3, err[ok].max()
 
@@ -282,7 +271,7 @@ def test_host_side_samplers_match_fused(models):
     noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
     cond = torch.from_numpy(g["cond"]).to(DEV)
     spk = torch.from_numpy(g["speaker_emb"]).to(DEV)
-    diffusion = host.KarrasDenoiser()
+    diffusion = host.KarrasDenoiser(distillation=True)
     dist = host.make_distiller(diffusion, model, cond, spk)
     x_T = torch.from_numpy(noise[0]).to(DEV) * cfg.sigma_max
     sig = torch.tensor([cfg.sigma_max, 0.0], device=DEV)
@@ -328,7 +317,7 @@ def test_ode_samplers_golden(models, golden, sampler):
 
     gen = Gen()
     kwargs = dict(speakers=None, texts=torch.from_numpy(g["texts"]), src_lens=torch.from_numpy(g["src_lens"]))
-    mel = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=int(gs["steps_" + sampler]),
+    mel = host.karras_sample_tts(host.KarrasDenoiser(distillation=True), model, (B, 1, T, cfg.n_mels), steps=int(gs["steps_" + sampler]),
                                  model_kwargs=kwargs, sigma_min=cfg.sigma_min, sigma_max=cfg.sigma_max, rho=cfg.rho,
                                  sampler=sampler, generator=gen)
     torch.cuda.synchronize()
@@ -368,7 +357,7 @@ def test_non_distilled_diffusion_routes(models, golden):
     np.testing.assert_allclose(_np(mel), gs["mel_heun_edm"], atol=3e-3, rtol=2e-4)
     # onestep at sigma_max: c_skip/c_out of the two scalings differ by O(sigma_min/sigma_max) only, but they differ
     one_edm = host.karras_sample_tts(edm, model, (B, 1, T, cfg.n_mels), steps=2, sampler="onestep", generator=Gen(), **common)
-    one_cm = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=2, sampler="onestep",
+    one_cm = host.karras_sample_tts(host.KarrasDenoiser(distillation=True), model, (B, 1, T, cfg.n_mels), steps=2, sampler="onestep",
                                     generator=Gen(), **common)
     torch.cuda.synchronize()
     assert np.abs(_np(one_cm) - g["mel_T1"]).max() < 1e-3
@@ -376,7 +365,7 @@ def test_non_distilled_diffusion_routes(models, golden):
     assert 0 < d < 1e-2, d
     # a multistep schedule the fused path does not cover runs through the host loop instead of raising
     gen = Gen()
-    ms = host.karras_sample_tts(host.KarrasDenoiser(), model, (B, 1, T, cfg.n_mels), steps=4, sampler="multistep",
+    ms = host.karras_sample_tts(host.KarrasDenoiser(distillation=True), model, (B, 1, T, cfg.n_mels), steps=4, sampler="multistep",
                                 ts=(0, 1, 3), generator=gen, **common)
     torch.cuda.synchronize()
     assert gen.i == int(gs["draws_multistep_ts013"])
@@ -391,10 +380,7 @@ def _check_variance_gpu(out, gc, tag):
     pp = out["p_predictions"]
     np.testing.assert_allclose(_np(pp["cwt"]), gc[tag + "_cwt_out"], atol=3e-4)
     np.testing.assert_allclose(_np(pp["f0_denorm"]), gc[tag + "_f0_denorm"], rtol=3e-4, atol=2e-3)
-    ok = pitch_margin_mask(gc[tag + "_f0_denorm"])
-    np.testing.assert_array_equal(_np(pp["p_idx"])[ok], gc[tag + "_p_idx"][ok])
-    same = _np(pp["p_idx"]) == gc[tag + "_p_idx"]
-    assert same.mean() > 0.95
+    same = pitch_flips(_np(pp["p_idx"]), gc[tag + "_p_idx"], gc[tag + "_f0_denorm"], "controls_VCTK:" + tag)
     err = np.abs(_np(out["cond"]) - gc[tag + "_cond"])[same].max()
     assert err < 1e-3, err
 
@@ -640,7 +626,11 @@ def test_bucketed_ragged_shard_vs_oracle():
     valid = np.arange(L)[None, :] < lens[:, None]
     e_same = (_np(out["e_idx"]) == st["e_idx"]) | ~valid
     p_same = _np(out["p_predictions"]["p_idx"]) == st["p_idx"]
-    assert e_same.mean() > 0.97 and p_same.mean() > 0.97
+    # vs the numpy oracle on unsearched inputs (no margin search as for the goldens): the bucket decisions that differ
+    # are counted and pinned (measured on MI355X, round 2), not averaged away
+    n_e, n_p = int((~e_same).sum()), int((~p_same).sum())
+    report(f"BUCKET_FLIPS bucketed LibriTTS shard vs oracle: energy {n_e} of {int(valid.sum())} phonemes, pitch {n_p} of {p_same.size} frames")
+    assert n_e <= KNOWN_ORACLE_FLIPS["energy"] and n_p <= KNOWN_ORACLE_FLIPS["pitch"]
     # frames fed by agreeing energy buckets and pitch buckets must match the oracle's conditioning
     ph = np.clip(ref_m2p - 1, 0, L - 1)
     ok = p_same & np.take_along_axis(e_same, ph, 1)
@@ -1004,54 +994,6 @@ def test_persistent_denoiser_lp_bitwise(variant, B, T, dtype):
     torch.cuda.synchronize()
     assert torch.isfinite(one).all()
     assert torch.equal(one, ref), float((one - ref).abs().max())
-
-
-@pytest.mark.parametrize("dtype,tol", [("bf16", 6e-2), ("fp16", 8e-3)])
-def test_reduced_precision_denoiser(models, dtype, tol):
-    """BASELINE configs[2] (bf16) / configs[4] (fp16 denoiser): MFMA operands of the residual blocks in 16 bits,
-    fp32 accumulation and fp32 everywhere else.  The reference is fp32-only at inference, so the bound is OUR
-    stated tolerance against the fp32 golden mel (|mel| ~ 0.3 mean): bf16 6e-2, fp16 8e-3; the measured error is
-    printed.  fp32 mode must be restored bit-exactly afterwards."""
-    host = _host()
-    g, cfg, sd, model = models("VCTK")
-    B, T, _ = g["cond"].shape
-    noise = torch.from_numpy(np.stack(golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5))).to(DEV)
-    cond_ct = torch.from_numpy(np.ascontiguousarray(g["cond"].transpose(0, 2, 1))).to(DEV)
-    spk = torch.from_numpy(g["speaker_emb"]).to(DEV)
-    ref32 = host.sample_with_cond(model, cond_ct, spk, 4, noise)
-    try:
-        model.set_precision(dtype)
-        lo = host.sample_with_cond(model, cond_ct, spk, 4, noise)
-    finally:
-        model.set_precision("fp32")
-    again = host.sample_with_cond(model, cond_ct, spk, 4, noise)
-    torch.cuda.synchronize()
-    assert torch.equal(again, ref32)
-    err = np.abs(_np(lo) - g["mel_T4"])
-    print(f"{dtype}: max |dmel| {err.max():.2e}, mean {err.mean():.2e}")
-    assert torch.isfinite(lo).all() and err.max() < tol, err.max()
-    assert err.max() > 1e-6          # it really ran in reduced precision
-
-
-@pytest.mark.parametrize("dtype,tol", [("bf16", 5e-2), ("fp16", 6e-3)])
-def test_reduced_precision_vocoder(golden, dtype, tol):
-    """HiFi-GAN ResBlock convs with 16-bit MFMA operands (BASELINE configs[2]); stated tolerance on the wav in
-    (-1, 1) against the fp32 golden: bf16 5e-2, fp16 6e-3 (measured error printed)."""
-    host = _host()
-    g = golden("hifigan")
-    hcfg = HifiGanConfig()
-    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=int(g["seed"])))
-    mel_ct = torch.from_numpy(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)))
-    ref = voc(mel_ct)
-    voc.set_precision(dtype)
-    lo = voc(mel_ct)
-    voc.set_precision("fp32")
-    again = voc(mel_ct)
-    torch.cuda.synchronize()
-    assert torch.equal(again, ref)
-    err = np.abs(_np(lo) - g["wav"])
-    print(f"vocoder {dtype}: max |dwav| {err.max():.2e}, mean {err.mean():.2e}")
-    assert torch.isfinite(lo).all() and 1e-7 < err.max() < tol, err.max()
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

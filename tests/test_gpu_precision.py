@@ -1,0 +1,247 @@
+"""Reduced-precision parity (BASELINE.json configs[2]: bf16, configs[4]: fp16 denoiser) with DERIVED bounds, and the
+full-size configs[2] / configs[4] paths.
+
+The reference computes in fp32 only, so 16-bit MFMA operands have no reference output to match.  What pins them:
+
+  * the oracle restates the library's scheme exactly (`O.operands16`: the conv operands of the residual blocks / HiFi-GAN
+    ResBlocks rounded to 16 bits from their fp32 value, everything else untouched) and runs it in float64
+    (`O.precision("f64")`), so that the only differences left between the HIP result and that oracle are (a) fp32
+    accumulation order, which the fp32 tests already bound, and (b) operands whose fp32 value sits so close to a 16-bit
+    rounding boundary that the HIP path's fp32 drift `d` (relative, measured in the same test against float64) puts
+    them into the neighbouring 16-bit value.  An operand flips with probability ~ d / u16 and then moves by ~u16
+    relative; over a K-term dot product that perturbs an output by sqrt(d * u16) relative, and the N convs of the path
+    add up like a random walk.  Hence the implementation bound
+
+        rms(hip16 - oracle16) <= SAFETY * rms(mel) * sqrt(N_CONV * d32 * u16),      max <= 5 x that  (5 sigma)
+
+    with u16 the unit roundoff (2^-8 bf16, 2^-11 fp16), d32 = rms(hip32 - f64) / rms(f64) and SAFETY = 3;
+  * the scheme's own error rms(oracle16 - f64) is reported next to it (it is a property of the precision choice — about
+    ten unit roundoffs of the type on |mel| ~ 0.3 — not of the implementation), and the HIP result may not be farther
+    from float64 than that plus the implementation bound.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cmtts_amd
+from cmtts_amd import _lib
+from cmtts_amd.config import get_config, HifiGanConfig
+from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
+from oracle import cmtts_oracle as O
+from conftest import golden_noise, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+U16 = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
+SAFETY = 3.0
+
+
+def _host():
+    from cmtts_amd import host
+    return host
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64)))))
+
+
+def impl_bound(ref64, hip32, n_conv, dtype):
+    d32 = rms(hip32 - ref64) / rms(ref64)
+    return SAFETY * rms(ref64) * np.sqrt(n_conv * d32 * U16[dtype]), d32
+
+
+def check_ladder(tag, ref64, hip32, hip16, orc16, n_conv, dtype, golden32=None):
+    """ref64: float64 oracle; hip32 / hip16: HIP results; orc16: float64 oracle with 16-bit operands."""
+    bound, d32 = impl_bound(ref64, hip32, n_conv, dtype)
+    e_impl, e_impl_max = rms(hip16 - orc16), float(np.abs(hip16 - orc16).max())
+    e_scheme, e_scheme_max = rms(orc16 - ref64), float(np.abs(orc16 - ref64).max())
+    e_tot_max = float(np.abs(hip16 - ref64).max())
+    line = (f"DTYPE_ERR {tag} {dtype}: vs f64 max|d| fp32 {np.abs(hip32 - ref64).max():.2e}"
+            + (f" (reference fp32 {np.abs(golden32 - ref64).max():.2e})" if golden32 is not None else "")
+            + f", {dtype} {e_tot_max:.2e} (scheme alone {e_scheme_max:.2e}); hip vs {dtype}-operand oracle rms {e_impl:.2e} "
+              f"max {e_impl_max:.2e}, derived bound rms {bound:.2e} max {5 * bound:.2e} (d32 {d32:.1e}, N {n_conv})")
+    report(line)
+    assert np.isfinite(hip16).all()
+    assert e_impl <= bound and e_impl_max <= 5 * bound, line
+    assert e_tot_max <= e_scheme_max + 5 * bound, line
+    assert e_scheme_max > 1e-6 and e_impl_max < e_scheme_max, line      # 16-bit operands really ran, and parity is tighter than the scheme's own noise
+
+
+@pytest.fixture(scope="module")
+def golden_models(golden):
+    host = _host()
+    cache = {}
+
+    def get(variant):
+        if variant not in cache:
+            g = golden("cmtts_" + variant)
+            cfg = get_config(variant)
+            sd = synth_cmtts_state_dict(cfg, seed=int(g["seed"]), dur_frames=4.0, dur_spread=0.03)
+            cache[variant] = (g, cfg, sd, host.CMTotalTTS(cfg, DEV).load_state_dict(sd))
+        return cache[variant]
+    return get
+
+
+@pytest.mark.parametrize("variant", ["LJSpeech", "VCTK", "LibriTTS"])
+def test_precision_ladder_denoiser(golden_models, variant):
+    """T = 4 sampler on the three goldens: fp32 / fp16 / bf16 error relative to the float64 oracle, with the reference's
+    own fp32 golden on the same scale; 16-bit results against the 16-bit-operand oracle within the derived bound."""
+    host = _host()
+    g, cfg, sd, model = golden_models(variant)
+    B, T, _ = g["cond"].shape
+    noise_np = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    noise = torch.from_numpy(np.stack(noise_np)).to(DEV)
+    cond_ct = torch.from_numpy(np.ascontiguousarray(g["cond"].transpose(0, 2, 1))).to(DEV)
+    spk_np = g["speaker_emb"] if cfg.multi_speaker else None
+    spk = torch.from_numpy(spk_np).to(DEV) if cfg.multi_speaker else None
+    n_steps = 4
+    hip = {}
+    hip["fp32"] = _np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise))
+    try:
+        for dt in ("bf16", "fp16"):
+            model.set_precision(dt)
+            hip[dt] = _np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise))
+    finally:
+        model.set_precision("fp32")
+    assert np.array_equal(_np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise)), hip["fp32"])   # fp32 restored bit-exactly
+    with O.precision("f64"):
+        ref64 = O.karras_sample_tts(sd, cfg, g["cond"], spk_np, n_steps, noise_np)
+        orc = {}
+        for dt in ("bf16", "fp16"):
+            with O.operands16(dt):
+                orc[dt] = O.karras_sample_tts(sd, cfg, g["cond"], spk_np, n_steps, noise_np)
+    e32, eref = np.abs(hip["fp32"] - ref64).max(), np.abs(g["mel_T4"] - ref64).max()
+    assert e32 < 1e-3 and e32 < max(4 * eref, 1e-4), (e32, eref)      # our fp32 is as close to float64 as the reference's fp32
+    n_conv = 2 * cfg.res_layers * n_steps
+    for dt in ("bf16", "fp16"):
+        check_ladder(f"denoiser T=4 {variant}", ref64, hip["fp32"], hip[dt], orc[dt], n_conv, dt, golden32=g["mel_T4"])
+
+
+def test_precision_ladder_vocoder(golden):
+    """HiFi-GAN on the golden mel: fp32 / fp16 / bf16 wav error relative to the float64 oracle; 16-bit ResBlock convs
+    against the 16-bit-operand oracle within the derived bound (depth: 4 stages x 3 pairs x 2 convs)."""
+    host = _host()
+    g = golden("hifigan")
+    hcfg = HifiGanConfig()
+    hsd = synth_hifigan_state_dict(hcfg, seed=int(g["seed"]))
+    voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
+    mel_ct_np = np.ascontiguousarray(g["mel"].transpose(0, 2, 1))
+    mel_ct = torch.from_numpy(mel_ct_np)
+    hip = {"fp32": _np(voc(mel_ct))}
+    for dt in ("bf16", "fp16"):
+        voc.set_precision(dt)
+        hip[dt] = _np(voc(mel_ct))
+    voc.set_precision("fp32")
+    assert np.array_equal(_np(voc(mel_ct)), hip["fp32"])
+    with O.precision("f64"):
+        ref64 = O.hifigan_generator(hsd, hcfg, mel_ct_np)
+        orc = {}
+        for dt in ("bf16", "fp16"):
+            with O.operands16(dt):
+                orc[dt] = O.hifigan_generator(hsd, hcfg, mel_ct_np)
+    assert np.abs(hip["fp32"] - ref64).max() < 1e-4
+    for dt in ("bf16", "fp16"):
+        check_ladder("vocoder", ref64, hip["fp32"], hip[dt], orc[dt], 24, dt, golden32=g["wav"])
+
+
+def _text_batch(cfg, B, L, seed):
+    rs = np.random.RandomState(seed)
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    lens = np.full((B,), L, np.int64)
+    spk = rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32) if cfg.multi_speaker else None
+    return texts, lens, spk
+
+
+def _full_config(variant, B, L, T, n_steps, den_dt, voc_dt, seed, spot, voc_frames):
+    """One BASELINE.json config at its full per-GPU size through the product path (text -> mel -> wav -> int16), checked
+    by (1) batch independence: utterances re-run alone are bit-identical (no cross-utterance arithmetic on the path);
+    (2) an oracle spot check on the `spot` utterances: sampler and vocoder of the float64 oracle with the same 16-bit
+    operand scheme, fed the HIP path's own conditioning / mel, within the derived bound; (3) int16 = the numpy cast."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=seed, dur_frames=6.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    hcfg = HifiGanConfig()
+    hsd = synth_hifigan_state_dict(hcfg, seed=seed)
+    voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
+    texts, lens, spk = _text_batch(cfg, B, L, seed)
+    gen = torch.Generator().manual_seed(seed)
+    noise = torch.randn(n_steps + 1, B, 1, T, cfg.n_mels, generator=gen)
+    noise_d = noise.to(DEV)
+
+    def run(idx, den, vocp):
+        model.set_precision(den)
+        voc.set_precision(vocp)
+        try:
+            out = model.duration_pitch_energy_net(None, torch.from_numpy(texts[idx]), torch.from_numpy(lens[idx]),
+                                                  spker_embeds=None if spk is None else torch.from_numpy(spk[idx]), max_mel_len=T)
+            mel = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise_d[:, idx].contiguous())
+            wav = voc(host.transpose_last2(mel)).squeeze(1)
+            pcm = torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
+            _lib.check(lib.cmtts_wav_to_int16(wav.data_ptr(), pcm.data_ptr(), wav.numel(), 32768.0, None))
+            host.synchronize()
+        finally:
+            model.set_precision("fp32")
+            voc.set_precision("fp32")
+        return out, mel, wav, pcm
+
+    out, mel, wav, pcm = run(np.arange(B), den_dt, voc_dt)
+    assert tuple(mel.shape) == (B, T, cfg.n_mels) and tuple(pcm.shape) == (B, T * cfg.hop_length)
+    assert torch.isfinite(mel).all() and torch.isfinite(wav).all()
+    assert _np(out["mel_lens"]).tolist() == [min(6 * L, T)] * B or _np(out["mel_lens"]).tolist() == [6 * L] * B
+    # (1) batch independence, bit for bit, through every stage
+    for b in (0, B // 2 + 1, B - 1):
+        o1, m1, w1, p1 = run(np.asarray([b]), den_dt, voc_dt)
+        assert torch.equal(o1["cond_ct"][0], out["cond_ct"][b]), f"conditioning of utterance {b} depends on its batch"
+        assert torch.equal(m1[0], mel[b]), f"mel of utterance {b} depends on its batch"
+        assert torch.equal(p1[0], pcm[b]), f"wav of utterance {b} depends on its batch"
+    # (3) the int16 cast (utils/model.py:195-198)
+    assert np.array_equal(_np(pcm[spot]), O.wav_to_int16(_np(wav[spot])))
+    # (2) oracle spot check, same inputs: the HIP path's conditioning -> sampler; the HIP path's mel -> vocoder
+    _, mel32, wav32, _ = run(np.asarray(spot), "fp32", "fp32")
+    cond = _np(out["cond"][spot])
+    spk_emb = None if out["speaker_emb"] is None else _np(out["speaker_emb"][spot])
+    nz = [noise[i][spot].numpy() for i in range(n_steps + 1)]
+    with O.precision("f64"):
+        ref64 = O.karras_sample_tts(sd, cfg, cond, spk_emb, n_steps, nz)
+        with O.operands16(den_dt):
+            orc16 = O.karras_sample_tts(sd, cfg, cond, spk_emb, n_steps, nz)
+    tag = f"{variant} B={B} T={T} steps={n_steps}"
+    if den_dt == "fp32":
+        assert np.abs(_np(mel[spot]) - ref64).max() < 1e-3
+    else:
+        check_ladder(tag + " mel", ref64, _np(mel32), _np(mel[spot]), orc16, 2 * cfg.res_layers * n_steps, den_dt)
+    # vocoder on the first `voc_frames` frames of the HIP mel (its receptive field is a few frames: compare the interior)
+    F, keep = voc_frames, (voc_frames - 24) * cfg.hop_length
+    mel_ct = np.ascontiguousarray(_np(mel[spot])[:, :F].transpose(0, 2, 1))
+    with O.precision("f64"):
+        w64 = O.hifigan_generator(hsd, hcfg, mel_ct)[:, 0, :keep]
+        with O.operands16(voc_dt):
+            w16 = O.hifigan_generator(hsd, hcfg, mel_ct)[:, 0, :keep]
+    # fp32 vocoder ON THE SAME (possibly 16-bit) mel: the drift yardstick for the vocoder stage
+    voc32_same_mel = _np(voc(host.transpose_last2(mel[spot])).squeeze(1))[:, :keep]
+    got = _np(wav[spot])[:, :keep]
+    if voc_dt == "fp32":
+        err = np.abs(got - w64).max()
+        report(f"DTYPE_ERR {tag} wav fp32 vocoder: max|d| vs f64 {err:.2e}")
+        assert err < 1e-4, err
+    else:
+        check_ladder(tag + " wav", w64, voc32_same_mel, got, w16, 24, voc_dt)
+
+
+def test_config2_full_size_bf16():
+    """BASELINE.json configs[2]: VCTK multi-speaker, batch 64, 80x512, T=2, bf16 residual blocks + universal-vocoder
+    architecture with bf16 ResBlock convs -> int16."""
+    _full_config("VCTK", B=64, L=85, T=512, n_steps=2, den_dt="bf16", voc_dt="bf16", seed=31, spot=[3, 40], voc_frames=160)
+
+
+def test_config4_full_size_fp16_denoiser_fp32_vocoder():
+    """BASELINE.json configs[4] (one rank's share): LibriTTS-trained multi-speaker model on foreign speaker vectors,
+    batch 16, 80x1024 (171 phonemes x 6 = 1026 frames, truncated by the bucket), T=4, fp16 residual blocks + fp32
+    vocoder -> int16."""
+    _full_config("LibriTTS", B=16, L=171, T=1024, n_steps=4, den_dt="fp16", voc_dt="fp32", seed=41, spot=[1, 9], voc_frames=160)

@@ -215,3 +215,31 @@ def test_variance_teacher_forced(golden):
                                       max_mel_len=gc["tf_cwt_spec"].shape[1], d_target=gc["tf_d_target"],
                                       e_target=gc["tf_e_target"], pitch_target=pt)
     _check_variance(st, gc, "tf", g, cfg)
+
+
+def test_precision_modes_of_the_oracle(golden):
+    """The float64 mode (the yardstick of the reduced-precision GPU tests) and the 16-bit-operand modes of the oracle:
+    f64 agrees with the reference's fp32 golden to fp32 roundoff and the oracle's own fp32 run is no farther from f64
+    than the reference's; bf16 / fp16 operand rounding perturbs the mel by about 10 / 1 unit roundoffs of the type."""
+    g, cfg, sd = _setup(golden, "VCTK")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    with O.precision("f64"):
+        m64 = O.karras_sample_tts(sd, cfg, g["cond"], g["speaker_emb"], 4, noise)
+        assert m64.dtype == np.float64
+        with O.operands16("bf16"):
+            mb = O.karras_sample_tts(sd, cfg, g["cond"], g["speaker_emb"], 4, noise)
+        with O.operands16("fp16"):
+            mh = O.karras_sample_tts(sd, cfg, g["cond"], g["speaker_emb"], 4, noise)
+    assert O.F32 is np.float32 and O._OPERAND16 is None
+    m32 = O.karras_sample_tts(sd, cfg, g["cond"], g["speaker_emb"], 4, noise)
+    e_ref, e_own = np.abs(g["mel_T4"] - m64).max(), np.abs(m32 - m64).max()
+    e_b, e_h = np.abs(mb - m64).max(), np.abs(mh - m64).max()
+    print(f"vs f64: reference fp32 {e_ref:.2e}, oracle fp32 {e_own:.2e}, bf16 operands {e_b:.2e}, fp16 operands {e_h:.2e}")
+    assert e_ref < 2e-4 and e_own < 2e-4
+    ub, uh = 2.0 ** -8, 2.0 ** -11
+    assert 1 * ub < e_b < 20 * ub and 1 * uh < e_h < 20 * uh
+    # quant16 is round-to-nearest-even from the fp32 value
+    q = O.quant16(np.float32([1.0, 1.00390625, 1.01171875, 65504.0]), "bf16")      # two ties (-> even), one overflow of the mantissa
+    assert q.tolist() == [1.0, 1.0, 1.015625, 65536.0]
+    assert O.quant16(np.float32([1.00048828125, 1.00146484375]), "fp16").tolist() == [1.0, 1.001953125]

@@ -98,6 +98,16 @@ def _worker_plan(rank, world, port, q):
         mels, lens = zip(*[_fake_synth(i if i >= 0 else ranks[rank][0], bucket) for i in mine])
         gathered[bucket] = shard.allgather_mels_async(torch.stack(mels), torch.tensor(lens, dtype=torch.int64)).wait()
     out = shard.restore_order(gathered, plan, len(FRAMES))
+    # the same shard through ONE all-gather for all buckets (north_star: "a single RCCL all-gather")
+    local = {}
+    for bucket, ranks in plan.items():
+        mels, lens = zip(*[_fake_synth(i if i >= 0 else ranks[rank][0], bucket) for i in ranks[rank]])
+        local[bucket] = (torch.stack(mels), torch.tensor(lens, dtype=torch.int64))
+    one = shard.allgather_buckets(local)
+    for b in plan:
+        assert torch.equal(one[b][0], gathered[b][0]) and torch.equal(one[b][1], gathered[b][1])
+    out1 = shard.restore_order(one, plan, len(FRAMES))
+    assert all(torch.equal(a, b) for a, b in zip(out, out1))
     q.put((rank, [o.numpy() for o in out]))
     dist.barrier()
     dist.destroy_process_group()
