@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcmtts_hip.so")
+LIB_PATH = os.environ.get("CMTTS_LIB") or os.path.join(_HERE, "libcmtts_hip.so")     # CMTTS_LIB: an experimental build of the same ABI (tools/)
 
 
 class CMTTSConfigStruct(C.Structure):

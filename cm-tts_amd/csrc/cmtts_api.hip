@@ -18,6 +18,7 @@
 #include "resblock_args.h"
 #include "persist_args.h"
 #include "cond_gemm.h"
+#include "resblock_pair.h"
 
 namespace {
 
@@ -136,6 +137,22 @@ std::vector<float> to_fragment_order(const std::vector<float>& p, int taps, int 
     return f;
 }
 
+// The same fragments in the ITERATION order of the fused ResBlock pair kernels (resblock_pair.hip): the K loop walks
+// (16-channel chunk, tap, 8-channel half), so [K/16][taps][2][M/32][64 lanes][4] makes the weight stream one linear walk.
+std::vector<float> to_fragment_iter_order(const std::vector<float>& p, int taps, int K, int M) {
+    std::vector<float> f((size_t)taps * K * M);
+    const int MTn = M / 32;
+    size_t o = 0;
+    for (int c = 0; c < K / 16; ++c)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int h = 0; h < 2; ++h)
+                for (int mt = 0; mt < MTn; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            f[o++] = p[((size_t)tap * K + 16 * c + 8 * h + 2 * j + (lane >> 5)) * M + 32 * mt + (lane & 31)];
+    return f;
+}
+
 inline unsigned short host_cvt16(float f, int mode) {   // mode 1 = bf16 (round to nearest even), 2 = fp16
     if (mode == 1) {
         unsigned u;
@@ -244,6 +261,8 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
+int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair.hip): 0 never, 1 yes
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
@@ -419,6 +438,7 @@ struct cmtts_vocoder {
     int rb_dil[3] = {1, 3, 5};
     PackedConv c1[12][3], c2[12][3];
     void *c1f[12][3][2] = {}, *c2f[12][3][2] = {};   // bf16 / fp16 fragment-order copies of the ResBlock convs
+    float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
     float *post_w = nullptr, *post_b = nullptr;
     int post_cin = 32, post_k = 7;
@@ -1292,11 +1312,13 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 GETV(b2, p + ".convs2." + std::to_string(mi) + ".bias", co);
                 std::vector<float> hp;
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
+                CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
                 }
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
+                CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
@@ -1389,8 +1411,45 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             hipStream_t q = sj[j];
             float *bT = bufTj[j], *bR = bufRj[j];
             const float* xr = bufU;
-            for (int mi = 0; mi < 3; ++mi) {   // ResBlock.forward (:96-103)
+            // narrow stages: conv1 -> LeakyReLU -> conv2 -> + x of a pair in ONE launch, xt never leaves the CU
+            // (resblock_pair.hip; the pair's output must not alias its input, so the chain ping-pongs bR / bT)
+            const bool pair_ok = g_voc_pair && co <= 64 && !v->precision && v->c1f32[r][0] && v->c2f32[r][0];
+            for (int mi = 0; mi < 3 && pair_ok; ++mi) {
+                const bool lastm = mi == 2;
+                if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                PairArgs pa;
+                memset(&pa, 0, sizeof(pa));
+                pa.x = xr; pa.y = lastm ? bufS : (mi == 0 ? bR : bT);
+                pa.w1f = v->c1f32[r][mi]; pa.b1 = v->c1[r][mi].bias; pa.w2f = v->c2f32[r][mi]; pa.b2 = v->c2[r][mi].bias;
+                pa.bstride = cs; pa.B = B; pa.C = co; pa.T = To; pa.ld = ld; pa.k = rk; pa.dil = v->rb_dil[mi];
+                pa.accum = lastm && j > 0; pa.slope = 0.1f;
+                const int prc = cmtts_launch_resblock_pair(&pa, (void*)q);
+                if (prc != 0) return fail(CMTTS_E_HIP, "resblock_pair launch failed");
+                if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                xr = pa.y;
+            }
+            for (int mi = 0; mi < 3 && !pair_ok; ++mi) {   // ResBlock.forward (:96-103)
                 const int dil = v->rb_dil[mi];
+                const bool lastm = mi == 2;
+                if (g_voc_xl && !v->precision && co >= 128 && v->c1f32[r][mi]) {   // wide stages: X-resident single convs
+                    ConvXlArgs xa;
+                    memset(&xa, 0, sizeof(xa));
+                    xa.x = xr; xa.y = bT; xa.wf = v->c1f32[r][mi]; xa.bias = v->c1[r][mi].bias;
+                    xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f;
+                    const int rc1 = cmtts_launch_conv_xl(&xa, (void*)q);
+                    if (rc1 == -3) return fail(CMTTS_E_HIP, "conv_xl launch failed");
+                    if (rc1 == 0) {
+                        if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                        // the residual operand is read at the positions this launch writes when y == res (in place: safe,
+                        // every output element reads only its own residual); the INPUT must not alias the output
+                        xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = v->c2f32[r][mi]; xa.bias = v->c2[r][mi].bias;
+                        xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
+                        if (cmtts_launch_conv_xl(&xa, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xl launch failed");
+                        if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                        xr = bR;
+                        continue;
+                    }
+                }
                 ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
                 if (v->precision) {
@@ -1400,7 +1459,6 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 } else {
                     CHK(launch(a, EPI_PLAIN, B, q));
                 }
-                const bool lastm = mi == 2;
                 // the MRF sum accumulates in ResBlock order (bit-identical to the in-line order): the last conv of
                 // chain j waits for the last conv of chain j-1
                 if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
@@ -1459,6 +1517,16 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "voc_xl")) {        // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel
+        const int prev = g_voc_xl;
+        if (value == 0 || value == 1) g_voc_xl = value;
+        return prev;
+    }
+    if (!strcmp(name, "voc_pair")) {      // HiFi-GAN ResBlock pairs of the C <= 64 stages fused into one launch
+        const int prev = g_voc_pair;
+        if (value == 0 || value == 1) g_voc_pair = value;
+        return prev;
     }
     if (!strcmp(name, "ffn_xres")) {
         const int prev = g_ffn_xres ? 1 : 0;
@@ -1521,6 +1589,7 @@ int cmtts_set_resblock_tile(int frames) {
 int cmtts_set_debug_stamps(void* dev_buf) {
     cmtts_resblock_set_debug((long long*)dev_buf);
     cmtts_persist_set_debug((long long*)dev_buf);
+    cmtts_pair_set_debug((long long*)dev_buf);
     return 0;
 }
 

@@ -1,0 +1,43 @@
+// Arguments of the fused HiFi-GAN ResBlock pair kernels (resblock_pair.hip: fp32; resblock_pair16.hip: 16-bit operands).
+#pragma once
+
+struct PairArgs {
+    const float* x;       // [B][C][ld] input of the pair = residual operand (batch stride bstride)
+    float* y;             // [B][C][ld] output (must not alias x: neighbouring tiles read x's halo columns)
+    const void* w1f;      // conv1 (k taps, dilation dil) weights in MFMA A-fragment order (fp32 or 16-bit)
+    const float* b1;
+    const void* w2f;      // conv2 (k taps, dilation 1)
+    const float* b2;
+    long bstride;
+    int B, C, T, ld;
+    int k, dil;
+    int accum;            // y += result (the MRF sum) instead of y = result
+    float slope;          // LeakyReLU slope of both activations (0.1)
+    long long* dbg;       // filled by the launcher: cycle stamps (PAIR_DBG == 5 builds only)
+};
+
+// One conv of a wide (C = 128 / 256) ResBlock, X-resident (conv_xl_kernel in resblock_pair.hip)
+struct ConvXlArgs {
+    const float* x;       // [B][C][ld] input (LeakyReLU(slope) applied while staging)
+    float* y;             // [B][C][ld] output (must not alias x)
+    const float* wf;      // weights, MFMA A fragments in iteration order
+    const float* bias;
+    const float* res;     // residual, indexed like y (may be null; may alias nothing written by this launch)
+    long bstride;
+    int B, C, T, ld;
+    int k, dil;
+    int accum;
+    float slope;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
+// 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error
+int cmtts_launch_resblock_pair(const PairArgs* a, void* stream);
+int cmtts_launch_resblock_pair16(const PairArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16
+void cmtts_pair_set_debug(long long* dbg);
+#ifdef __cplusplus
+}
+#endif

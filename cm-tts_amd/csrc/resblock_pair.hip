@@ -1,0 +1,400 @@
+// HiFi-GAN ResBlock pair for the narrow stages (C = 64 and C = 32), fp32 — one launch per
+//   xt = conv1(leaky_relu(x, 0.1))  [k taps, dilation d];   y = conv2(leaky_relu(xt, 0.1)) + x  [k taps, dilation 1]
+// (hifigan/models.py:96-103, one iteration of ResBlock.forward's loop), instead of two launches of the generic kernel.
+//
+// Why: at C = 32 / 64 a layer-granular conv does 2*C*k = 192 ... 1408 FLOP per output element against 8-12 B of HBM
+// traffic — on or below the fp32 ridge (157 TFLOP/s : 6.3 TB/s = 25 FLOP/B) — and re-stages a weight tile every
+// (16-channel chunk, tap) iteration for a K loop that is only C*k/2 = 48 ... 352 MFMAs long: SQ counters put the matrix
+// pipe at 57 % (C = 64) and 44 % (C = 32) busy (profiles/r01_pmc_mfma_busy.md).  Here a workgroup keeps a 256-column tile
+// on chip for BOTH convs:
+//
+//   * LDS holds the raw x tile [C][256 + 2*r1] (r1 = d*(k-1)/2: conv1's halo; it is also the residual operand) and the
+//     xt tile [C][256] (+ k-1 slack columns): x crosses HBM once per pair (plus 10-24 % halo re-reads served by L2), xt
+//     never leaves the CU, y is written once: 2 tensor passes instead of 5.  conv1 is evaluated on 256 columns of which
+//     256 - (k-1) produce outputs (conv2's halo is recomputed, not exchanged: 1-4 % extra MFMAs);
+//   * every wave owns ONE 32-row m-tile x TWO 32-column n-tiles; its weights stream L2 -> VGPR in MFMA A-fragment order
+//     (one global_load_dwordx4 = the A operand of 4 k-steps = 8 MFMAs) through a 4-deep register ring: no weight tile in
+//     LDS, no barrier inside a conv's K loop, three barriers per tile.  128 B of weights per MFMA — the per-CU L2 -> CU
+//     ingest measured in tools/mfma_probe.hip carries 192;
+//   * B operands are conflict-free ds_read_b32 (32 consecutive floats per half-wave), one k-group ahead of their MFMAs;
+//     the LeakyReLU of conv1's operand is applied on the fly (x stays raw for the residual), conv2's operand is stored
+//     activated by conv1's epilogue.
+//
+// Accumulation order = the generic kernel's (16-channel chunk, tap, k) and the same epilogue expressions ((acc + b) + x
+// [+ y_old]) => BITWISE equal to the two-launch path (tests/test_gpu_parity.py::test_vocoder_pair_kernel_bitwise).
+#include <hip/hip_runtime.h>
+#include "resblock_pair.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Ablation builds (tools/pair_ablation.sh; results are WRONG, timing only): 1 = no weight stream (A loaded once),
+// 2 = no LDS operand reads in the K loops, 3 = no LeakyReLU on conv1's operand, 4 = no x staging / no output stores
+#ifndef PAIR_DBG
+#define PAIR_DBG 0
+#endif
+
+namespace {
+
+// Columns of xt per workgroup: 256 at C = 32 and 128 at C = 64 — both give 8 accumulator tiles (4 waves x 2) and
+// <= 80 KB of LDS, i.e. TWO workgroups per CU: one stages / stores while the other multiplies (one 144-KB workgroup per
+// CU at C = 64 left the matrix pipe idle through every staging and epilogue phase).
+#define N1_OF(C) ((C) == 32 ? 256 : 128)
+constexpr int NT = 2;            // n-tiles per wave
+constexpr int RING = 4;          // register ring depth of the weight stream (k-groups of 8 input channels in flight)
+constexpr int R1MAX = 25;        // largest conv1 halo: k = 11, d = 5
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// One conv of the pair on this wave's (m-tile mt) x (n-tiles nq*2, nq*2+1): acc = W * act(src), K loop over
+// (16-channel chunk, tap, 8-channel half) in the generic kernel's order.  src: LDS tile [C][ld]; output column c reads
+// src column c + tap * dil.  wfrag holds the A fragments in ITERATION order ([chunk][tap][half][m-tile][lane][4], packed by
+// cmtts_finalize), so the weight stream is one linear walk: the only per-group index arithmetic left is a handful of
+// scalar updates of the B-operand offset.  Loads are threaded between the MFMAs (one ds_read2_b32 + the A load of a
+// later group per k-step): a wave's instructions issue in order, so loads bunched between two groups of MFMAs would
+// leave the matrix pipe idle while they issue (first version of this kernel: 60-68 % pipe busy).
+template <int C, int KT>
+__device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __restrict__ wfrag, const float* __restrict__ src,
+                                          int ld, int dil, int mt, int col0, int lane) {
+    constexpr int MTILES = C / 32;
+    constexpr int NG = (C / 8) * KT;            // k-groups: (chunk, tap, half); a multiple of RING for C in {32, 64}
+    static_assert(NG % RING == 0, "no tail in the ring loop");
+    const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* wl = wfrag + mt * 256 + lane * 4;
+    auto load_a = [&](f32x4& dst, int it) {
+        dst = *reinterpret_cast<const f32x4*>(wl + (long)min(it, NG - 1) * (MTILES * 256));
+    };
+    const float* bl = src + khalf * ld + col0 + l31;     // this lane's B element of (row 0, tap 0)
+    // scalar walk over (chunk, tap, half): boff = float offset of the group's first row / tap column
+    int boff = 0, tap = 0, half = 0;
+    auto advance = [&]() {
+        if (half == 0) { half = 1; boff += 8 * ld; }
+        else {
+            half = 0; boff -= 8 * ld; ++tap; boff += dil;
+            if (tap == KT) { tap = 0; boff += 16 * ld - KT * dil; }
+        }
+    };
+    auto load_b = [&](float (&dst)[4][NT], int off) {
+        const float* bs = bl + off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * ld + j * 32];
+    };
+    f32x4 A[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+    float Bv[2][4][NT];
+    load_b(Bv[0], boff);
+#pragma unroll 1
+    for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            advance();                                   // -> offset of group it + s + 1 (past the end: harmless, in-bounds reads)
+            const int off_n = min(boff, (C - 8) * ld + (KT - 1) * dil);
+            const float* bs = bl + off_n;
+            if (PAIR_DBG != 1) load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (PAIR_DBG != 2) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * ld + j * 32];
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
+                }
+                if (PAIR_DBG != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read2_b32 (next group's k-step kk) ...
+                if (kk == 0 && PAIR_DBG != 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... the A load of a later group ...
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);     // ... under this k-step's MFMAs
+            }
+        }
+    }
+}
+
+template <int C, int KT>
+__global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairArgs a) {
+    constexpr int N1 = N1_OF(C);                // columns of xt a workgroup evaluates
+    constexpr int XW = N1 + 2 * R1MAX, XTW = N1 + 10;
+    constexpr int NWAVES = 4;
+    constexpr int NTW = (C / 32) * (N1 / 32) / NWAVES;      // 32x32 tiles per wave = NT
+    static_assert(NTW == NT, "every wave owns one m-tile x NT n-tiles");
+    constexpr int R2 = (KT - 1) / 2;
+    constexpr int TT = N1 - 2 * R2;             // output columns per workgroup
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                           // [C][XW]   leaky(x), column j <-> t = t0 - R2 - r1 + j
+    float* XTs = smem + C * XW;                 // [C][XTW]  leaky(xt), column c <-> t = t0 - R2 + c
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int WPM = NWAVES / (C / 32);      // waves per m-tile
+    const int mt = w / WPM, nq = w % WPM;
+    const int l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int T = a.T, dil = a.dil;
+    const int r1 = dil * R2;
+    const int xw = N1 + 2 * r1;                 // x columns this tile needs
+    const float* xb = a.x + (long)b * a.bstride;
+    // PAIR_DBG == 5: cycle stamps of every wave at the phase boundaries (tools/pair_phases.py)
+    auto stamp = [&](int slot) {
+        if (PAIR_DBG == 5 && a.dbg && lane == 0)
+            a.dbg[(((long)b * gridDim.x + blockIdx.x) * NWAVES + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    stamp(0);
+
+    // ---- stage the x tile, ACTIVATED (zero outside [0, T)): rows over waves, columns over lanes; all of a lane's loads
+    // (column blocks x rows) are in flight before the first LDS store: one HBM round trip per tile
+    {
+        const int tbase = t0 - R2 - r1;
+        constexpr int ROWS_PER_WAVE = C / NWAVES;          // 8 / 16
+        constexpr int XBLK = (XW + 63) / 64;               // 5 / 3
+        float v[XBLK][ROWS_PER_WAVE];
+#pragma unroll
+        for (int jb = 0; jb < XBLK; ++jb) {
+            const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
+#pragma unroll
+            for (int q = 0; q < ROWS_PER_WAVE; ++q)
+                v[jb][q] = PAIR_DBG == 4 ? (float)t_c : xb[(long)(w * ROWS_PER_WAVE + q) * a.ld + t_c];
+        }
+#pragma unroll
+        for (int jb = 0; jb < XBLK; ++jb) {
+            const int j = jb * 64 + lane;
+            const int t = tbase + j;
+            if (j < xw) {
+#pragma unroll
+                for (int q = 0; q < ROWS_PER_WAVE; ++q)
+                    Xs[(w * ROWS_PER_WAVE + q) * XW + j] = (t >= 0 && t < T) ? leaky(v[jb][q], a.slope) : 0.f;
+            }
+        }
+        // slack columns of the xt tile (read only by the k - 1 columns whose outputs are never stored): defined values
+        if (tid < C) {
+#pragma unroll
+            for (int q = 0; q < XTW - N1; ++q) XTs[tid * XTW + N1 + q] = 0.f;
+        }
+    }
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+
+    f32x16 acc[NT];
+    const int col0 = nq * (NT * 32);
+    // ---- conv1: xt column c = sum_tap W1[tap] . leaky(x)[c + tap * dil]
+    conv_loop<C, KT>(acc, (const float*)a.w1f, Xs, XW, dil, mt, col0, lane);
+    stamp(3);
+    {   // epilogue: (acc + b1), zero outside the sequence (conv2's zero padding), stored ACTIVATED for conv2
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = a.b1[mt * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = col0 + j * 32 + l31;
+            const int t = t0 - R2 + c;
+            const bool in = t >= 0 && t < T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[j][r] + bi[r];
+                XTs[(mt * 32 + acc_row(r, lane)) * XTW + c] = in ? leaky(v, a.slope) : 0.f;
+            }
+        }
+    }
+    // the residual operand x (raw; the LDS tile holds it activated) and, for the MRF sum, the old y: requested now, they
+    // arrive under conv2's K loop (x was read by this workgroup a moment ago: L2)
+    float* yb = a.y + (long)b * a.bstride;
+    float xres[NT][16], yo[NT][16];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t_c = min(t0 + col0 + j * 32 + l31, T - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long off = (long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c;
+            xres[j][r] = xb[off];
+            yo[j][r] = a.accum ? yb[off] : 0.f;
+        }
+    }
+    stamp(4);
+    __syncthreads();
+    stamp(5);
+
+    // ---- conv2: y column o = sum_tap W2[tap] . xt_act[o + tap]   (o < TT valid)
+    conv_loop<C, KT>(acc, (const float*)a.w2f, XTs, XTW, 1, mt, col0, lane);
+    stamp(6);
+    {   // epilogue: ((acc + b2) + x) [+ y_old]  — the generic kernel's expression order
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = a.b2[mt * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int o = col0 + j * 32 + l31;
+            const int t = t0 + o;
+            const bool ok = o < TT && t < T && !(PAIR_DBG == 4 && a.slope != -12345.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + acc_row(r, lane);
+                float v = acc[j][r] + bi[r];
+                v += xres[j][r];
+                if (a.accum) v += yo[j][r];
+                if (ok) yb[(long)m * a.ld + t] = v;
+            }
+        }
+    }
+    stamp(7);
+}
+
+template <int C, int KT>
+int launch_pair(const PairArgs& a, hipStream_t stream) {
+    constexpr int N1 = N1_OF(C);
+    constexpr int TT = N1 - (KT - 1);
+    const size_t lds = (size_t)C * (N1 + 2 * R1MAX + N1 + 10) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_pair_kernel<C, KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.T + TT - 1) / TT, a.B);
+    hipLaunchKernelGGL((resblock_pair_kernel<C, KT>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- One ResBlock conv of the WIDE stages (C = 128 / 256: the pair does not fit in LDS) on the same K loop: the
+// workgroup's whole x tile [C][64 + (k-1)*d] is staged once, activated, and every wave walks all of K for its m-tile x two
+// n-tiles with weights streamed L2 -> VGPR: no per-(chunk, tap) weight staging, no barrier in the K loop (the generic
+// kernel: one barrier + one weight tile per 16 MFMAs per wave, 69 % pipe busy at these shapes).  C = 128: 58 KB of LDS,
+// two workgroups per CU; C = 256: 117 KB, one 8-wave workgroup.  Epilogue = the generic kernel's: (acc + bias) [+ res]
+// [+ y_old]; same accumulation order => bitwise equal.
+constexpr int XL_BN = 64;
+
+template <int C, int KT>
+__global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
+    constexpr int XW = XL_BN + 2 * R1MAX;
+    constexpr int NWAVES = C / 32;                          // one m-tile per wave, both n-tiles
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                        // [C][XW] leaky(x), column j <-> t = t0 - pad + j
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * XL_BN;
+    const int T = a.T, dil = a.dil;
+    const int pad = dil * ((KT - 1) / 2);
+    const int xw = XL_BN + 2 * pad;
+    const float* xb = a.x + (long)b * a.bstride;
+    {
+        const int tbase = t0 - pad;
+        constexpr int ROWS_PER_WAVE = C / NWAVES;           // 32
+        constexpr int XBLK = (XW + 63) / 64;                // 2
+#pragma unroll
+        for (int h = 0; h < ROWS_PER_WAVE; h += 16) {       // 32 loads in flight per lane
+            float v[XBLK][16];
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[jb][q] = xb[(long)(w * ROWS_PER_WAVE + h + q) * a.ld + t_c];
+            }
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int j = jb * 64 + lane;
+                const int t = tbase + j;
+                if (j < xw) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        Xs[(w * ROWS_PER_WAVE + h + q) * XW + j] = (t >= 0 && t < T) ? leaky(v[jb][q], a.slope) : 0.f;
+                }
+            }
+        }
+    }
+    // residual / old y of this wave's tiles: requested before the K loop, consumed after it
+    float* yb = a.y + (long)b * a.bstride;
+    const float* rb = a.res ? a.res + (long)b * a.bstride : nullptr;
+    float xres[NT][16], yo[NT][16];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t_c = min(t0 + j * 32 + l31, T - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long off = (long)(w * 32 + acc_row(r, lane)) * a.ld + t_c;
+            xres[j][r] = rb ? rb[off] : 0.f;
+            yo[j][r] = a.accum ? yb[off] : 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+    conv_loop<C, KT>(acc, a.wf, Xs, XW, dil, w, 0, lane);
+    float bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bi[r] = a.bias[w * 32 + acc_row(r, lane)];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = t0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[j][r] + bi[r];
+            if (rb) v += xres[j][r];
+            if (a.accum) v += yo[j][r];
+            if (t < T) yb[(long)(w * 32 + acc_row(r, lane)) * a.ld + t] = v;
+        }
+    }
+}
+
+template <int C, int KT>
+int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)C * (XL_BN + 2 * R1MAX) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B);
+    hipLaunchKernelGGL((conv_xl_kernel<C, KT>), grid, dim3(2 * C), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+long long* g_pair_dbg = nullptr;
+
+}  // namespace
+
+extern "C" void cmtts_pair_set_debug(long long* dbg) { g_pair_dbg = dbg; }
+
+// 0 = launched, -2 = shape not covered (the caller runs the two generic launches), -3 = HIP error
+extern "C" int cmtts_launch_resblock_pair(const PairArgs* ap, void* stream_) {
+    PairArgs a = *ap;
+    a.dbg = g_pair_dbg;
+    hipStream_t s = (hipStream_t)stream_;
+    if (a.B <= 0 || a.T <= 0) return 0;
+    if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y) return -2;
+    if (a.C == 64) {
+        if (a.k == 3) return launch_pair<64, 3>(a, s);
+        if (a.k == 7) return launch_pair<64, 7>(a, s);
+        if (a.k == 11) return launch_pair<64, 11>(a, s);
+    } else if (a.C == 32) {
+        if (a.k == 3) return launch_pair<32, 3>(a, s);
+        if (a.k == 7) return launch_pair<32, 7>(a, s);
+        if (a.k == 11) return launch_pair<32, 11>(a, s);
+    }
+    return -2;
+}
+
+// One conv (k taps, dilation dil, 'same' padding) of a C = 128 / 256 ResBlock: 0 = launched, -2 = not covered, -3 = HIP error
+extern "C" int cmtts_launch_conv_xl(const ConvXlArgs* ap, void* stream_) {
+    const ConvXlArgs& a = *ap;
+    hipStream_t s = (hipStream_t)stream_;
+    if (a.B <= 0 || a.T <= 0) return 0;
+    if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y) return -2;
+    if (a.C == 128) {
+        if (a.k == 3) return launch_xl<128, 3>(a, s);
+        if (a.k == 7) return launch_xl<128, 7>(a, s);
+        if (a.k == 11) return launch_xl<128, 11>(a, s);
+    } else if (a.C == 256) {
+        if (a.k == 3) return launch_xl<256, 3>(a, s);
+        if (a.k == 7) return launch_xl<256, 7>(a, s);
+        if (a.k == 11) return launch_xl<256, 11>(a, s);
+    }
+    return -2;
+}

@@ -15,7 +15,7 @@ from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
 from oracle import cmtts_oracle as O
 from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report
 
-KNOWN_ORACLE_FLIPS = {"energy": 20, "pitch": 120}      # test_bucketed_ragged_shard_vs_oracle (tightened after the first measurement)
+KNOWN_ORACLE_FLIPS = {"energy": 0, "pitch": 0}      # test_bucketed_ragged_shard_vs_oracle: measured on MI355X (round 2): none
 
 pytestmark = pytest.mark.gpu
 VARIANTS = ["LJSpeech", "VCTK", "LibriTTS"]
@@ -1016,6 +1016,41 @@ def test_vocoder_mrf_streams_bitwise(dtype):
             assert torch.equal(got, ref)
     finally:
         lib.cmtts_set_option(b"branch_streams", prev)
+
+
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130)])
+def test_vocoder_pair_kernel_bitwise(B, T):
+    """resblock_pair.hip (C = 64 / 32 stages: conv1 -> LeakyReLU -> conv2 -> + x of a ResBlock pair in one launch, the x
+    tile and xt on chip) keeps the generic kernel's (chunk, tap, k) accumulation order and epilogue expressions: the
+    wav must not change by a bit against the two-launch path.  T = 61 / 130 mel frames = many 256-column tiles per
+    utterance with ragged last tiles; T = 7 = utterances shorter than one tile (every column is halo or padding)."""
+    host = _host()
+    lib = _lib.load()
+    hcfg = HifiGanConfig()
+    hsd = synth_hifigan_state_dict(hcfg, seed=6)
+    voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
+    prev = lib.cmtts_set_option(b"voc_pair", 0)
+    prev_x = lib.cmtts_set_option(b"voc_xl", 0)
+    prev_b = lib.cmtts_set_option(b"branch_streams", 0)
+    try:
+        ref = voc(mel).clone()
+        lib.cmtts_set_option(b"voc_pair", 1)
+        lib.cmtts_set_option(b"voc_xl", 1)        # C = 128 / 256 stages: X-resident single convs (conv_xl_kernel)
+        got = voc(mel).clone()
+        lib.cmtts_set_option(b"branch_streams", 1)       # the three ResBlock chains of a stage on three streams
+        got_s = voc(mel).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"voc_pair", prev)
+        lib.cmtts_set_option(b"voc_xl", prev_x)
+        lib.cmtts_set_option(b"branch_streams", prev_b)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert torch.equal(got_s, ref), float((got_s - ref).abs().max())
+    if T == 61:
+        refo = O.hifigan_generator(hsd, hcfg, _np(mel))
+        assert np.abs(_np(got) - refo).max() < 1e-4
 
 
 def test_hifigan_vs_oracle_other_shape():

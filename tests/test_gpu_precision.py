@@ -5,19 +5,25 @@ The reference computes in fp32 only, so 16-bit MFMA operands have no reference o
 
   * the oracle restates the library's scheme exactly (`O.operands16`: the conv operands of the residual blocks / HiFi-GAN
     ResBlocks rounded to 16 bits from their fp32 value, everything else untouched) and runs it in float64
-    (`O.precision("f64")`), so that the only differences left between the HIP result and that oracle are (a) fp32
-    accumulation order, which the fp32 tests already bound, and (b) operands whose fp32 value sits so close to a 16-bit
-    rounding boundary that the HIP path's fp32 drift `d` (relative, measured in the same test against float64) puts
-    them into the neighbouring 16-bit value.  An operand flips with probability ~ d / u16 and then moves by ~u16
-    relative; over a K-term dot product that perturbs an output by sqrt(d * u16) relative, and the N convs of the path
-    add up like a random walk.  Hence the implementation bound
+    (`O.precision("f64")`).  Its distance from the plain float64 result is the SCHEME's error: a property of the
+    precision choice (about ten unit roundoffs of the type on |mel| ~ 0.3), not of the implementation.
+  * SHALLOW paths (one residual layer; the vocoder, depth 24): the HIP result must match the 16-bit-operand oracle.  The
+    only differences left are fp32 accumulation order (bounded by the fp32 tests) and operands whose fp32 value sits so
+    close to a 16-bit rounding boundary that the HIP path's fp32 drift `d` (relative, measured in the same test
+    against float64) puts them into the neighbouring 16-bit value: an operand flips with probability ~ d / u16 and
+    then moves by ~u16 relative; over a K-term dot product that perturbs an output by sqrt(d * u16) relative, and N
+    convs add up like a random walk:
 
-        rms(hip16 - oracle16) <= SAFETY * rms(mel) * sqrt(N_CONV * d32 * u16),      max <= 5 x that  (5 sigma)
+        rms(hip16 - oracle16) <= SAFETY * rms(out) * sqrt(N_CONV * d32 * u16),      max <= 5 x that  (5 sigma)
 
-    with u16 the unit roundoff (2^-8 bf16, 2^-11 fp16), d32 = rms(hip32 - f64) / rms(f64) and SAFETY = 3;
-  * the scheme's own error rms(oracle16 - f64) is reported next to it (it is a property of the precision choice — about
-    ten unit roundoffs of the type on |mel| ~ 0.3 — not of the implementation), and the HIP result may not be farther
-    from float64 than that plus the implementation bound.
+    with u16 the unit roundoff (2^-8 bf16, 2^-11 fp16), d32 = rms(hip32 - f64) / rms(f64), SAFETY = 4 (the model is an
+    order-of-magnitude estimate; measured on MI355X: 2.2x the model for the vocoder).
+  * DEEP paths (20 layers x T steps = 40-160 convs): every flipped operand perturbs the next layer's operands by a
+    fraction of a 16-bit ulp, which flips more of them — after a few layers the HIP run and the oracle run are two
+    independent realisations of the same rounding noise (measured: rms(hip16 - oracle16) ~ rms(oracle16 - f64)), so
+    an element-wise match is not a meaningful criterion.  What is: the HIP result is no farther from float64 than the
+    scheme itself, in rms (x 1.3) and in max (x 1.6: two draws of a 5-sigma extreme), i.e. the implementation adds
+    nothing to the scheme's own rounding noise; and the fp32 result stays as close to float64 as the reference's.
 """
 import numpy as np
 import pytest
@@ -33,7 +39,7 @@ from conftest import golden_noise, report
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 U16 = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
-SAFETY = 3.0
+SAFETY = 4.0
 
 
 def _host():
@@ -54,21 +60,26 @@ def impl_bound(ref64, hip32, n_conv, dtype):
     return SAFETY * rms(ref64) * np.sqrt(n_conv * d32 * U16[dtype]), d32
 
 
-def check_ladder(tag, ref64, hip32, hip16, orc16, n_conv, dtype, golden32=None):
+def check_ladder(tag, ref64, hip32, hip16, orc16, n_conv, dtype, golden32=None, deep=False):
     """ref64: float64 oracle; hip32 / hip16: HIP results; orc16: float64 oracle with 16-bit operands."""
     bound, d32 = impl_bound(ref64, hip32, n_conv, dtype)
     e_impl, e_impl_max = rms(hip16 - orc16), float(np.abs(hip16 - orc16).max())
     e_scheme, e_scheme_max = rms(orc16 - ref64), float(np.abs(orc16 - ref64).max())
-    e_tot_max = float(np.abs(hip16 - ref64).max())
+    e_tot, e_tot_max = rms(hip16 - ref64), float(np.abs(hip16 - ref64).max())
     line = (f"DTYPE_ERR {tag} {dtype}: vs f64 max|d| fp32 {np.abs(hip32 - ref64).max():.2e}"
             + (f" (reference fp32 {np.abs(golden32 - ref64).max():.2e})" if golden32 is not None else "")
-            + f", {dtype} {e_tot_max:.2e} (scheme alone {e_scheme_max:.2e}); hip vs {dtype}-operand oracle rms {e_impl:.2e} "
-              f"max {e_impl_max:.2e}, derived bound rms {bound:.2e} max {5 * bound:.2e} (d32 {d32:.1e}, N {n_conv})")
+            + f", {dtype} rms {e_tot:.2e} max {e_tot_max:.2e} (scheme alone rms {e_scheme:.2e} max {e_scheme_max:.2e}); "
+              f"hip vs {dtype}-operand oracle rms {e_impl:.2e} max {e_impl_max:.2e}"
+            + ("" if deep else f", derived bound rms {bound:.2e} max {5 * bound:.2e} (d32 {d32:.1e}, N {n_conv})"))
     report(line)
     assert np.isfinite(hip16).all()
-    assert e_impl <= bound and e_impl_max <= 5 * bound, line
-    assert e_tot_max <= e_scheme_max + 5 * bound, line
-    assert e_scheme_max > 1e-6 and e_impl_max < e_scheme_max, line      # 16-bit operands really ran, and parity is tighter than the scheme's own noise
+    assert e_scheme_max > 1e-6 and e_tot_max > 1e-6, line            # 16-bit operands really ran
+    if deep:      # two realisations of the same rounding noise
+        assert e_tot <= 1.3 * e_scheme and e_tot_max <= 1.6 * e_scheme_max, line
+        assert e_impl <= 1.6 * e_scheme, line                       # sqrt(2) for independent draws, with margin
+    else:         # element-wise match with the 16-bit-operand oracle
+        assert e_impl <= bound and e_impl_max <= 5 * bound, line
+        assert e_tot_max <= e_scheme_max + 5 * bound, line
 
 
 @pytest.fixture(scope="module")
@@ -118,7 +129,37 @@ def test_precision_ladder_denoiser(golden_models, variant):
     assert e32 < 1e-3 and e32 < max(4 * eref, 1e-4), (e32, eref)      # our fp32 is as close to float64 as the reference's fp32
     n_conv = 2 * cfg.res_layers * n_steps
     for dt in ("bf16", "fp16"):
-        check_ladder(f"denoiser T=4 {variant}", ref64, hip["fp32"], hip[dt], orc[dt], n_conv, dt, golden32=g["mel_T4"])
+        check_ladder(f"denoiser T=4 {variant}", ref64, hip["fp32"], hip[dt], orc[dt], n_conv, dt, golden32=g["mel_T4"], deep=True)
+
+
+@pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
+def test_precision_one_residual_layer(variant):
+    """A ONE-layer denoiser (res_layers = 1, one evaluation): shallow enough for the element-wise match with the
+    16-bit-operand oracle (2 convs), on 2 x 200 frames — the tight check of the 16-bit residual-block kernels
+    (operand rounding, fragment order, fp32 accumulate, fp32 gate / bias / residual arithmetic)."""
+    import dataclasses
+    host = _host()
+    cfg = dataclasses.replace(get_config(variant), res_layers=1)
+    sd = synth_cmtts_state_dict(cfg, seed=23)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(7)
+    B, T = 2, 200
+    x = rs.standard_normal(size=(B, 1, T, cfg.n_mels)).astype(np.float32)
+    cond = rs.standard_normal(size=(B, T, cfg.hidden)).astype(np.float32)
+    spk = rs.standard_normal(size=(B, cfg.hidden)).astype(np.float32) if cfg.multi_speaker else None
+    t = np.full((B,), 1095.5, np.float32)
+    args = (torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(cond), None if spk is None else torch.from_numpy(spk))
+    hip = {"fp32": _np(model.net(*args))}
+    for dt in ("bf16", "fp16"):
+        model.set_precision(dt)
+        hip[dt] = _np(model.net(*args))
+    model.set_precision("fp32")
+    with O.precision("f64"):
+        ref64 = O.denoiser_forward(sd, cfg, x, t, cond, spk)
+        for dt in ("bf16", "fp16"):
+            with O.operands16(dt):
+                orc = O.denoiser_forward(sd, cfg, x, t, cond, spk)
+            check_ladder(f"one residual layer {variant}", ref64, hip["fp32"], hip[dt], orc, 2, dt)
 
 
 def test_precision_ladder_vocoder(golden):
@@ -215,7 +256,7 @@ def _full_config(variant, B, L, T, n_steps, den_dt, voc_dt, seed, spot, voc_fram
     if den_dt == "fp32":
         assert np.abs(_np(mel[spot]) - ref64).max() < 1e-3
     else:
-        check_ladder(tag + " mel", ref64, _np(mel32), _np(mel[spot]), orc16, 2 * cfg.res_layers * n_steps, den_dt)
+        check_ladder(tag + " mel", ref64, _np(mel32), _np(mel[spot]), orc16, 2 * cfg.res_layers * n_steps, den_dt, deep=True)
     # vocoder on the first `voc_frames` frames of the HIP mel (its receptive field is a few frames: compare the interior)
     F, keep = voc_frames, (voc_frames - 24) * cfg.hop_length
     mel_ct = np.ascontiguousarray(_np(mel[spot])[:, :F].transpose(0, 2, 1))
