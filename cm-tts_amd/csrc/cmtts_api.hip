@@ -262,7 +262,7 @@ struct Profile {
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
-int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair.hip): 0 never, 1 yes
+int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
@@ -1413,17 +1413,25 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             const float* xr = bufU;
             // narrow stages: conv1 -> LeakyReLU -> conv2 -> + x of a pair in ONE launch, xt never leaves the CU
             // (resblock_pair.hip; the pair's output must not alias its input, so the chain ping-pongs bR / bT)
-            const bool pair_ok = g_voc_pair && co <= 64 && !v->precision && v->c1f32[r][0] && v->c2f32[r][0];
+            // 16-bit operands: the pair kernel wins where the pair is bound by tensor passes (k = 3: 0.40 vs 0.60-0.64 ms per
+            // pair at C = 32 / 64; k = 7 at C = 32: 0.45 vs 0.60) and loses where its per-tile weight stream dominates (k = 11 at
+            // C = 64: 180 KB of 16-bit weights per 246 columns, 0.83 vs 0.64 ms; profiles/r02_vocoder_bf16.md): g_voc_pair == 2 forces it
+            const bool pair16_pays = g_voc_pair == 2 || rk == 3 || (rk == 7 && co == 32);
+            const bool pair_ok = g_voc_pair && co <= 64 &&
+                                 (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
                 if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
                 PairArgs pa;
                 memset(&pa, 0, sizeof(pa));
                 pa.x = xr; pa.y = lastm ? bufS : (mi == 0 ? bR : bT);
-                pa.w1f = v->c1f32[r][mi]; pa.b1 = v->c1[r][mi].bias; pa.w2f = v->c2f32[r][mi]; pa.b2 = v->c2[r][mi].bias;
+                pa.b1 = v->c1[r][mi].bias; pa.b2 = v->c2[r][mi].bias;
+                if (v->precision) { pa.w1f = v->c1f[r][mi][v->precision - 1]; pa.w2f = v->c2f[r][mi][v->precision - 1]; }
+                else { pa.w1f = v->c1f32[r][mi]; pa.w2f = v->c2f32[r][mi]; }
                 pa.bstride = cs; pa.B = B; pa.C = co; pa.T = To; pa.ld = ld; pa.k = rk; pa.dil = v->rb_dil[mi];
                 pa.accum = lastm && j > 0; pa.slope = 0.1f;
-                const int prc = cmtts_launch_resblock_pair(&pa, (void*)q);
+                const int prc = v->precision ? cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q)
+                                             : cmtts_launch_resblock_pair(&pa, (void*)q);
                 if (prc != 0) return fail(CMTTS_E_HIP, "resblock_pair launch failed");
                 if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                 xr = pa.y;
@@ -1525,7 +1533,7 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "voc_pair")) {      // HiFi-GAN ResBlock pairs of the C <= 64 stages fused into one launch
         const int prev = g_voc_pair;
-        if (value == 0 || value == 1) g_voc_pair = value;
+        if (value >= 0 && value <= 2) g_voc_pair = value;
         return prev;
     }
     if (!strcmp(name, "ffn_xres")) {

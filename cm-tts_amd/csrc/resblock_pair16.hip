@@ -1,0 +1,236 @@
+// HiFi-GAN ResBlock pair with 16-bit MFMA operands (bf16 / fp16, fp32 accumulate) for the narrow stages (C = 64, 32):
+//   xt = conv1(leaky_relu(x));  y = conv2(leaky_relu(xt)) + x      (hifigan/models.py:96-103)
+// in ONE launch — the 16-bit twin of resblock_pair.hip.  At 16x the fp32 MFMA rate these convs are bound by bytes, not
+// by the matrix pipe: the two-launch path moves 5 tensor passes per pair (read x, write xt16, read xt16, read x, write y);
+// here x is staged once (converted while staged, as conv_mfma16.hip does), xt stays on chip as the 16-bit activated image
+// conv2 would have read from HBM, the residual re-read of x is served by L2 (this workgroup fetched the same lines a few
+// microseconds earlier) and y is written once.
+//
+//   * LDS: x^T tile [256 + 2*r1][C] and xt^T tile [256 + k - 1][C], 16-bit, row stride C + 4 halves: a B fragment (lane l:
+//     8 consecutive channels of column l & 31) is two conflict-free ds_read_b64 and a dilated tap is a row offset;
+//   * every wave owns ONE 32-row m-tile x NT 32-column n-tiles (C = 64: 1 x 4, C = 32: 1 x 2); weights stream L2 -> VGPR in
+//     MFMA A-fragment order, one global_load_dwordx4 per k-group of 16 channels feeding NT MFMAs, 4-deep ring;
+//   * same conversions (v_cvt_pk_{bf16,f16}_f32 of leaky_relu(.)), same (32-channel chunk, tap, k-group) accumulation
+//     order and the same epilogue expressions as conv_mfma16.hip => BITWISE equal to the two-launch 16-bit path.
+#include <hip/hip_runtime.h>
+#include "resblock_pair.h"
+#include "cvt16.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int N1 = 256;          // columns of xt per workgroup
+constexpr int RING = 4;
+constexpr int R1MAX = 25;
+
+template <int MODE>
+__device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if (MODE == 1)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// acc = W * src over K = C * KT in conv_mfma16.hip's order: 32-channel chunk -> tap -> k-group of 16 within the chunk.
+// wfrag: [tap][C/16][C/32][64 lanes] u32x4 (A fragments);  src: LDS [cols][RS] 16-bit, output column c reads row c + tap*dil.
+template <int C, int KT, int NT, int MODE>
+__device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
+                                            int dil, int mt, int col0, int lane) {
+    constexpr int RS = C + 4;
+    constexpr int G = C / 16, MTn = C / 32;
+    constexpr int NG = G * KT;                      // MFMA k-groups: (chunk, tap, k-group-in-chunk)
+    const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // the K loop is fully unrolled (NG <= 44 groups): chunk / tap / k-group and the ring slots are compile-time, the only
+    // runtime term of an operand address is tap * dil
+    auto grp = [&](int it, int& chunk, int& tap, int& kgl) {
+        chunk = it / (2 * KT);
+        const int rr = it - chunk * (2 * KT);
+        tap = rr >> 1;
+        kgl = rr & 1;
+    };
+    auto load_a = [&](u32x4& dst, int it) {
+        int chunk, tap, kgl;
+        grp(it, chunk, tap, kgl);
+        dst = wfrag[((long)(tap * G + 2 * chunk + kgl) * MTn + mt) * 64 + lane];
+    };
+    const unsigned short* bl = src + (col0 + l31) * RS + khalf * 8;
+    auto load_b = [&](u32x4 (&dst)[NT], int it) {
+        int chunk, tap, kgl;
+        grp(it, chunk, tap, kgl);
+        const unsigned short* p = bl + (tap * dil) * RS + chunk * 32 + kgl * 16;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
+            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    u32x4 A[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+    u32x4 Bf[2][NT];
+    load_b(Bf[0], 0);
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+        if (it + RING - 1 < NG) load_a(A[(it + RING - 1) % RING], it + RING - 1);
+        if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
+        if (it + RING - 1 < NG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // the A load of a later group,
+        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);       // the next group's B fragments,
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // under this group's MFMAs
+    }
+}
+
+template <int C, int KT, int MODE>
+__global__ __launch_bounds__(256, 2) void resblock_pair16_kernel(const PairArgs a) {
+    constexpr int RS = C + 4;
+    constexpr int NT = (C / 32) * (N1 / 32) / 4;            // 32x32 tiles per wave: one m-tile x NT n-tiles
+    constexpr int WPM = 4 / (C / 32);                       // waves per m-tile
+    constexpr int R2 = (KT - 1) / 2;
+    constexpr int TT = N1 - 2 * R2;
+    constexpr int XROWS = N1 + 2 * R1MAX;                   // the xt^T tile has N1 + KT - 1 rows
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short* Xs = smem16;                            // [XROWS][RS]  convert(leaky(x)),  row j <-> t = t0 - R2 - r1 + j
+    unsigned short* XTs = smem16 + XROWS * RS;              // [XTROWS][RS] convert(leaky(xt)), row c <-> t = t0 - R2 + c
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mt = w / WPM, nq = w % WPM;
+    const int l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int T = a.T, dil = a.dil;
+    const int r1 = dil * R2;
+    const int xw = N1 + 2 * r1;
+    const float* xb = a.x + (long)b * a.bstride;
+    const float slope = a.slope;
+
+    // ---- stage x^T: wave w converts channel pairs w*(C/8) .. of every column; lanes run over columns (coalesced rows)
+    {
+        const int tbase = t0 - R2 - r1;
+        constexpr int PAIRS = C / 8;                        // channel pairs per wave: 8 / 4
+        constexpr int XBLK = (XROWS + 63) / 64;             // 5 column blocks
+#pragma unroll
+        for (int jb = 0; jb < XBLK; ++jb) {
+            const int j = jb * 64 + lane;
+            const int t = tbase + j;
+            const int t_c = min(max(t, 0), T - 1);
+            const bool in = t >= 0 && t < T;
+            const float fpos = in ? 1.f : 0.f, fneg = in ? slope : 0.f;     // conv_mfma16.hip's staging arithmetic
+            float v[PAIRS][2];
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p) * 2 + h) * a.ld + t_c];
+            if (j < xw) {
+#pragma unroll
+                for (int p = 0; p < PAIRS; ++p) {
+                    const float v0 = v[p][0], v1 = v[p][1];
+                    const unsigned pk = pack16<MODE>(v0 * (v0 > 0.f ? fpos : fneg), v1 * (v1 > 0.f ? fpos : fneg));
+                    *reinterpret_cast<unsigned*>(Xs + j * RS + (w * PAIRS + p) * 2) = pk;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+    const int col0 = nq * (NT * 32);
+    conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w1f, Xs, dil, mt, col0, lane);
+    {   // xt = acc + b1 -> convert(leaky(xt)) (what conv2's staging reads from HBM on the two-launch path), zero outside [0, T)
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = a.b1[mt * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = col0 + j * 32 + l31;
+            const int t = t0 - R2 + c;
+            const bool in = t >= 0 && t < T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[j][r] + bi[r];
+                v = v * (v > 0.f ? 1.f : slope);
+                XTs[c * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+            }
+        }
+    }
+    __syncthreads();
+
+    conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w2f, XTs, 1, mt, col0, lane);
+    {   // ((acc + b2) + x) + y_old: conv_mfma16.hip's epilogue; all loads of a 32x32 tile before its stores
+        float* yb = a.y + (long)b * a.bstride;
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = a.b2[mt * 32 + acc_row(r, lane)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int o = col0 + j * 32 + l31;
+            const int t = t0 + o;
+            const bool ok = o < TT && t < T;
+            const int t_c = min(t, T - 1);
+            float rv[16], yv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long off = (long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c;
+                rv[r] = xb[off];
+                yv[r] = a.accum ? yb[off] : 0.f;
+            }
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = ((acc[j][r] + bi[r]) + rv[r]) + yv[r];
+            }
+        }
+    }
+}
+
+template <int C, int KT, int MODE>
+int launch_pair16(const PairArgs& a, hipStream_t stream) {
+    constexpr int TT = N1 - (KT - 1);
+    const size_t lds = (size_t)(N1 + 2 * R1MAX + N1 + KT - 1) * (C + 4) * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_pair16_kernel<C, KT, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.T + TT - 1) / TT, a.B);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, KT, MODE>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int MODE>
+int dispatch16(const PairArgs& a, hipStream_t s) {
+    if (a.C == 64) {
+        if (a.k == 3) return launch_pair16<64, 3, MODE>(a, s);
+        if (a.k == 7) return launch_pair16<64, 7, MODE>(a, s);
+        if (a.k == 11) return launch_pair16<64, 11, MODE>(a, s);
+    } else if (a.C == 32) {
+        if (a.k == 3) return launch_pair16<32, 3, MODE>(a, s);
+        if (a.k == 7) return launch_pair16<32, 7, MODE>(a, s);
+        if (a.k == 11) return launch_pair16<32, 11, MODE>(a, s);
+    }
+    return -2;
+}
+
+}  // namespace
+
+// w1f / w2f: the 16-bit fragment-order weights conv_mfma16.hip uses ([tap][C/16][C/32][64][8]).  mode 1 = bf16, 2 = fp16.
+extern "C" int cmtts_launch_resblock_pair16(const PairArgs* ap, int mode, void* stream_) {
+    const PairArgs& a = *ap;
+    hipStream_t s = (hipStream_t)stream_;
+    if (a.B <= 0 || a.T <= 0) return 0;
+    if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y || (mode != 1 && mode != 2)) return -2;
+    return mode == 1 ? dispatch16<1>(a, s) : dispatch16<2>(a, s);
+}

@@ -1018,6 +1018,29 @@ def test_vocoder_mrf_streams_bitwise(dtype):
         lib.cmtts_set_option(b"branch_streams", prev)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7)])
+def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
+    """resblock_pair16.hip (16-bit operands, C = 64 / 32 stages, one launch per ResBlock pair): same conversions, same
+    (chunk, tap, k-group) accumulation order and epilogue as conv_mfma16.hip -> bitwise equal to the two-launch 16-bit path."""
+    host = _host()
+    lib = _lib.load()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=6))
+    voc.set_precision(dtype)
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
+    prev = lib.cmtts_set_option(b"voc_pair", 0)
+    try:
+        ref = voc(mel).clone()
+        lib.cmtts_set_option(b"voc_pair", 2)          # 2 = every (C, k); 1 leaves k = 11 (and k = 7 at C = 64) to the two-launch path
+        got = voc(mel).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"voc_pair", prev)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130)])
 def test_vocoder_pair_kernel_bitwise(B, T):
     """resblock_pair.hip (C = 64 / 32 stages: conv1 -> LeakyReLU -> conv2 -> + x of a ResBlock pair in one launch, the x
