@@ -261,6 +261,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_voc_pair16p = 0;          // 16-bit ResBlock pairs through the persistent register-resident-weight kernel (resblock_pair16.hip): measured slower (one wave per SIMD serialises its staging / epilogue work, profiles/r02_vocoder_bf16.md): off
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
@@ -1416,7 +1417,8 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             // 16-bit operands: the pair kernel wins where the pair is bound by tensor passes (k = 3: 0.40 vs 0.60-0.64 ms per
             // pair at C = 32 / 64; k = 7 at C = 32: 0.45 vs 0.60) and loses where its per-tile weight stream dominates (k = 11 at
             // C = 64: 180 KB of 16-bit weights per 246 columns, 0.83 vs 0.64 ms; profiles/r02_vocoder_bf16.md): g_voc_pair == 2 forces it
-            const bool pair16_pays = g_voc_pair == 2 || rk == 3 || (rk == 7 && co == 32);
+            // g_voc_pair16p: the persistent form with register-resident weights has no per-tile weight stream: every (C, k)
+            const bool pair16_pays = g_voc_pair16p || g_voc_pair == 2 || rk == 3 || (rk == 7 && co == 32);
             const bool pair_ok = g_voc_pair && co <= 64 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
@@ -1430,8 +1432,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 else { pa.w1f = v->c1f32[r][mi]; pa.w2f = v->c2f32[r][mi]; }
                 pa.bstride = cs; pa.B = B; pa.C = co; pa.T = To; pa.ld = ld; pa.k = rk; pa.dil = v->rb_dil[mi];
                 pa.accum = lastm && j > 0; pa.slope = 0.1f;
-                const int prc = v->precision ? cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q)
-                                             : cmtts_launch_resblock_pair(&pa, (void*)q);
+                int prc;
+                if (!v->precision) prc = cmtts_launch_resblock_pair(&pa, (void*)q);
+                else if (g_voc_pair16p) prc = cmtts_launch_resblock_pair16p(&pa, v->precision, persist_blocks(), (void*)q);
+                else prc = cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q);
                 if (prc != 0) return fail(CMTTS_E_HIP, "resblock_pair launch failed");
                 if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                 xr = pa.y;
@@ -1525,6 +1529,11 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "voc_pair16p")) {   // 16-bit pairs: persistent kernel with register-resident weights (1) or the per-tile streamed form (0)
+        const int prev = g_voc_pair16p;
+        if (value == 0 || value == 1) g_voc_pair16p = value;
+        return prev;
     }
     if (!strcmp(name, "voc_xl")) {        // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel
         const int prev = g_voc_xl;

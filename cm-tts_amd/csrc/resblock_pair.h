@@ -37,6 +37,7 @@ int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
 // 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error
 int cmtts_launch_resblock_pair(const PairArgs* a, void* stream);
 int cmtts_launch_resblock_pair16(const PairArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16
+int cmtts_launch_resblock_pair16p(const PairArgs* a, int mode, int n_cus, void* stream);   // persistent, register-resident weights
 void cmtts_pair_set_debug(long long* dbg);
 #ifdef __cplusplus
 }

@@ -1019,7 +1019,7 @@ def test_vocoder_mrf_streams_bitwise(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,T", [(2, 61), (1, 7)])
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (40, 33)])
 def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     """resblock_pair16.hip (16-bit operands, C = 64 / 32 stages, one launch per ResBlock pair): same conversions, same
     (chunk, tap, k-group) accumulation order and epilogue as conv_mfma16.hip -> bitwise equal to the two-launch 16-bit path."""
@@ -1031,14 +1031,22 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
     prev = lib.cmtts_set_option(b"voc_pair", 0)
     try:
+        prev_p = lib.cmtts_set_option(b"voc_pair16p", 0)
         ref = voc(mel).clone()
-        lib.cmtts_set_option(b"voc_pair", 2)          # 2 = every (C, k); 1 leaves k = 11 (and k = 7 at C = 64) to the two-launch path
+        lib.cmtts_set_option(b"voc_pair", 2)          # 2 = every (C, k) through the per-tile streamed pair kernel
         got = voc(mel).clone()
+        lib.cmtts_set_option(b"voc_pair", 1)
+        lib.cmtts_set_option(b"voc_pair16p", 1)       # persistent form: register-resident weights, LDS-DMA staging
+        got_p = voc(mel).clone()
+        got_p2 = voc(mel).clone()                     # back to back: stale LDS / staging state must not leak
         torch.cuda.synchronize()
     finally:
         lib.cmtts_set_option(b"voc_pair", prev)
+        lib.cmtts_set_option(b"voc_pair16p", prev_p)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert torch.equal(got_p, ref), float((got_p - ref).abs().max())
+    assert torch.equal(got_p2, ref)
 
 
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130)])

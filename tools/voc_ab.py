@@ -12,6 +12,7 @@ lib = _lib.load()
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
 mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
+lib.cmtts_set_option(b"voc_pair16p", int(os.environ.get("VP16P", 0)))
 for prec in os.environ.get("VP", "fp32").split(","):
     voc.set_precision(prec)
     outs = []

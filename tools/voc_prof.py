@@ -12,6 +12,7 @@ from cmtts_amd.weights import synth_hifigan_state_dict
 lib = _lib.load()
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
 lib.cmtts_set_option(b"voc_pair", int(os.environ.get("VPAIR", 1)))
+lib.cmtts_set_option(b"voc_pair16p", int(os.environ.get("VP16P", 0)))
 lib.cmtts_set_option(b"voc_xl", int(os.environ.get("VXL", os.environ.get("VPAIR", 1))))
 lib.cmtts_set_option(b"branch_streams", int(os.environ.get("VSTREAMS", 1)))      # 0: the three ResBlock chains in line (clean per-kernel times)
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
