@@ -1,0 +1,187 @@
+// Fused multi-head self-attention of the FFT blocks (model/blocks.py:266-312: F.multi_head_attention_forward's
+// softmax(q k^T / sqrt(dh) + key_padding_mask) v, no biases) for gfx950 — one launch per layer instead of three
+// (S^T = K^T Q GEMM -> softmax_cols -> O = V P^T GEMM with the [2B, L, L] scores crossing HBM twice).
+//
+// Workgroup = one (utterance, head); wave w = queries 32w .. 32w+31 against ALL keys (L <= 192: up to 6 waves).
+//   * K and V head tiles (dh = 128 channels x 64 keys per chunk) are staged through LDS, coalesced along the key axis, and
+//     shared by the workgroup's waves; a wave's 32 query columns of Q live in registers as MFMA B operands;
+//   * S^T = K^T Q on v_mfma_f32_32x32x2_f32: one 32x32 accumulator per 32 keys (<= 6), K^T fragments = conflict-free
+//     ds_read_b32 (32 consecutive keys of one channel per half-wave);
+//   * softmax over keys entirely in registers: a query's scores sit in one lane column of the accumulators (16 registers x
+//     two lane halves x the key tiles), so the row maximum and sum are in-lane reductions plus ONE cross-half exchange
+//     (__shfl_xor 32) — no LDS, no [L, L] buffer anywhere;
+//   * O = V P^T feeds the probabilities to the matrix pipe straight from the accumulator registers: MFMA k-step r of key tile
+//     m multiplies keys {32m + (r&3) + 8(r>>2) + 4h} — exactly what lane half h holds in register r — so P never moves; the
+//     V fragment addresses follow that key order (V^T tile in LDS with a 65-float row stride: conflict-free).
+// Numerics: same operations as the three-launch path (scale after the dot product, max-subtracted expf, division by the
+// sum) in a different summation order (fp32: ~1e-7 relative); every (utterance, head, query block) is computed the same
+// way whatever the batch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "attention.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DH = 128;          // head dimension (hidden 256 / 2 heads)
+constexpr int KB = 64;           // keys per staged chunk
+constexpr int VLD = KB + 1;      // row stride of the V tile [DH][KB]: lanes walk down the channels
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int NMT>               // 32-key tiles = waves (query blocks): L in (32 (NMT-1), 32 NMT]
+__global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
+    constexpr int NCH = (NMT + 1) / 2;
+    constexpr int NTHREADS = 64 * NMT;
+    __shared__ __attribute__((aligned(16))) float tile[DH * VLD];     // K chunks [d][KB], then V chunks [d][VLD] (padded rows)
+    float* Ks = tile;
+    float* Vs = tile;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
+    const int L = a.L, ld = a.ld;
+    const int len = min((int)a.lens[b], L);
+    const float* qb = a.qkv + (long)b * a.bstride + (long)(h * DH) * ld;                   // Q_h [DH][ld]
+    const float* kb = a.qkv + (long)b * a.bstride + (long)(a.H * DH + h * DH) * ld;        // K_h
+    const float* vb = a.qkv + (long)b * a.bstride + (long)(2 * a.H * DH + h * DH) * ld;    // V_h
+
+    // ---- this wave's queries as B operands: lane (i = l31, khalf) holds Q[d = 2 kk + khalf][32 w + i] for kk < 64
+    float Qr[DH / 2];
+    {
+        const int i_c = min(32 * w + l31, L - 1);
+#pragma unroll
+        for (int kk = 0; kk < DH / 2; ++kk) Qr[kk] = qb[(long)(2 * kk + khalf) * ld + i_c];
+    }
+
+    auto stage = [&](const float* src, float* dst, int dst_ld, int key0) {
+        // [DH][KB] tile, keys beyond L zero-filled; float4 loads along the key axis (rows are 16-B aligned: ld % 4 == 0)
+        for (int idx = tid; idx < DH * (KB / 4); idx += NTHREADS) {
+            const int d = idx / (KB / 4), c4 = idx - d * (KB / 4);
+            const int j = key0 + 4 * c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < ld) v = *reinterpret_cast<const f32x4*>(src + (long)d * ld + j);
+            float* p = dst + d * dst_ld + 4 * c4;
+            p[0] = j + 0 < L ? v[0] : 0.f;
+            p[1] = j + 1 < L ? v[1] : 0.f;
+            p[2] = j + 2 < L ? v[2] : 0.f;
+            p[3] = j + 3 < L ? v[3] : 0.f;
+        }
+    };
+
+    // ---- S^T[key][query] = sum_d K[d][key] Q[d][query]
+    f32x16 S[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[m][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c > 0) __syncthreads();
+        stage(kb, Ks, KB, c * KB);
+        __syncthreads();
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl) {
+            const int m = 2 * c + mtl;
+            if (m < NMT) {
+                const float* ks = Ks + khalf * KB + mtl * 32 + l31;
+                float av = ks[0];
+#pragma unroll
+                for (int kk = 0; kk < DH / 2; ++kk) {
+                    const float nav = kk + 1 < DH / 2 ? ks[(kk + 1) * 2 * KB] : 0.f;
+                    S[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Qr[kk], S[m], 0, 0, 0);
+                    av = nav;
+                }
+            }
+        }
+    }
+
+    // ---- softmax over keys, per query column, in registers
+    {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * m + acc_row(r, lane);
+                const float v = S[m][r] * a.scale;
+                S[m][r] = v;
+                if (key < len) mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * m + acc_row(r, lane);
+                const float e = key < len ? expf(S[m][r] - mx) : 0.f;
+                S[m][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[m][r] = S[m][r] / (sum > 0.f ? sum : 1.f);     // len == 0: all probabilities 0
+    }
+
+    // ---- O[d][query] = sum_key V[d][key] P[key][query]; P stays where the accumulators left it
+    __syncthreads();                 // every wave is done with the last K chunk: the tile is re-used for V
+    f32x16 O[DH / 32];
+#pragma unroll
+    for (int mt = 0; mt < DH / 32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[mt][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c > 0) __syncthreads();
+        stage(vb, Vs, VLD, c * KB);
+        __syncthreads();
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl) {
+            const int m = 2 * c + mtl;
+            if (m < NMT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = mtl * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;     // key of this k-step for this lane half
+#pragma unroll
+                    for (int mt = 0; mt < DH / 32; ++mt)
+                        O[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(mt * 32 + l31) * VLD + kl], S[m][r], O[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- store channel-major [H*DH][ld], queries contiguous
+    float* ob = a.out + (long)b * a.obstride + (long)(h * DH) * ld;
+    const int i = 32 * w + l31;
+    if (i < L) {
+#pragma unroll
+        for (int mt = 0; mt < DH / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long)(mt * 32 + acc_row(r, lane)) * ld + i] = O[mt][r];
+    }
+}
+
+}  // namespace
+
+// 0 = launched, -2 = shape not covered (L > 192 or head_dim != 128: the caller runs the three-launch path), -3 = HIP error
+extern "C" int cmtts_launch_attention(const AttnArgs* ap, void* stream_) {
+    const AttnArgs& a = *ap;
+    hipStream_t s = (hipStream_t)stream_;
+    if (a.B <= 0 || a.L <= 0) return 0;
+    if (a.dh != DH || a.L > 192 || (a.ld & 3)) return -2;
+    const int nmt = (a.L + 31) / 32;
+    dim3 grid(a.B * a.H);
+    switch (nmt) {
+        case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(192), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(attention_kernel<5>, grid, dim3(320), 0, s, a); break;
+        default: hipLaunchKernelGGL(attention_kernel<6>, grid, dim3(384), 0, s, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

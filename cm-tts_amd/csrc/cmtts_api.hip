@@ -19,6 +19,7 @@
 #include "persist_args.h"
 #include "cond_gemm.h"
 #include "resblock_pair.h"
+#include "attention.h"
 
 namespace {
 
@@ -261,6 +262,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip) when L <= 192: 0 = three-launch path
 int g_voc_pair16p = 0;          // 16-bit ResBlock pairs through the persistent register-resident-weight kernel (resblock_pair16.hip): measured slower (one wave per SIMD serialises its staging / epilogue work, profiles/r02_vocoder_bf16.md): off
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
@@ -381,8 +383,8 @@ int persist_blocks() {          // workgroups that are certainly co-resident: on
 
 struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-    PackedConv qk, wo, ffn1, ffn2;
-    float* ffn1_f = nullptr;   // ffn1 in MFMA A-fragment order (conv_xres.hip)
+    PackedConv qk, qkv, wo, ffn1, ffn2;     // qkv: the whole in_proj_weight as one [3H][H] contraction (fused attention path)
+    float* ffn1_f = nullptr;   // ffn1 as MFMA A fragments in iteration order (conv_xres.hip)
     float* wvT;  // [256 c][256 d]
 };
 struct Predictor {
@@ -509,6 +511,8 @@ int finalize_model(cmtts_model* m) {
         HostTensor qk; qk.shape = {2 * H, H, 1};
         qk.data.assign(inw->data.begin(), inw->data.begin() + (size_t)2 * H * H);
         CHK(pack_conv(al, qk, nullptr, nullptr, &L.qk));
+        HostTensor qkv = *inw; qkv.shape = {3 * H, H, 1};
+        CHK(pack_conv(al, qkv, nullptr, nullptr, &L.qkv));
         CHK(al.upload(transpose2d(inw->data.data() + (size_t)2 * H * H, H, H), &L.wvT));
         GET(ow, p + "self_attn.out_proj.weight", H, H);
         HostTensor ow3 = *ow; ow3.shape = {H, H, 1};
@@ -517,8 +521,8 @@ int finalize_model(cmtts_model* m) {
         {
             std::vector<float> hp;
             CHK(pack_conv(al, *f1w, f1b, nullptr, &L.ffn1, &hp));
-            if (L.ffn1.cin % 8 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
-                CHK(al.upload(to_fragment_order(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_f));
+            if (L.ffn1.cin % 32 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
+                CHK(al.upload(to_fragment_iter_order(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_f));
         }
         GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
         HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
@@ -706,8 +710,8 @@ TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
     w.spk = cv.take<float>((size_t)B * H);
     w.x = cv.take<float>(n);
     w.h = cv.take<float>(n);
-    w.qk = cv.take<float>(2 * n);
-    w.vt = cv.take<float>(n);
+    w.qk = cv.take<float>(3 * n);      // fused attention: [B][3H][Lp] (Q | K | V); three-launch path: Q,K [B][2H][Lp] + V^T [B][Lp][H] behind it
+    w.vt = w.qk + 2 * n;
     w.st = cv.take<float>((size_t)B * c.enc_heads * Lp * Lp);
     w.o = cv.take<float>(n);
     w.f = cv.take<float>(4 * n);
@@ -1010,8 +1014,23 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
     for (size_t i = 0; i < layers.size(); ++i) {
         const EncLayer& E = layers[i];
         k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+        bool attn_done = false;
+        if (g_attn_fused && dh == 128 && L <= 192) {
+            // q, k, v = h * W_in^T as ONE contraction, then softmax(q k^T / sqrt(dh) + mask) v in one launch per layer:
+            // scores and probabilities never leave the CU (attention.hip)
+            ConvArgs a = conv_args(E.qkv, w.h, L, Lp, hs, w.qk, Lp, 3 * hs, L);
+            CHK(launch(a, EPI_PLAIN, B, s));
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.qkv = w.qk; at.out = w.o; at.lens = src_lens; at.bstride = 3 * hs; at.obstride = hs;
+            at.B = B; at.H = NH; at.dh = dh; at.L = L; at.ld = Lp; at.scale = (float)(1.0 / sqrt((double)dh));
+            const int arc = cmtts_launch_attention(&at, (void*)s);
+            if (arc == -3) return fail(CMTTS_E_HIP, "attention launch failed");
+            attn_done = arc == 0;
+        }
         // the V projection is needed only by the PV product: side stream, joined after the softmax
-        SideStream* ss = side_for(s);
+        SideStream* ss = attn_done ? nullptr : side_for(s);
+        if (!attn_done) {
         hipStream_t sv = ss ? ss->side : s;
         if (ss) CHK(branch_fork(ss));
         {   // Q,K = h * W[0:2H]^T, channel-major [B][2H][Lp]
@@ -1054,6 +1073,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             o.Y = w.o; o.y_zs0 = hs; o.y_zs1 = (long)dh * Lp; o.ldy = Lp; o.Tout = L; o.ostride = 1; o.alpha = 1.f; o.div = 1.f;
             CHK(launch(a, EPI_PLAIN, B * NH, s));
         }
+        }   // three-launch attention
         {   // x = (x + out_proj(o)) * nonpad      (model/blocks.py:609-610)
             ConvArgs a = conv_args(E.wo, w.o, L, Lp, hs, w.x, Lp, hs, L);
             a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
@@ -1103,8 +1123,7 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     CHK(fft_stack(m, m->enc, w, src_lens, B, L, s));
     k_layernorm_ct(w.x, w.x, m->encln_g, m->encln_b, 1e-5f, src_lens, B, L, Lp, s);
     if (enc_out_ct)
-        HIPCHK(hipMemcpy2DAsync(enc_out_ct, (size_t)L * 4, w.x, (size_t)Lp * 4, (size_t)L * 4, (size_t)B * H,
-                                hipMemcpyDeviceToDevice, s));
+        k_copy_rows(enc_out_ct, L, w.x, Lp, L, (long)B * H, s);
     if (c.multi_speaker) {
         k_dense_small(spker_embeds, c.external_speaker_dim, 1, m->spk_wt, m->spk_b, nullptr, w.spk, B,
                       c.external_speaker_dim, H, DENSE_NONE, s);
@@ -1530,6 +1549,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
     }
+    if (!strcmp(name, "attn_fused")) {    // FFT-block attention: 1 = QKV projection + one fused kernel (L <= 192), 0 = three launches
+        const int prev = g_attn_fused;
+        if (value == 0 || value == 1) g_attn_fused = value;
+        return prev;
+    }
     if (!strcmp(name, "voc_pair16p")) {   // 16-bit pairs: persistent kernel with register-resident weights (1) or the per-tile streamed form (0)
         const int prev = g_voc_pair16p;
         if (value == 0 || value == 1) g_voc_pair16p = value;
@@ -1661,11 +1685,11 @@ int cmtts_decoder_forward(cmtts_model* m, const float* x_ct, const int64_t* lens
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "decoder workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int H = c.hidden, Tp = round_up(T, 4);
-    HIPCHK(hipMemcpy2DAsync(w.f, (size_t)Tp * 4, x_ct, (size_t)T * 4, (size_t)T * 4, (size_t)B * H, hipMemcpyDeviceToDevice, s));
+    k_copy_rows(w.f, Tp, x_ct, T, T, (long)B * H, s);
     k_pos_embed_add(w.f, w.x, m->dec_alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, T, Tp, s, lens);
     CHK(fft_stack(m, m->dec, w, lens, B, T, s));
     k_layernorm_ct(w.x, w.x, m->decln_g, m->decln_b, 1e-5f, lens, B, T, Tp, s);
-    HIPCHK(hipMemcpy2DAsync(out_ct, (size_t)T * 4, w.x, (size_t)Tp * 4, (size_t)T * 4, (size_t)B * H, hipMemcpyDeviceToDevice, s));
+    k_copy_rows(out_ct, T, w.x, Tp, T, (long)B * H, s);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -511,6 +511,46 @@ def test_branch_streams_bitwise(variant, B, L):
         lib.cmtts_set_option(b"branch_streams", prev)
 
 
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 171), ("VCTK", 4, 33), ("LJSpeech", 2, 1), ("LJSpeech", 2, 192)])
+def test_fused_attention_matches_three_launch_path(variant, B, L):
+    """attention.hip (QKV projection as one contraction + softmax(q k^T / sqrt(dh) + key mask) v in one launch, scores in
+    registers) against the three-launch path (K^T Q GEMM -> softmax_cols -> V P^T GEMM): the same operations in a
+    different fp32 summation order -> encoder output within 2e-5, integer stages identical; ragged lengths exercise the
+    key mask, L = 171 / 192 the six-wave form, L = 1 the degenerate one."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=19, dur_frames=3.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(L)
+    lens = np.maximum((rs.uniform(0.3, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    prev = lib.cmtts_set_option(b"attn_fused", 0)
+    try:
+        ref = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+        lib.cmtts_set_option(b"attn_fused", 1)
+        got = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+        again = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"attn_fused", prev)
+    assert torch.isfinite(got["enc_out"]).all()
+    err = float((got["enc_out"] - ref["enc_out"]).abs().max())
+    assert err < 2e-5, err
+    assert err > 0 or L == 1                     # it really took the other path
+    assert torch.equal(got["mel_lens"], ref["mel_lens"]) and torch.equal(got["mel2ph"], ref["mel2ph"])
+    assert torch.equal(again["enc_out"], got["enc_out"])        # deterministic
+    if L == 33:   # one utterance alone: bit-identical to its rows in the batch
+        one = model.duration_pitch_energy_net(None, torch.from_numpy(texts[1:2, :int(lens[1])]), torch.from_numpy(lens[1:2]),
+                                              spker_embeds=None if spk is None else spk[1:2], max_mel_len=3 * L)
+        n = int(lens[1])
+        if n == L:
+            assert torch.equal(one["enc_out"][0, :n], got["enc_out"][1, :n])
+
+
 def test_length_mask_kernel():
     """get_mask_from_lengths utils/tools.py:275-283 (True = padding): bit-exact against arange >= len."""
     host = _host()
