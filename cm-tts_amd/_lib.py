@@ -16,7 +16,7 @@ class CMTTSConfigStruct(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_symbols", "hidden", "enc_layers", "enc_heads", "ffn_kernel",
         "pred_filter", "pred_layers", "pred_kernel", "dur_layers", "dur_kernel", "cwt_hidden",
-        "pitch_bins", "energy_bins", "use_uv", "multi_speaker", "external_speaker_dim",
+        "pitch_bins", "energy_bins", "use_uv", "multi_speaker", "external_speaker_dim", "n_speaker",
         "n_mels", "res_layers", "res_channels")] + [(n, C.c_float) for n in (
             "cwt_std_scale", "pitch_norm_eps", "sigma_min", "sigma_max", "sigma_data", "rho")]
 
@@ -38,7 +38,7 @@ SIGNATURES = {
     "cmtts_finalize": (_i, [_vp]),
     "cmtts_destroy": (None, [_vp]),
     "cmtts_text_workspace_bytes": (_sz, [_vp, _i, _i]),
-    "cmtts_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_text_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_set_variance_controls": (_i, [_vp, C.POINTER(VarianceControlsStruct)]),
     "cmtts_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_frame_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -67,6 +67,11 @@ SIGNATURES = {
     "cmtts_decoder_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_decoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_length_mask": (_i, [_vp, _vp, _i, _i, _vp]),
+    "cmtts_comm_unique_id": (_i, [_vp]),
+    "cmtts_comm_init_rank": (_i, [C.POINTER(_vp), _i, _i, _vp]),
+    "cmtts_comm_destroy": (_i, [_vp]),
+    "cmtts_allgather_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "cmtts_allgather_mels": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cmtts_pack_conv_weight": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i)]),
     "cmtts_free_device": (None, [_vp]),

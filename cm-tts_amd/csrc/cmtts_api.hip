@@ -416,7 +416,7 @@ struct cmtts_model {
     // FastspeechDecoder (model/modules.py:154-165): optional, present when the state dict holds "decoder.*"
     std::vector<EncLayer> dec;
     float *decln_g = nullptr, *decln_b = nullptr, *dec_alpha = nullptr;
-    float *spk_wt = nullptr, *spk_b = nullptr;
+    float *spk_wt = nullptr, *spk_b = nullptr, *spk_table = nullptr;
     Predictor dur, energy, cwt;
     PackedConv cwt_in;
     float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
@@ -546,7 +546,10 @@ int finalize_model(cmtts_model* m) {
         }
     }
 
-    if (c.multi_speaker) {
+    if (c.multi_speaker && c.n_speaker > 0) {   // speaker_embedder "none": nn.Embedding(n_speaker, hidden) (model/cmtts.py:26-38)
+        GET(sw, "duration_pitch_energy_net.speaker_emb.weight", c.n_speaker, H);
+        UP(m->spk_table, sw);
+    } else if (c.multi_speaker) {
         GET(sw, "duration_pitch_energy_net.speaker_emb.weight", H, c.external_speaker_dim);
         GET(sb, "duration_pitch_energy_net.speaker_emb.bias", H);
         CHK(al.upload(transpose2d(sw->data.data(), H, c.external_speaker_dim), &m->spk_wt));
@@ -968,6 +971,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
 extern "C" {
 
 const char* cmtts_last_error(void) { return g_err.c_str(); }
+int cmtts_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : "?"); }     // for the other translation units (rccl_gather.hip)
 const char* cmtts_version(void) { return "cmtts_hip 0.1 (gfx950)"; }
 
 int cmtts_create(const cmtts_config* cfg, cmtts_model** out) {
@@ -1102,13 +1106,14 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
 }
 
 int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
-                       int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
+                       const int64_t* speakers, int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
                        float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
                        void* text_ws, size_t text_ws_bytes, void* stream) {
     if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
     if (!texts || !src_lens || !text_ws || B <= 0 || L <= 0) return fail(CMTTS_E_INVALID, "cmtts_text_forward: bad argument");
     const cmtts_config& c = m->cfg;
-    if (c.multi_speaker && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
+    if (c.multi_speaker && c.n_speaker > 0 && !speakers) return fail(CMTTS_E_INVALID, "speakers (ids into the speaker_emb table) are required (model/cmtts.py:78)");
+    if (c.multi_speaker && c.n_speaker <= 0 && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
     TextWs w = carve_text(c, B, L, text_ws);
     if (text_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "text workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -1125,7 +1130,8 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     if (enc_out_ct)
         k_copy_rows(enc_out_ct, L, w.x, Lp, L, (long)B * H, s);
     if (c.multi_speaker) {
-        k_dense_small(spker_embeds, c.external_speaker_dim, 1, m->spk_wt, m->spk_b, nullptr, w.spk, B,
+        if (c.n_speaker > 0) k_gather_rows(m->spk_table, speakers, w.spk, B, H, c.n_speaker, s);
+        else k_dense_small(spker_embeds, c.external_speaker_dim, 1, m->spk_wt, m->spk_b, nullptr, w.spk, B,
                       c.external_speaker_dim, H, DENSE_NONE, s);
         k_add_rowvec(w.x, w.spk, B, H, L, Lp, s);
         if (speaker_emb) HIPCHK(hipMemcpyAsync(speaker_emb, w.spk, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));

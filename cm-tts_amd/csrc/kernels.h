@@ -44,6 +44,7 @@ void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipSt
 void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t s);    // mask[b][t] = t >= lens[b]
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s);   // [B][R][Cn] -> [B][Cn][R]
 void k_fill_lens(int64_t* lens, int64_t v, int B, hipStream_t s);
+void k_gather_rows(const float* table, const int64_t* idx, float* out, int B, int C, int n_rows, hipStream_t s);
 void k_copy_rows(float* dst, int dst_ld, const float* src, int src_ld, int width, long rows, hipStream_t s);
 void k_scale(const float* in, float* out, long n, float sc, hipStream_t s);
 void k_fill_float(float* p, float v, int n, hipStream_t s);

@@ -616,6 +616,16 @@ void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s) {
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), B), dim3(256), 0, s, in, out, R, Cn);
 }
+// ---- out[b][c] = table[clamp(idx[b])][c]: speaker_emb = nn.Embedding(n_speaker, hidden)(speakers), model/cmtts.py:77-78
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out, int C, int n_rows) {
+    const int b = blockIdx.x;
+    long r = idx[b];
+    r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(long)b * C + c] = table[r * C + c];
+}
+void k_gather_rows(const float* table, const int64_t* idx, float* out, int B, int C, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, s, table, idx, out, C, n_rows);
+}
 // ---- dst[r][0..width) = src[r][0..width) for `rows` rows with different row strides (re-pitching a channel-major
 // tensor between its padded workspace form and the caller's dense form).  hipMemcpy2DAsync splits such a copy into dozens
 // of blit kernels (33 per call at B = 32: 0.15 ms of a 13.5 ms step); this is one launch.

@@ -119,11 +119,20 @@ class CMTotalTTS(torch.nn.Module):
             self._h = None
 
     def load_state_dict(self, state_dict, strict=True):
-        with torch.cuda.device(self.device):
-            _push_state_dict(self.lib, self.lib.cmtts_set_tensor, self._h, state_dict)
-            _lib.check(self.lib.cmtts_finalize(self._h))
-        self._ready = True
+        """Takes the reference checkpoint's flat state dict.  The tensors are handed to the library under their original
+        keys (host side: cmtts_set_tensor copies them); cmtts_finalize re-packs and uploads — at once when a GPU is present,
+        otherwise on first use (so that host code which builds the object graph before a device is selected still runs)."""
+        _push_state_dict(self.lib, self.lib.cmtts_set_tensor, self._h, state_dict)
+        self._pending = True
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            self._finalize()
         return self
+
+    def _finalize(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cmtts_finalize(self._h))
+        self._pending = False
+        self._ready = True
 
     def eval(self):
         return self
@@ -135,20 +144,38 @@ class CMTotalTTS(torch.nn.Module):
         return self
 
     def _require(self):
+        if not self._ready and getattr(self, "_pending", False):
+            if not torch.cuda.is_available():
+                raise RuntimeError("CMTotalTTS: no GPU — cmtts_amd has no CPU fallback (the weights are loaded, the kernels cannot run)")
+            self.device = _norm_device(self.device if self.device.type == "cuda" else "cuda")
+            self._finalize()
         if not self._ready:
             raise RuntimeError("CMTotalTTS: load_state_dict() first")
+
+    def to(self, *args, **kwargs):
+        """nn.Module.to: the weights live in the library's packed device buffers on the device given at construction;
+        moving to that device (what synthesize.py:84 does) is a no-op, anything else is refused rather than ignored."""
+        dev = kwargs.get("device", args[0] if args and isinstance(args[0], (str, torch.device, int)) else None)
+        if dev is not None and self._ready and torch.cuda.is_available() and _norm_device(dev) != self.device:
+            raise RuntimeError(f"CMTotalTTS was built on {self.device}; build another instance for {dev}")
+        return self
 
     def get_segmentation_model(self):
         """tts_net.py:66-73 -> (duration_pitch_energy_net, denoise_fun)."""
         return self.duration_pitch_energy_net, self.net.forward
 
-    def forward(self, x, timesteps, speakers=None, texts=None, src_lens=None, spker_embeds=None,
+    def forward(self, x, timesteps, speakers=None, texts=None, src_lens=None, pitch=None, f0=None, uv=None, cwt_spec=None,
+                f0_mean=None, f0_std=None, mel_lens=None, e_targets=None, d_targets=None, mel2phs=None, spker_embeds=None,
                 p_control=1.0, e_control=1.0, d_control=1.0, **kwargs):
-        """tts_net.py:75-183: re-runs the duration net with max_mel_len = x.size(2), then the denoiser."""
-        out = self.duration_pitch_energy_net(speakers, texts, src_lens, mels=x, spker_embeds=spker_embeds,
-                                             p_control=p_control, e_control=e_control, d_control=d_control,
-                                             **{k: kwargs[k] for k in ("mel_lens", "p_targets", "e_targets", "d_targets",
-                                                                       "mel2phs") if k in kwargs})
+        """tts_net.py:75-183: re-runs the duration net with max_mel_len = x.size(2) (mels=x), then the denoiser.  The
+        pitch target is assembled exactly like the reference does (:121-131): only when `pitch` is given, from
+        pitch / f0 / uv / cwt_spec / f0_mean / f0_std.  The loss bookkeeping of :166-181 is training-only (not built)."""
+        p_targets = None if pitch is None else {"pitch": pitch, "f0": f0, "uv": uv, "cwt_spec": cwt_spec,
+                                                "f0_mean": f0_mean, "f0_std": f0_std}
+        out = self.duration_pitch_energy_net(speakers=speakers, texts=texts, src_lens=src_lens, mels=x, mel_lens=mel_lens,
+                                             p_targets=p_targets, e_targets=e_targets, d_targets=d_targets, mel2phs=mel2phs,
+                                             spker_embeds=spker_embeds, p_control=p_control, e_control=e_control,
+                                             d_control=d_control)
         return self.net(x, timesteps, out["cond"], out["speaker_emb"], out["mel_masks"])
 
 
@@ -185,9 +212,17 @@ class DurationPitchSpeakerNet(torch.nn.Module):
         texts = _i64(texts, dev)
         src_lens = _i64(src_lens, dev)
         B, L = texts.shape
-        spk_in = _f32(spker_embeds, dev) if (cfg.multi_speaker and spker_embeds is not None) else None
-        if cfg.multi_speaker and spk_in is None:
+        table = cfg.multi_speaker and cfg.n_speaker > 0          # preprocess.yaml speaker_embedder "none": nn.Embedding(speakers)
+        spk_in = _f32(spker_embeds, dev) if (cfg.multi_speaker and not table and spker_embeds is not None) else None
+        if cfg.multi_speaker and not table and spk_in is None:
             raise AssertionError("Speaker embedding should not be None")
+        spk_ids = None
+        if table:
+            if speakers is None:
+                raise AssertionError("speakers (ids into the speaker_emb table) should not be None")
+            if not speakers.is_cuda and (int(speakers.min()) < 0 or int(speakers.max()) >= cfg.n_speaker):
+                raise IndexError("index out of range in self")          # what nn.Embedding raises (model/cmtts.py:78)
+            spk_ids = _i64(speakers, dev)
         H = cfg.hidden
         with torch.cuda.device(dev):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -201,7 +236,7 @@ class DurationPitchSpeakerNet(torch.nn.Module):
             if vc is not None:
                 _lib.check(lib.cmtts_set_variance_controls(o._h, C.byref(vc)))
             try:
-                _lib.check(lib.cmtts_text_forward(o._h, _ptr(texts), _ptr(src_lens), _ptr(spk_in), B, L, float(d_control),
+                _lib.check(lib.cmtts_text_forward(o._h, _ptr(texts), _ptr(src_lens), _ptr(spk_in), _ptr(spk_ids), B, L, float(d_control),
                                                   _ptr(log_d), _ptr(d_rounded), _ptr(mel_len), _ptr(e_pred), _ptr(e_idx),
                                                   _ptr(enc_ct), _ptr(spk), _ptr(tws), nb, _stream()))
                 if mels is not None:
@@ -590,11 +625,17 @@ class Generator(torch.nn.Module):
         sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in state_dict.items()}
         if any(k.endswith("weight_g") for k in sd):
             sd = fold_weight_norm(sd)
-        with torch.cuda.device(self.device):
-            _push_state_dict(self.lib, self.lib.cmtts_vocoder_set_tensor, self._h, sd)
-            _lib.check(self.lib.cmtts_vocoder_finalize(self._h))
-        self._ready = True
+        _push_state_dict(self.lib, self.lib.cmtts_vocoder_set_tensor, self._h, sd)
+        self._pending = True
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            self._finalize()
         return self
+
+    def _finalize(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cmtts_vocoder_finalize(self._h))
+        self._pending = False
+        self._ready = True
 
     def remove_weight_norm(self):
         return self
@@ -609,6 +650,11 @@ class Generator(torch.nn.Module):
         return self
 
     def forward(self, x):
+        if not self._ready and getattr(self, "_pending", False):
+            if not torch.cuda.is_available():
+                raise RuntimeError("Generator: no GPU — cmtts_amd has no CPU fallback (the weights are loaded, the kernels cannot run)")
+            self.device = _norm_device(self.device if self.device.type == "cuda" else "cuda")
+            self._finalize()
         if not self._ready:
             raise RuntimeError("Generator: load_state_dict() first")
         dev = self.device
@@ -728,35 +774,125 @@ class BucketedSynthesizer:
 
 
 class CMTotalTTSSynthesize:
-    """synthesize.py:35-153.  The reference reloads the checkpoint for every batch (:203-206); here
-    the model object is built once and handed in."""
+    """synthesize.py:35-153 with the reference's constructor: CMTotalTTSSynthesize(model_path, model_step_num, args,
+    preprocess_config, model_config, train_config, p_control, e_control, d_control).  The checkpoint
+    <model_path>/CMDenoiserTTS/model{step:06d}.pt is read with torch.load and handed to CMTotalTTS.load_state_dict
+    (cmtts_set_tensor + cmtts_finalize).  `from_model` keeps the model-object form (the reference reloads the checkpoint
+    for every batch, :203-206; a serving host builds the model once)."""
 
-    def __init__(self, model: CMTotalTTS, T=1, generator=None):
-        self.model = model
-        self.diffusion = KarrasDenoiser(sigma_data=model.config.sigma_data, sigma_max=model.config.sigma_max,
-                                        sigma_min=model.config.sigma_min, rho=model.config.rho, distillation=True)
-        self.duration_pitch_energy_net, self.denoise_net = model.get_segmentation_model()
-        self.T = int(T)
+    def __init__(self, model_path, model_step_num, args, preprocess_config, model_config, train_config,
+                 p_control=1.0, e_control=1.0, d_control=1.0, device=None, generator=None, n_speaker=None):
+        import os.path as osp
+        self.device = _norm_device(device if device is not None else "cuda") if torch.cuda.is_available() else torch.device("cpu")
+        self.CMDenoiserTTS_path = osp.join(model_path, "CMDenoiserTTS", "model{:06d}.pt".format(int(model_step_num)))
+        self.args = args
+        self.train_config = train_config
+        self.model, self.diffusion = self.load_cm_model(args, preprocess_config, model_config, train_config, n_speaker=n_speaker)
+        self.duration_pitch_energy_net, self.denoise_net = self.model.get_segmentation_model()
+        self.p_control, self.e_control, self.d_control = p_control, e_control, d_control
         self.generator = generator
 
+    @classmethod
+    def from_model(cls, model: CMTotalTTS, T=1, generator=None, p_control=1.0, e_control=1.0, d_control=1.0):
+        """A synthesizer around an already loaded model (no checkpoint I/O); T = sampling steps (args.T)."""
+        import argparse
+        self = cls.__new__(cls)
+        cfg = model.config
+        self.device = model.device
+        self.CMDenoiserTTS_path = None
+        self.args = argparse.Namespace(T=int(T))
+        self.train_config = {"cm": {"sigma_min": cfg.sigma_min, "sigma_max": cfg.sigma_max}}
+        self.model = model
+        self.diffusion = KarrasDenoiser(sigma_data=cfg.sigma_data, sigma_max=cfg.sigma_max, sigma_min=cfg.sigma_min,
+                                        rho=cfg.rho, distillation=True)
+        self.duration_pitch_energy_net, self.denoise_net = model.get_segmentation_model()
+        self.p_control, self.e_control, self.d_control = p_control, e_control, d_control
+        self.generator = generator
+        return self
+
+    def load_cm_model(self, args, preprocess_config, model_config, train_config, n_speaker=None):
+        """synthesize.py:59-86: distillation from cm.training_mode, model + diffusion from the `cm` block
+        (script_util.py:56-76: sigma_min / sigma_max / sigma_data / rho, weight_schedule, loss_norm), torch.load of the
+        checkpoint -> load_state_dict -> to(device) -> eval()."""
+        from .config import config_from_reference
+        cm = train_config["cm"]
+        mode = cm["training_mode"]
+        if mode == "progdist":
+            distillation = False
+        elif "consistency" in mode:
+            distillation = True
+        else:
+            raise ValueError(f"unknown training mode {mode}")
+        cfg = config_from_reference(preprocess_config, model_config, train_config, n_speaker=n_speaker)
+        model = CMTotalTTS(cfg, self.device)
+        diffusion = KarrasDenoiser(sigma_data=cfg.sigma_data, sigma_max=cfg.sigma_max, sigma_min=cfg.sigma_min, rho=cfg.rho,
+                                   weight_schedule=cm.get("weight_schedule", "karras"), distillation=distillation,
+                                   loss_norm=cm.get("loss_norm", "lpips"))
+        state = torch.load(self.CMDenoiserTTS_path, map_location="cpu")
+        model.load_state_dict(state)
+        model.to(self.device)
+        model.eval()
+        return model, diffusion
+
     def synthesize(self, batch):
-        """batch = (ids, raw_texts, speakers, texts, src_lens, max_src_len, spker_embeds) after to_device."""
+        """batch = (ids, raw_texts, speakers, texts, src_lens, max_src_len, spker_embeds) after to_device (:88-153)."""
         kw = {"speakers": batch[2], "texts": batch[3], "src_lens": batch[4], "spker_embeds": batch[-1]}
         out_dict = self.duration_pitch_energy_net(**kw)
         B, T, _ = out_dict["cond"].shape
         cfg = self.model.config
-        if self.T == 1:
+        steps = int(self.args.T)
+        if steps == 1:
             n_steps, draws = 1, 1
-        elif self.T in (2, 4):
-            n_steps, draws = self.T, self.T + 1
+        elif steps in (2, 4):
+            n_steps, draws = steps, steps + 1
         else:
             raise ValueError("T must be 1, 2 or 4 (synthesize.py:111-147)")
+        cm = self.train_config["cm"]
+        fusable = getattr(self.diffusion, "distillation", False) and \
+            abs(float(cm.get("sigma_max", cfg.sigma_max)) - cfg.sigma_max) < 1e-6 * cfg.sigma_max and \
+            abs(float(cm.get("sigma_min", cfg.sigma_min)) - cfg.sigma_min) < 1e-6 * cfg.sigma_min
         gen = self.generator or DummyGenerator()
-        x0 = gen.randn(B, 1, T, cfg.n_mels, device=self.model.device)
-        noise = torch.stack([x0] + [gen.randn_like(x0) for _ in range(draws - 1)], 0).float()
-        sample = sample_with_cond(self.model, out_dict["cond_ct"], out_dict["speaker_emb"], n_steps, noise)
+        if not fusable:      # e.g. a progdist teacher: the reference's sampler loops, host-side (karras_sample_tts routes)
+            sample = karras_sample_tts(self.diffusion, self.model, (B, 1, T, cfg.n_mels), steps=2, model_kwargs=kw,
+                                       device=self.device, sigma_min=float(cm.get("sigma_min", cfg.sigma_min)),
+                                       sigma_max=float(cm.get("sigma_max", cfg.sigma_max)),
+                                       sampler="onestep" if steps == 1 else "multistep",
+                                       ts=None if steps == 1 else (0,) * steps + (1,), generator=gen)
+        else:                # the duration net ran once above; the reference's in-sampler re-runs are bit-identical (SURVEY.md §7)
+            x0 = gen.randn(B, 1, T, cfg.n_mels, device=self.model.device)
+            noise = torch.stack([x0] + [gen.randn_like(x0) for _ in range(draws - 1)], 0).float()
+            sample = sample_with_cond(self.model, out_dict["cond_ct"], out_dict["speaker_emb"], n_steps, noise)
         out_put = [None] * 12
         out_put[0] = sample
         out_put[10] = kw["src_lens"]
         out_put[11] = out_dict["mel_lens"]
         return out_put
+
+
+def get_vocoder(config, device, root="."):
+    """utils/model.py:155-184: config["vocoder"] = {"model": "HiFi-GAN", "speaker": "LJSpeech" | "universal"} ->
+    hifigan/config.json + hifigan/generator_<speaker>.pth.tar (ckpt["generator"], weight-norm pairs folded like
+    remove_weight_norm) under `root` (the reference resolves them against the working directory).  MelGAN comes from
+    torch.hub (network) in the reference and is not part of this path."""
+    import json
+    import os
+    name, speaker = config["vocoder"]["model"], config["vocoder"]["speaker"]
+    if name != "HiFi-GAN":
+        raise NotImplementedError(f"vocoder {name!r}: only HiFi-GAN is on the hot path (MelGAN needs torch.hub)")
+    if speaker not in ("LJSpeech", "universal"):
+        raise ValueError(f"unknown vocoder speaker {speaker!r}")
+    with open(os.path.join(root, "hifigan", "config.json")) as f:
+        hc = json.load(f)
+    h = HifiGanConfig(num_mels=hc.get("num_mels", 80), upsample_rates=tuple(hc["upsample_rates"]),
+                      upsample_kernel_sizes=tuple(hc["upsample_kernel_sizes"]),
+                      upsample_initial_channel=hc["upsample_initial_channel"],
+                      resblock_kernel_sizes=tuple(hc["resblock_kernel_sizes"]),
+                      resblock_dilation_sizes=tuple(tuple(d) for d in hc["resblock_dilation_sizes"]))
+    if h != HifiGanConfig():
+        raise NotImplementedError("the vocoder kernels are specialised for hifigan/config.json (V1 generator)")
+    ckpt = torch.load(os.path.join(root, "hifigan", f"generator_{speaker}.pth.tar"), map_location="cpu")
+    vocoder = Generator(h, device)
+    vocoder.load_state_dict(ckpt["generator"])
+    vocoder.eval()
+    vocoder.remove_weight_norm()
+    return vocoder

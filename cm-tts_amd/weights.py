@@ -128,7 +128,9 @@ def synth_cmtts_state_dict(cfg: CMTTSConfig, seed: int = 0, dur_frames: float = 
     N(va + "energy_embedding.weight", (cfg.energy_bins, H), H ** -0.5)
     sd[va + "energy_embedding.weight"][0] = 0.0
 
-    if cfg.multi_speaker:
+    if cfg.multi_speaker and getattr(cfg, "n_speaker", 0) > 0:
+        N("duration_pitch_energy_net.speaker_emb.weight", (cfg.n_speaker, H), 1.0)      # nn.Embedding: N(0, 1), no bias
+    elif cfg.multi_speaker:
         N("duration_pitch_energy_net.speaker_emb.weight", (H, cfg.external_speaker_dim),
           1.0 / math.sqrt(cfg.external_speaker_dim))
         N("duration_pitch_energy_net.speaker_emb.bias", (H,), 0.1)

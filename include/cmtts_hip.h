@@ -43,6 +43,8 @@ typedef struct cmtts_config {
     int32_t n_symbols, hidden, enc_layers, enc_heads, ffn_kernel;
     int32_t pred_filter, pred_layers, pred_kernel, dur_layers, dur_kernel, cwt_hidden;
     int32_t pitch_bins, energy_bins, use_uv, multi_speaker, external_speaker_dim;
+    int32_t n_speaker;   /* > 0: preprocess.yaml speaker_embedder "none" — speaker_emb is nn.Embedding(n_speaker, hidden) indexed by
+                            `speakers` (model/cmtts.py:26-38,77-78); 0: nn.Linear(external_speaker_dim, hidden) of spker_embeds */
     int32_t n_mels, res_layers, res_channels;
     float cwt_std_scale, pitch_norm_eps;
     float sigma_min, sigma_max, sigma_data, rho;
@@ -65,12 +67,13 @@ void cmtts_destroy(cmtts_model* m);
  * energy predictors, durations, cumulative sums.  The phoneme-level state needed by
  * cmtts_frame_forward stays in `text_ws`.  Optional outputs may be NULL.
  *   texts int64 [B,L] (0 = pad), src_lens int64 [B], spker_embeds fp32 [B,external_speaker_dim]
- *   (multi-speaker only, else NULL).
+ *   (multi-speaker with an external embedder, else NULL), speakers int64 [B] (multi-speaker with n_speaker > 0:
+ *   rows of the speaker_emb table, else NULL / ignored).
  *   out: log_d fp32 [B,L], d_rounded fp32 [B,L], mel_len int64 [B], e_pred fp32 [B,L],
  *        e_idx int64 [B,L], enc_out_ct fp32 [B,hidden,L], speaker_emb fp32 [B,hidden]. */
 size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L);
 int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const float* spker_embeds,
-                       int B, int L, float d_control,
+                       const int64_t* speakers, int B, int L, float d_control,
                        float* log_d, float* d_rounded, int64_t* mel_len, float* e_pred, int64_t* e_idx,
                        float* enc_out_ct, float* speaker_emb,
                        void* text_ws, size_t text_ws_bytes, void* stream);
@@ -203,6 +206,24 @@ int cmtts_profile_end(double* total_ms, int* n_launches);
 size_t cmtts_decoder_workspace_bytes(const cmtts_model* m, int B, int T);
 int cmtts_decoder_forward(cmtts_model* m, const float* x_ct, const int64_t* lens, int B, int T, float* out_ct,
                           void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the path's one collective (new work: the reference's inference is single-process, synthesize.py:32,43):
+ * every rank contributes its padded mel block [Bl,T,M] and mel_len [Bl] and receives all ranks' blocks in rank order.
+ * RCCL (librccl.so, the library torch.distributed's "nccl" backend uses on ROCm) is opened at run time with dlopen — the
+ * library does not link against it and every other entry point works without it.  A host that is not Python builds its
+ * communicator here: rank 0 calls cmtts_comm_unique_id and ships the 128 bytes to the other ranks by any means, every rank
+ * calls cmtts_comm_init_rank (one process per GPU, device already selected with hipSetDevice).
+ *   cmtts_allgather_mels: mel fp32 [Bl,T,M], mel_len int64 [Bl] (device) -> out_mel fp32 [world*Bl,T,M], out_len int64
+ *   [world*Bl] (device); ws = device scratch of cmtts_allgather_workspace_bytes(world, Bl, T, M) bytes (the packed send /
+ *   receive buffers: mel_len rides in the same buffer as a trailing column, so it is ONE ncclAllGather); everything is
+ *   enqueued on `stream`.  The persistent denoiser needs every CU: issue it after the gather has completed on the stream
+ *   (same stream: automatic). */
+int cmtts_comm_unique_id(void* id128_host);
+int cmtts_comm_init_rank(void** comm, int world, int rank, const void* id128_host);
+int cmtts_comm_destroy(void* comm);
+size_t cmtts_allgather_workspace_bytes(int world, int Bl, int T, int M);
+int cmtts_allgather_mels(void* comm, int world, const float* mel, const int64_t* mel_len, int Bl, int T, int M,
+                         float* out_mel, int64_t* out_len, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- get_mask_from_lengths (utils/tools.py:275-283): mask[b][t] = (t >= lens[b]) as one byte per element
  * (True = padding), lens int64 [B], mask [B,W]. */

@@ -439,14 +439,17 @@ def variance_adaptor(sd, cfg, enc_out, src_mask, speaker_emb=None, max_len=None,
                 mel_mask=get_mask_from_lengths(mel_len, T))
 
 
-def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_mel_len=None, **va_kwargs):
+def duration_pitch_speaker_net(sd, cfg, texts, src_lens, spker_embeds=None, max_mel_len=None, speakers=None, **va_kwargs):
     """DurationPitchSpeakerNet.forward model/cmtts.py:44-122 (va_kwargs: controls / targets of
-    variance_adaptor)."""
+    variance_adaptor).  Multi-speaker: Linear(512 -> 256) of the external vector (:39-42,81), or — preprocess.yaml
+    speaker_embedder "none", cfg.n_speaker > 0 — the row of the nn.Embedding table that `speakers` names (:26-38,78)."""
     B, L = texts.shape
     src_mask = get_mask_from_lengths(src_lens, L)
     enc = text_encoder(sd, cfg, texts, src_mask)
     spk = None
-    if cfg.multi_speaker:
+    if cfg.multi_speaker and getattr(cfg, "n_speaker", 0) > 0:
+        spk = np.asarray(sd["duration_pitch_energy_net.speaker_emb.weight"], F32)[np.asarray(speakers, np.int64)]
+    elif cfg.multi_speaker:
         spk = linear(spker_embeds, sd["duration_pitch_energy_net.speaker_emb.weight"],
                      sd["duration_pitch_energy_net.speaker_emb.bias"]).astype(F32)
     out = variance_adaptor(sd, cfg, enc, src_mask, spk, max_mel_len, **va_kwargs)

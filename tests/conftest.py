@@ -72,7 +72,7 @@ def pitch_margin_mask(f0_denorm, thr=2e-3):
 FLIP_MARGIN = 2e-3
 KNOWN_PITCH_FLIPS = {
     "cmtts_LJSpeech": 0, "cmtts_VCTK": 0, "cmtts_LibriTTS": 0,
-    "controls_VCTK:ctl": 0, "controls_VCTK:tf": 0,
+    "controls_VCTK:ctl": 0, "controls_VCTK:tf": 0, "cmtts_VCTK_table": 0,
 }
 
 

@@ -9,7 +9,8 @@ reference's own ``load_state_dict``; inputs/noise come from seeded ``numpy.rando
 
 Outputs (data only — inputs and the reference's outputs, no reference source):
     tests/golden/cmtts_<variant>.npz   for LJSpeech / VCTK / LibriTTS
-    tests/golden/hifigan.npz
+    tests/golden/hifigan.npz, samplers_LJSpeech.npz, controls_VCTK.npz, decoder_LJSpeech.npz, text.json
+    tests/golden/cmtts_VCTK_table.npz  (speaker_embedder "none": the nn.Embedding speaker table)
 Usage:  python tests/golden/make_golden.py
 """
 import argparse
@@ -67,7 +68,9 @@ def import_reference():
     sys.modules["model.diffgantts"] = ref_cmtts
 
 
-def build_reference_model(variant, cfg):
+def build_reference_model(variant, cfg, table_speakers=0):
+    """table_speakers > 0: preprocess.yaml `speaker_embedder: none` with a fabricated speakers.json of that many entries
+    (model/cmtts.py:26-38: speaker_emb = nn.Embedding(n_speaker, hidden) indexed by `speakers`)."""
     from model.cm_tool.script_util import (create_model_and_diffusion_tts,
                                            model_and_diffusion_defaults, args_to_dict)
     load = lambda n: yaml.load(open(f"{REF}/config/{variant}/{n}.yaml"), Loader=yaml.FullLoader)
@@ -75,6 +78,10 @@ def build_reference_model(variant, cfg):
     tmp = tempfile.mkdtemp()
     with open(os.path.join(tmp, "stats.json"), "w") as f:
         json.dump({"energy": [cfg.energy_min, cfg.energy_max, 0, 1], "f0": [200, 50]}, f)
+    if table_speakers:
+        pre["preprocessing"]["speaker_embedder"] = "none"
+        with open(os.path.join(tmp, "speakers.json"), "w") as f:
+            json.dump({f"p{225 + i}": i for i in range(table_speakers)}, f)
     pre["path"]["preprocessed_path"] = tmp
     pre["preprocessing"]["pitch"]["cwt_scales"] = 0.01 * 2.0 ** np.arange(10)
     kw = args_to_dict(argparse.Namespace(**tr["cm"]), model_and_diffusion_defaults().keys())
@@ -368,6 +375,51 @@ def golden_controls():
     np.savez_compressed(os.path.join(HERE, f"controls_{variant}.npz"), **out)
 
 
+def golden_speaker_table():
+    """The `speaker_embedder: none` branch (model/cmtts.py:26-38,77-78): VCTK configs with the speaker embedding TABLE
+    (nn.Embedding(108, 256)) indexed by `speakers` instead of the Linear of an external 512-d vector.  Same texts as the
+    VCTK golden; speaker ids 3 / 57 / 107 (first, middle, last row region of the table)."""
+    from model.cm_tool.karras_diffusion import karras_sample_tts
+    from utils.pitch_tools import f0_to_coarse
+    from utils.tools import dur_to_mel2ph
+    cfg = get_config("VCTK_table")
+    model, diffusion = build_reference_model("VCTK", cfg, table_speakers=cfg.n_speaker)
+    speakers = np.asarray([3, 57, 107], np.int64)
+    for seed in range(1, 200):       # a seed whose rounding decisions have comfortable margins (as find_seed does)
+        sd = synth_cmtts_state_dict(cfg, seed=seed, dur_frames=4.0, dur_spread=0.03)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        texts, src_lens, _ = make_inputs(cfg, seed)
+        with torch.no_grad():
+            d = model.duration_pitch_energy_net(torch.from_numpy(speakers), torch.from_numpy(texts), torch.from_numpy(src_lens))
+        md, me = margins(d["log_d_predictions"].numpy(), d["e_predictions"].numpy(),
+                         sd["duration_pitch_energy_net.variance_adaptor.energy_bins"], src_lens)
+        if md > MIN_MARGIN_DUR and me > MIN_MARGIN_ENERGY:
+            break
+    else:
+        raise RuntimeError("no seed with comfortable margins")
+    t_texts, t_lens, t_spk = torch.from_numpy(texts), torch.from_numpy(src_lens), torch.from_numpy(speakers)
+    out = {"seed": np.int64(seed), "texts": texts, "src_lens": src_lens, "speakers": speakers}
+    with torch.no_grad():
+        net = model.duration_pitch_energy_net
+        d = net(t_spk, t_texts, t_lens)
+        pp = d["p_predictions"]
+        B, T, _ = d["cond"].shape
+        out.update(speaker_emb=d["speaker_emb"].numpy(), log_d=d["log_d_predictions"].numpy(), d_rounded=d["d_rounded"].numpy(),
+                   mel_len=d["mel_lens"].numpy(), e_pred=d["e_predictions"].numpy(), cond=d["cond"].numpy(),
+                   f0_denorm=pp["f0_denorm"].numpy(), p_idx=f0_to_coarse(pp["f0_denorm"].clone()).numpy(),
+                   mel2ph=dur_to_mel2ph(d["d_rounded"], d["src_masks"]).numpy())
+        noise = draw_noise(seed, (B, 1, T, cfg.n_mels), 5)
+        gen = FixedNoise([torch.from_numpy(n) for n in noise])
+        mel = karras_sample_tts(diffusion=diffusion, model=model, shape=(B, 1, T, cfg.n_mels),
+                                model_kwargs=dict(speakers=t_spk, texts=t_texts, src_lens=t_lens, spker_embeds=None),
+                                device="cpu", sigma_max=cfg.sigma_max, sigma_min=cfg.sigma_min, sampler="multistep", steps=2,
+                                ts=(0, 0, 1), generator=gen)
+        out["mel_T2"] = mel.numpy()
+    m_dur, m_en = margins(out["log_d"], out["e_pred"], sd["duration_pitch_energy_net.variance_adaptor.energy_bins"], src_lens)
+    print(f"[speaker table] T={T} mel_len={out['mel_len']} margins: dur {m_dur:.4f} energy {m_en:.5f} |mel_T2| {np.abs(out['mel_T2']).mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, "cmtts_VCTK_table.npz"), **out)
+
+
 def golden_text():
     """Vocabulary table (360 symbols -> ids, text/symbols.py:21-29) and text_to_sequence outputs
     (text/__init__.py:15-41) for val.txt-style `{ARPAbet}` lines (dataset.py:271-283)."""
@@ -405,3 +457,5 @@ if __name__ == "__main__":
         golden_controls()
     if not only or "decoder" in only:
         golden_decoder()
+    if not only or "speaker_table" in only:
+        golden_speaker_table()

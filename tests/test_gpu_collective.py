@@ -79,3 +79,36 @@ def test_async_gather_then_persistent_launch(nccl_group, cooperative):
     finally:
         lib.cmtts_set_option(b"cooperative_launch", prev_c)
         lib.cmtts_set_persistent_denoiser(prev_p)
+
+
+def test_c_abi_allgather_on_a_one_rank_communicator():
+    """cmtts_comm_unique_id / cmtts_comm_init_rank / cmtts_allgather_mels / cmtts_comm_destroy (include/cmtts_hip.h): the
+    collective a non-Python host calls.  A 1-rank RCCL communicator runs the real ncclAllGather; the packed buffer carries
+    mel_len next to the mel block; the result must be the input, bit for bit, and the no-communicator form (world = 1,
+    comm = NULL) must agree."""
+    import ctypes as C
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    uid = (C.c_char * 128)()
+    _lib.check(lib.cmtts_comm_unique_id(C.cast(uid, C.c_void_p)))
+    comm = C.c_void_p()
+    _lib.check(lib.cmtts_comm_init_rank(C.byref(comm), 1, 0, C.cast(uid, C.c_void_p)))
+    try:
+        Bl, T, M = 5, 96, 80
+        g = torch.Generator().manual_seed(4)
+        mel = torch.randn(Bl, T, M, generator=g).to(DEV)
+        mel_len = torch.tensor([96, 1, 50, 77, 13], dtype=torch.int64, device=DEV)
+        for use_comm in (True, False):
+            out_mel = torch.full((Bl, T, M), float("nan"), device=DEV)
+            out_len = torch.zeros(Bl, dtype=torch.int64, device=DEV)
+            nb = lib.cmtts_allgather_workspace_bytes(1, Bl, T, M)
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.cmtts_allgather_mels(comm if use_comm else None, 1, mel.data_ptr(), mel_len.data_ptr(), Bl, T, M,
+                                                out_mel.data_ptr(), out_len.data_ptr(), ws.data_ptr(), nb,
+                                                torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            assert torch.equal(out_mel, mel) and torch.equal(out_len, mel_len)
+        assert lib.cmtts_allgather_mels(None, 2, mel.data_ptr(), mel_len.data_ptr(), Bl, T, M, mel.data_ptr(), mel_len.data_ptr(),
+                                        mel.data_ptr(), 1 << 30, None) < 0            # world > 1 needs a communicator
+    finally:
+        _lib.check(lib.cmtts_comm_destroy(comm))

@@ -144,6 +144,48 @@ def test_duration_pitch_speaker_net_golden(models, variant):
     np.testing.assert_allclose(_np(out["cond"])[same], g["cond"][same], atol=5e-5)
 
 
+def test_speaker_table_variant_golden(golden):
+    """preprocess.yaml `speaker_embedder: none` (model/cmtts.py:26-38,77-78): speaker_emb = nn.Embedding(n_speaker, 256)
+    indexed by `speakers` — the reference's own output for that branch (tests/golden/cmtts_VCTK_table.npz), end to end
+    through synthesize()'s call surface with T = 2."""
+    host = _host()
+    g = golden("cmtts_VCTK_table")
+    cfg = get_config("VCTK_table")
+    sd = synth_cmtts_state_dict(cfg, seed=int(g["seed"]), dur_frames=4.0, dur_spread=0.03)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    speakers, texts, lens = torch.from_numpy(g["speakers"]), torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
+    out = model.duration_pitch_energy_net(speakers, texts, lens)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(out["speaker_emb"]), g["speaker_emb"])              # a gather: bit-exact
+    np.testing.assert_allclose(_np(out["log_d_predictions"]), g["log_d"], atol=5e-5)
+    assert np.array_equal(_np(out["d_rounded"]), g["d_rounded"])
+    assert np.array_equal(_np(out["mel_lens"]), g["mel_len"]) and np.array_equal(_np(out["mel2ph"]), g["mel2ph"])
+    same = pitch_flips(_np(out["p_predictions"]["p_idx"]), g["p_idx"], g["f0_denorm"], "cmtts_VCTK_table")
+    np.testing.assert_allclose(_np(out["cond"])[same], g["cond"][same], atol=5e-5)
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[Gen.i]).to(DEV)
+            Gen.i += 1
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    batch = (["a", "b", "c"], ["x", "y", "z"], speakers, texts, lens, int(lens.max()), None)
+    res = host.CMTotalTTSSynthesize.from_model(model, T=2, generator=Gen()).synthesize(batch)
+    host.synchronize()
+    assert np.abs(_np(res[0]) - g["mel_T2"])[near_flip_mask(same)].max() < 1e-3
+    with pytest.raises(AssertionError):
+        model.duration_pitch_energy_net(None, texts, lens)                         # speakers are required
+    with pytest.raises(IndexError):
+        model.duration_pitch_energy_net(torch.tensor([0, 1, cfg.n_speaker]), texts, lens)
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_denoiser_forward_golden(models, variant):
     """CMDenoiserTTS.forward on the reference's own conditioning."""
@@ -237,12 +279,50 @@ def test_synthesize_driver(models, T_steps):
     texts, lens = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
     spk = torch.from_numpy(g["spker_embeds"])
     batch = (["a", "b", "c"], ["x", "y", "z"], torch.zeros(B, dtype=torch.long), texts, lens, int(lens.max()), spk)
-    out = host.CMTotalTTSSynthesize(model, T=T_steps, generator=Gen()).synthesize(batch)
+    out = host.CMTotalTTSSynthesize.from_model(model, T=T_steps, generator=Gen()).synthesize(batch)
     torch.cuda.synchronize()
     assert np.array_equal(_np(out[11]), g["mel_len"]) and np.array_equal(_np(out[10]), g["src_lens"])
     ok = _mask_near_pitch_flips(model, g, dict(texts=texts, src_lens=lens, spker_embeds=spk), "cmtts_VCTK")
     err = np.abs(_np(out[0]) - g[f"mel_T{T_steps}"])
     assert err[ok].max() < 1e-3, err[ok].max()
+
+
+def test_synthesizer_reference_constructor_end_to_end(models, tmp_path):
+    """CMTotalTTSSynthesize(model_path, model_step_num, args, preprocess_config, model_config, train_config) exactly as
+    synthesize.py:35-86 builds it — checkpoint on disk, YAML dicts — must synthesise what the from_model form does."""
+    import argparse
+    from test_host_module_cpu import _reference_configs
+    host = _host()
+    g, cfg, sd, model = models("VCTK")
+    pre, mod, tr = _reference_configs()
+    (tmp_path / "CMDenoiserTTS").mkdir()
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "CMDenoiserTTS" / "model000300.pt")
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+
+    class Gen:
+        def __init__(self):
+            self.i = 0
+
+        def randn(self, *shape, **kw):
+            t = torch.from_numpy(noise[self.i]).to(DEV)
+            self.i += 1
+            return t
+
+        def randn_like(self, x):
+            return self.randn(*x.shape)
+
+    texts, lens, spk = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]), torch.from_numpy(g["spker_embeds"])
+    batch = (["a", "b", "c"], ["x", "y", "z"], torch.zeros(B, dtype=torch.long), texts, lens, int(lens.max()), spk)
+    syn = host.CMTotalTTSSynthesize(str(tmp_path), 300, argparse.Namespace(T=4), pre, mod, tr, device=DEV, generator=Gen())
+    out = syn.synthesize(batch)
+    ref = host.CMTotalTTSSynthesize.from_model(model, T=4, generator=Gen()).synthesize(batch)
+    host.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[11], ref[11]) and out[10] is batch[4]
+    assert np.abs(_np(out[0]) - g["mel_T4"]).max() < 1e-3
+    assert syn.model.to(DEV) is syn.model
+    with pytest.raises(RuntimeError):
+        syn.model.to("cpu")
 
 
 def test_generic_denoise_path_matches_fused_sampler(models):

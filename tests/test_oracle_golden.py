@@ -243,3 +243,24 @@ def test_precision_modes_of_the_oracle(golden):
     q = O.quant16(np.float32([1.0, 1.00390625, 1.01171875, 65504.0]), "bf16")      # two ties (-> even), one overflow of the mantissa
     assert q.tolist() == [1.0, 1.0, 1.015625, 65536.0]
     assert O.quant16(np.float32([1.00048828125, 1.00146484375]), "fp16").tolist() == [1.0, 1.001953125]
+
+
+def test_speaker_table_variant(golden):
+    """speaker_embedder "none" (model/cmtts.py:26-38,77-78): the speaker vector is a row of the nn.Embedding table."""
+    g = golden("cmtts_VCTK_table")
+    cfg = get_config("VCTK_table")
+    sd = synth_cmtts_state_dict(cfg, seed=int(g["seed"]), dur_frames=4.0, dur_spread=0.03)
+    assert sd["duration_pitch_energy_net.speaker_emb.weight"].shape == (cfg.n_speaker, cfg.hidden)
+    st = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], speakers=g["speakers"])
+    np.testing.assert_array_equal(st["speaker_emb"], g["speaker_emb"])          # a gather: bit-exact
+    np.testing.assert_allclose(st["log_d"], g["log_d"], atol=2e-5)
+    np.testing.assert_array_equal(st["d_rounded"], g["d_rounded"])
+    np.testing.assert_array_equal(st["mel_len"], g["mel_len"])
+    np.testing.assert_array_equal(st["mel2ph"], g["mel2ph"])
+    same = st["p_idx"] == g["p_idx"]
+    assert same.mean() > 0.97
+    np.testing.assert_allclose(st["cond"][same], g["cond"][same], atol=2e-5)
+    B, T, _ = g["cond"].shape
+    noise = golden_noise(int(g["seed"]), (B, 1, T, cfg.n_mels), 5)
+    mel = O.karras_sample_tts(sd, cfg, g["cond"], g["speaker_emb"], 2, noise)
+    np.testing.assert_allclose(mel, g["mel_T2"], atol=2e-4)
