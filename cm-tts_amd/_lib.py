@@ -1,8 +1,9 @@
-"""ctypes binding of libcmtts_hip.so (the C ABI in include/cmtts_hip.h).
-
-``cffi`` is not installed in this image — ctypes binds the same symbols with the
-same signatures.  There is NO fallback: if the shared library is missing or a symbol is absent the
-import of the compute path fails loudly.
+"""Binding of libcmtts_hip.so (the C ABI in include/cmtts_hip.h): cffi in ABI mode when the module is importable
+(BASELINE.json north_star: "a thin C-ABI cffi layer"; declarations parsed from the header itself), ctypes otherwise —
+``cffi`` is not installed in this image, so ctypes is what runs here and what the tests exercise;
+both bind the same symbols with the same signatures behind the same call sites (``CMTTS_FFI=ctypes|cffi`` forces one).
+There is NO compute fallback: if the shared library is missing or a symbol is absent the import of the compute path
+fails loudly.
 """
 import ctypes as C
 import os
@@ -79,6 +80,83 @@ SIGNATURES = {
 }
 
 _lib = None
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cmtts_hip.h")
+
+
+def cdef_from_header(path=HEADER_PATH):
+    """The header as cffi.FFI.cdef() takes it: comments, preprocessor lines and the extern "C" wrapper removed."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    lines = [ln for ln in text.splitlines() if not ln.lstrip().startswith("#")]
+    text = "\n".join(lines)
+    text = text.replace('extern "C" {', "")
+    text = re.sub(r"^\}\s*$", "", text, flags=re.M)          # the closing brace of extern "C" (struct bodies end in "} name;")
+    return text
+
+
+def address_of(arg):
+    """Integer address of whatever the call sites pass for a pointer parameter: None, an int, a ctypes pointer value
+    (c_void_p, cast), byref(obj), a ctypes array / structure, or an object with data_ptr()."""
+    if arg is None:
+        return 0
+    if isinstance(arg, int):
+        return arg
+    if isinstance(arg, C.c_void_p):
+        return arg.value or 0
+    if hasattr(arg, "_obj"):                       # byref(x)
+        return C.addressof(arg._obj)
+    if isinstance(arg, (C.Array, C.Structure)):
+        return C.addressof(arg)
+    if isinstance(arg, C._Pointer):
+        return C.cast(arg, C.c_void_p).value or 0
+    if hasattr(arg, "data_ptr"):
+        return int(arg.data_ptr())
+    raise TypeError(f"cannot take the address of {type(arg).__name__}")
+
+
+class _CffiLib:
+    """libcmtts_hip.so through cffi (ABI mode: ffi.dlopen, no compiler), callable exactly like the ctypes object: pointer
+    parameters accept what address_of() understands, `const char*` parameters take bytes, `const char*` results come back
+    as bytes."""
+
+    def __init__(self, path):
+        import cffi
+        self.ffi = cffi.FFI()
+        self.ffi.cdef(cdef_from_header())
+        self._c = self.ffi.dlopen(path)
+        for name, (res, args) in SIGNATURES.items():
+            setattr(self, name, self._wrap(name, res, args))
+
+    def _wrap(self, name, res, args):
+        ffi, fn = self.ffi, getattr(self._c, name)          # AttributeError if the .so lacks the symbol
+        ctypes_ = ffi.typeof(fn).args
+        assert len(ctypes_) == len(args), name
+
+        def call(*a):
+            conv = []
+            for v, ct, at in zip(a, ctypes_, args):
+                if at is C.c_char_p:
+                    conv.append(ffi.NULL if v is None else v)
+                elif ct.kind == "pointer":
+                    conv.append(ffi.cast(ct, address_of(v)))
+                else:
+                    conv.append(v.value if hasattr(v, "value") else v)
+            r = fn(*conv)
+            if res is C.c_char_p:
+                return None if r == ffi.NULL else ffi.string(r)
+            return None if res is None else int(r)
+        call.__name__ = name
+        return call
+
+
+def _load_ctypes():
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks the symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
@@ -95,13 +173,24 @@ def load():
     # that HIP runtime (same SONAME) and shares torch's device context and streams.  Loaded the other way round, the
     # process ends up with /opt/rocm's runtime under torch and "no ROCm-capable device is detected".
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the .so lacks the symbol
-        fn.restype = res
-        fn.argtypes = args
+    want = os.environ.get("CMTTS_FFI", "")
+    lib = None
+    if want != "ctypes":
+        try:
+            import cffi  # noqa: F401
+            lib = _CffiLib(LIB_PATH)
+        except ImportError:
+            if want == "cffi":
+                raise
+    if lib is None:
+        lib = _load_ctypes()
     _lib = lib
     return lib
+
+
+def backend():
+    """"cffi" or "ctypes": which binding load() picked."""
+    return "cffi" if isinstance(load(), _CffiLib) else "ctypes"
 
 
 def check(rc):

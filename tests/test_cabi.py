@@ -74,3 +74,36 @@ def test_fold_weight_norm_matches_torch():
     np.testing.assert_allclose(folded["a.weight"], conv.weight.detach().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(folded["b.weight"], tconv.weight.detach().numpy(), rtol=1e-6, atol=1e-7)
     assert set(folded) == {"a.weight", "a.bias", "b.weight", "b.bias"}
+
+
+def test_cffi_declarations_from_the_header_and_address_helper():
+    """The cffi ABI-mode loader (used when `cffi` is importable; this image has none, so ctypes runs): its cdef text is the
+    header minus comments / preprocessor lines and must still declare every entry point; the address helper must
+    understand everything the call sites pass for pointer parameters.  With cffi present the adapter is exercised for real."""
+    import numpy as np
+    text = _lib.cdef_from_header()
+    assert "#" not in text and "/*" not in text and 'extern "C"' not in text
+    for n in _declared():
+        assert re.search(r"\b" + n + r"\s*\(", text), n
+    assert "typedef struct cmtts_config {" in text and "} cmtts_config;" in text
+    cs = _lib.CMTTSConfigStruct()
+    arr = (ctypes.c_float * 4)()
+    assert _lib.address_of(None) == 0 and _lib.address_of(1234) == 1234
+    assert _lib.address_of(ctypes.byref(cs)) == ctypes.addressof(cs)
+    assert _lib.address_of(arr) == ctypes.addressof(arr)
+    assert _lib.address_of(ctypes.c_void_p(77)) == 77 and _lib.address_of(ctypes.c_void_p()) == 0
+    assert _lib.address_of(ctypes.cast(arr, ctypes.c_void_p)) == ctypes.addressof(arr)
+    a = np.zeros(3, np.float32)
+    assert _lib.address_of(a.ctypes.data_as(ctypes.c_void_p)) == a.ctypes.data
+    try:
+        import cffi  # noqa: F401
+    except ImportError:
+        assert _lib.backend() == "ctypes"
+        return
+    lib = _lib._CffiLib(_lib.LIB_PATH)
+    assert b"gfx950" in lib.cmtts_version()
+    assert lib.cmtts_create(None, None) == -1 and b"null" in lib.cmtts_last_error()
+    h = ctypes.c_void_p()
+    cs = _lib.CMTTSConfigStruct()
+    assert lib.cmtts_create(ctypes.byref(cs), ctypes.byref(h)) == 0 and h.value
+    lib.cmtts_destroy(h)
