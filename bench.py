@@ -3,8 +3,8 @@
 
 One "step" = one pass of the whole text->mel hot path over one synthetic batch per GPU:
 FFT-block encoder -> variance adaptor / length regulator -> T=4 consistency sampling
-(BASELINE.json configs[1]: LJSpeech model, batch 32, 80x512 mels, T=4, fp32), inputs and noise
-already resident in HBM.  N>1: one process per GPU (launched by torch.distributed.run), every rank
+(BASELINE.json configs[1]: LJSpeech model, batch 32, 80x512 mels, T=4, fp32), inputs resident in HBM,
+the sampler's noise drawn on the device inside the step (as the reference draws it inside its sampler).  N>1: one process per GPU (launched by torch.distributed.run), every rank
 runs its own batch (weak scaling, utterances shard with no data-path collective) and the step ends
 with the single RCCL all-gather that collates the mels.
 
@@ -89,6 +89,7 @@ def cpu_baseline(cfg, sd):
     from oracle import cmtts_oracle as O
     O.set_backend("torch")            # oneDNN/MKL conv + GEMM primitives: what the reference's CPU path runs
     threads = torch.get_num_threads()
+    all_threads = threads
     rs = np.random.RandomState(0)
     B = 8
     texts = rs.randint(1, cfg.n_symbols, size=(B, PHONEMES)).astype(np.int64)
@@ -123,9 +124,56 @@ def cpu_baseline(cfg, sd):
     dt, threads, B = full, best_threads, Bf
     O.set_backend("numpy")
     return {"value": round(float(mel_len.sum()) / dt, 1), "unit": "mel-frames/s", "cores": int(threads),
-            "kind": "port",
+            "kind": "port", "threads_tried": sorted({min(all_threads, n) for n in (16, 32, 64, all_threads)}),
             "sample": f"oracle graph in stock torch-CPU ops (oneDNN/MKL; sampler end-to-end in torch), text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
                       f"T={N_STEPS} (the GPU step's own batch), thread count chosen on B=8 from {{16,32,64,all}}, best of 3 passes = {dt:.2f} s"}
+
+
+def host_info():
+    """nproc, CPU model and torch's thread count of the box the run happened on."""
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model, "torch_threads": torch.get_num_threads()}
+
+
+def cpu_baseline_small(cfg, sd, hcfg, hsd, threads):
+    """The reference's own CPU-runnable shapes (BASELINE.json configs[0]) on the oracle graph in torch-CPU ops:
+    (a) one 25-phoneme utterance, text -> mel at T = 1; (b) the HiFi-GAN generator on that utterance's 150 frames."""
+    from oracle import cmtts_oracle as O
+    O.set_backend("torch")
+    torch.set_num_threads(threads)
+    rs = np.random.RandomState(1)
+    L = 25
+    texts = rs.randint(1, cfg.n_symbols, size=(1, L)).astype(np.int64)
+    lens = np.asarray([L], np.int64)
+    noise = [rs.standard_normal(size=(1, 1, L * DUR, cfg.n_mels)).astype(np.float32)]
+    best_m, best_v, mel = None, None, None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        mel, mel_len, _ = O.synthesize(sd, cfg, texts, lens, None, 1, noise, torch_sampler=True)
+        d = time.perf_counter() - t0
+        best_m = d if best_m is None or d < best_m else best_m
+    mel_ct = np.ascontiguousarray(mel.transpose(0, 2, 1))
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.hifigan_generator(hsd, hcfg, mel_ct)
+        d = time.perf_counter() - t0
+        best_v = d if best_v is None or d < best_v else best_v
+    O.set_backend("numpy")
+    frames = L * DUR
+    audio = frames * cfg.hop_length / cfg.sampling_rate
+    return {"cfg1_text_to_mel_T1": {"value": round(frames / best_m, 1), "unit": "mel-frames/s", "seconds": round(best_m, 4),
+                                    "rtf": round(best_m / audio, 5), "cores": threads,
+                                    "sample": f"B=1, {L} phonemes -> {frames} frames, T=1, best of 4"},
+            "vocoder_b1": {"value": round(frames / best_v, 1), "unit": "mel-frames/s", "seconds": round(best_v, 4),
+                           "rtf": round(best_v / audio, 5), "cores": threads,
+                           "sample": f"HiFi-GAN generator, B=1 x {frames} frames (614.1 MFLOP/frame), best of 3"}}
 
 
 def main():
@@ -177,11 +225,15 @@ def main():
         if pend is not None:
             state["gathered"], state["gathered_len"] = pend.wait()
 
-    def step(n_steps=N_STEPS):
+    def step(n_steps=N_STEPS, fixed_noise=None):
         # the text side of this batch runs while RCCL collates the previous batch's mels over xGMI
         out = model.duration_pitch_energy_net(None, texts, lens, max_mel_len=FRAMES_PAD)
         flush()       # the persistent denoiser needs every CU: RCCL's kernels must be off the GPU before it starts
-        mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, noise)
+        # the sampler's noise is drawn INSIDE the step, on the device, like the reference does (karras_diffusion.py:534,852:
+        # generator.randn / randn_like per sampling call): x_T and one draw per re-noising
+        nz = fixed_noise if fixed_noise is not None else \
+            torch.randn(n_steps + 1 if n_steps > 1 else 1, BATCH, 1, FRAMES_PAD, cfg.n_mels, device=device)
+        mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, nz)
         if gather:
             state["pending"] = shard.allgather_mels_async(mel, out["mel_lens"], force=True)
         state["mel"], state["mel_len"] = mel, out["mel_lens"]
@@ -241,6 +293,9 @@ def main():
                    "parallelism": f"dp{world} (utterance shards + one all-gather)"},
         "rtf_mel_only": round((dt / args.steps) / audio_s, 6),
         "frames_per_s_per_gpu": round(value / world, 1),
+        "padded_frames_per_s": round(BATCH * FRAMES_PAD * world * args.steps / dt, 1),
+        "noise": "drawn on the device inside the timed step (torch.randn, one x_T + one draw per re-noising)",
+        "host": host_info(),
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -270,7 +325,7 @@ def main():
         k = args.steps
         d = timed(step_pipelined, k, 3, 1)
         torch.cuda.synchronize()
-        step()
+        step(fixed_noise=noise)
         torch.cuda.synchronize()
         assert torch.equal(state["mel_p"], state["mel"]), "pipelined result differs"
         extras["frames_per_s_T4_two_stream_pipeline"] = round(frames_rank * k / d, 1)
@@ -340,6 +395,27 @@ def main():
         assert torch.isfinite(state["wav"]).all()
         extras["frames_per_s_end_to_end_wav_T4"] = round(frames_rank * k / d, 1)
         extras["rtf_end_to_end_T4"] = round((d / k) / audio_s, 6)
+        # the reference's own RTF (p_rtf_cm.py:191-230): the clock starts AFTER the duration net and covers the sampler +
+        # vocoder of the whole batch; the denominator is the FIRST utterance's duration only
+        out_r = model.duration_pitch_energy_net(None, texts, lens, max_mel_len=FRAMES_PAD)
+        first_s = float(out_r["mel_lens"][0].item()) * cfg.hop_length / cfg.sampling_rate
+
+        def ref_style(n_steps):
+            nz = torch.randn(n_steps + 1 if n_steps > 1 else 1, BATCH, 1, FRAMES_PAD, cfg.n_mels, device=device)
+            m_ = host.sample_with_cond(model, out_r["cond_ct"], None, n_steps, nz)
+            state["wav"] = voc(m_.transpose(1, 2).contiguous())
+        for n in (1, 4):
+            d_ = timed(lambda: ref_style(n), 3, 1, 1)
+            extras[f"rtf_reference_style_T{n}"] = round((d_ / 3) / first_s, 6)
+        extras["rtf_reference_style_note"] = ("p_rtf_cm.py:191-230: (sampler + vocoder time of the whole B=32 batch) / (duration of the first "
+                                              "utterance); fp32 vocoder, no file I/O")
+        # the vocoder alone: the end-to-end bottleneck, with its own roofline (614.1 MFLOP per mel frame, fp32 MFMA)
+        mel_v = state["mel"].transpose(1, 2).contiguous()
+        d_v = timed(lambda: state.__setitem__("wav", voc(mel_v)), 5, 2, 1) / 5
+        vflops = 614105088.0 * BATCH * FRAMES_PAD
+        extras["vocoder_fp32"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
+                                  "frac_of_fp32_mfma_peak": round(vflops / d_v / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                  "bound": "mfma", "flops_per_batch": vflops}
         # BASELINE.json configs[2] shape: bf16 residual blocks + bf16 HiFi-GAN ResBlock convs (fp32 accumulate)
         model.set_precision("bf16")
         voc.set_precision("bf16")
@@ -348,9 +424,18 @@ def main():
         voc.set_precision("fp32")
         assert torch.isfinite(state["wav"]).all()
         extras["frames_per_s_end_to_end_wav_T4_bf16"] = round(frames_rank * k / d, 1)
+        voc.set_precision("bf16")
+        d_v = timed(lambda: state.__setitem__("wav", voc(mel_v)), 5, 2, 1) / 5
+        voc.set_precision("fp32")
+        extras["vocoder_bf16"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
+                                  "note": "bf16 ResBlock-conv operands; bound by tensor passes, not by the 2.5 PFLOP/s pipe (profiles/r02_vocoder_bf16.md)"}
+        state["hifigan"] = (hcfg, synth_hifigan_state_dict(hcfg, seed=0))
         result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd)
+        result["cpu_baseline"]["host_cores"] = os.cpu_count()
+        hcfg_c, hsd_c = state.get("hifigan") or (HifiGanConfig(), synth_hifigan_state_dict(HifiGanConfig(), seed=0))
+        result["cpu_baseline"]["small_shapes"] = cpu_baseline_small(cfg, sd, hcfg_c, hsd_c, result["cpu_baseline"]["cores"])
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     # RCCL writes a banner ("Librccl path : ...") through C stdio, which is fully buffered on a pipe and would land
