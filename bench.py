@@ -273,11 +273,14 @@ def main():
     else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
         kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD
-    traffic = None
+    traffic, pmc_cal, pmc_commit = None, (1.0, 1.0), "?"
     try:   # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 pass of this workload
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["denoiser_persist_kernel" if persistent else "resblock_fused_kernel"]
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = pj["denoiser_persist_kernel" if persistent else "resblock_fused_kernel"]
         if not args.unfused and pmc["B"] == BATCH and pmc["T"] == FRAMES_PAD:
             traffic = pmc["bytes_per_launch"]
+            pmc_cal = (pj["calibration"]["dword_4B_per_lane"]["fetch_factor"], pj["calibration"]["dword_4B_per_lane"]["write_factor"])
+            pmc_commit = pj.get("commit", "?")
     except Exception:
         pass
     avg_ms = tot_ms.value / max(n_l.value, 1)
@@ -299,9 +302,12 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE in separate --pmc passes (profiles/pmc_traffic.json); "
-                                     "algorithmic %.1f MB (the excess is each layer's 2.1 MB weight set missing once in each of the 8 per-XCD L2s "
-                                     "+ the polled 8-byte granules) -> HBM fraction %.3f" % (
+                     "traffic_note": "fabric-side bytes/launch = rocprofv3 FETCH_SIZE x %.1f + WRITE_SIZE x %.1f (separate --pmc passes of this "
+                                     "workload at commit %s; the factors come from known-byte-count streams measured in the same session: "
+                                     "FETCH_SIZE reads 1/2 on gfx950, profiles/pmc_traffic.json); Infinity-Cache hits are counted. Algorithmic "
+                                     "%.1f MB; the excess = each layer's 2.1 MB weight set once per XCD L2 (8 x 42 MB), the cp tiles touched "
+                                     "twice (L2-warming dword per line, then the read) and the polled 8-byte granules -> %.3f of the 8 TB/s HBM peak" % (
+                                         pmc_cal[0], pmc_cal[1], pmc_commit,
                                          (BATCH * FRAMES_PAD * (1024 * (cfg.res_layers + 1) + 8 * cfg.n_mels) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
                                          (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
