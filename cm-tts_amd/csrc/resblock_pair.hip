@@ -271,7 +271,8 @@ constexpr int XL_BN = 64;
 
 template <int C, int KT>
 __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
-    constexpr int XW = XL_BN + 2 * R1MAX;
+    constexpr int XW = XL_BN + (KT - 1) * 5 + 2;            // widest halo of this kernel size (dilation <= 5): k = 7 at C = 128 leaves
+                                                            // 49 KB per workgroup = three per CU, k = 3 38 KB
     constexpr int NWAVES = C / 32;                          // one m-tile per wave, both n-tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                        // [C][XW] leaky(x), column j <-> t = t0 - pad + j
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
 
 template <int C, int KT>
 int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
-    const size_t lds = (size_t)C * (XL_BN + 2 * R1MAX) * sizeof(float);
+    const size_t lds = (size_t)C * (XL_BN + (KT - 1) * 5 + 2) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT>),
@@ -386,7 +387,7 @@ extern "C" int cmtts_launch_conv_xl(const ConvXlArgs* ap, void* stream_) {
     const ConvXlArgs& a = *ap;
     hipStream_t s = (hipStream_t)stream_;
     if (a.B <= 0 || a.T <= 0) return 0;
-    if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y) return -2;
+    if (a.dil < 1 || a.dil > 5 || a.x == a.y) return -2;          // the X tile is sized for dilation <= 5 (HiFi-GAN: 1, 3, 5)
     if (a.C == 128) {
         if (a.k == 3) return launch_xl<128, 3>(a, s);
         if (a.k == 7) return launch_xl<128, 7>(a, s);
