@@ -336,12 +336,15 @@ def main():
         assert torch.equal(state["mel_p"], state["mel"]), "pipelined result differs"
         extras["frames_per_s_T4_two_stream_pipeline"] = round(frames_rank * k / d, 1)
         # reduced-precision denoiser operands (BASELINE.json configs[2]/[4]); NOT the headline (fp32)
-        for dt in ("bf16", "fp16"):
+        for dt in ("bf16", "fp16", "fp16x3"):
             model.set_precision(dt)
             k = max(4, args.steps // 2)
             d = timed(step, k, 2, 1)
             extras[f"frames_per_s_T4_{dt}_resblocks"] = round(frames_rank * k / d, 1)
         model.set_precision("fp32")
+        extras["fp16x3_note"] = ("residual-block operands as hi + lo fp16 pairs (22 bits), three fp16 MFMAs per product, fp32 accumulate: "
+                                 "fp32-class accuracy (tests/test_gpu_precision.py: error vs float64 within 2x of the exact-fp32 kernels'); "
+                                 "exploratory — the headline `value` is the exact-fp32 path")
         # north-star shape: 80x1024 frames per utterance (BASELINE.json north_star), same batch of 32, T=4
         L2, T2 = 171, 1024
         rs2 = np.random.RandomState(99)

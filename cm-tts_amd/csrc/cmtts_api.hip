@@ -181,6 +181,20 @@ std::vector<unsigned short> to_fragment16(const std::vector<float>& p, int taps,
     return f;
 }
 
+// fp16x3 operands: every weight as hi = fp16(w) and lo = fp16(w - hi); the lo fragment set follows the hi set
+std::vector<unsigned short> to_fragment16_split(const std::vector<float>& p, int taps, int K, int M) {
+    std::vector<float> hi(p.size()), lo(p.size());
+    for (size_t i = 0; i < p.size(); ++i) {
+        const _Float16 h = (_Float16)p[i];
+        hi[i] = (float)h;
+        lo[i] = p[i] - (float)h;
+    }
+    std::vector<unsigned short> f = to_fragment16(hi, taps, K, M, 2);
+    const std::vector<unsigned short> fl = to_fragment16(lo, taps, K, M, 2);
+    f.insert(f.end(), fl.begin(), fl.end());
+    return f;
+}
+
 // nn.Linear weight [N][K] -> transposed [K][N] (dense_small operand / X operand of a GEMM)
 std::vector<float> transpose2d(const float* w, int N, int K) {
     std::vector<float> t((size_t)K * N);
@@ -397,7 +411,7 @@ struct ResLayer {
     PackedConv cond, conv3, outp;
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
-    void *w3f16[2] = {nullptr, nullptr}, *wof16[2] = {nullptr, nullptr};   // bf16 / fp16 fragment-order copies
+    void *w3f16[3] = {nullptr, nullptr, nullptr}, *wof16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies
 };
 
 }  // namespace
@@ -630,6 +644,10 @@ int finalize_model(cmtts_model* m) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
                 CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].w3f16[mode - 1]));
             }
+            {
+                const std::vector<unsigned short> fs = to_fragment16_split(hp, 3, C, 2 * C);
+                CHK(al.upload_bytes(fs.data(), fs.size() * 2, &m->res[l].w3f16[2]));
+            }
             std::vector<float> bperm(2 * C);
             for (int r = 0; r < 2 * C; ++r) bperm[r] = b3->data[perm16[r]];
             CHK(al.upload(bperm, &m->res[l].b3f));
@@ -643,6 +661,10 @@ int finalize_model(cmtts_model* m) {
         for (int mode = 1; mode <= 2; ++mode) {
             const std::vector<unsigned short> f16 = to_fragment16(hp, 1, C, 2 * C, mode);
             CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].wof16[mode - 1]));
+        }
+        {
+            const std::vector<unsigned short> fs = to_fragment16_split(hp, 1, C, 2 * C);
+            CHK(al.upload_bytes(fs.data(), fs.size() * 2, &m->res[l].wof16[2]));
         }
         GET(wd, p + "diffusion_projection.linear.weight", C, C);
         for (int n = 0; n < C; ++n)
@@ -888,6 +910,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
         const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        // fp16x3 exists as the persistent stack only: shapes that do not take it run the exact fp32 kernels
         const int need = cmtts_persist_plan(B, T, NL, persist_blocks(), g_persist == 2);
         if (need) CHK(persist_admit(s, need, persist_blocks()));
         if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
@@ -914,7 +937,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0;
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
             int lrc;
-            if (m->precision == 0) {
+            if (m->precision == 0 || m->precision == 3) {
                 // few 32-frame tiles: one workgroup per tile leaves most of the chip idle for 83 us per layer; four
                 // workgroups per tile in two launches finish sooner (measured crossover, tools/latency_bench.py)
                 const long tiles32 = (long)((T + 31) / 32) * B;
@@ -1604,7 +1627,7 @@ int cmtts_set_fused_resblock(int on) {
 }
 
 int cmtts_set_precision(cmtts_model* m, int mode) {
-    if (!m || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
+    if (!m || mode < 0 || mode > 3) return fail(CMTTS_E_INVALID, "cmtts_set_precision: mode 0 (fp32), 1 (bf16), 2 (fp16) or 3 (fp16x3)");
     m->precision = mode;
     return 0;
 }

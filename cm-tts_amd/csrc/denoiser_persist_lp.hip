@@ -6,6 +6,12 @@
 // 5 KB); at this MFMA rate the layer time is set by the weight fill (1.05 MB per workgroup per layer).
 // Same arithmetic and (tap, k-group) accumulation order as resblock_fused_lp.hip: BITWISE equal to the per-layer
 // 16-bit kernels (tests/test_gpu_parity.py::test_persistent_denoiser_lp_bitwise).
+//
+// MODE 3 ("fp16x3"): every operand is carried as TWO fp16 numbers, hi = fp16(v) and lo = fp16(v - hi) (22 significant
+// bits together), and every product as three MFMAs, a_lo b_hi + a_hi b_lo + a_hi b_hi, accumulated in fp32 (the dropped
+// a_lo b_lo term is 2^-22 relative): fp32-class results (|d mel| vs float64 within 2x of the exact-fp32 kernels', tested)
+// at 3/16 of the fp32 MFMA cost.  The weight stream doubles (hi and lo fragments = the fp32 kernel's bytes), so a layer
+// takes about half of the fp32 kernel's time instead of a quarter.  Exploratory: the bench headline stays exact fp32.
 #include <hip/hip_runtime.h>
 #include "cvt16.h"
 #include "gate.h"
@@ -24,7 +30,7 @@ namespace {
 constexpr int C = 256;
 constexpr int NW = 8;           // waves per workgroup, each owning 2 m-tiles x 2 n-tiles
 constexpr int MT = 2;
-constexpr int RING = 6;         // 16-channel k-groups of weights in flight
+constexpr int RING = 6;         // 16-channel k-groups of weights in flight (4 in the split mode: two fragment sets)
 constexpr int FN = 64;
 constexpr int NT = FN / 32;
 constexpr int RS = 260;         // 16-bit elements per LDS row (520 B)
@@ -47,8 +53,38 @@ __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f3
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// fp32 pair -> one dword of two 16-bit values in the hi image (and, MODE 3, the fp16 remainders in the lo image IMG
+// elements further on)
+template <int MODE>
+__device__ __forceinline__ void put2(unsigned short* hi_img, int off, float v0, float v1, bool valid, int IMG) {
+    if (MODE != 3) {
+        *reinterpret_cast<unsigned*>(hi_img + off) = valid ? pack16<MODE>(v0, v1) : 0u;
+    } else {
+        const unsigned ph = pack16<2>(v0, v1);
+        const cvt_f16x2 h = __builtin_bit_cast(cvt_f16x2, ph);
+        const unsigned pl = pack16<2>(v0 - (float)h[0], v1 - (float)h[1]);
+        *reinterpret_cast<unsigned*>(hi_img + off) = valid ? ph : 0u;
+        *reinterpret_cast<unsigned*>(hi_img + IMG + off) = valid ? pl : 0u;
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void put1(unsigned short* hi_img, int off, float v, bool valid, int IMG) {
+    if (MODE != 3) {
+        hi_img[off] = valid ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+    } else {
+        const unsigned ph = pack16<2>(v, 0.f);
+        const cvt_f16x2 h = __builtin_bit_cast(cvt_f16x2, ph);
+        hi_img[off] = valid ? (unsigned short)ph : (unsigned short)0;
+        hi_img[IMG + off] = valid ? (unsigned short)pack16<2>(v - (float)h[0], 0.f) : (unsigned short)0;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const PersistArgs a) {
+    constexpr int MM = MODE == 3 ? 2 : MODE;          // MFMA element type: fp16 in the split mode
+    constexpr int RINGM = MODE == 3 ? 4 : RING;       // even: the B double buffer alternates with s
+    constexpr int IMG = (2 * FN + 2) * RS;            // elements of one set of images (u^T + z^T); the lo set follows the hi set
+    constexpr long W3LO = (long)3 * (C / 16) * (2 * C / 32) * 64, WOLO = (long)(C / 16) * (2 * C / 32) * 64;   // u32x4 per fragment set
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     unsigned short* ut = lds16;                       // u^T [FN + 2][RS], row j = frame t0 - 1 + j
     unsigned short* zt = lds16 + (FN + 2) * RS;       // z^T [FN][RS]
@@ -85,7 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 const int m = 2 * (w + NW * (i + q));
                 const float u0 = c0[q] + (x0[q] + d0[q]);
                 const float u1 = c1[q] + (x1[q] + d1[q]);
-                *reinterpret_cast<unsigned*>(ut + (1 + lane) * RS + m) = t < T ? pack16<MODE>(u0, u1) : 0u;
+                put2<MODE>(ut, (1 + lane) * RS + m, u0, u1, t < T, IMG);
             }
         }
         {
@@ -94,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             const int th = right ? t0 + FN : t0 - 1;
             const int thc = min(max(th, 0), T - 1);
             const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
-            ut[(right ? FN + 1 : 0) * RS + m] = (th >= 0 && th < T) ? (unsigned short)pack16<MODE>(uh, 0.f) : (unsigned short)0;
+            put1<MODE>(ut, (right ? FN + 1 : 0) * RS + m, uh, th >= 0 && th < T, IMG);
         }
     }
     f32x16 st[MT][NT];
@@ -120,31 +156,45 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
-    // weights [group][m-tile (16)][lane][8 x 16-bit]: k=3 conv tiles 2w, 2w+1; projection tiles w (residual half), NW+w (skip half)
-    auto load_a = [&](u32x4 (&dst)[MT], const void* wfrag, int group) {
+    // weights [group][m-tile (16)][lane][8 x 16-bit]: k=3 conv tiles 2w, 2w+1; projection tiles w (residual half), NW+w (skip half).
+    // Operand sets: index 0 = the (hi) fragments; MODE 3 adds index 1 = the lo fragments (W + W3LO / WOLO, LDS image + IMG)
+    constexpr int NS = MODE == 3 ? 2 : 1;
+    auto load_a = [&](u32x4 (&dst)[NS][MT], const void* wfrag, int group) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                dst[q][i] = *(reinterpret_cast<const u32x4*>(wfrag) + q * W3LO + ((long)group * (2 * C / 32) + w * MT + i) * 64 + lane);
+    };
+    auto load_ao = [&](u32x4 (&dst)[NS][MT], const void* wfrag, int group) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                dst[q][i] = *(reinterpret_cast<const u32x4*>(wfrag) + q * WOLO + ((long)group * (2 * C / 32) + i * NW + w) * 64 + lane);
+    };
+    auto load_b = [&](u32x4 (&dst)[NS][NT], const unsigned short* src, int kg, int row_off) {      // 16 bytes = 8 k-values of one frame
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* p = src + q * IMG + (j * 32 + l31 + row_off) * RS + kg * 16 + khalf * 8;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
+                dst[q][j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+    };
+    auto mma_group = [&](const u32x4 (&af)[NS][MT], const u32x4 (&bv)[NS][NT]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            dst[i] = *(reinterpret_cast<const u32x4*>(wfrag) + ((long)group * (2 * C / 32) + w * MT + i) * 64 + lane);
-    };
-    auto load_ao = [&](u32x4 (&dst)[MT], const void* wfrag, int group) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            dst[i] = *(reinterpret_cast<const u32x4*>(wfrag) + ((long)group * (2 * C / 32) + i * NW + w) * 64 + lane);
-    };
-    auto load_b = [&](u32x4 (&dst)[NT], const unsigned short* src, int kg, int row_off) {      // 16 bytes = 8 k-values of one frame
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const unsigned short* p = src + (j * 32 + l31 + row_off) * RS + kg * 16 + khalf * 8;
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    auto mma_group = [&](const u32x4 (&af)[MT], const u32x4 (&bv)[NT]) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mma16<MODE>(af[i], bv[j], acc[i][j]);
+            for (int j = 0; j < NT; ++j) {
+                if (MODE == 3) {      // small terms first: a_lo b_hi + a_hi b_lo, then a_hi b_hi
+                    acc[i][j] = mma16<MM>(af[1][i], bv[0][j], acc[i][j]);
+                    acc[i][j] = mma16<MM>(af[0][i], bv[1][j], acc[i][j]);
+                }
+                acc[i][j] = mma16<MM>(af[0][i], bv[0][j], acc[i][j]);
+            }
     };
 
     bool gave_up = false;
@@ -152,9 +202,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         const bool more = l + 1 < a.NL;
         constexpr int NGB = 3 * (C / 16);        // k=3 conv: group = tap * 16 + k-group
         constexpr int NGC = C / 16;
-        u32x4 A[RING][MT];
+        u32x4 A[RINGM][NS][MT];
 #pragma unroll
-        for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.W3f[l], s);          // the weight stream does not depend on u
+        for (int s = 0; s < RINGM - 1; ++s) load_a(A[s], a.W3f[l], s);         // the weight stream does not depend on u
         __syncthreads();   // (1) u^T of layer l complete
         if (more) {        // pull the next layer's cp tile towards L2: one dword per 128-B line
             const float* cpn = cp_b + (long)(l + 1) * C * T;
@@ -166,13 +216,13 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         // =========================================================== phase B: gated k=3 conv, 48 k-groups
         {
             zero_acc();
-            u32x4 Bv[2][NT];
+            u32x4 Bv[2][NS][NT];
             load_b(Bv[0], ut, 0, 0);
 #pragma unroll 1
-            for (int it = 0; it < NGB; it += RING) {
+            for (int it = 0; it < NGB; it += RINGM) {
 #pragma unroll
-                for (int s = 0; s < RING; ++s) {
-                    load_a(A[(s + RING - 1) % RING], a.W3f[l], min(it + s + RING - 1, NGB - 1));
+                for (int s = 0; s < RINGM; ++s) {
+                    load_a(A[(s + RINGM - 1) % RINGM], a.W3f[l], min(it + s + RINGM - 1, NGB - 1));
                     const int nx = min(it + s + 1, NGB - 1);
                     load_b(Bv[(s + 1) & 1], ut, nx & 15, nx >> 4);
                     __builtin_amdgcn_sched_barrier(0);
@@ -182,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             }
         }
 #pragma unroll
-        for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
+        for (int s = 0; s < RINGM - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
         {   // gate -> z^T (own buffer: no barrier between the conv and the gate)
             const float* b3 = a.b3[l];
             const int ln = opaque(lane);
@@ -204,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                         const float z0 = cmtts_gate(acc[i][j][r] + bg[i][r], acc[i][j][r + 8] + bf[i][r]);
                         const float z1 = cmtts_gate(acc[i][j][r + 1] + bg[i][r + 1], acc[i][j][r + 9] + bf[i][r + 1]);
                         const int ch = (w * MT + i) * 16 + acc_row(r, ln);
-                        *reinterpret_cast<unsigned*>(zt + (j * 32 + (ln & 31)) * RS + ch) = pack16<MODE>(z0, z1);
+                        put2<MODE>(zt, (j * 32 + (ln & 31)) * RS + ch, z0, z1, true, IMG);
                     }
         }
         __syncthreads();   // (3) z^T complete, u^T of this layer dead
@@ -212,13 +262,13 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         // =========================================================== phase C: output projection, 16 k-groups
         {
             zero_acc();
-            u32x4 Bv[2][NT];
+            u32x4 Bv[2][NS][NT];
             load_b(Bv[0], zt, 0, 0);
 #pragma unroll 1
-            for (int it = 0; it < NGC; it += RING) {
+            for (int it = 0; it < NGC; it += RINGM) {
 #pragma unroll
-                for (int s = 0; s < RING; ++s) {
-                    load_ao(A[(s + RING - 1) % RING], a.Wof[l], min(it + s + RING - 1, NGC - 1));
+                for (int s = 0; s < RINGM; ++s) {
+                    load_ao(A[(s + RINGM - 1) % RINGM], a.Wof[l], min(it + s + RINGM - 1, NGC - 1));
                     load_b(Bv[(s + 1) & 1], zt, min(it + s + 1, NGC - 1), 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NGC) mma_group(A[s], Bv[s & 1]);
@@ -282,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                     const int m = mrow0 + acc_row(r, ln);
                     const float u0 = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
                     const float u1 = cpc[j][r + 1] + (st[0][j][r + 1] + ldg(dpn, (unsigned)(m + 1)));
-                    *reinterpret_cast<unsigned*>(ut + (1 + j * 32 + c31) * RS + m) = t < T ? pack16<MODE>(u0, u1) : 0u;
+                    put2<MODE>(ut, (1 + j * 32 + c31) * RS + m, u0, u1, t < T, IMG);
                 }
             }
         }
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             for (int k = 0; k < C / 64; ++k) {
                 const int m = ln + 64 * k;
                 const float uh = cph[k] + (xv[k] + dpn[m]);
-                ut[(right ? FN + 1 : 0) * RS + m] = inside ? (unsigned short)pack16<MODE>(uh, 0.f) : (unsigned short)0;
+                put1<MODE>(ut, (right ? FN + 1 : 0) * RS + m, uh, inside, IMG);
             }
         }
     }
@@ -354,7 +404,7 @@ template <int MODE>
 int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t stream) {
     static bool attr_set = false;
     // the fp32 tail overlays two [256][68] float buffers on the 16-bit u^T / z^T images
-    const size_t lds16b = (size_t)(2 * FN + 2) * RS * sizeof(unsigned short), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
+    const size_t lds16b = (size_t)(MODE == 3 ? 2 : 1) * (2 * FN + 2) * RS * sizeof(unsigned short), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
     const size_t lds = a.tail && ldstail > lds16b ? ldstail : lds16b;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>),
@@ -393,16 +443,17 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
 
 }  // namespace
 
-// mode 1 = bf16, 2 = fp16; a->W3f / a->Wof point to the 16-bit fragment-order weights of each layer.  Return
+// mode 1 = bf16, 2 = fp16, 3 = fp16x3 (hi fragments followed by lo fragments); a->W3f / a->Wof point to the 16-bit fragment-order weights of each layer.  Return
 // codes and the residency rule are those of cmtts_launch_denoiser_persist.
 extern "C" int cmtts_launch_denoiser_persist_lp(const PersistArgs* a_in, int mode, int max_blocks, int force, void* stream_) {
     PersistArgs a = *a_in;
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles = (a.T + FN - 1) / FN;
-    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30) || (mode != 1 && mode != 2)) return -2;
+    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30) || mode < 1 || mode > 3) return -2;
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = nullptr;
     if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
+    if (mode == 3) return launch_mode<3>(a, tiles, max_blocks, stream);
     return mode == 1 ? launch_mode<1>(a, tiles, max_blocks, stream) : launch_mode<2>(a, tiles, max_blocks, stream);
 }

@@ -185,7 +185,11 @@ int cmtts_poll_error(void);
 int cmtts_set_option(const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
- * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4]. */
+ * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4].
+ * 3 = "fp16x3": every operand carried as hi = fp16(v), lo = fp16(v - hi) and every product as three fp16 MFMAs
+ * (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate): fp32-class accuracy (error vs float64 within 2x of the fp32
+ * kernels', tests/test_gpu_precision.py) at 3/16 of the fp32 matrix cost; used by the persistent stack (large
+ * batches), other shapes run the exact fp32 kernels. */
 int cmtts_set_precision(cmtts_model* m, int mode);
 /* Same switch for the HiFi-GAN ResBlock convs (94 % of the generator's FLOPs); conv_pre, the transposed
  * convs, conv_post and all activations in HBM stay fp32. */

@@ -56,7 +56,7 @@ class operands16:
     else (biases, gate, residual arithmetic, conv_pre / transposed convs / conv_post) is untouched."""
 
     def __init__(self, mode):
-        assert mode in (None, "fp32", "bf16", "fp16")
+        assert mode in (None, "fp32", "bf16", "fp16", "fp16x3")
         self.mode = None if mode == "fp32" else mode
 
     def __enter__(self):
@@ -79,6 +79,10 @@ def quant16(a, mode=None):
     a32 = np.ascontiguousarray(a, dtype=np.float32)
     if mode == "fp16":
         return a32.astype(np.float16).astype(F32)
+    if mode == "fp16x3":      # hi = fp16(v), lo = fp16(v - hi): the operand the library carries is hi + lo (22 significant bits);
+        hi = a32.astype(np.float16).astype(np.float32)          # its three-MFMA product omits only lo*lo (2^-22 relative)
+        lo = (a32 - hi).astype(np.float16).astype(np.float32)
+        return hi.astype(F32) + lo.astype(F32)
     u = a32.view(np.uint32)
     r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
     return r.astype(F32)

@@ -133,6 +133,23 @@ def test_precision_ladder_denoiser(golden_models, variant):
     n_conv = 2 * cfg.res_layers * n_steps
     for dt in ("bf16", "fp16"):
         check_ladder(f"denoiser T=4 {variant}", ref64, hip["fp32"], hip[dt], orc[dt], n_conv, dt, golden32=g["mel_T4"], deep=True)
+    # fp16x3 (two fp16 numbers per operand, three MFMAs per product): fp32-class — within 2x of the exact-fp32 kernels' own
+    # distance from float64, far inside the north-star 1e-3; forced onto the persistent stack (its only implementation)
+    lib = _lib.load()
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    try:
+        model.set_precision("fp16x3")
+        x3 = _np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise))
+    finally:
+        model.set_precision("fp32")
+        lib.cmtts_set_persistent_denoiser(prev)
+    with O.precision("f64"), O.operands16("fp16x3"):
+        o3 = O.karras_sample_tts(sd, cfg, g["cond"], spk_np, n_steps, noise_np)
+    e3, e3o = float(np.abs(x3 - ref64).max()), float(np.abs(o3 - ref64).max())
+    report(f"DTYPE_ERR denoiser T=4 {variant} fp16x3: vs f64 max|d| {e3:.2e} (exact fp32 kernels {e32:.2e}, 22-bit-operand oracle {e3o:.2e}); "
+           f"vs the reference's fp32 golden {np.abs(x3 - g['mel_T4']).max():.2e}")
+    assert e3 > 0 and not np.array_equal(x3, hip["fp32"])
+    assert e3 <= 2 * e32 + 2 * e3o and np.abs(x3 - g["mel_T4"]).max() < 1e-3
 
 
 @pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
