@@ -438,6 +438,17 @@ def main():
         voc.set_precision("fp32")
         extras["vocoder_bf16"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
                                   "note": "bf16 ResBlock-conv operands; bound by tensor passes, not by the 2.5 PFLOP/s pipe (profiles/r02_vocoder_bf16.md)"}
+        # fp16x3 everywhere (residual blocks + HiFi-GAN ResBlock convs): fp32-class accuracy, exploratory
+        model.set_precision("fp16x3")
+        voc.set_precision("fp16x3")
+        d = timed(e2e, k, 1, 1)
+        d_v = timed(lambda: state.__setitem__("wav", voc(mel_v)), 5, 2, 1) / 5
+        model.set_precision("fp32")
+        voc.set_precision("fp32")
+        assert torch.isfinite(state["wav"]).all()
+        extras["frames_per_s_end_to_end_wav_T4_fp16x3"] = round(frames_rank * k / d, 1)
+        extras["vocoder_fp16x3"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
+                                    "note": "fp16 hi + lo operands, three MFMAs per product (fp32-class; tests/test_gpu_precision.py)"}
         state["hifigan"] = (hcfg, synth_hifigan_state_dict(hcfg, seed=0))
         result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

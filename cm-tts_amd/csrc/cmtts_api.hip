@@ -454,7 +454,7 @@ struct cmtts_vocoder {
     int rb_kernel[3] = {3, 7, 11};
     int rb_dil[3] = {1, 3, 5};
     PackedConv c1[12][3], c2[12][3];
-    void *c1f[12][3][2] = {}, *c2f[12][3][2] = {};   // bf16 / fp16 fragment-order copies of the ResBlock convs
+    void *c1f[12][3][3] = {}, *c2f[12][3][3] = {};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies of the ResBlock convs
     float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
     float *post_w = nullptr, *post_b = nullptr;
@@ -1366,11 +1366,19 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
                 }
+                {
+                    const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
+                    CHK(al.upload_bytes(fs.data(), fs.size() * 2, &v->c1f[r][mi][2]));
+                }
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
+                }
+                {
+                    const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
+                    CHK(al.upload_bytes(fs.data(), fs.size() * 2, &v->c2f[r][mi][2]));
                 }
             }
         }
@@ -1467,7 +1475,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             // C = 64: 180 KB of 16-bit weights per 246 columns, 0.83 vs 0.64 ms; profiles/r02_vocoder_bf16.md): g_voc_pair == 2 forces it
             // g_voc_pair16p: the persistent form with register-resident weights has no per-tile weight stream: every (C, k)
             const bool pair16_pays = g_voc_pair16p || g_voc_pair == 2 || rk == 3 || (rk == 7 && co == 32);
-            const bool pair_ok = g_voc_pair && co <= 64 &&
+            const bool pair_ok = g_voc_pair && co <= 64 && v->precision != 3 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
@@ -1512,7 +1520,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 }
                 ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
-                if (v->precision) {
+                if (v->precision == 3) {                  // fp16x3: fp32 xt in HBM, operands split into hi + lo fp16 while staged
+                    if (cmtts_launch_conv16(&a, v->c1f[r][mi][2], 3, B, (void*)q) != 0)
+                        return fail(CMTTS_E_HIP, "conv16 launch failed");
+                } else if (v->precision) {
                     a.y16 = 1; a.y16_slope = 0.1f;        // xt crosses HBM as convert(leaky_relu(xt)) in 16 bits
                     if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
@@ -1526,7 +1537,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 b.pre_slope = 0.1f;
                 b.out[0].res = xr; b.out[0].r_zs0 = cs; b.out[0].ldr = ld;
                 b.out[0].accum = lastm && j > 0;
-                if (v->precision) {
+                if (v->precision == 3) {
+                    if (cmtts_launch_conv16(&b, v->c2f[r][mi][2], 3, B, (void*)q) != 0)
+                        return fail(CMTTS_E_HIP, "conv16 launch failed");
+                } else if (v->precision) {
                     b.x16 = 1;
                     if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
@@ -1645,7 +1659,7 @@ int cmtts_set_variance_controls(cmtts_model* m, const cmtts_variance_controls* v
 }
 
 int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode) {
-    if (!v || mode < 0 || mode > 2) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_precision: mode 0 (fp32), 1 (bf16) or 2 (fp16)");
+    if (!v || mode < 0 || mode > 3) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_precision: mode 0 (fp32), 1 (bf16), 2 (fp16) or 3 (fp16x3)");
     v->precision = mode;
     return 0;
 }

@@ -39,13 +39,20 @@ __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f3
 // IO: 0 = fp32 in / fp32 out, 1 = fp32 in / 16-bit activated out (conv1 of a ResBlock pair), 2 = 16-bit activated in /
 // fp32 out (conv2): the intermediate xt of a pair crosses HBM in 16 bits, with exactly the value conv2's staging would
 // have produced from an fp32 xt (convert(leaky_relu(xt))), so results do not change.
+// MODE 3 ("fp16x3", IO 0 only): operands carried as hi = fp16(v), lo = fp16(v - hi) — two LDS images of the X tile, two
+// fragment sets of the weights (lo follows hi) — and every product as three fp16 MFMAs (a_lo b_hi + a_hi b_lo + a_hi b_hi,
+// fp32 accumulate): fp32-class results at 3/16 of the fp32 matrix cost.
 template <int BM, int BN, int WM, int WN, int MODE, int IO>
-__global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(const ConvArgs a, const u32x4* __restrict__ wfrag) {
+__global__ __launch_bounds__(256, (BN > 128 || MODE == 3) ? 2 : 3) void conv1d_mfma16_kernel(const ConvArgs a, const u32x4* __restrict__ wfrag) {
     constexpr int MT = BM / (WM * 32);
     constexpr int NT = BN / (WN * 32);
+    constexpr int MM = MODE == 3 ? 2 : MODE;              // MFMA element type
+    constexpr int NS = MODE == 3 ? 2 : 1;                 // operand sets: (hi) [, lo]
+    static_assert(MODE != 3 || IO == 0, "fp16x3 keeps fp32 activations in HBM");
     constexpr int XJ = BN / 64 + 1;       // frames per lane of a staged channel row (halo <= 64)
     static_assert(WM * WN == 4, "4 waves");
-    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [2][XJ * 64][RSX]
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];   // [2 buffers][NS images][XJ * 64][RSX]
+    constexpr int IMG = (XJ * 64) * RSX;                  // elements of one image
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
             }
     };
     auto store_x = [&](int buf) {
-        unsigned short* xb = xs + buf * (XJ * 64) * RSX;
+        unsigned short* xb = xs + buf * NS * IMG;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -103,7 +110,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
                     pk = fpos[j] != 0.f ? (__float_as_uint(xr[p][0][j]) | (__float_as_uint(xr[p][1][j]) << 16)) : 0u;
                 } else {
                     const float v0 = xr[p][0][j], v1 = xr[p][1][j];
-                    pk = pack16<MODE>(v0 * (v0 > 0.f ? fpos[j] : fneg[j]), v1 * (v1 > 0.f ? fpos[j] : fneg[j]));
+                    const float a0 = v0 * (v0 > 0.f ? fpos[j] : fneg[j]), a1 = v1 * (v1 > 0.f ? fpos[j] : fneg[j]);
+                    pk = pack16<MM>(a0, a1);
+                    if (MODE == 3) {
+                        const cvt_f16x2 h = __builtin_bit_cast(cvt_f16x2, pk);
+                        *reinterpret_cast<unsigned*>(xb + IMG + (lane + 64 * j) * RSX + (wid * 4 + p) * 2) =
+                            pack16<2>(a0 - (float)h[0], a1 - (float)h[1]);
+                    }
                 }
                 *reinterpret_cast<unsigned*>(xb + (lane + 64 * j) * RSX + (wid * 4 + p) * 2) = pk;
             }
@@ -117,20 +130,26 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto load_a = [&](u32x4 (&dst)[MT], int tap, int kg) {
+    const long wset = (long)a.taps * G * MTn * 64;        // u32x4 per fragment set (MODE 3: the lo set follows the hi set)
+    auto load_a = [&](u32x4 (&dst)[NS][MT], int tap, int kg) {
         const int kgc = min(kg, G - 1);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mt = min(m0 / 32 + wm * MT + i, MTn - 1);
-            dst[i] = wfrag[((long)(tap * G + kgc) * MTn + mt) * 64 + lane];
-        }
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mt = min(m0 / 32 + wm * MT + i, MTn - 1);
+                dst[s][i] = wfrag[s * wset + ((long)(tap * G + kgc) * MTn + mt) * 64 + lane];
+            }
     };
-    auto load_b = [&](u32x4& dst, const unsigned short* xb, int q, int j) {    // q = tap * 2 + k-group-in-chunk
+    auto load_b = [&](u32x4 (&dst)[NS], const unsigned short* xb, int q, int j) {    // q = tap * 2 + k-group-in-chunk
         const int tap = q >> 1, kgl = q & 1;
-        const unsigned short* p = xb + ((wn * NT + j) * 32 + l31 + tap * a.dil - tap_min) * RSX + kgl * 16 + khalf * 8;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
-        dst = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned short* p = xb + s * IMG + ((wn * NT + j) * 32 + l31 + tap * a.dil - tap_min) * RSX + kgl * 16 + khalf * 8;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(p);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + 4);
+            dst[s] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
     };
 
     load_x(0);
@@ -140,10 +159,10 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool has_next = chunk + 1 < nchunks;
         if (has_next) load_x(chunk + 1);
-        const unsigned short* xb = xs + (chunk & 1) * (XJ * 64) * RSX;
+        const unsigned short* xb = xs + (chunk & 1) * NS * IMG;
         // A fragments one (tap, k-group) ahead; B fragments one MFMA column ahead (rolling pair), so a wave
         // never holds more than two B fragments.
-        u32x4 A[2][MT], Bf[2];
+        u32x4 A[2][NS][MT], Bf[2][NS];
         load_a(A[0], 0, chunk * 2);
         load_b(Bf[0], xb, 0, 0);
         for (int q = 0; q < nq; q += 2) {
@@ -158,7 +177,13 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
                     else load_b(Bf[cur ^ 1], xb, qn, 0);
                     // a chunk whose second k-group lies beyond K contributes zeros (X rows are zero-filled)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = mma16<MODE>(A[s][i], Bf[cur], acc[i][j]);
+                    for (int i = 0; i < MT; ++i) {
+                        if (MODE == 3) {      // small terms first
+                            acc[i][j] = mma16<MM>(A[s][1][i], Bf[cur][0], acc[i][j]);
+                            acc[i][j] = mma16<MM>(A[s][0][i], Bf[cur][1], acc[i][j]);
+                        }
+                        acc[i][j] = mma16<MM>(A[s][0][i], Bf[cur][0], acc[i][j]);
+                    }
                 }
             }
         }
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256, BN > 128 ? 2 : 3) void conv1d_mfma16_kernel(co
                     const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                     float v = acc[i][j][r] + bi[r];
                     v = v * (v > 0.f ? 1.f : a.y16_slope);
-                    if (n < a.N && m < a.M) y16[(unsigned)m * (unsigned)o.ldy + (unsigned)n] = (unsigned short)pack16<MODE>(v, 0.f);
+                    if (n < a.N && m < a.M) y16[(unsigned)m * (unsigned)o.ldy + (unsigned)n] = (unsigned short)pack16<MM>(v, 0.f);
                 }
             } else if (full_m) {
                 if (n < a.N) {
@@ -223,9 +248,14 @@ int launch16(const ConvArgs& a, const void* wfrag, int mode, int nbatch, hipStre
     const int adil = a.dil < 0 ? -a.dil : a.dil;
     const int halo = (a.taps - 1) * adil;
     if (halo > 64) return -2;
-    const size_t lds = (size_t)2 * (BN + 64) * RSX * sizeof(unsigned short);
+    const size_t lds = (size_t)(mode == 3 ? 2 : 1) * 2 * (BN + 64) * RSX * sizeof(unsigned short);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch);
     const int io = a.y16 ? 1 : (a.x16 ? 2 : 0);
+    if (mode == 3) {
+        if (io != 0) return -2;
+        hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, 3, 0>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
 #define CMTTS_L16(M_, IO_) hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, M_, IO_>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag)
     if (mode == 1) { if (io == 1) CMTTS_L16(1, 1); else if (io == 2) CMTTS_L16(1, 2); else CMTTS_L16(1, 0); }
     else { if (io == 1) CMTTS_L16(2, 1); else if (io == 2) CMTTS_L16(2, 2); else CMTTS_L16(2, 0); }
@@ -244,7 +274,7 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
     hipStream_t stream = (hipStream_t)stream_;
     if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
     const ConvOut& o = a.out[0];
-    if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || (mode != 1 && mode != 2) || a.K % KC != 0) return -2;
+    if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || mode < 1 || mode > 3 || a.K % KC != 0) return -2;
     if ((a.x16 && a.y16) || (a.y16 && (o.res || o.accum)) || (a.x16 && (a.pre_div != 1.f))) return -2;
     if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||
         o.row_off != 0 || o.Tout != a.N)

@@ -643,8 +643,9 @@ class Generator(torch.nn.Module):
         return self
 
     def set_precision(self, dtype="fp32"):
-        """Operand precision of the ResBlock convs: "fp32" (reference), "bf16" or "fp16"."""
-        mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}[dtype]
+        """Operand precision of the ResBlock convs: "fp32" (reference), "bf16", "fp16", or "fp16x3" (operands as hi + lo fp16
+        pairs, three fp16 MFMAs per product, fp32 accumulate: fp32-class results, activations stay fp32 in HBM)."""
+        mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2, "fp16x3": 3}[dtype]
         _lib.check(self.lib.cmtts_vocoder_set_precision(self._h, mode))
         return self
 

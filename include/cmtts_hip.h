@@ -192,7 +192,7 @@ int cmtts_set_option(const char* name, int value);
  * batches), other shapes run the exact fp32 kernels. */
 int cmtts_set_precision(cmtts_model* m, int mode);
 /* Same switch for the HiFi-GAN ResBlock convs (94 % of the generator's FLOPs); conv_pre, the transposed
- * convs, conv_post and all activations in HBM stay fp32. */
+ * convs, conv_post and all activations in HBM stay fp32.  Mode 3 = fp16x3 as above (fp32-class). */
 int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode);
 
 /* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still

@@ -207,6 +207,12 @@ def test_precision_ladder_vocoder(golden):
     assert np.abs(hip["fp32"] - ref64).max() < 1e-4
     for dt in ("bf16", "fp16"):
         check_ladder("vocoder", ref64, hip["fp32"], hip[dt], orc[dt], 24, dt, golden32=g["wav"])
+    voc.set_precision("fp16x3")
+    x3 = _np(voc(mel_ct))
+    voc.set_precision("fp32")
+    e3, e32 = float(np.abs(x3 - ref64).max()), float(np.abs(hip["fp32"] - ref64).max())
+    report(f"DTYPE_ERR vocoder fp16x3: vs f64 max|d| {e3:.2e} (exact fp32 kernels {e32:.2e}); vs the reference's fp32 golden {np.abs(x3 - g['wav']).max():.2e}")
+    assert 0 < e3 <= 4 * e32 + 1e-6 and np.abs(x3 - g["wav"]).max() < 1e-4 and not np.array_equal(x3, hip["fp32"])
 
 
 def _text_batch(cfg, B, L, seed):
