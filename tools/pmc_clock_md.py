@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Effective shader clock per kernel from a rocprofv3 --pmc pass with GRBM_GUI_ACTIVE (+ SQ_VALU_MFMA_BUSY_CYCLES,
-SQ_BUSY_CYCLES when present): clock = GRBM_GUI_ACTIVE / kernel duration (MI355X_MICROARCH.md, DVFS give-back).
-MFMA busy is then given twice: against the nominal 2.4 GHz and against the cycles the kernel actually had."""
+"""Effective shader clock per kernel from a rocprofv3 --pmc pass with GRBM_GUI_ACTIVE (+ SQ_VALU_MFMA_BUSY_CYCLES when
+present): clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (the counter is summed over the 8 XCDs; MI355X_MICROARCH.md,
+DVFS give-back).  MFMA busy is then given twice: against the nominal 2.4 GHz and against the cycles the kernel actually
+had.  Kernels shorter than 100 us are left out (the counter's window is not the kernel's)."""
+XCDS = 8
 import csv, glob, re, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 agg, seen = collections.OrderedDict(), set()
@@ -21,10 +23,12 @@ tot = sum(v["_ns"] for _, v in rows)
 print("| kernel | launches | avg µs | effective clock (GRBM_GUI_ACTIVE / time) | MFMA busy vs 2.4 GHz nominal | MFMA busy vs actual cycles |")
 print("|---|---:|---:|---:|---:|---:|")
 for k, v in rows:
-    if v["_ns"] < 0.002 * tot:
+    if v["_ns"] < 0.002 * tot or v["_ns"] / v["_n"] < 1e5:
         continue
-    ghz = v.get("GRBM_GUI_ACTIVE", 0.0) / v["_ns"]
+    cyc = v.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
+    ghz = cyc / v["_ns"]
     busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-    print("| `%s` | %d | %.1f | %.2f GHz | %.1f %% | %.1f %% |" % (
-        k, v["_n"], v["_ns"] / v["_n"] / 1e3, ghz, 100 * busy / (v["_ns"] * 2.4 * 1024),
-        100 * busy / max(v.get("GRBM_GUI_ACTIVE", 0.0) * 1024, 1.0)))
+    print("| `%s` | %d | %.1f | %.2f GHz | %s | %s |" % (
+        k, v["_n"], v["_ns"] / v["_n"] / 1e3, ghz,
+        "%.1f %%" % (100 * busy / (v["_ns"] * 2.4 * 1024)) if busy else "–",
+        "%.1f %%" % (100 * busy / max(cyc * 1024, 1.0)) if busy else "–"))
