@@ -5,20 +5,25 @@
 // Why: at C = 32 / 64 a layer-granular conv does 2*C*k = 192 ... 1408 FLOP per output element against 8-12 B of HBM
 // traffic — on or below the fp32 ridge (157 TFLOP/s : 6.3 TB/s = 25 FLOP/B) — and re-stages a weight tile every
 // (16-channel chunk, tap) iteration for a K loop that is only C*k/2 = 48 ... 352 MFMAs long: SQ counters put the matrix
-// pipe at 57 % (C = 64) and 44 % (C = 32) busy (profiles/r01_pmc_mfma_busy.md).  Here a workgroup keeps a 256-column tile
-// on chip for BOTH convs:
+// pipe at 57 % (C = 64) and 44 % (C = 32) busy (profiles/r01_pmc_mfma_busy.md).  Here a workgroup keeps a column tile on
+// chip for BOTH convs:
 //
-//   * LDS holds the raw x tile [C][256 + 2*r1] (r1 = d*(k-1)/2: conv1's halo; it is also the residual operand) and the
-//     xt tile [C][256] (+ k-1 slack columns): x crosses HBM once per pair (plus 10-24 % halo re-reads served by L2), xt
-//     never leaves the CU, y is written once: 2 tensor passes instead of 5.  conv1 is evaluated on 256 columns of which
-//     256 - (k-1) produce outputs (conv2's halo is recomputed, not exchanged: 1-4 % extra MFMAs);
-//   * every wave owns ONE 32-row m-tile x TWO 32-column n-tiles; its weights stream L2 -> VGPR in MFMA A-fragment order
-//     (one global_load_dwordx4 = the A operand of 4 k-steps = 8 MFMAs) through a 4-deep register ring: no weight tile in
-//     LDS, no barrier inside a conv's K loop, three barriers per tile.  128 B of weights per MFMA — the per-CU L2 -> CU
-//     ingest measured in tools/mfma_probe.hip carries 192;
-//   * B operands are conflict-free ds_read_b32 (32 consecutive floats per half-wave), one k-group ahead of their MFMAs;
-//     the LeakyReLU of conv1's operand is applied on the fly (x stays raw for the residual), conv2's operand is stored
-//     activated by conv1's epilogue.
+//   * LDS holds the x tile [C][N1 + 2*r1] (r1 = d*(k-1)/2: conv1's halo), stored ACTIVATED (LeakyReLU applied once by the
+//     staging pass, not per MFMA operand), and the activated xt tile [C][N1 + k - 1]: x crosses HBM once per pair (plus
+//     10-24 % halo re-reads served by L2), xt never leaves the CU, the raw residual operand is prefetched from global (L2)
+//     into registers before conv2's K loop, y is written once: 2 tensor passes instead of 5.  conv1 is evaluated on N1
+//     columns of which N1 - (k-1) produce outputs (conv2's halo is recomputed, not exchanged: 1-8 % extra MFMAs).
+//     N1 = 256 (C = 32) / 128 (C = 64): <= 80 KB => TWO workgroups per CU, one stages / stores while the other multiplies;
+//   * every wave owns ONE 32-row m-tile x TWO 32-column n-tiles; its weights stream L2 -> VGPR in MFMA A-fragment order,
+//     packed host-side in the K loop's ITERATION order ([chunk][tap][half][m-tile][lane][4]: one linear walk, one
+//     global_load_dwordx4 = the A operand of 4 k-steps = 8 MFMAs) through a 4-deep register ring: no weight tile in LDS,
+//     no barrier inside a conv's K loop, three barriers per tile.  128 B of weights per MFMA — the per-CU L2 -> CU ingest
+//     measured in tools/mfma_probe.hip carries 192;
+//   * B operands are conflict-free ds_read_b32 (32 consecutive floats per half-wave); the LDS reads and the A load of a
+//     later k-group are THREADED between the MFMAs of the current one (sched_group_barrier), because a wave issues in
+//     order and a bunch of loads between two runs of MFMAs idles the pipe while they issue.
+//
+// conv_xl_kernel (C = 128 / 256) is the same K loop for ONE conv per launch with the whole activated x tile staged once.
 //
 // Accumulation order = the generic kernel's (16-channel chunk, tap, k) and the same epilogue expressions ((acc + b) + x
 // [+ y_old]) => BITWISE equal to the two-launch path (tests/test_gpu_parity.py::test_vocoder_pair_kernel_bitwise).
