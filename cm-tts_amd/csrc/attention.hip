@@ -56,17 +56,32 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
     }
 
     auto stage = [&](const float* src, float* dst, int dst_ld, int key0) {
-        // [DH][KB] tile, keys beyond L zero-filled; float4 loads along the key axis (rows are 16-B aligned: ld % 4 == 0)
-        for (int idx = tid; idx < DH * (KB / 4); idx += NTHREADS) {
+        // [DH][KB] tile, keys beyond L zero-filled; float4 loads along the key axis (rows are 16-B aligned: ld % 4 == 0).
+        // ALL of a thread's loads are issued (unconditional, clamped addresses) before the first LDS write: one memory round
+        // trip per chunk instead of one per float4
+        constexpr int NV = DH * (KB / 4);
+        constexpr int PER = (NV + NTHREADS - 1) / NTHREADS;
+        f32x4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = min(tid + u * NTHREADS, NV - 1);
             const int d = idx / (KB / 4), c4 = idx - d * (KB / 4);
-            const int j = key0 + 4 * c4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (j < ld) v = *reinterpret_cast<const f32x4*>(src + (long)d * ld + j);
-            float* p = dst + d * dst_ld + 4 * c4;
-            p[0] = j + 0 < L ? v[0] : 0.f;
-            p[1] = j + 1 < L ? v[1] : 0.f;
-            p[2] = j + 2 < L ? v[2] : 0.f;
-            p[3] = j + 3 < L ? v[3] : 0.f;
+            const int j = min(key0 + 4 * c4, ld - 4);
+            v[u] = *reinterpret_cast<const f32x4*>(src + (long)d * ld + j);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < NV) {
+                const int d = idx / (KB / 4), c4 = idx - d * (KB / 4);
+                const int j = key0 + 4 * c4;
+                const bool in = j <= ld - 4;          // a float4 starting beyond the row lies wholly beyond L
+                float* p = dst + d * dst_ld + 4 * c4;
+                p[0] = in && j + 0 < L ? v[u][0] : 0.f;
+                p[1] = in && j + 1 < L ? v[u][1] : 0.f;
+                p[2] = in && j + 2 < L ? v[u][2] : 0.f;
+                p[3] = in && j + 3 < L ? v[u][3] : 0.f;
+            }
         }
     };
 

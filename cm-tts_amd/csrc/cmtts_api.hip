@@ -276,6 +276,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip) when L <= 192: 0 = three-launch path
 int g_voc_pair16p = 0;          // 16-bit ResBlock pairs through the persistent register-resident-weight kernel (resblock_pair16.hip): measured slower (one wave per SIMD serialises its staging / epilogue work, profiles/r02_vocoder_bf16.md): off
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
@@ -399,6 +400,8 @@ struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     PackedConv qk, qkv, wo, ffn1, ffn2;     // qkv: the whole in_proj_weight as one [3H][H] contraction (fused attention path)
     float* ffn1_f = nullptr;   // ffn1 as MFMA A fragments in iteration order (conv_xres.hip)
+    float* qkv_f = nullptr;    // the same for the in-projection and the out-projection (round 2: LayerNorm + projection in one launch)
+    float* wo_f = nullptr;
     float* wvT;  // [256 c][256 d]
 };
 struct Predictor {
@@ -526,11 +529,19 @@ int finalize_model(cmtts_model* m) {
         qk.data.assign(inw->data.begin(), inw->data.begin() + (size_t)2 * H * H);
         CHK(pack_conv(al, qk, nullptr, nullptr, &L.qk));
         HostTensor qkv = *inw; qkv.shape = {3 * H, H, 1};
-        CHK(pack_conv(al, qkv, nullptr, nullptr, &L.qkv));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, qkv, nullptr, nullptr, &L.qkv, &hp));
+            if (H % 32 == 0 && L.qkv.ld == L.qkv.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, H, 3 * H), &L.qkv_f));
+        }
         CHK(al.upload(transpose2d(inw->data.data() + (size_t)2 * H * H, H, H), &L.wvT));
         GET(ow, p + "self_attn.out_proj.weight", H, H);
         HostTensor ow3 = *ow; ow3.shape = {H, H, 1};
-        CHK(pack_conv(al, ow3, nullptr, nullptr, &L.wo));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, ow3, nullptr, nullptr, &L.wo, &hp));
+            if (H % 32 == 0 && L.wo.ld == L.wo.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, H, H), &L.wo_f));
+        }
         GET(f1w, p + "ffn.ffn_1.weight", 4 * H, H, c.ffn_kernel); GET(f1b, p + "ffn.ffn_1.bias", 4 * H);
         {
             std::vector<float> hp;
@@ -1038,15 +1049,35 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
     const cmtts_config& c = m->cfg;
     const int H = c.hidden, Lp = round_up(L, 4), NH = c.enc_heads, dh = H / NH;
     const long hs = (long)H * Lp;
+    // X-resident kernel (conv_xres.hip) for the K = 256 contractions when its 96-column tiles pad no more than 64-column ones
+    const int t96 = (L + 95) / 96, t64 = (L + 63) / 64;
+    const bool xres_cols = g_ffn_xres && t96 * 96 <= t64 * 64;
     for (size_t i = 0; i < layers.size(); ++i) {
         const EncLayer& E = layers[i];
-        k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+        const bool fused_attn = g_attn_fused && dh == 128 && L <= 192;
+        // LayerNorm1 as the prologue of the in-projection: one launch, no normalised copy in HBM
+        const bool ln_qkv = fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && (long)t96 * (3 * H / 128) * B >= 128;
+        if (!ln_qkv) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
         bool attn_done = false;
-        if (g_attn_fused && dh == 128 && L <= 192) {
+        if (fused_attn) {
             // q, k, v = h * W_in^T as ONE contraction, then softmax(q k^T / sqrt(dh) + mask) v in one launch per layer:
             // scores and probabilities never leave the CU (attention.hip)
-            ConvArgs a = conv_args(E.qkv, w.h, L, Lp, hs, w.qk, Lp, 3 * hs, L);
-            CHK(launch(a, EPI_PLAIN, B, s));
+            int rq = -2;
+            if (ln_qkv) {
+                ConvArgs a = conv_args(E.qkv, w.x, L, Lp, hs, w.qk, Lp, 3 * hs, L);
+                a.ln_g = E.ln1_g; a.ln_b = E.ln1_b; a.ln_eps = 1e-12f;
+                if (g_text_xres & 8) {   // debugging aid: the projection on the X-resident kernel behind a separate LayerNorm launch
+                    k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+                    a.X = w.h; a.ln_g = a.ln_b = nullptr;
+                }
+                rq = cmtts_launch_conv_xres(&a, E.qkv_f, B, (void*)s);
+                if (rq == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+                if (rq != 0) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+            }
+            if (rq != 0) {
+                ConvArgs a = conv_args(E.qkv, w.h, L, Lp, hs, w.qk, Lp, 3 * hs, L);
+                CHK(launch(a, EPI_PLAIN, B, s));
+            }
             AttnArgs at;
             memset(&at, 0, sizeof(at));
             at.qkv = w.qk; at.out = w.o; at.lens = src_lens; at.bstride = 3 * hs; at.obstride = hs;
@@ -1104,20 +1135,31 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
         {   // x = (x + out_proj(o)) * nonpad      (model/blocks.py:609-610)
             ConvArgs a = conv_args(E.wo, w.o, L, Lp, hs, w.x, Lp, hs, L);
             a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
-            CHK(launch(a, EPI_PLAIN, B, s));
-        }
-        k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
-        {   // gelu((conv_k9(h) + b) * k^-0.5)      (model/blocks.py:539-546)
-            ConvArgs a = conv_args(E.ffn1, w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
-            a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
-            a.out[0].act = ACT_GELU_ERF;
-            // X-resident kernel when it fills the chip and its 96-column tiles pad no more than the 64-column ones
-            const int t96 = (L + 95) / 96, t64 = (L + 63) / 64;
             int rc = -2;
-            if (g_ffn_xres && E.ffn1_f && t96 * 96 <= t64 * 64 && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128)
-                rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
+            if ((g_text_xres & 2) && E.wo_f && xres_cols && (long)t96 * (H / 128) * B >= 64)
+                rc = cmtts_launch_conv_xres(&a, E.wo_f, B, (void*)s);
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        {   // gelu((conv_k9(LayerNorm2(x)) + b) * k^-0.5)      (model/blocks.py:539-546, 612-615)
+            // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
+            const bool xr = xres_cols && E.ffn1_f && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128;
+            const bool ln_ffn = xr && (g_text_xres & 4);
+            if (!ln_ffn) k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+            ConvArgs a = conv_args(E.ffn1, ln_ffn ? w.x : w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
+            a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
+            a.out[0].act = ACT_GELU_ERF;
+            if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; }
+            int rc = -2;
+            if (xr) rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
+            if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+            if (rc != 0) {
+                if (ln_ffn) {
+                    k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+                    a.X = w.h; a.ln_g = a.ln_b = nullptr;
+                }
+                CHK(launch(a, EPI_PLAIN, B, s));
+            }
         }
         {   // x = (x + ffn_2(.)) * nonpad          (:551, :616-617)
             ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.x, Lp, hs, L);
@@ -1592,6 +1634,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
     }
+    if (!strcmp(name, "text_xres")) {     // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection, 2 = out-projection, 4 = LayerNorm2 + FFN conv on the X-resident kernel
+        const int prev = g_text_xres;
+        if (value >= 0 && value <= 15) g_text_xres = value;
+        return prev;
+    }
     if (!strcmp(name, "attn_fused")) {    // FFT-block attention: 1 = QKV projection + one fused kernel (L <= 192), 0 = three launches
         const int prev = g_attn_fused;
         if (value == 0 || value == 1) g_attn_fused = value;
@@ -1674,6 +1721,7 @@ int cmtts_set_debug_stamps(void* dev_buf) {
     cmtts_resblock_set_debug((long long*)dev_buf);
     cmtts_persist_set_debug((long long*)dev_buf);
     cmtts_pair_set_debug((long long*)dev_buf);
+    cmtts_xres_set_debug((long long*)dev_buf);
     return 0;
 }
 

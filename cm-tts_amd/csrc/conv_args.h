@@ -52,6 +52,10 @@ struct ConvArgs {
     int x16;              // X holds 16-bit values that are already activated (no pre_div / pre_slope applied)
     int y16;              // Y is written as 16-bit leaky_relu(v, y16_slope) instead of fp32 v
     float y16_slope;
+    // X-resident kernel only (conv_xres.hip): LayerNorm over the K rows of X as a prologue on the staged tile (null = none)
+    const float* ln_g;
+    const float* ln_b;
+    float ln_eps;
 };
 
 #ifdef __cplusplus
@@ -64,6 +68,7 @@ int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
 int cmtts_launch_conv16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
 // X-resident variant for short sequences (conv_xres.hip): wfrag = fp32 fragment-order weights; -2 = unsupported.
 int cmtts_launch_conv_xres(const ConvArgs* a, const float* wfrag, int nbatch, void* stream);
+void cmtts_xres_set_debug(long long* dbg);   // cycle stamps [workgroup][wave][8] (tools/xres_phases.py); nullptr = off
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,14 @@
 // (iteration order [chunk][tap][half][m-tile][lane][4], one dwordx4 per 12 MFMAs) through a register ring — no weight staging,
 // no barrier in the K loop.  Same (16-channel chunk, tap, k) accumulation order and the same epilogue arithmetic as
 // the generic kernel: BITWISE equal (tests/test_gpu_parity.py::test_xres_conv_bitwise).
+//
+// Round 2: the same kernel runs the other K = 256 contractions of an FFT block (QKV projection, k = 1), optionally with the
+// block's LayerNorm as a PROLOGUE on the staged tile (a.ln_g != nullptr: mean / variance over the K rows of every column,
+// two lane halves x 128 rows each, partial sums exchanged with __shfl_xor — no LDS scratch, no extra launch, no normalised
+// copy in HBM; layernorm_ct_kernel's summation order => the same bits); the tile is staged with 16-byte loads, 13 in flight per lane, when rows are 16-byte aligned; the epilogue is
+// compiled per activation (the run-time switch of the generic epilogue cost 32 k of this kernel's 315 k cycles per wave).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "conv_args.h"
 #include "conv_epilogue.h"
 
@@ -21,12 +28,31 @@ constexpr int HALO = 8;         // (taps - 1) * dil <= 8
 constexpr int X_LD = BN + HALO; // 104
 constexpr int RING = 4;
 
-__global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag) {
+template <bool LN>
+__global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // cycle stamps per wave (tools/xres_phases.py; dbg == nullptr in normal operation)
+    auto stamp = [&](int slot) {
+        if (dbg && lane == 0)
+            dbg[((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + w) * 8 + slot] =
+                (long long)__builtin_readcyclecounter();
+    };
+    stamp(0);
+    // workgroup -> (m-block, utterance): consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own L2);
+    // with one column tile per utterance and a multiple of 8 utterances, all m-blocks of an utterance are put on ONE XCD, so
+    // the burst that stages X at the start of the launch reads every utterance's tile from HBM once instead of once per XCD
+    // (the weights, whose stream is spread over the whole K loop, are then read by every XCD)
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.x == 1 && (gridDim.z & 7) == 0) {
+        const int lin = blockIdx.y + gridDim.y * blockIdx.z;
+        const int slot = lin >> 3;
+        by = slot % gridDim.y;
+        bz = (lin & 7) + 8 * (slot / gridDim.y);
+    }
     const int n0 = blockIdx.x * BN;
-    const int mt = blockIdx.y * 4 + w;             // this wave's m-tile
-    const int z = blockIdx.z;
+    const int mt = by * 4 + w;             // this wave's m-tile
+    const int z = bz;
     const int l31 = lane & 31, khalf = lane >> 5;
     const float* Xb = a.X + z * a.x_zs0;
     const int MTn = (a.M + 31) / 32;
@@ -43,9 +69,39 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
 
-    {   // stage X[k][n0 - pad + c], c in [0, X_LD): zero outside [0, Tin); lane = column (two passes), a quarter of the
+    const int xw = BN + (a.taps - 1) * a.dil;
+    float* gs = xs + a.K * X_LD;                   // LayerNorm weight / bias [2][256] behind the tile
+    if (LN) { gs[tid] = a.ln_g[tid]; gs[256 + tid] = a.ln_b[tid]; }
+    if (((n0 - a.pad) & 3) == 0 && (a.ldx & 3) == 0 && ((uintptr_t)Xb & 15) == 0) {
+        // 16-byte loads: tile row = X_LD / 4 = 26 float4; a float4 that starts outside [0, ldx - 4] lies wholly outside [0, Tin)
+        constexpr int V = X_LD / 4, U = 26;
+        const int nvec = a.K * V;
+        const int t00 = n0 - a.pad;
+#pragma unroll 1
+        for (int base = tid; base < nvec; base += 256 * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = min(base + 256 * u, nvec - 1);
+                const int row = idx / V, c4 = idx - row * V;
+                const int t4 = min(max(t00 + 4 * c4, 0), a.ldx - 4);
+                v[u] = *reinterpret_cast<const f32x4*>(Xb + (long)row * a.ldx + t4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + 256 * u;
+                if (idx < nvec) {
+                    const int row = idx / V, c4 = idx - row * V;
+                    const int c = 4 * c4, t = t00 + c;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (c + e < xw && t + e >= 0 && t + e < a.Tin) ? v[u][e] : 0.f;
+                    *reinterpret_cast<f32x4*>(xs + row * X_LD + c) = o;
+                }
+            }
+        }
+    } else {   // stage X[k][n0 - pad + c], c in [0, X_LD): zero outside [0, Tin); lane = column (two passes), a quarter of the
         // rows per wave, 32 unconditional clamped loads in flight per lane
-        const int xw = BN + (a.taps - 1) * a.dil;
         const int rows = a.K / 4;
 #pragma unroll
         for (int cp = 0; cp < 2; ++cp) {
@@ -66,7 +122,68 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
             }
         }
     }
+    stamp(1);
     __syncthreads();
+    if (LN) {
+        // LayerNorm over the K = 256 rows of every staged column that lies inside [0, Tin) (model/blocks.py:88-107; padding
+        // columns stay 0: the conv pads the NORMALISED sequence).  Column = 32 w + (lane & 31); the summation order is
+        // layernorm_ct_kernel's (kernels.hip: eight partial sums over rows y + 8 i, added in the order y = 0..7), four partials
+        // per lane half, exchanged with __shfl_xor => the same bits as the separate launch, whatever path a batch takes.
+        const int c = 32 * w + l31;
+        const int t = n0 - a.pad + c;
+        const bool on = c < xw && t >= 0 && t < a.Tin;
+        const float* col = xs + min(c, X_LD - 1);
+        float p[4] = {0.f, 0.f, 0.f, 0.f}, q[4];
+        const float* cr = col + 4 * khalf * X_LD;
+#pragma unroll 8
+        for (int i2 = 0; i2 < 32; ++i2)          // four independent chains, rows y + 8 i2: loads of a whole unrolled block in flight
+#pragma unroll
+            for (int y = 0; y < 4; ++y) p[y] += cr[(y + 8 * i2) * X_LD];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) q[y] = __shfl_xor(p[y], 32);
+        float tot = 0.f;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) tot += khalf ? q[y] : p[y];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) tot += khalf ? p[y] : q[y];
+        const float mean = tot / 256.0f;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) p[y] = 0.f;
+#pragma unroll 8
+        for (int i2 = 0; i2 < 32; ++i2)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { const float d = cr[(y + 8 * i2) * X_LD] - mean; p[y] = __fmaf_rn(d, d, p[y]); }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) q[y] = __shfl_xor(p[y], 32);
+        float var = 0.f;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) var += khalf ? q[y] : p[y];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) var += khalf ? p[y] : q[y];
+        var = var / 256.0f;
+        const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+        if (on) {
+            float* wc = xs + c + 4 * khalf * X_LD;
+            const float* g = gs + 4 * khalf;
+            const float* be = gs + 256 + 4 * khalf;
+#pragma unroll 1
+            for (int i0 = 0; i0 < 32; i0 += 4) {      // 16 rows per batch: all reads issued before the first write (the compiler
+                float xv[16], gv[16], bv[16];         // cannot reorder LDS reads over LDS writes on its own)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = (e & 3) + 8 * (i0 + (e >> 2));
+                    xv[e] = wc[k * X_LD]; gv[e] = g[k]; bv[e] = be[k];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = (e & 3) + 8 * (i0 + (e >> 2));
+                    wc[k * X_LD] = __fmaf_rn((xv[e] - mean) * rstd, gv[e], bv[e]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    stamp(2);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -111,16 +228,39 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
             }
         }
     }
+    stamp(3);
     if (mt >= MTn) return;
     const ConvOut& o = a.out[0];
+#if defined(XRES_ABL) && XRES_ABL == 2
+    if (epi_simple(o)) {       // timing-only build: no activation
 #pragma unroll
-    for (int j = 0; j < NT; ++j) epi_tile(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z, 0);
+        for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_NONE>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);
+    } else
+#endif
+    if (epi_simple(o) && o.act == ACT_GELU_ERF) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_GELU_ERF>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);
+    } else if (epi_simple(o) && o.act == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_RELU>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);
+    } else if (epi_simple(o) && o.act == ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_NONE>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) epi_tile(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z, 0);
+    }
+    stamp(4);
 }
+
+long long* g_xres_dbg = nullptr;
 
 }  // namespace
 
+extern "C" void cmtts_xres_set_debug(long long* dbg) { g_xres_dbg = dbg; }
+
 // Conv1d with fp32 weights as MFMA A fragments in iteration order [K/16][taps][2][ceil(M/32)][64][4]; zdiv == 1, split == INT_MAX,
-// dil > 0, K % 32 == 0, K <= 256, (taps-1)*dil <= 8, no pre-activation.  Meant for short sequences (N of a few 96-column tiles)
+// dil > 0, K % 32 == 0, K <= 256, (taps-1)*dil <= 8, no pre-activation; a.ln_g / ln_b / ln_eps = LayerNorm prologue over the K rows.  Meant for short sequences (N of a few 96-column tiles)
 // with many output rows.  Returns 0, -2 (unsupported: use cmtts_launch_conv) or -3.
 extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, int nbatch, void* stream_) {
     const ConvArgs& a = *ap;
@@ -128,15 +268,23 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
     if (!wfrag || a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || a.K % 32 != 0 || a.K > KMAX || (a.taps - 1) * a.dil > HALO ||
         a.pre_div != 1.0f || a.pre_slope != 1.0f)
         return -2;
+    if (a.ln_g && (!a.ln_b || a.K != 256)) return -2;
     static bool attr_set = false;
-    const size_t lds = (size_t)a.K * X_LD * sizeof(float);
+    const size_t lds = (size_t)a.K * X_LD * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)KMAX * X_LD * sizeof(float))) != hipSuccess)
+        const int mx = (int)((size_t)KMAX * X_LD * sizeof(float) + 2 * 256 * sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return -3;
         attr_set = true;
     }
     dim3 grid((a.N + BN - 1) / BN, ((a.M + 31) / 32 + 3) / 4, nbatch);
-    hipLaunchKernelGGL(conv_xres_kernel, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag);
+    long long* dbg = g_xres_dbg;
+    if (dbg) {    // CMTTS_XRES_DBG_M=<rows>: stamps of the launches with that many output rows only (tools/xres_phases.py)
+        static const char* want = getenv("CMTTS_XRES_DBG_M");
+        if (want && atoi(want) != a.M) dbg = nullptr;
+    }
+    if (a.ln_g) hipLaunchKernelGGL(conv_xres_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag, dbg);
+    else hipLaunchKernelGGL(conv_xres_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag, dbg);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, floa
     __syncthreads();
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; sq += d * d; }
+    for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; sq = __fmaf_rn(d, d, sq); }   // explicit: conv_xres.hip's fused LayerNorm repeats exactly this sequence
     red[ty][tx] = sq;
     __syncthreads();
     float var = 0.f;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, floa
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int c = ty + 8 * i;
-            const float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            const float y = __fmaf_rn((v[i] - mean) * rstd, gamma[c], beta[c]);
             out[((long)b * C + c) * ld + t] = keep ? y : 0.f;
         }
     }

@@ -916,7 +916,8 @@ def test_split_resblock_bitwise(variant, B, T):
 def test_xres_conv_bitwise(models):
     """conv_xres.hip (k=9 FFN conv with the utterance's X tile resident in LDS, 96-column tiles) keeps the generic
     kernel's accumulation order and epilogue: the text encoder output must not change by a bit (B=32 x L=85 takes the
-    X-resident path, the ragged golden batch the generic one)."""
+    X-resident path, the ragged golden batch the generic one).  Round 2: the same for the LayerNorm prologue (the fused
+    normalisation keeps layernorm_ct_kernel's summation order) and for the in- / out-projections on that kernel."""
     host = _host()
     lib = _lib.load()
     g, cfg, sd, model = models("LJSpeech")
@@ -927,15 +928,23 @@ def test_xres_conv_bitwise(models):
     texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     prev = lib.cmtts_set_option(b"ffn_xres", 1)
+    prev_t = lib.cmtts_set_option(b"text_xres", 0)
     try:
-        one = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        one = run()                                   # X-resident k=9 conv, separate LayerNorm launches
+        outs = []
+        for bits in (9, 1, 2, 4, 7):                     # LayerNorm1 + in-projection | out-projection | LayerNorm2 + FFN conv | all
+            lib.cmtts_set_option(b"text_xres", bits)
+            outs.append((f"text_xres={bits}", run()))
         lib.cmtts_set_option(b"ffn_xres", 0)
-        ref = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        ref = run()
     finally:
         lib.cmtts_set_option(b"ffn_xres", prev)
+        lib.cmtts_set_option(b"text_xres", prev_t)
     torch.cuda.synchronize()
     for k in ("enc_out", "log_d_predictions", "cond"):
-        assert torch.equal(one[k], ref[k]), (k, float((one[k] - ref[k]).abs().max()))
+        for name, got in [("xres", one)] + outs:
+            assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
 
 
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
