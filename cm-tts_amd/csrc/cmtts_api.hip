@@ -276,6 +276,8 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
+int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
 int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip) when L <= 192: 0 = three-launch path
 int g_voc_pair16p = 0;          // 16-bit ResBlock pairs through the persistent register-resident-weight kernel (resblock_pair16.hip): measured slower (one wave per SIMD serialises its staging / epilogue work, profiles/r02_vocoder_bf16.md): off
@@ -406,6 +408,7 @@ struct EncLayer {
 };
 struct Predictor {
     std::vector<PackedConv> convs;
+    std::vector<float*> convs_f;     // 256 -> 256 convs as MFMA A fragments in iteration order (conv_xl_kernel), else null
     std::vector<float*> ln_g, ln_b;
     float *lin_w = nullptr, *lin_b = nullptr, *alpha = nullptr;
     int odim = 0;
@@ -588,7 +591,13 @@ int finalize_model(cmtts_model* m) {
             const int cin = li == 0 ? idim : c.pred_filter;
             const std::string q = p + "conv." + std::to_string(li);
             GET(w, q + ".1.weight", c.pred_filter, cin, k); GET(b, q + ".1.bias", c.pred_filter);
-            CHK(pack_conv(al, *w, b, nullptr, &P.convs[li]));
+            {
+                std::vector<float> hp;
+                CHK(pack_conv(al, *w, b, nullptr, &P.convs[li], &hp));
+                P.convs_f.resize(n_layers, nullptr);
+                if ((cin == 256 || (cin == 128 && k == 5)) && c.pred_filter == 256 && P.convs[li].ld == 256)
+                    CHK(al.upload(to_fragment_iter_order(hp, k, cin, c.pred_filter), &P.convs_f[li]));
+            }
             GET(lg, q + ".3.weight", c.pred_filter); GET(lb, q + ".3.bias", c.pred_filter);
             UP(P.ln_g[li], lg); UP(P.ln_b[li], lb);
         }
@@ -818,19 +827,39 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 
 // conv stack of Duration/Pitch/Energy predictors (model/modules.py:477-487): Conv1d + ReLU ->
 // LayerNorm over channels (eps 1e-12) [-> mask].  Result ends in bufB.
-int predictor_convs(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* lens,
-                    float* bufA, float* bufB, hipStream_t s) {
+// conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
+// block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_set_option("pred_head", 0)
+int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
+              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s) {
     const float* cur = in;
     int ldc = ld_in;
     for (size_t li = 0; li < P.convs.size(); ++li) {
         const PackedConv& w = P.convs[li];
-        ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, bufA, ld, (long)w.cout * ld, T);
-        a.out[0].act = ACT_RELU;
-        CHK(launch(a, EPI_PLAIN, B, s));
-        k_layernorm_ct(bufA, bufB, P.ln_g[li], P.ln_b[li], 1e-12f, lens, B, T, ld, s);
+        int rx = -2;
+        if (g_pred_xl && P.convs_f[li] && ldc == ld && bufA != cur && (long)((T + 63) / 64) * B >= 192) {
+            // frame-level 256 -> 256 conv: whole x tile + halo resident in LDS, weights streamed as A fragments (the HiFi-GAN
+            // kernel, resblock_pair.hip; same accumulation order and epilogue expressions as the generic kernel => same bits)
+            ConvXlArgs xa;
+            memset(&xa, 0, sizeof(xa));
+            xa.x = cur; xa.y = bufA; xa.wf = P.convs_f[li]; xa.bias = w.bias; xa.bstride = (long)w.cout * ld;
+            xa.B = B; xa.C = 256; xa.T = T; xa.ld = ld; xa.k = w.taps; xa.dil = 1; xa.slope = 1.0f; xa.relu = 1;
+            if (w.cin != 256) { xa.cin = w.cin; xa.xbstride = (long)w.cin * ldc; }
+            rx = cmtts_launch_conv_xl(&xa, (void*)s);
+            if (rx == -3) return fail(CMTTS_E_HIP, "conv_xl launch failed");
+        }
+        if (rx != 0) {
+            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, bufA, ld, (long)w.cout * ld, T);
+            a.out[0].act = ACT_RELU;
+            CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
+            k_ln_linear(bufA, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
+            return 0;
+        k_layernorm_ct(bufA, bufB, P.ln_g[li], P.ln_b[li], 1e-12f, ln_lens, B, T, ld, s);
         cur = bufB;
         ldc = ld;
     }
+    k_chan_linear(cur, P.lin_w, P.lin_b, out, out_lens, B, P.convs.back().cout, T, ld, O, s);
     return 0;
 }
 
@@ -1209,12 +1238,10 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     float* ec2 = ss ? w.qk + (size_t)B * H * Lp : w.c2;
     if (ss) CHK(branch_fork(ss));
     // duration predictor (masked) -> log_d
-    CHK(predictor_convs(m->dur, w.x, Lp, B, L, Lp, src_lens, w.c1, w.c2, s));
-    k_chan_linear(w.c2, m->dur.lin_w, m->dur.lin_b, log_d, src_lens, B, c.pred_filter, L, Lp, 1, s);
+    CHK(predictor(m->dur, w.x, Lp, B, L, Lp, src_lens, src_lens, w.c1, w.c2, log_d, 1, s));
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
-    CHK(predictor_convs(m->energy, w.h, Lp, B, L, Lp, nullptr, ec1, ec2, se));
-    k_chan_linear(ec2, m->energy.lin_w, m->energy.lin_b, e_pred, nullptr, B, c.pred_filter, L, Lp, 1, se);
+    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, nullptr, nullptr, ec1, ec2, e_pred, 1, se));
     if (ss) CHK(branch_join(ss));
     k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
                    w.out1, e_idx, B, H, L, Lp, s);
@@ -1262,8 +1289,7 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
         CHK(launch(a, EPI_PLAIN, B, s));
     }
     k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
-    CHK(predictor_convs(m->cwt, w.hp, T, B, T, T, nullptr, w.c1, w.c2, s));
-    k_chan_linear(w.c2, m->cwt.lin_w, m->cwt.lin_b, cwt_out, nullptr, B, c.pred_filter, T, T, O, s);
+    CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s));
     if (ss) CHK(branch_join(ss));
     if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
     if (m->vc.cwt_spec) {   // teacher-forced pitch: target spectrogram, statistics and uv (:379-390)
@@ -1633,6 +1659,16 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "pred_xl")) {       // frame-level predictor convs on conv_xl_kernel (1) or the generic kernel (0); same bits
+        const int prev = g_pred_xl;
+        if (value == 0 || value == 1) g_pred_xl = value;
+        return prev;
+    }
+    if (!strcmp(name, "pred_head")) {     // predictors: last LayerNorm + linear head in one launch (1) or as two (0)
+        const int prev = g_pred_head;
+        if (value == 0 || value == 1) g_pred_head = value;
+        return prev;
     }
     if (!strcmp(name, "text_xres")) {     // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection, 2 = out-projection, 4 = LayerNorm2 + FFN conv on the X-resident kernel
         const int prev = g_text_xres;

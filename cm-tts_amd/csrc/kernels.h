@@ -25,6 +25,11 @@ void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const 
                     hipStream_t s);
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
                  int B, int L, hipStream_t s);
+void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
+                 int B, int L, hipStream_t s);
+// LayerNorm(256 channels) + Linear(256 -> O) in one launch, O in {1, 10, 11} (false: not covered); out is time-major [B][T][O]
+bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
+                 const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s);
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);
 void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t s);
 void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl,

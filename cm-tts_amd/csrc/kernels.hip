@@ -220,6 +220,87 @@ __global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const 
     }
 }
 
+// ---- LayerNorm over 256 channels + Linear(256 -> O <= 16) in ONE launch: the head of the duration / energy / cwt predictors
+// (the last conv block's LayerNorm, model/modules.py:497-499 / 546-548, feeding self.linear, :505-506 / :554).  A wave =
+// 16 positions x 4 channel quarters (lane = 16 q + column): every lane holds its 64 channels in registers (64 loads in
+// flight), and the mean, the variance and the O dot products are reduced across the four quarters with two __shfl_xor each
+// — no LDS scratch, no barrier after the weights are staged.  ln_lens: positions >= ln_lens[b] enter the linear layer as
+// zeros (the masked LayerNorm output); out_lens: those positions are written as 0.
+constexpr int LNL_PAD = 65;      // a quarter's 64 weights + 1: the four quarters of one lane group hit different LDS banks
+template <int O>
+__global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        const int64_t* ln_lens, const int64_t* out_lens, int T, int ld) {
+    constexpr int C = 256, CQ = 64;
+    constexpr int NV = (O + 2) * C / 4;            // float4 of W rows, gamma, beta
+    constexpr int PER = (NV + 255) / 256;
+    __shared__ float lsm[(O + 2) * 4 * LNL_PAD];   // [O + 2][4][LNL_PAD]
+    {   // all of a thread's loads before its first LDS write: one memory round trip
+        float4 wv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i4 = min((int)threadIdx.x + 256 * u, NV - 1);
+            const int r = i4 >> 6, c4 = i4 & 63;
+            const float* src = r < O ? W + (long)r * C : (r == O ? gamma : beta);
+            wv[u] = *reinterpret_cast<const float4*>(src + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i4 = threadIdx.x + 256 * u;
+            if (i4 < NV) {
+                const int r = i4 >> 6, c = 4 * (i4 & 63);
+                float* d = lsm + (r * 4 + (c >> 6)) * LNL_PAD + (c & 63);
+                d[0] = wv[u].x; d[1] = wv[u].y; d[2] = wv[u].z; d[3] = wv[u].w;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const int t = blockIdx.x * 64 + w * 16 + col;
+    const int b = blockIdx.y;
+    const int tc = min(t, T - 1);
+    const float* xb = x + ((long)b * C + q * CQ) * ld + tc;
+    float v[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) v[i] = xb[(long)i * ld];
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) s += v[i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) { const float d = v[i] - mean; sq = __fmaf_rn(d, d, sq); }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    const bool ln_keep = !(ln_lens && (int64_t)t >= ln_lens[b]);
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    const float* wq = lsm + q * LNL_PAD;
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+        float y = __fmaf_rn((v[i] - mean) * rstd, wq[(O * 4) * LNL_PAD + i], wq[((O + 1) * 4) * LNL_PAD + i]);
+        if (!ln_keep) y = 0.f;
+#pragma unroll
+        for (int o = 0; o < O; ++o) acc[o] = __fmaf_rn(y, wq[(o * 4) * LNL_PAD + i], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        acc[o] += __shfl_xor(acc[o], 16);
+        acc[o] += __shfl_xor(acc[o], 32);
+    }
+    if (q == 0 && t < T) {
+        const bool keep = !(out_lens && (int64_t)t >= out_lens[b]);
+#pragma unroll
+        for (int o = 0; o < O; ++o) out[((long)b * T + t) * O + o] = keep ? acc[o] + bias[o] : 0.f;
+    }
+}
+
 // ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
 // Workgroup = 64 output columns x KS K-slices (one wave per slice), DB batch rows per thread: Wt (up to
 // 5 MB for the stacked per-layer projections) is streamed once per DB rows, 8 independent loads in
@@ -314,6 +395,33 @@ __global__ void durations_kernel(const float* logd, float d_control, float* d_ro
         cum[(long)b * L + l] = run;
     }
     mel_len[b] = run;
+}
+
+// The same, one WAVE per utterance: the durations of 64 phonemes at a time in parallel and an in-wave inclusive scan of their
+// integer parts (__shfl_up; integer adds, so the order does not matter) instead of one thread walking the utterance.
+__global__ __launch_bounds__(64) void durations_wave_kernel(const float* logd, float d_control, float* d_rounded, int* cum,
+                                                            int64_t* mel_len, int L) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int carry = 0;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        const int l = l0 + lane;
+        float d = 0.f;
+        if (l < L) {
+            d = rintf(expf(logd[(long)b * L + l]) - 1.0f) * d_control;
+            d = d > 0.f ? d : 0.f;
+            d_rounded[(long)b * L + l] = d;
+        }
+        int v = (int)d;            // LengthRegulator.expand: int(expand_size)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(v, off);
+            if (lane >= off) v += n;
+        }
+        v += carry;
+        if (l < L) cum[(long)b * L + l] = v;
+        carry = __shfl(v, 63);
+    }
+    if (lane == 0) mel_len[b] = carry;
 }
 
 // ---- cumulative sums of already-rounded durations (LengthRegulator.expand: max(int(d), 0))
@@ -581,7 +689,21 @@ void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const 
 }
 void k_durations(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
                  hipStream_t s) {
+    hipLaunchKernelGGL(durations_wave_kernel, dim3(B), dim3(64), 0, s, logd, d_control, d_rounded, cum, mel_len, L);
+}
+void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
+                        hipStream_t s) {
     hipLaunchKernelGGL(durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, logd, d_control, d_rounded, cum, mel_len, B, L);
+}
+bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
+                 const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s) {
+    const dim3 grid(cdiv(T, 64), B), block(256);
+    switch (O) {     // the heads of this model family: 1 (duration, energy), 10 / 11 (cwt spectrogram without / with the uv logit)
+        case 1: hipLaunchKernelGGL(ln_linear_kernel<1>, grid, block, 0, s, x, gamma, beta, eps, W, bias, out, ln_lens, out_lens, T, ld); return true;
+        case 10: hipLaunchKernelGGL(ln_linear_kernel<10>, grid, block, 0, s, x, gamma, beta, eps, W, bias, out, ln_lens, out_lens, T, ld); return true;
+        case 11: hipLaunchKernelGGL(ln_linear_kernel<11>, grid, block, 0, s, x, gamma, beta, eps, W, bias, out, ln_lens, out_lens, T, ld); return true;
+        default: return false;
+    }
 }
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s) {
     hipLaunchKernelGGL(cumsum_durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, dur, cum, mel_len, B, L);

@@ -27,7 +27,10 @@ struct ConvXlArgs {
     int B, C, T, ld;
     int k, dil;
     int accum;
-    float slope;
+    float slope;          // 1 = no activation on the input
+    int relu;             // ReLU after the bias (variance-predictor convs, model/modules.py:470-499); 0 for HiFi-GAN
+    int cin;              // input channels when they differ from C (0 = C); x then has its own batch stride:
+    long xbstride;
 };
 
 #ifdef __cplusplus

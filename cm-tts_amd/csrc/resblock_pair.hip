@@ -59,11 +59,11 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 // scalar updates of the B-operand offset.  Loads are threaded between the MFMAs (one ds_read2_b32 + the A load of a
 // later group per k-step): a wave's instructions issue in order, so loads bunched between two groups of MFMAs would
 // leave the matrix pipe idle while they issue (first version of this kernel: 60-68 % pipe busy).
-template <int C, int KT>
+template <int C, int KT, int CIN = C>
 __device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __restrict__ wfrag, const float* __restrict__ src,
                                           int ld, int dil, int mt, int col0, int lane) {
-    constexpr int MTILES = C / 32;
-    constexpr int NG = (C / 8) * KT;            // k-groups: (chunk, tap, half); a multiple of RING for C in {32, 64}
+    constexpr int MTILES = C / 32;              // output m-tiles (C output channels); CIN input channels
+    constexpr int NG = (CIN / 8) * KT;          // k-groups: (chunk, tap, half); a multiple of RING for CIN in {32, 64, ...}
     static_assert(NG % RING == 0, "no tail in the ring loop");
     const int l31 = lane & 31, khalf = lane >> 5;
 #pragma unroll
@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __rest
 #pragma unroll
         for (int s = 0; s < RING; ++s) {
             advance();                                   // -> offset of group it + s + 1 (past the end: harmless, in-bounds reads)
-            const int off_n = min(boff, (C - 8) * ld + (KT - 1) * dil);
+            const int off_n = min(boff, (CIN - 8) * ld + (KT - 1) * dil);
             const float* bs = bl + off_n;
             if (PAIR_DBG != 1) load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
 #pragma unroll
@@ -274,7 +274,7 @@ int launch_pair(const PairArgs& a, hipStream_t stream) {
 // [+ y_old]; same accumulation order => bitwise equal.
 constexpr int XL_BN = 64;
 
-template <int C, int KT>
+template <int C, int KT, int CIN = C>
 __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
     constexpr int XW = XL_BN + (KT - 1) * 5 + 2;            // widest halo of this kernel size (dilation <= 5): k = 7 at C = 128 leaves
                                                             // 49 KB per workgroup = three per CU, k = 3 38 KB
@@ -288,10 +288,10 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
     const int T = a.T, dil = a.dil;
     const int pad = dil * ((KT - 1) / 2);
     const int xw = XL_BN + 2 * pad;
-    const float* xb = a.x + (long)b * a.bstride;
+    const float* xb = a.x + (long)b * (a.xbstride ? a.xbstride : a.bstride);
     {
         const int tbase = t0 - pad;
-        constexpr int ROWS_PER_WAVE = C / NWAVES;           // 32
+        constexpr int ROWS_PER_WAVE = CIN / NWAVES;         // 32 (16 for the 128 -> 256 predictor conv)
         constexpr int XBLK = (XW + 63) / 64;                // 2
 #pragma unroll
         for (int h = 0; h < ROWS_PER_WAVE; h += 16) {       // 32 loads in flight per lane
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
     }
     __syncthreads();
     f32x16 acc[NT];
-    conv_loop<C, KT>(acc, a.wf, Xs, XW, dil, w, 0, lane);
+    conv_loop<C, KT, CIN>(acc, a.wf, Xs, XW, dil, w, 0, lane);
     float bi[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bi[r] = a.bias[w * 32 + acc_row(r, lane)];
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[j][r] + bi[r];
+            if (a.relu) v = v > 0.f ? v : 0.f;
             if (rb) v += xres[j][r];
             if (a.accum) v += yo[j][r];
             if (t < T) yb[(long)(w * 32 + acc_row(r, lane)) * a.ld + t] = v;
@@ -347,18 +348,18 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
     }
 }
 
-template <int C, int KT>
+template <int C, int KT, int CIN = C>
 int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
-    const size_t lds = (size_t)C * (XL_BN + (KT - 1) * 5 + 2) * sizeof(float);
+    const size_t lds = (size_t)CIN * (XL_BN + (KT - 1) * 5 + 2) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT, CIN>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
     dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B);
-    hipLaunchKernelGGL((conv_xl_kernel<C, KT>), grid, dim3(2 * C), lds, stream, a);
+    hipLaunchKernelGGL((conv_xl_kernel<C, KT, CIN>), grid, dim3(2 * C), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -393,12 +394,17 @@ extern "C" int cmtts_launch_conv_xl(const ConvXlArgs* ap, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (a.B <= 0 || a.T <= 0) return 0;
     if (a.dil < 1 || a.dil > 5 || a.x == a.y) return -2;          // the X tile is sized for dilation <= 5 (HiFi-GAN: 1, 3, 5)
+    if (a.cin && a.cin != a.C) {      // variance-predictor input conv over frames: cwt_hidden 128 -> filter_size 256, kernel 5
+        if (a.C == 256 && a.cin == 128 && a.k == 5 && !a.res && !a.accum) return launch_xl<256, 5, 128>(a, s);
+        return -2;
+    }
     if (a.C == 128) {
         if (a.k == 3) return launch_xl<128, 3>(a, s);
         if (a.k == 7) return launch_xl<128, 7>(a, s);
         if (a.k == 11) return launch_xl<128, 11>(a, s);
     } else if (a.C == 256) {
         if (a.k == 3) return launch_xl<256, 3>(a, s);
+        if (a.k == 5) return launch_xl<256, 5>(a, s);        // variance-predictor convs over frames (filter_size 256, kernel 5)
         if (a.k == 7) return launch_xl<256, 7>(a, s);
         if (a.k == 11) return launch_xl<256, 11>(a, s);
     }

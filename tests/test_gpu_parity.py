@@ -631,6 +631,74 @@ def test_fused_attention_matches_three_launch_path(variant, B, L):
             assert torch.equal(one["enc_out"][0, :n], got["enc_out"][1, :n])
 
 
+def test_predictor_conv_xl_bitwise(models):
+    """The frame-level 256 -> 256 predictor conv (cwt predictor, k = 5, ReLU) on conv_xl_kernel (x tile + halo resident in
+    LDS, weights streamed as MFMA A fragments) keeps the generic kernel's accumulation order and epilogue: not a bit changes
+    (B = 32 x 512 frames takes it, the small golden batches the generic kernel)."""
+    host = _host()
+    lib = _lib.load()
+    g, cfg, sd, model = models("LJSpeech")
+    rs = np.random.RandomState(5)
+    B, L = 32, 85
+    lens = rs.randint(60, L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+    prev = lib.cmtts_set_option(b"pred_xl", 1)
+    try:
+        one = run()
+        lib.cmtts_set_option(b"pred_xl", 0)
+        ref = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"pred_xl", prev)
+    assert torch.equal(one["p_predictions"]["cwt"], ref["p_predictions"]["cwt"])
+    assert torch.equal(one["cond"], ref["cond"]) and torch.equal(one["p_predictions"]["p_idx"], ref["p_predictions"]["p_idx"])
+
+
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 40), ("LibriTTS", 1, 7)])
+def test_predictor_head_fused_matches_two_launch_path(variant, B, L):
+    """ln_linear_kernel (last LayerNorm of a predictor + its linear head in one launch, reductions by wave shuffles) against
+    layernorm_ct + chan_linear: the same operations in another fp32 summation order -> predictions within 1e-5, integer
+    stages (durations, energy / pitch buckets, mel2ph) identical; masked phonemes give exactly 0 in the duration head; the
+    wave-parallel durations kernel gives the serial one's cumulative sums (checked through mel_lens / mel2ph)."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=23, dur_frames=3.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(100 + L)
+    lens = np.maximum((rs.uniform(0.4, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+    prev = lib.cmtts_set_option(b"pred_head", 0)
+    try:
+        ref = run()
+        lib.cmtts_set_option(b"pred_head", 1)
+        got = run()
+        again = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"pred_head", prev)
+    for k in ("log_d_predictions", "e_predictions"):
+        err = float((got[k] - ref[k]).abs().max())
+        assert err < 1e-5, (k, err)
+        assert torch.equal(again[k], got[k])
+    err = float((got["p_predictions"]["cwt"] - ref["p_predictions"]["cwt"]).abs().max())
+    assert 0 < err < 1e-5, err
+    pad = torch.arange(L)[None, :] >= torch.from_numpy(lens)[:, None]
+    assert float(got["log_d_predictions"].cpu()[pad].abs().max() if pad.any() else 0.0) == 0.0
+    for k in ("d_rounded", "mel_lens", "mel2ph", "e_idx"):
+        assert torch.equal(got[k], ref[k]), k
+    flips = int((got["p_predictions"]["p_idx"] != ref["p_predictions"]["p_idx"]).sum())
+    assert flips == 0, flips
+    assert float((got["cond"] - ref["cond"]).abs().max()) < 1e-5
+
+
 def test_length_mask_kernel():
     """get_mask_from_lengths utils/tools.py:275-283 (True = padding): bit-exact against arange >= len."""
     host = _host()
