@@ -181,6 +181,22 @@ std::vector<unsigned short> to_fragment16(const std::vector<float>& p, int taps,
     return f;
 }
 
+// The same fragments in the ITERATION order of conv_mfma16.hip's deep-ring variant: its K loop walks (32-channel chunk, tap,
+// k-group of the chunk), so [K/32][taps][2][M/32][64 lanes][8] makes the weight stream one linear walk (K % 32 == 0).
+std::vector<unsigned short> to_fragment16_iter(const std::vector<float>& p, int taps, int K, int M, int mode) {
+    std::vector<unsigned short> f((size_t)taps * K * M);
+    const int MTn = M / 32;
+    size_t o = 0;
+    for (int c = 0; c < K / 32; ++c)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int h = 0; h < 2; ++h)
+                for (int mt = 0; mt < MTn; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j)
+                            f[o++] = host_cvt16(p[((size_t)tap * K + 32 * c + 16 * h + 8 * (lane >> 5) + j) * M + 32 * mt + (lane & 31)], mode);
+    return f;
+}
+
 // fp16x3 operands: every weight as hi = fp16(w) and lo = fp16(w - hi); the lo fragment set follows the hi set
 std::vector<unsigned short> to_fragment16_split(const std::vector<float>& p, int taps, int K, int M) {
     std::vector<float> hi(p.size()), lo(p.size());
@@ -276,6 +292,8 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
+int g_voc_ring16 = 1;           // 16-bit HiFi-GAN convs at C >= 128: deep weight ring on iteration-order fragments (same bits); 0 = one step ahead
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
 int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
 int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
@@ -461,6 +479,7 @@ struct cmtts_vocoder {
     int rb_dil[3] = {1, 3, 5};
     PackedConv c1[12][3], c2[12][3];
     void *c1f[12][3][3] = {}, *c2f[12][3][3] = {};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies of the ResBlock convs
+    void *c1fi[12][3][2] = {}, *c2fi[12][3][2] = {};  // bf16 / fp16 once more in iteration order: wide stages (C >= 128), deep-ring kernel
     float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
     float *post_w = nullptr, *post_b = nullptr;
@@ -1433,6 +1452,10 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
+                    if (co >= 128 && co % 32 == 0) {
+                        const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
+                        CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c1fi[r][mi][mode - 1]));
+                    }
                 }
                 {
                     const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
@@ -1443,6 +1466,10 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
+                    if (co >= 128 && co % 32 == 0) {
+                        const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
+                        CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c2fi[r][mi][mode - 1]));
+                    }
                 }
                 {
                     const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
@@ -1538,11 +1565,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             const float* xr = bufU;
             // narrow stages: conv1 -> LeakyReLU -> conv2 -> + x of a pair in ONE launch, xt never leaves the CU
             // (resblock_pair.hip; the pair's output must not alias its input, so the chain ping-pongs bR / bT)
-            // 16-bit operands: the pair kernel wins where the pair is bound by tensor passes (k = 3: 0.40 vs 0.60-0.64 ms per
-            // pair at C = 32 / 64; k = 7 at C = 32: 0.45 vs 0.60) and loses where its per-tile weight stream dominates (k = 11 at
-            // C = 64: 180 KB of 16-bit weights per 246 columns, 0.83 vs 0.64 ms; profiles/r02_vocoder_bf16.md): g_voc_pair == 2 forces it
-            // g_voc_pair16p: the persistent form with register-resident weights has no per-tile weight stream: every (C, k)
-            const bool pair16_pays = g_voc_pair16p || g_voc_pair == 2 || rk == 3 || (rk == 7 && co == 32);
+            // 16-bit operands: with the weight ring issued by hand (resblock_pair16.hip: the compiler had sunk every fragment load
+            // next to its use) the pair kernel wins for every (C, k): 0.37-0.55 ms per pair against 0.60-0.64 for two launches
+            // (profiles/r02_vocoder_bf16.md).  g_voc_pair16p: the persistent form with register-resident weights
+            const bool pair16_pays = true;
             const bool pair_ok = g_voc_pair && co <= 64 && v->precision != 3 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
@@ -1586,6 +1612,24 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         continue;
                     }
                 }
+                if (g_voc_xl16 && (v->precision == 1 || v->precision == 2) && co >= 128 && v->c1f[r][mi][v->precision - 1]) {
+                    // wide stages, 16-bit operands: X-resident single convs (conv_xl16_kernel); xt crosses HBM in 16 bits
+                    ConvXlArgs xa;
+                    memset(&xa, 0, sizeof(xa));
+                    xa.x = xr; xa.y = bT; xa.wf = (const float*)v->c1f[r][mi][v->precision - 1]; xa.bias = v->c1[r][mi].bias;
+                    xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f;
+                    const int rc1 = cmtts_launch_conv_xl16(&xa, v->precision, 1, (void*)q);
+                    if (rc1 == -3) return fail(CMTTS_E_HIP, "conv_xl16 launch failed");
+                    if (rc1 == 0) {
+                        if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                        xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = (const float*)v->c2f[r][mi][v->precision - 1];
+                        xa.bias = v->c2[r][mi].bias; xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
+                        if (cmtts_launch_conv_xl16(&xa, v->precision, 2, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xl16 launch failed");
+                        if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                        xr = bR;
+                        continue;
+                    }
+                }
                 ConvArgs a = conv_args(v->c1[r][mi], xr, To, ld, cs, bT, ld, cs, To);
                 a.dil = dil; a.pad = (rk * dil - dil) / 2; a.pre_slope = 0.1f;
                 if (v->precision == 3) {                  // fp16x3: fp32 xt in HBM, operands split into hi + lo fp16 while staged
@@ -1593,6 +1637,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else if (v->precision) {
                     a.y16 = 1; a.y16_slope = 0.1f;        // xt crosses HBM as convert(leaky_relu(xt)) in 16 bits
+                    if (g_voc_ring16) a.wfrag_iter = v->c1fi[r][mi][v->precision - 1];
                     if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
@@ -1610,6 +1655,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else if (v->precision) {
                     b.x16 = 1;
+                    if (g_voc_ring16) b.wfrag_iter = v->c2fi[r][mi][v->precision - 1];
                     if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
@@ -1659,6 +1705,16 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "voc_xl16")) {      // 16-bit wide ResBlock convs: X-resident kernel (1) or the chunked one (0); same bits
+        const int prev = g_voc_xl16;
+        if (value == 0 || value == 1) g_voc_xl16 = value;
+        return prev;
+    }
+    if (!strcmp(name, "voc_ring16")) {    // 16-bit wide ResBlock convs: deep weight ring (1) or one step ahead (0); same bits
+        const int prev = g_voc_ring16;
+        if (value == 0 || value == 1) g_voc_ring16 = value;
+        return prev;
     }
     if (!strcmp(name, "pred_xl")) {       // frame-level predictor convs on conv_xl_kernel (1) or the generic kernel (0); same bits
         const int prev = g_pred_xl;

@@ -37,6 +37,8 @@ struct ConvXlArgs {
 extern "C" {
 #endif
 int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
+// 16-bit twin (resblock_pair16.hip): io 1 = fp32 in / 16-bit activated out (conv1 of a pair), io 2 = 16-bit in / fp32 out (conv2)
+int cmtts_launch_conv_xl16(const ConvXlArgs* a, int mode, int io, void* stream);
 // 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error
 int cmtts_launch_resblock_pair(const PairArgs* a, void* stream);
 int cmtts_launch_resblock_pair16(const PairArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16

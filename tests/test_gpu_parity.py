@@ -1218,8 +1218,9 @@ def test_vocoder_mrf_streams_bitwise(dtype):
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (40, 33)])
 def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
-    """resblock_pair16.hip (16-bit operands, C = 64 / 32 stages, one launch per ResBlock pair): same conversions, same
-    (chunk, tap, k-group) accumulation order and epilogue as conv_mfma16.hip -> bitwise equal to the two-launch 16-bit path."""
+    """resblock_pair16.hip (16-bit operands, C = 64 / 32 stages, one launch per ResBlock pair) and its conv_xl16_kernel (C = 128 /
+    256 stages, one X-resident launch per conv): same conversions, same (chunk, tap, k-group) accumulation order and epilogue
+    as conv_mfma16.hip -> bitwise equal to the chunked two-launch 16-bit path."""
     host = _host()
     lib = _lib.load()
     hcfg = HifiGanConfig()
@@ -1227,9 +1228,12 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     voc.set_precision(dtype)
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
     prev = lib.cmtts_set_option(b"voc_pair", 0)
+    prev_x = lib.cmtts_set_option(b"voc_xl16", 0)
     try:
         prev_p = lib.cmtts_set_option(b"voc_pair16p", 0)
-        ref = voc(mel).clone()
+        ref = voc(mel).clone()                        # every ResBlock conv on the chunked conv_mfma16 kernel
+        lib.cmtts_set_option(b"voc_xl16", 1)          # C = 128 / 256 stages on the X-resident conv_xl16 kernel
+        got_x = voc(mel).clone()
         lib.cmtts_set_option(b"voc_pair", 2)          # 2 = every (C, k) through the per-tile streamed pair kernel
         got = voc(mel).clone()
         lib.cmtts_set_option(b"voc_pair", 1)
@@ -1240,7 +1244,9 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     finally:
         lib.cmtts_set_option(b"voc_pair", prev)
         lib.cmtts_set_option(b"voc_pair16p", prev_p)
+        lib.cmtts_set_option(b"voc_xl16", prev_x)
     assert torch.isfinite(got).all()
+    assert torch.equal(got_x, ref), float((got_x - ref).abs().max())
     assert torch.equal(got, ref), float((got - ref).abs().max())
     assert torch.equal(got_p, ref), float((got_p - ref).abs().max())
     assert torch.equal(got_p2, ref)
