@@ -105,9 +105,18 @@ int pack_conv(Allocs& al, const HostTensor& W, const HostTensor* bias, const std
 }
 
 // ConvTranspose1d W [Cin][Cout][K], stride s -> polyphase [s][K/s][Cin][ld]: phase r uses taps k = r + s*q
-int pack_conv_transpose(Allocs& al, const HostTensor& W, const HostTensor& bias, int s, PackedConv* out) {
+int pack_conv_transpose(Allocs& al, const HostTensor& W, const HostTensor& bias, int s, PackedConv* out,
+                        std::vector<float>* two_tap = nullptr) {
     const int Cin = (int)W.dim(0), Cout = (int)W.dim(1), K = (int)W.dim(2);
     const int Q = K / s, ld = round_up(Cout, 4);
+    if (two_tap && Q == 2) {   // the same weights as ONE two-tap conv with s * Cout stacked rows (row = phase * Cout + co): [2][Cin][s * Cout]
+        two_tap->assign((size_t)2 * Cin * s * Cout, 0.f);
+        for (int q = 0; q < 2; ++q)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int r = 0; r < s; ++r)
+                    for (int co = 0; co < Cout; ++co)
+                        (*two_tap)[((size_t)q * Cin + ci) * s * Cout + (size_t)r * Cout + co] = W.data[((size_t)ci * Cout + co) * K + (r + s * q)];
+    }
     std::vector<float> p((size_t)s * Q * Cin * ld, 0.f);
     for (int r = 0; r < s; ++r)
         for (int q = 0; q < Q; ++q)
@@ -292,6 +301,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
 int g_voc_ring16 = 1;           // 16-bit HiFi-GAN convs at C >= 128: deep weight ring on iteration-order fragments (same bits); 0 = one step ahead
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
@@ -473,6 +483,7 @@ struct cmtts_vocoder {
     Allocs al;
     PackedConv conv_pre;
     PackedConv ups[4];
+    float* ups_f[4] = {nullptr, nullptr, nullptr, nullptr};   // two-tap stacked-phase weights as iteration-order fragments (convT_xl_kernel)
     int up_rate[4] = {8, 8, 2, 2};
     int up_kernel[4] = {16, 16, 4, 4};
     int rb_kernel[3] = {3, 7, 11};
@@ -1437,7 +1448,12 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
         const int co = ch / 2;
         GETV(uw, "ups." + std::to_string(i) + ".weight", ch, co, v->up_kernel[i]);
         GETV(ub, "ups." + std::to_string(i) + ".bias", co);
-        CHK(pack_conv_transpose(al, *uw, *ub, v->up_rate[i], &v->ups[i]));
+        {
+            std::vector<float> tt;
+            CHK(pack_conv_transpose(al, *uw, *ub, v->up_rate[i], &v->ups[i], &tt));
+            const int mrows = v->up_rate[i] * co;
+            if (!tt.empty() && ch % 16 == 0 && mrows % 32 == 0) CHK(al.upload(to_fragment_iter_order(tt, 2, ch, mrows), &v->ups_f[i]));
+        }
         for (int j = 0; j < 3; ++j) {
             const int r = i * 3 + j;
             for (int mi = 0; mi < 3; ++mi) {
@@ -1542,6 +1558,12 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         const int st = v->up_rate[i], K = v->up_kernel[i], pd = (K - st) / 2, co = ch / 2, To = Ti * st;
         {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
             const PackedConv& U = v->ups[i];
+            int rt = -2;
+            if (g_voc_upsT && v->ups_f[i] && K == 2 * st)      // all phases in one X-resident launch (same bits)
+                rt = cmtts_launch_convT(bufA, bufU, v->ups_f[i], U.bias, (long)ch * (Ti + P), (long)co * (To + P), B, ch, co, Ti, To,
+                                        Ti + P, To + P, st, i > 0 ? 3.0f : 1.0f, 0.1f, (void*)s);
+            if (rt == -3) return fail(CMTTS_E_HIP, "convT launch failed");
+            if (rt != 0) {
             ConvArgs a = conv_args(U, bufA, Ti, Ti + P, (long)ch * (Ti + P), bufU, To + P, (long)co * (To + P), Ti + 1);
             a.dil = -1; a.pad = 0;
             a.zdiv = st; a.a_zs0 = 0; a.a_zs1 = U.phase_stride; a.x_zs0 = (long)ch * (Ti + P); a.x_zs1 = 0;
@@ -1550,6 +1572,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             ConvOut& o = a.out[0];
             o.Tout = To; o.ostride = st; o.ooff_base = -pd; o.ooff_mul = 1; o.y_zs0 = (long)co * (To + P); o.y_zs1 = 0;
             CHK(launch(a, EPI_PLAIN, B * st, s));
+            }
         }
         const int ld = To + P;               // row stride: not a power of two (HBM channel spread)
         const long cs = (long)co * ld;
@@ -1706,6 +1729,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
     }
+    if (!strcmp(name, "voc_upsT")) {      // upsampling transposed convs on convT_xl_kernel (1) or the generic kernel (0); same bits
+        const int prev = g_voc_upsT;
+        if (value == 0 || value == 1) g_voc_upsT = value;
+        return prev;
+    }
     if (!strcmp(name, "voc_xl16")) {      // 16-bit wide ResBlock convs: X-resident kernel (1) or the chunked one (0); same bits
         const int prev = g_voc_xl16;
         if (value == 0 || value == 1) g_voc_xl16 = value;
@@ -1814,6 +1842,12 @@ int cmtts_set_debug_stamps(void* dev_buf) {
     cmtts_persist_set_debug((long long*)dev_buf);
     cmtts_pair_set_debug((long long*)dev_buf);
     cmtts_xres_set_debug((long long*)dev_buf);
+    {   // generic conv kernel: CMTTS_CONV_DBG_MK="M,K" selects the launches to stamp (tools/conv_phases.py)
+        int M = 0, K = 0;
+        const char* mk = getenv("CMTTS_CONV_DBG_MK");
+        if (mk && sscanf(mk, "%d,%d", &M, &K) == 2) cmtts_conv_set_debug(dev_buf ? (long long*)dev_buf : nullptr, M, K);
+        else cmtts_conv_set_debug(nullptr, 0, 0);
+    }
     return 0;
 }
 

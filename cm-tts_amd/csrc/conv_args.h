@@ -71,6 +71,7 @@ int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
 int cmtts_launch_conv16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
 // X-resident variant for short sequences (conv_xres.hip): wfrag = fp32 fragment-order weights; -2 = unsupported.
 int cmtts_launch_conv_xres(const ConvArgs* a, const float* wfrag, int nbatch, void* stream);
+void cmtts_conv_set_debug(long long* dbg, int M, int K);   // generic kernel: cycle counters of the launches with this (M, K)
 void cmtts_xres_set_debug(long long* dbg);   // cycle stamps [workgroup][wave][8] (tools/xres_phases.py); nullptr = off
 #ifdef __cplusplus
 }

@@ -31,6 +31,11 @@ namespace {
 // TB = taps staged (and multiplied) per barrier-separated iteration: 1 for the large launches; 5 for the small k>1
 // launches (text-side FFN / predictors), whose 8 MFMAs per wave per tap cannot hide a barrier.  The (chunk, tap, k)
 // accumulation order is the same for every TB.
+// Debugging aid (tools/conv_phases.py): cycle counts per wave of the launches whose (M, K) match — [workgroup][wave][8]:
+// start, after the prologue, sum of the MFMA blocks, sum of (LDS stores + barrier), before the epilogue, end.
+__device__ long long* d_conv_dbg = nullptr;
+__device__ int d_conv_dbg_m = 0, d_conv_dbg_k = 0;
+
 template <int BM, int BN, int WM, int WN, int EPI, int KC, int TB>
 __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
     constexpr int MT = BM / (WM * 32);
@@ -76,16 +81,27 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
     // The raw loaded values stay untouched in registers until store time (after the MFMAs): the
     // zero-fill selects and the pre-activation are applied in store_*, so nothing waits on vmcnt
     // between issuing the prefetch and the MFMA block.
+    // Address arithmetic of the prefetch in 32 bits on precomputed per-thread terms (round 2: issuing the 36 loads of a
+    // 64-channel iteration cost 1.9 k cycles against 2 k of MFMAs — 64-bit multiplies and clamps per element; every operand
+    // slice of this path is far below 2^32 elements): wave-uniform base pointer + unsigned per-lane offset
+    int wrow[WV];
+    unsigned wcol[WV];
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+        const int i = min(tid + v * 256, KC * WQ - 1);
+        wrow[v] = i / WQ;
+        wcol[v] = (unsigned)min(m0 + (i - wrow[v] * WQ) * 4, a.a_cols - 4);
+    }
+    const unsigned a_ldu = (unsigned)a.a_ld, a_tsu = (unsigned)a.a_tap_stride;
     auto load_w = [&](int chunk, int tap0) {
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
             const int tap = min(tap0 + tb, a.taps - 1);          // taps beyond the kernel are loaded again and never used
+            const unsigned tbase_w = (unsigned)tap * a_tsu;
 #pragma unroll
             for (int v = 0; v < WV; ++v) {
-                const int i = min(tid + v * 256, KC * WQ - 1);
-                const int row = i / WQ, c4 = i - row * WQ;
-                const int krow_c = min(chunk * KC + row, a.K - 1), m_c = min(m0 + c4 * 4, a.a_cols - 4);
-                wreg[tb][v] = *reinterpret_cast<const float4*>(Ab + tap * a.a_tap_stride + (long)krow_c * a.a_ld + m_c);
+                const unsigned krow_c = (unsigned)min(chunk * KC + wrow[v], a.K - 1);
+                wreg[tb][v] = *reinterpret_cast<const float4*>(Ab + (tbase_w + krow_c * a_ldu + wcol[v]));
             }
         }
     };
@@ -102,32 +118,65 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
                 if (i < KC * WQ) *reinterpret_cast<float4*>(Ws + (buf * TB + tb) * KC * BM + i * 4) = w;
             }
     };
+    unsigned xcol[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) xcol[j] = (unsigned)min(max(tbase + lane + 64 * j, 0), a.Tin - 1);
+    const unsigned ldxu = (unsigned)a.ldx;
     auto load_x = [&](int chunk) {
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
-            const int krow = chunk * KC + wid + 4 * r;
-            const float* xrow = Xb + (long)min(krow, a.K - 1) * a.ldx;
+            const unsigned rowoff = (unsigned)min(chunk * KC + wid + 4 * r, a.K - 1) * ldxu;      // wave-uniform
 #pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-                const int t = tbase + lane + 64 * j;
-                xreg[r][j] = xrow[min(max(t, 0), a.Tin - 1)];
-            }
+            for (int j = 0; j < XJ; ++j) xreg[r][j] = Xb[rowoff + xcol[j]];
         }
     };
+    // The pre-activation is chosen ONCE per call (wave-uniform branches around three copies of the element loop), and the
+    // column validity is a per-lane mask computed before the loop: written inside the loop, "if (pre_div != 1) v /= pre_div"
+    // became an unconditional IEEE division + select, the slope a scalar load + lgkmcnt(0), and "col < XW" an exec-mask
+    // branch — ~28 instructions per staged element, 3.6 k cycles per 64-channel chunk against its 2 k cycles of MFMAs
+    // (round 2, found in the ISA of the 64 x 64 configuration: the FFT blocks' out-projection / FFN linear, the predictors)
+    const float pre_div = a.pre_div, pre_slope = a.pre_slope;
+    bool colok[XJ], tok[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int col = lane + 64 * j, t = tbase + col;
+        colok[j] = col < XW;
+        tok[j] = t >= 0 && t < a.Tin;
+    }
     auto store_x = [&](int buf, int chunk) {
-        float* xs = Xs + buf * KC * XW;
+        float* xs = Xs + buf * KC * XW + wid * XW + lane;
+        if (pre_div == 1.0f && pre_slope == 1.0f) {
 #pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int krow = chunk * KC + wid + 4 * r;
+            for (int r = 0; r < XR; ++r) {
+                const bool kok = chunk * KC + wid + 4 * r < a.K;
 #pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-                const int col = lane + 64 * j;
-                const int t = tbase + col;
-                const bool ok = krow < a.K && t >= 0 && t < a.Tin;
-                float v = ok ? xreg[r][j] : 0.f;
-                if (a.pre_div != 1.0f) v = v / a.pre_div;
-                v = v > 0.f ? v : v * a.pre_slope;
-                if (col < XW) xs[(wid + 4 * r) * XW + col] = v;
+                for (int j = 0; j < XJ; ++j) {
+                    const float v = (kok && tok[j]) ? xreg[r][j] : 0.f;
+                    if (j == 0 || colok[j]) xs[4 * r * XW + 64 * j] = v;      // XW >= BN >= 64: the first 64 columns always exist
+                }
+            }
+        } else if (pre_div == 1.0f) {
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                const bool kok = chunk * KC + wid + 4 * r < a.K;
+#pragma unroll
+                for (int j = 0; j < XJ; ++j) {
+                    float v = (kok && tok[j]) ? xreg[r][j] : 0.f;
+                    v = v > 0.f ? v : v * pre_slope;
+                    if (j == 0 || colok[j]) xs[4 * r * XW + 64 * j] = v;      // XW >= BN >= 64: the first 64 columns always exist
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                const bool kok = chunk * KC + wid + 4 * r < a.K;
+#pragma unroll
+                for (int j = 0; j < XJ; ++j) {
+                    float v = (kok && tok[j]) ? xreg[r][j] : 0.f;
+                    v = v / pre_div;
+                    v = v > 0.f ? v : v * pre_slope;
+                    if (j == 0 || colok[j]) xs[4 * r * XW + 64 * j] = v;      // XW >= BN >= 64: the first 64 columns always exist
+                }
             }
         }
     };
@@ -140,6 +189,10 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    long long* dbg = d_conv_dbg;
+    if (dbg && (a.M != d_conv_dbg_m || a.K != d_conv_dbg_k)) dbg = nullptr;
+    long long t_start = 0, t_pro = 0, t_mma = 0, t_sync = 0, tq = 0;
+    if (dbg) t_start = (long long)__builtin_readcyclecounter();
     // prologue: stage iteration 0
     load_w(0, 0);
     load_x(0);
@@ -147,6 +200,7 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
     store_x(0, 0);
     __syncthreads();
 
+    if (dbg) t_pro = (long long)__builtin_readcyclecounter();
     int chunk = 0, tap = 0;
     const int a_off = wm * MT * 32 + (lane & 31);
     const int b_off = wn * NT * 32 + (lane & 31);
@@ -160,6 +214,7 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
         if (has_next) load_w(nchunk, ntap);
         if (next_x) load_x(nchunk);
         __builtin_amdgcn_sched_barrier(0);           // prefetch loads stay above the MFMA block
+        if (dbg) tq = (long long)__builtin_readcyclecounter();
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
             if (tap + tb < a.taps) {                 // wave-uniform
@@ -195,12 +250,21 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
             }
         }
 
+        if (dbg) { const long long t = (long long)__builtin_readcyclecounter(); t_mma += t - tq; tq = t; }
         if (has_next) store_w((it + 1) & 1, nchunk);
         if (next_x) store_x(nchunk & 1, nchunk);
         __syncthreads();
+        if (dbg) t_sync += (long long)__builtin_readcyclecounter() - tq;
         tap = ntap;
         chunk = nchunk;
     }
+    const long long t_epi = dbg ? (long long)__builtin_readcyclecounter() : 0;
+    auto dbg_out = [&]() {
+        if (dbg && lane == 0) {
+            long long* p = dbg + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+            p[0] = t_start; p[1] = t_pro; p[2] = t_mma; p[3] = t_sync; p[4] = t_epi; p[5] = (long long)__builtin_readcyclecounter();
+        }
+    };
 
     // ------------------------------------------------------------------ epilogue
     const int rbase = 4 * khalf;
@@ -236,6 +300,7 @@ __global__ __launch_bounds__(256, (KC > 16 || TB > 1) ? 2 : 3) void conv1d_mfma_
             for (int j = 0; j < NT; ++j)
                 epi_tile(o, acc[i][j], m0 + (wm * MT + i) * 32, rbase, n0 + (wn * NT + j) * 32 + col, a.M, a.N, zq, zr);
     }
+    dbg_out();
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int KC = 16, int TB = 1>
@@ -285,4 +350,11 @@ extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* 
         return launch_cfg<64, 64, 2, 2, EPI_PLAIN, 64>(a, nbatch, stream);
     if (a.M > 32) return launch_cfg<64, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
     return launch_cfg<32, 256, 1, 4, EPI_PLAIN>(a, nbatch, stream);
+}
+
+// stamps buffer (device) + the (M, K) of the launches to stamp; nullptr = off
+extern "C" void cmtts_conv_set_debug(long long* dbg, int M, int K) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_conv_dbg), &dbg, sizeof(dbg));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_conv_dbg_m), &M, sizeof(M));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_conv_dbg_k), &K, sizeof(K));
 }

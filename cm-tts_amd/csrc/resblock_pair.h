@@ -37,6 +37,9 @@ struct ConvXlArgs {
 extern "C" {
 #endif
 int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
+// HiFi-GAN upsampler (ConvTranspose1d, kernel 2 s, stride s, padding s / 2), all phases in one X-resident launch (resblock_pair.hip)
+int cmtts_launch_convT(const float* x, float* y, const float* wf, const float* bias, long xbstride, long ybstride, int B, int cin,
+                       int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, void* stream);
 // 16-bit twin (resblock_pair16.hip): io 1 = fp32 in / 16-bit activated out (conv1 of a pair), io 2 = 16-bit in / fp32 out (conv2)
 int cmtts_launch_conv_xl16(const ConvXlArgs* a, int mode, int io, void* stream);
 // 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error

@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __rest
 #pragma unroll
         for (int s = 0; s < RING; ++s) {
             advance();                                   // -> offset of group it + s + 1 (past the end: harmless, in-bounds reads)
-            const int off_n = min(boff, (CIN - 8) * ld + (KT - 1) * dil);
+            const int off_n = min(boff, (CIN - 8) * ld + (KT - 1) * max(dil, 0));   // past-the-end prefetch: harmless in-bounds read
             const float* bs = bl + off_n;
             if (PAIR_DBG != 1) load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
 #pragma unroll
@@ -117,6 +117,65 @@ __device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __rest
                 if (PAIR_DBG != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read2_b32 (next group's k-step kk) ...
                 if (kk == 0 && PAIR_DBG != 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... the A load of a later group ...
                 __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);     // ... under this k-step's MFMAs
+            }
+        }
+    }
+}
+
+// conv_loop for the transposed convs: two taps at dilation -1 (output column c reads tile columns c + 1, c), CIN input channels,
+// m-tile `mt` of `mtiles` (run-time: s * CO / 32 stacked rows) in the iteration-order fragments [chunk][tap][half][mtiles][64][4]
+template <int CIN>
+__device__ __forceinline__ void conv_loop_rt(f32x16 (&acc)[NT], const float* __restrict__ wfrag, const float* __restrict__ src,
+                                             int ld, int mt, int mtiles, int lane) {
+    constexpr int KT = 2;
+    constexpr int NG = (CIN / 8) * KT;
+    static_assert(NG % RING == 0, "no tail in the ring loop");
+    const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* wl = wfrag + mt * 256 + lane * 4;
+    const long gstride = (long)mtiles * 256;
+    auto load_a = [&](f32x4& dst, int it) { dst = *reinterpret_cast<const f32x4*>(wl + (long)min(it, NG - 1) * gstride); };
+    const float* bl = src + khalf * ld + 1 + l31;            // tap 0 reads column c + 1 (x[m]), tap 1 column c (x[m - 1])
+    int boff = 0, tap = 0, half = 0;
+    auto advance = [&]() {
+        if (half == 0) { half = 1; boff += 8 * ld; }
+        else {
+            half = 0; boff -= 8 * ld; ++tap; boff -= 1;
+            if (tap == KT) { tap = 0; boff += 16 * ld + KT; }
+        }
+    };
+    auto load_b = [&](float (&dst)[4][NT], int off) {
+        const float* bs = bl + off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * ld + j * 32];
+    };
+    f32x4 A[RING];
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+    float Bv[2][4][NT];
+    load_b(Bv[0], boff);
+#pragma unroll 1
+    for (int it = 0; it < NG; it += RING) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            advance();
+            const int off_n = min(boff, (CIN - 8) * ld);
+            const float* bs = bl + off_n;
+            load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * ld + j * 32];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
             }
         }
     }
@@ -363,6 +422,115 @@ int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ConvTranspose1d(CIN -> CO, kernel 2 s, stride s, padding s / 2) of the HiFi-GAN upsamplers (hifigan/models.py:152-153), all s
+// output phases in one X-resident launch:  y[co][s m + r - s/2] = b[co] + sum_ci sum_{q in {0, 1}} W[ci][co][r + s q] act(x[ci][m - q]),
+// i.e. a two-tap convolution with s * CO output rows (row = r * CO + co) whose store interleaves the phases.  The generic kernel
+// ran it as s separate launches-in-z that each re-staged the input through 16-channel chunks (47-57 % of the fp32 pipe, 5.2 ms
+// of a 32 x 512-frame batch); here a workgroup stages act(x) = leaky_relu(x / pre_div, 0.1) of 64 + 1 columns once for NW
+// m-tiles (NW <= 8 waves: 256 rows) and runs conv_loop on it (taps in the generic kernel's order q = 0, 1: dilation -1).  Same
+// staging arithmetic (true division, then the slope), accumulation order and epilogue ((acc + b)) => the same bits.
+struct ConvTArgs {
+    const float* x;       // [B][CIN][ldx]
+    float* y;             // [B][CO][ldy]
+    const float* wf;      // iteration-order fragments of the [2][CIN][s * CO] two-tap weights
+    const float* bias;    // [CO]
+    long xbstride, ybstride;
+    int B, CO, Ti, To, ldx, ldy, s;
+    float pre_div, slope;
+};
+
+template <int CIN, int NW>
+__global__ __launch_bounds__(64 * NW, CIN >= 512 ? 2 : (NW >= 8 ? 4 : 2)) void convT_xl_kernel(const ConvTArgs a, int MTILES_rt) {
+    constexpr int XW = XL_BN + 1 + 2;                        // columns t0 - 1 .. t0 + 63 (+ pad against bank conflicts)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                        // [CIN][XW] act(x), column j <-> m = t0 - 1 + j
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * XL_BN;
+    const int Ti = a.Ti;
+    const float* xb = a.x + (long)b * a.xbstride;
+    {
+        constexpr int ROWS = CIN / NW;                       // rows per wave
+        const int jcol[2] = {lane, lane + 64};
+#pragma unroll
+        for (int h = 0; h < ROWS; h += 16) {
+            float v[2][16];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int m_c = min(max(t0 - 1 + jcol[jb], 0), Ti - 1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[jb][q] = xb[(long)(w * ROWS + h + q) * a.ldx + m_c];
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int j = jcol[jb];
+                const int m = t0 - 1 + j;
+                const bool ok = m >= 0 && m < Ti;
+                if (j < XL_BN + 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float u = ok ? v[jb][q] : 0.f;
+                        if (a.pre_div != 1.0f) u = u / a.pre_div;
+                        u = u > 0.f ? u : u * a.slope;
+                        Xs[(w * ROWS + h + q) * XW + j] = u;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // wave -> (phase, 32-channel block); the workgroup walks over its share of the channel blocks with the x tile resident: one
+    // staging pass feeds all s * CO stacked rows (a grid split over blockIdx.z only where the tiles alone cannot fill the chip).
+    // (Interleaving the phases through an LDS output tile to store whole lines instead of 4 bytes at a stride of 4 s was tried:
+    // no gain, the stores are not what bounds this kernel.)
+    const int S = a.s;
+    const int phase = w % S, cbl = w / S;                    // NW % s == 0 (launcher)
+    const int per = NW / S;                                  // channel blocks per pass
+    const int passes = (a.CO / 32) / per / gridDim.z;
+    const int pd = S / 2;
+    float* yb = a.y + (long)b * a.ybstride;
+    for (int ps = 0; ps < passes; ++ps) {
+        const int cb = (blockIdx.z * passes + ps) * per + cbl;
+        const int mt = phase * (a.CO / 32) + cb;
+        f32x16 acc[NT];
+        conv_loop_rt<CIN>(acc, a.wf, Xs, XW, mt, MTILES_rt, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + acc_row(r, lane);
+            const float bi = a.bias[co];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = t0 + j * 32 + l31;
+                const int t = n * S + phase - pd;
+                if (n <= Ti && t >= 0 && t < a.To) yb[(long)co * a.ldy + t] = acc[j][r] + bi;
+            }
+        }
+    }
+}
+
+template <int CIN, int NW>
+int launch_convT(const ConvTArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)CIN * (XL_BN + 3) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl_kernel<CIN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    const int mtiles = a.s * a.CO / 32;
+    if (NW % a.s || mtiles % NW) return -2;                  // a pass = all s phases of NW / s channel blocks
+    const int npass = mtiles / NW;                           // passes over the x tile if one workgroup did them all
+    const long tiles = (long)((a.Ti + 1 + XL_BN - 1) / XL_BN) * a.B;
+    int zs = 1;                                              // split the passes over blockIdx.z until ~16 workgroups per CU exist (a workgroup of ups1 runs 0.3 ms: with 2080 of them on 512 slots the fifth, nearly empty round costs 20 %)
+    while (tiles * zs < 4096 && zs * 2 <= npass && npass % (zs * 2) == 0) zs *= 2;
+    dim3 grid((a.Ti + 1 + XL_BN - 1) / XL_BN, a.B, zs);
+    hipLaunchKernelGGL((convT_xl_kernel<CIN, NW>), grid, dim3(64 * NW), lds, stream, a, mtiles);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 long long* g_pair_dbg = nullptr;
 
 }  // namespace
@@ -408,5 +576,22 @@ extern "C" int cmtts_launch_conv_xl(const ConvXlArgs* ap, void* stream_) {
         if (a.k == 7) return launch_xl<256, 7>(a, s);
         if (a.k == 11) return launch_xl<256, 11>(a, s);
     }
+    return -2;
+}
+
+// HiFi-GAN upsampler ConvTranspose1d(cin -> co, kernel 2 s, stride s, padding s / 2) on [B][cin][ldx] -> [B][co][ldy], input
+// activation leaky_relu(x / pre_div, slope).  wf: to_fragment_iter_order of the [2][cin][s * co] two-tap weights (row = phase * co +
+// channel).  0 = launched, -2 = shape not covered, -3 = HIP error.
+extern "C" int cmtts_launch_convT(const float* x, float* y, const float* wf, const float* bias, long xbstride, long ybstride, int B,
+                                  int cin, int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (B <= 0 || Ti <= 0) return 0;
+    if (!wf || (s * co) % 32 || To != Ti * s || s < 2 || (s & 1)) return -2;
+    ConvTArgs a{x, y, wf, bias, xbstride, ybstride, B, co, Ti, To, ldx, ldy, s, pre_div, slope};
+    const int mtiles = s * co / 32;
+    if (cin == 512 && mtiles >= 8) return launch_convT<512, 8>(a, st);
+    if (cin == 256 && mtiles >= 8) return launch_convT<256, 8>(a, st);
+    if (cin == 128 && mtiles >= 4) return launch_convT<128, 4>(a, st);
+    if (cin == 64 && mtiles >= 2) return launch_convT<64, 2>(a, st);
     return -2;
 }

@@ -1252,6 +1252,29 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     assert torch.equal(got_p2, ref)
 
 
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
+def test_vocoder_upsampler_kernel_bitwise(B, T):
+    """convT_xl_kernel (all stride phases of a HiFi-GAN ConvTranspose1d in one X-resident launch: a two-tap conv with s * C_out
+    stacked rows and a phase-interleaving store) against the generic kernel run once per phase: same staging arithmetic (x / 3,
+    LeakyReLU), tap order, accumulation order and epilogue -> the wav must not change by a bit; T = 1 and 7 exercise tiles that
+    are all halo, 61 / 130 ragged last tiles."""
+    host = _host()
+    lib = _lib.load()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=8))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(50 + T)) * 1.5 - 4).to(DEV)
+    prev = lib.cmtts_set_option(b"voc_upsT", 0)
+    try:
+        ref = voc(mel).clone()
+        lib.cmtts_set_option(b"voc_upsT", 1)
+        got = voc(mel).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"voc_upsT", prev)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130)])
 def test_vocoder_pair_kernel_bitwise(B, T):
     """resblock_pair.hip (C = 64 / 32 stages: conv1 -> LeakyReLU -> conv2 -> + x of a ResBlock pair in one launch, the x
