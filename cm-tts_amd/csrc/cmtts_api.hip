@@ -301,6 +301,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
 int g_voc_ring16 = 1;           // 16-bit HiFi-GAN convs at C >= 128: deep weight ring on iteration-order fragments (same bits); 0 = one step ahead
@@ -768,8 +769,13 @@ int finalize_model(cmtts_model* m) {
 }
 
 // ---------------------------------------------------------------- workspaces
+// The FFN linear (K = 4 H = 1024 -> H) is DEFINED as FFN2_SEG partial sums over 128-row K segments, added in ascending order,
+// then + bias, + residual, mask — for every batch size and path: the segments are independent GEMMs (8x the workgroups of a
+// launch whose single 1024-long accumulation chain per tile left most of the chip waiting: 60 us for 1.4 GFLOP) and a
+// batch's values still do not depend on its size.
+constexpr int FFN2_SEG = 8;
 struct TextWs {
-    float *x, *h, *qk, *vt, *st, *o, *f, *c1, *c2, *spk, *out1, *logd, *dround, *epred;
+    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *logd, *dround, *epred;
     int* cum;
     int64_t *eidx, *mlen;
     size_t bytes;
@@ -790,6 +796,7 @@ TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
     w.st = cv.take<float>((size_t)B * c.enc_heads * Lp * Lp);
     w.o = cv.take<float>(n);
     w.f = cv.take<float>(4 * n);
+    w.part = cv.take<float>(FFN2_SEG * n);     // partial sums of the FFN linear, one [B][H][Lp] slab per K segment
     w.c1 = cv.take<float>(n);
     w.c2 = cv.take<float>(n);
     w.logd = cv.take<float>((size_t)B * L);
@@ -1220,7 +1227,17 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                 CHK(launch(a, EPI_PLAIN, B, s));
             }
         }
-        {   // x = (x + ffn_2(.)) * nonpad          (:551, :616-617)
+        if (g_ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1) {
+            // x = (x + ffn_2(.)) * nonpad          (:551, :616-617) as FFN2_SEG independent partial GEMMs + one reduction
+            const int kseg = E.ffn2.cin / FFN2_SEG;
+            ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.part, Lp, (long)FFN2_SEG * hs, L);
+            a.K = kseg;
+            a.zdiv = FFN2_SEG; a.a_zs0 = 0; a.a_zs1 = (long)kseg * a.a_ld; a.x_zs1 = (long)kseg * Lp;
+            a.out[0].y_zs1 = hs; a.out[0].bias = nullptr;
+            // (64x64 tiles for the 85-phoneme case — a 128-column tile is one third padding — were tried: 59 vs 44 us)
+            CHK(launch(a, EPI_PLAIN, B * FFN2_SEG, s));
+            k_reduce_partials(w.part, FFN2_SEG, E.ffn2.bias, w.x, src_lens, w.x, B, H, L, Lp, s);
+        } else {   // x = (x + ffn_2(.)) * nonpad          (:551, :616-617)
             ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.x, Lp, hs, L);
             a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
             CHK(launch(a, EPI_PLAIN, B, s));
@@ -1728,6 +1745,11 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
+        const int prev = g_ffn2_split;
+        if (value == 0 || value == 1) g_ffn2_split = value;
+        return prev;
     }
     if (!strcmp(name, "voc_upsT")) {      // upsampling transposed convs on convT_xl_kernel (1) or the generic kernel (0); same bits
         const int prev = g_voc_upsT;

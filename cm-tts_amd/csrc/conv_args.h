@@ -52,6 +52,7 @@ struct ConvArgs {
     int x16;              // X holds 16-bit values that are already activated (no pre_div / pre_slope applied)
     int y16;              // Y is written as 16-bit leaky_relu(v, y16_slope) instead of fp32 v
     float y16_slope;
+    int small_tiles;      // fp32 kernel: prefer 64x64 tiles even where the launch would fill the chip with 128x128 ones (N far from a multiple of 128)
     // 16-bit kernel only: the weights once more in ITERATION order [K/32][taps][2][M/32][64][8] for the deep-ring variant of
     // the wide convs (null = none; the launcher then runs the one-step-ahead form on `wfrag`)
     const void* wfrag_iter;

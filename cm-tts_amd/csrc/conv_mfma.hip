@@ -332,7 +332,7 @@ extern "C" int cmtts_launch_conv(const ConvArgs* ap, int epi, int nbatch, void* 
         // 128x128 tiles: use 64x64
         const long big = (long)((a.N + 127) / 128) * ((a.M + 127) / 128) * nbatch;
         // (measured on cfg2: below two 128x128 workgroups per CU the 64x64 tiling wins, 18.2 -> 17.9 ms/step)
-        if (big < 512 && a.split == INT_MAX) {
+        if ((big < 512 || a.small_tiles) && a.split == INT_MAX) {
             // k=1 contractions only: there a 64-channel chunk accumulates in the same order as four 16-channel
             // chunks, so an utterance's result does not depend on which configuration its batch size selects
             // (tests: every utterance bit-identical to synthesising it alone)

@@ -27,6 +27,9 @@ void k_durations(const float* logd, float d_control, float* d_rounded, int* cum,
                  int B, int L, hipStream_t s);
 void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
                  int B, int L, hipStream_t s);
+// out = mask(sum_s part[b][s] (ascending) + bias + res); part: [B][nseg][C][ld]
+void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
+                       int L, int ld, hipStream_t s);
 // LayerNorm(256 channels) + Linear(256 -> O) in one launch, O in {1, 10, 11} (false: not covered); out is time-major [B][T][O]
 bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
                  const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s);

@@ -301,6 +301,23 @@ __global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict_
     }
 }
 
+// ---- out[b][c][t] = mask(((p_0 + p_1) + ... + p_{n-1}) + bias[c] + res[b][c][t]): the reduction of the FFN linear's K-segment
+// partial sums (part: [B][nseg][C][ld]) with the generic conv epilogue's order (accumulator, + bias, + residual, length mask)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nseg, const float* __restrict__ bias,
+                                                              const float* res, const int64_t* lens, float* out, int C, int L, int ld) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (t >= L || c >= C) return;
+    const float* p = part + ((long)b * nseg * C + c) * ld + t;
+    float v = p[0];
+    for (int s = 1; s < nseg; ++s) v += p[(long)s * C * ld];
+    v += bias[c];
+    v += res[((long)b * C + c) * ld + t];
+    if (lens && (int64_t)t >= lens[b]) v = 0.f;
+    out[((long)b * C + c) * ld + t] = v;
+}
+
 // ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
 // Workgroup = 64 output columns x KS K-slices (one wave per slice), DB batch rows per thread: Wt (up to
 // 5 MB for the stacked per-layer projections) is streamed once per DB rows, 8 independent loads in
@@ -694,6 +711,10 @@ void k_durations(const float* logd, float d_control, float* d_rounded, int* cum,
 void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
                         hipStream_t s) {
     hipLaunchKernelGGL(durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, logd, d_control, d_rounded, cum, mel_len, B, L);
+}
+void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
+                       int L, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(L, 64), cdiv(C, 4), B), dim3(256), 0, s, part, nseg, bias, res, lens, out, C, L, ld);
 }
 bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
                  const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s) {
