@@ -19,6 +19,7 @@
 #include "persist_args.h"
 #include "cond_gemm.h"
 #include "resblock_pair.h"
+#include "inproj.h"
 #include "attention.h"
 
 namespace {
@@ -301,6 +302,8 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
+int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
@@ -471,11 +474,18 @@ struct cmtts_model {
     float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
     float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
     PackedConv in_proj, skip_proj, out_proj;
+    float* in_proj_f = nullptr;   // input projection as MFMA A fragments (inproj.hip)
     float *skip_f = nullptr, *outp_f = nullptr;   // skip / output projection in fragment order (persistent kernel's tail)
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
+    // Step-embedding cache (round 2): the DiffusionEmbedding -> MLP -> 20 stacked diffusion projections of a timestep depend
+    // on nothing but the timestep, and the consistency sampler evaluates every batch at the same few sigmas: the row
+    // [NL * C] of each rescaled timestep seen by cmtts_sample is kept on the device (first use computes and copies it; an
+    // entry is used once the event recorded behind that copy has completed, whatever stream asks).
+    struct StepRow { float t; float* row; hipEvent_t ready; };
+    std::vector<StepRow> step_rows;
 };
 
 struct cmtts_vocoder {
@@ -659,7 +669,11 @@ int finalize_model(cmtts_model* m) {
     // ---- denoiser
     {
         GET(w, "net.input_projection.0.conv.weight", C, c.n_mels, 1); GET(b, "net.input_projection.0.conv.bias", C);
-        CHK(pack_conv(al, *w, b, nullptr, &m->in_proj));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, *w, b, nullptr, &m->in_proj, &hp));
+            if (c.n_mels % 8 == 0 && C % 32 == 0 && m->in_proj.ld == C) CHK(al.upload(to_fragment_order(hp, 1, c.n_mels, C), &m->in_proj_f));
+        }
         GET(m0, "net.mlp.0.linear.weight", 4 * C, C); GET(m2, "net.mlp.2.linear.weight", C, 4 * C);
         CHK(al.upload(transpose2d(m0->data.data(), 4 * C, C), &m->mlp0_wt));
         CHK(al.upload(transpose2d(m2->data.data(), C, 4 * C), &m->mlp2_wt));
@@ -919,17 +933,49 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
 // DiffusionEmbedding -> mlp (Linear, Mish, Linear) -> the 20 stacked diffusion (+ speaker) projections
 // (model/blocks.py:633-640,669-674; model/modules.py:579-583,626-627).  Depends only on the timesteps and
 // the speaker vector, so the sampler re-uses it across evaluations at the same sigma (T = 2, 4: always 80).
-int step_embedding(cmtts_model* m, const DenWs& w, const float* timesteps, const float* spk, int B, hipStream_t s) {
+// t_host: the (rescaled) timestep every row of `timesteps` holds, when the caller knows it (cmtts_sample); NaN otherwise
+int step_embedding(cmtts_model* m, const DenWs& w, const float* timesteps, const float* spk, int B, hipStream_t s,
+                   float t_host = NAN) {
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers;
+    if (c.multi_speaker && !spk) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
+    const bool cacheable = g_step_cache && t_host == t_host;
+    if (cacheable) {
+        for (const cmtts_model::StepRow& e : m->step_rows)
+            if (e.t == t_host && hipEventQuery(e.ready) == hipSuccess) {
+                // the same bits as the computation below: every row of dproj is that computation on the same timestep
+                k_broadcast_row(e.row, w.dproj, B, NL * C, s);
+                if (c.multi_speaker) {   // dp = dproj + speaker projection (dense_small's "sum, then + add")
+                    k_dense_small(spk, c.hidden, 1, m->sproj_wt, nullptr, nullptr, w.sproj, B, c.hidden, NL * C, DENSE_NONE, s);
+                    k_add_rows(w.dproj, w.sproj, w.dp, (long)B * NL * C, s);
+                }
+                return 0;
+            }
+    }
     k_diff_embed(timesteps, m->omega_res, w.emb, B, C, s);
     k_dense_small(w.emb, C, 1, m->mlp0_wt, nullptr, nullptr, w.e1, B, C, 4 * C, DENSE_MISH, s);
     k_dense_small(w.e1, 4 * C, 1, m->mlp2_wt, nullptr, nullptr, w.e2, B, 4 * C, C, DENSE_NONE, s);
     k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, nullptr, w.dproj, B, C, NL * C, DENSE_NONE, s);
     if (c.multi_speaker) {
-        if (!spk) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
         k_dense_small(spk, c.hidden, 1, m->sproj_wt, nullptr, nullptr, w.sproj, B, c.hidden, NL * C, DENSE_NONE, s);
         k_dense_small(w.e2, C, 1, m->dproj_wt, nullptr, w.sproj, w.dp, B, C, NL * C, DENSE_NONE, s);
+    }
+    if (cacheable && m->step_rows.size() < 16) {
+        bool known = false;
+        for (const cmtts_model::StepRow& e : m->step_rows) known = known || e.t == t_host;
+        if (!known) {
+            cmtts_model::StepRow e{t_host, nullptr, nullptr};
+            void* p = nullptr;
+            if (hipMalloc(&p, (size_t)NL * C * sizeof(float)) == hipSuccess && hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) == hipSuccess) {
+                e.row = (float*)p;
+                m->al.ptrs.push_back(p);
+                HIPCHK(hipMemcpyAsync(e.row, w.dproj, (size_t)NL * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipEventRecord(e.ready, s));
+                m->step_rows.push_back(e);
+            } else if (p) {
+                (void)hipFree(p);
+            }
+        }
     }
     return 0;
 }
@@ -944,7 +990,7 @@ struct MelPost {
 
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
                   const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
-                  SideStream* pending = nullptr) {   // pending: a side branch (the conditioner GEMM) to join before the layers
+                  SideStream* pending = nullptr, float t_host = NAN) {   // pending: a side branch (the conditioner GEMM) to join before the layers
     if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
@@ -952,13 +998,26 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
-    k_mel_prep(x_src, nullptr, in_scale, w.hin, B, T, M, s);
-    {
+    bool halo_zeroed = false;
+    int rin = -2;
+    if (g_inproj_fused && m->in_proj_f) {   // c_in scaling + transpose + input projection (+ halo clearing) in one launch: same bits
+        InProjArgs ia;
+        memset(&ia, 0, sizeof(ia));
+        ia.x = x_src; ia.scale = in_scale; ia.wf = m->in_proj_f; ia.bias = m->in_proj.bias; ia.h = w.h;
+        ia.B = B; ia.T = T; ia.M = M; ia.C = C;
+        const bool persist_path = g_fused_resblock && g_persist && NL <= PERSIST_MAX_LAYERS;
+        if (persist_path) { ia.zero = w.halo; ia.zero_f4 = (long)(cmtts_persist_halo_bytes(B, T) / 16); }
+        rin = cmtts_launch_inproj(&ia, (void*)s);
+        if (rin == -3) return fail(CMTTS_E_HIP, "inproj launch failed");
+        halo_zeroed = rin == 0 && persist_path && cmtts_persist_halo_bytes(B, T) % 16 == 0;
+    }
+    if (rin != 0) {
+        k_mel_prep(x_src, nullptr, in_scale, w.hin, B, T, M, s);
         ConvArgs a = conv_args(m->in_proj, w.hin, T, T, (long)M * T, w.h, T, cs, T);
         a.out[0].act = ACT_RELU;   // relu(relu(.)) == relu(.), model/modules.py:575-577,624
         CHK(launch(a, EPI_PLAIN, B, s));
     }
-    if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s));
+    if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s, t_host));
     if (pending) CHK(branch_join(pending));
     const float* dp = m->cfg.multi_speaker ? w.dp : w.dproj;
     const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
@@ -973,6 +1032,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         pa.dp = dp; pa.d = w.dproj; pa.vec_stride = (long)NL * C;
         pa.skip = w.skip; pa.halo = w.halo; pa.tmo = g_tmo_host;
         pa.B = B; pa.T = T; pa.NL = NL;
+        pa.halo_zeroed = halo_zeroed;
         const int prec = m->precision;
         if (g_persist_tail && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
             pa.tail = 1;
@@ -1100,6 +1160,7 @@ int cmtts_finalize(cmtts_model* m) {
 
 void cmtts_destroy(cmtts_model* m) {
     if (!m) return;
+    for (cmtts_model::StepRow& e : m->step_rows) (void)hipEventDestroy(e.ready);
     m->al.release();
     delete m;
 }
@@ -1435,7 +1496,7 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
         const bool renoise = renoise_std[i] >= 0.0f;
         const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
                               renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr));
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr, t_resc));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1745,6 +1806,16 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "inproj_fused")) {  // denoiser input as one launch (1) or mel_prep + generic conv + memset (0); same bits
+        const int prev = g_inproj_fused;
+        if (value == 0 || value == 1) g_inproj_fused = value;
+        return prev;
+    }
+    if (!strcmp(name, "step_cache")) {    // cmtts_sample: cached step-embedding rows (1) or recomputed per call (0); same bits
+        const int prev = g_step_cache;
+        if (value == 0 || value == 1) g_step_cache = value;
+        return prev;
     }
     if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
         const int prev = g_ffn2_split;

@@ -459,7 +459,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         attr_set = true;
     }
     // every granule tag must be stale (0) when a launch starts
-    if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
+    if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     // utterance chunks: all workgroups of a launch must be resident (one per CU); chunks are balanced so that the last
     // one does not run on a sliver of the chip
     const int B = a.B;

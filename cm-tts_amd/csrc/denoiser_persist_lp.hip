@@ -453,7 +453,7 @@ extern "C" int cmtts_launch_denoiser_persist_lp(const PersistArgs* a_in, int mod
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = nullptr;
-    if (hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
+    if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     if (mode == 3) return launch_mode<3>(a, tiles, max_blocks, stream);
     return mode == 1 ? launch_mode<1>(a, tiles, max_blocks, stream) : launch_mode<2>(a, tiles, max_blocks, stream);
 }

@@ -27,6 +27,8 @@ void k_durations(const float* logd, float d_control, float* d_rounded, int* cum,
                  int B, int L, hipStream_t s);
 void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len,
                  int B, int L, hipStream_t s);
+void k_broadcast_row(const float* row, float* out, int B, int n, hipStream_t s);      // out[b][:] = row[:]
+void k_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s);     // out = a + b
 // out = mask(sum_s part[b][s] (ascending) + bias + res); part: [B][nseg][C][ld]
 void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
                        int L, int ld, hipStream_t s);

@@ -318,6 +318,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     out[((long)b * C + c) * ld + t] = v;
 }
 
+// ---- out[b][:] = row[:] for b < B (the cached step-embedding row to every utterance) and out = a + b element-wise
+__global__ void broadcast_row_kernel(const float* __restrict__ row, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(long)blockIdx.y * n + i] = row[i];
+}
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // ---- tiny dense layer out[b][n] = act(sum_k in[b][k] * Wt[k][n] + bias[n]) + add[b][n].
 // Workgroup = 64 output columns x KS K-slices (one wave per slice), DB batch rows per thread: Wt (up to
 // 5 MB for the stacked per-layer projections) is streamed once per DB rows, 8 independent loads in
@@ -711,6 +721,12 @@ void k_durations(const float* logd, float d_control, float* d_rounded, int* cum,
 void k_durations_serial(const float* logd, float d_control, float* d_rounded, int* cum, int64_t* mel_len, int B, int L,
                         hipStream_t s) {
     hipLaunchKernelGGL(durations_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, logd, d_control, d_rounded, cum, mel_len, B, L);
+}
+void k_broadcast_row(const float* row, float* out, int B, int n, hipStream_t s) {
+    hipLaunchKernelGGL(broadcast_row_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, s, row, out, n);
+}
+void k_add_rows(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
 }
 void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
                        int L, int ld, hipStream_t s) {

@@ -33,6 +33,7 @@ struct PersistArgs {
     const float* noise;   // [B][T][n_mels] or null
     float c_out, c_skip, nstd;
     float* out;           // [B][T][n_mels]
+    int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
 };
 

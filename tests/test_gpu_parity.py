@@ -631,6 +631,68 @@ def test_fused_attention_matches_three_launch_path(variant, B, L):
             assert torch.equal(one["enc_out"][0, :n], got["enc_out"][1, :n])
 
 
+@pytest.mark.parametrize("B,T", [(3, 96), (2, 77), (32, 512), (1, 5)])
+def test_fused_input_projection_bitwise(B, T):
+    """inproj.hip (c_in scaling + [B,T,80] -> [B,80,T] + relu(input_projection) + clearing of the persistent kernel's halo
+    granules in one launch) against mel_prep + the generic conv kernel + hipMemsetAsync: same products in the same order and
+    the same epilogue -> the sampler output must not change by a bit (T = 77 / 5: ragged and sub-tile utterances; B = 32 x 512
+    takes the persistent stack, whose halo buffer the fused kernel clears)."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("LJSpeech")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=33))
+    gen = torch.Generator(device="cpu").manual_seed(T)
+    cond = torch.randn(B, cfg.hidden, T, generator=gen).to(DEV)
+    noise = torch.randn(5, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    prev = lib.cmtts_set_option(b"inproj_fused", 0)
+    try:
+        ref = host.sample_with_cond(model, cond, None, 4, noise).clone()
+        lib.cmtts_set_option(b"inproj_fused", 1)
+        got = host.sample_with_cond(model, cond, None, 4, noise).clone()
+        again = host.sample_with_cond(model, cond, None, 4, noise).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.cmtts_set_option(b"inproj_fused", prev)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert torch.equal(again, ref)
+    host.check_async_error()
+
+
+@pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
+def test_step_embedding_cache_bitwise(variant):
+    """cmtts_sample keeps the timestep-only part of the step embedding (DiffusionEmbedding -> MLP -> 20 diffusion projections)
+    per rescaled timestep on the device and re-uses it in later calls: a cache hit must give the bits of the computation it
+    replaces — single-speaker and with the per-utterance speaker projection added on top — and so must the first (filling) call."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=31))
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    B, T = 3, 96
+    cond = torch.randn(B, cfg.hidden, T, generator=gen).to(DEV)
+    spk = torch.randn(B, cfg.hidden, generator=gen).to(DEV) if cfg.multi_speaker else None
+    outs = {}
+    prev = lib.cmtts_set_option(b"step_cache", 0)
+    try:
+        for n_steps in (1, 4):
+            noise = torch.randn(n_steps + 1 if n_steps > 1 else 1, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+            lib.cmtts_set_option(b"step_cache", 0)
+            ref = host.sample_with_cond(model, cond, spk, n_steps, noise).clone()
+            lib.cmtts_set_option(b"step_cache", 1)
+            first = host.sample_with_cond(model, cond, spk, n_steps, noise).clone()      # fills the cache (or hits it: T = 4 after T = 1)
+            torch.cuda.synchronize()
+            hit = host.sample_with_cond(model, cond, spk, n_steps, noise).clone()        # the copy has completed: a hit
+            torch.cuda.synchronize()
+            outs[n_steps] = (ref, first, hit)
+    finally:
+        lib.cmtts_set_option(b"step_cache", prev)
+    for n_steps, (ref, first, hit) in outs.items():
+        assert torch.isfinite(ref).all()
+        assert torch.equal(first, ref), (n_steps, float((first - ref).abs().max()))
+        assert torch.equal(hit, ref), (n_steps, float((hit - ref).abs().max()))
+
+
 def test_predictor_conv_xl_bitwise(models):
     """The frame-level 256 -> 256 predictor conv (cwt predictor, k = 5, ReLU) on conv_xl_kernel (x tile + halo resident in
     LDS, weights streamed as MFMA A fragments) keeps the generic kernel's accumulation order and epilogue: not a bit changes
