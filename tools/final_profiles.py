@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Assemble the committed profile documents from the raw outputs of tools/final_prof_1.sh + tools/final_prof_2.sh
+(gpurun_out/final/).  Usage: python tools/final_profiles.py <commit>.  Sections named "## Final commit" in the appended
+documents are replaced, not duplicated."""
+import json, re, subprocess, sys
+commit = sys.argv[1]
+O = "gpurun_out/final/"
+rd = lambda f: open(O + f).read()
+strip = lambda t: "\n".join(l for l in t.split("\n") if "amdgpu.ids" not in l)
+
+def cut(path):
+    s = open(path).read()
+    i = s.find("\n## Final commit")
+    return s if i < 0 else s[:i + 1]
+
+open("profiles/r02_bench_default.json", "w").write(rd("bench_default.json"))
+open("profiles/r02_bench_profiled.json", "w").write(rd("bench_profiled.json"))
+bp, bd = json.loads(rd("bench_profiled.json")), json.loads(rd("bench_default.json"))
+lines = rd("bench_kernel_stats.md").strip().split("\n")
+out = [lines[0].rstrip("|") + "| ms/step |", lines[1] + "---:|"]
+for l in lines[2:]:
+    if not l.startswith("|"):
+        out.append(l); continue
+    c = [x.strip() for x in l.strip("|").split("|")]
+    out.append(l.rstrip() + " %.3f |" % (float(c[2]) / 13 / 1000))
+open("profiles/r02_bench_kernel_stats.md", "w").write(f"""# Round 2 (final, commit {commit}) — rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline`
+
+MI355X, ROCm 7.2; 13 passes of the hot path in the trace (1 check + 2 warm-up + 10 timed); the bench line of the same process is `profiles/r02_bench_profiled.json`
+({bp["ms_per_step"]} ms/step, persistent launch {bp["roofline"]["avg_launch_us"]} µs by HIP events — the trace's average for the same kernel is in the first row); the un-profiled default run is
+`profiles/r02_bench_default.json` ({bd["ms_per_step"]} ms/step = {bd["value"]:,.0f} mel-frames/s, roofline.frac {bd["roofline"]["frac"]}).  Earlier tables of this round: git history of this file.
+
+""" + "\n".join(out) + "\n")
+
+s = open("profiles/r02_pmc_mfma_busy.md").read()
+i = s.index("## `python bench.py --steps 4")
+j = s.find("\n## ", i + 5)
+j = len(s) if j < 0 else j + 1
+s = s[:i] + f"## `python bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline` (text→mel, B=32, 80×512, T=4, fp32) — final commit {commit}\n\n" + rd("bench_mfma.md") + "\n" + s[j:]
+open("profiles/r02_pmc_mfma_busy.md", "w").write(s)
+
+open("profiles/r02_clock.md", "w").write(cut("profiles/r02_clock.md") + f"""
+## Final commit {commit}
+
+### bench, GRBM_GUI_ACTIVE + SQ_VALU_MFMA_BUSY_CYCLES in one pass
+
+{rd("bench_clock.md")}
+### HiFi-GAN generator fp32 (`VSTREAMS=0 python tools/voc_prof.py`)
+
+{rd("voc_fp32_clock.md")}
+### HiFi-GAN generator with bf16 ResBlock-conv operands
+
+{rd("voc_bf16_clock.md")}
+The 16-bit kernels are the ones the chip throttles hardest: the C = 128, k = 11 convs run at 1.7–1.8 GHz (profiles/r02_vocoder_bf16.md).
+""")
+ab = "\n".join(l for l in rd("voc_ab.txt").split("\n") if l.startswith(("fp32", "bf16", "fp16")))
+open("profiles/r02_vocoder_fp32.md", "w").write(cut("profiles/r02_vocoder_fp32.md") + f"""
+## Final commit {commit} (upsamplers on `convT_xl_kernel`)
+
+```
+{ab}
+```
+
+### fp32, per kernel (3 passes, chains in line)
+
+{rd("voc_fp32_stats.md")}
+### fp32, fabric-side traffic (FETCH_SIZE ×2 calibrated + WRITE_SIZE)
+
+{rd("voc_fp32_hbm.md")}
+Upsamplers: ConvTranspose1d as ONE X-resident launch over all stride phases (`convT_xl_kernel<C_in, waves>`, bitwise equal to the generic kernel run once per
+phase): 3.1 ms in the fp32 run (0.74 / 1.22 / 0.67 / 0.47), 46–73 % pipe busy, where the generic kernel took 5.06 ms (47–57 %).
+""")
+open("profiles/r02_vocoder_bf16.md", "w").write(cut("profiles/r02_vocoder_bf16.md") + f"""
+## Final commit {commit}
+
+(see the A/B lines in profiles/r02_vocoder_fp32.md, final section; bench extras in profiles/r02_bench_default.json)
+
+{rd("voc_bf16_stats.md")}
+""")
+cfg = rd("configs.txt")
+k = cfg.rindex("| config (per GPU)")
+open("profiles/r02_configs.md", "w").write(f"""# Round 2 (final, commit {commit}) — the five BASELINE.json configs, per-GPU share each (`python tools/config_bench.py`)
+
+{cfg[k:]}
+Round 2 before the second half (git history of this file): configs[0] 4.94 ms; configs[1] 1.217 M / 166.8 k to wav; configs[2] 4.82 M / 593 k; configs[3] 637 k; configs[4] 2.95 M / 181 k.
+Round 1 (profiles/r01_configs.md): configs[0] 5.3 ms; configs[1] + fp32 vocoder 145 k; configs[2] 4.84 M text→mel / 563 k to wav; configs[3] 630–710 k; configs[4] 3.04 M / 157 k.
+""")
+open("profiles/r02_small_batch_latency.md", "w").write(f"""# Round 2 (final, commit {commit}) — small-batch latency (`python tools/latency_bench.py`)
+
+```
+{strip(rd("latency.txt"))}```
+Before the second half of the round (git history): B=1 L=25: text side 1.386 ms, T=1 text→mel 2.23 ms, to int16 wav 4.96 ms, vocoder fp32 2.46 / bf16 1.15 ms.
+""")
+open("profiles/r02_text_side.md", "w").write(cut("profiles/r02_text_side.md") + f"""
+## Final commit {commit}
+
+`python tools/text_side_bench.py`:
+```
+{strip(rd("text_side.txt"))}```
+Since the table above: predictor heads as `ln_linear` (LayerNorm + linear, shuffle reductions: 44–59 → 8–13 µs), frame-level predictor convs on `conv_xl_kernel<256, 5, CIN>`
+(138 → 93, 73 → 52 µs), wave-parallel duration scan (20 → 4.7 µs), the generic kernel's staging (pre-activation chosen once per call, 32-bit addressing), FFN linear as
+eight K-segment partial GEMMs + reduction (60 → 44 + 9 µs; one request: 1.17 → 1.04 ms).  Generic-kernel phase counters for the FFN linear before the split
+(`tools/conv_phases.py`, cycles per wave, 16 iterations of a 64-channel chunk): MFMA blocks 55 k (512 MFMAs in ONE dependent chain: 108 cycles each), LDS stores +
+barriers 49 k, prefetch issue 23–31 k, prologue 6 k, epilogue 13 k.
+
+Timeline of one pass at B = 32, L = 85:
+```
+{rd("ts32_timeline.txt")}```
+and of one request (B = 1, L = 25):
+```
+{rd("ts1_timeline.txt")}```
+""")
+subprocess.check_call([sys.executable, "tools/pmc_traffic.py", O + "bf", O + "bw", O + "cf", O + "cw", commit], stdout=subprocess.DEVNULL)
+print("profiles refreshed for", commit)
