@@ -305,6 +305,7 @@ bool g_persist_tail = true;     // skip head + post-scaling inside the persisten
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
+int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
 int g_voc_ring16 = 1;           // 16-bit HiFi-GAN convs at C >= 128: deep weight ring on iteration-order fragments (same bits); 0 = one step ahead
@@ -1664,6 +1665,30 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             hipStream_t q = sj[j];
             float *bT = bufTj[j], *bR = bufRj[j];
             const float* xr = bufU;
+            static const char* rb_only = getenv("CMTTS_RB16_ONLY");      // debugging aid: "C,k" restricts the fused ResBlock to one shape
+            int rbC = 0, rbK = 0;
+            const bool rb_sel = !rb_only || (sscanf(rb_only, "%d,%d", &rbC, &rbK) == 2 && rbC == co && rbK == rk);
+            // measured per ResBlock (bf16, 32 x 512 frames): C = 32: 0.51 / 0.83 / 1.10 ms (k = 3 / 7 / 11) against 1.21 / 1.30 / 1.40 for three
+            // pair launches; C = 64 (8 waves, one 118-KB workgroup per CU): 0.76 / 1.31 / 1.91 against 1.15 / 1.40 / 1.66 — at k = 11 the halo
+            // recompute (+45 % MFMAs) costs more than the four tensor passes saved (g_voc_rb16 == 2: the fused form always)
+            const bool rb_pays = co == 32 || rk <= 7 || g_voc_rb16 == 2;
+            if (g_voc_rb16 && rb_pays && rb_sel && (v->precision == 1 || v->precision == 2) && co <= 64 && v->c1f[r][0][v->precision - 1]) {
+                // narrow stages, 16-bit operands: the WHOLE ResBlock (three pairs) in one launch — x in, MRF sum out: 2 tensor
+                // passes instead of 6 (resblock16_kernel; bitwise equal to three pair launches)
+                const void *w1[3], *w2[3];
+                const float *bb1[3], *bb2[3];
+                for (int mi = 0; mi < 3; ++mi) {
+                    w1[mi] = v->c1f[r][mi][v->precision - 1]; w2[mi] = v->c2f[r][mi][v->precision - 1];
+                    bb1[mi] = v->c1[r][mi].bias; bb2[mi] = v->c2[r][mi].bias;
+                }
+                if (ss && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));     // MRF sum in ResBlock order
+                const int rrc = cmtts_launch_resblock16(xr, bufS, w1, w2, bb1, bb2, cs, B, co, To, ld, rk, j > 0, 0.1f, v->precision, (void*)q);
+                if (rrc == -3) return fail(CMTTS_E_HIP, "resblock16 launch failed");
+                if (rrc == 0) {
+                    if (ss && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                    continue;
+                }
+            }
             // narrow stages: conv1 -> LeakyReLU -> conv2 -> + x of a pair in ONE launch, xt never leaves the CU
             // (resblock_pair.hip; the pair's output must not alias its input, so the chain ping-pongs bR / bT)
             // 16-bit operands: with the weight ring issued by hand (resblock_pair16.hip: the compiler had sunk every fragment load
@@ -1820,6 +1845,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
         const int prev = g_ffn2_split;
         if (value == 0 || value == 1) g_ffn2_split = value;
+        return prev;
+    }
+    if (!strcmp(name, "voc_rb16")) {      // 16-bit narrow stages: whole ResBlock per launch (1) or one launch per pair (0); same bits
+        const int prev = g_voc_rb16;
+        if (value >= 0 && value <= 2) g_voc_rb16 = value;
         return prev;
     }
     if (!strcmp(name, "voc_upsT")) {      // upsampling transposed convs on convT_xl_kernel (1) or the generic kernel (0); same bits

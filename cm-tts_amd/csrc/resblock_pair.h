@@ -45,6 +45,10 @@ int cmtts_launch_conv_xl16(const ConvXlArgs* a, int mode, int io, void* stream);
 // 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error
 int cmtts_launch_resblock_pair(const PairArgs* a, void* stream);
 int cmtts_launch_resblock_pair16(const PairArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16
+// a whole ResBlock (three pairs, dilations 1 / 3 / 5) of a C = 64 / 32 stage in one launch, 16-bit operands; -2 = not covered
+int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, const void* const* w2f, const float* const* b1,
+                            const float* const* b2, long bstride, int B, int C, int T, int ld, int k, int accum, float slope,
+                            int mode, void* stream);
 int cmtts_launch_resblock_pair16p(const PairArgs* a, int mode, int n_cus, void* stream);   // persistent, register-resident weights
 void cmtts_pair_set_debug(long long* dbg);
 #ifdef __cplusplus

@@ -1291,8 +1291,11 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
     prev = lib.cmtts_set_option(b"voc_pair", 0)
     prev_x = lib.cmtts_set_option(b"voc_xl16", 0)
+    prev_r = lib.cmtts_set_option(b"voc_rb16", 2)      # 2 = for every (C, k) of the narrow stages
     try:
         prev_p = lib.cmtts_set_option(b"voc_pair16p", 0)
+        got_rb = voc(mel).clone()                     # C = 64 / 32 stages: a whole ResBlock (three pairs) per launch
+        lib.cmtts_set_option(b"voc_rb16", 0)
         ref = voc(mel).clone()                        # every ResBlock conv on the chunked conv_mfma16 kernel
         lib.cmtts_set_option(b"voc_xl16", 1)          # C = 128 / 256 stages on the X-resident conv_xl16 kernel
         got_x = voc(mel).clone()
@@ -1307,6 +1310,8 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
         lib.cmtts_set_option(b"voc_pair", prev)
         lib.cmtts_set_option(b"voc_pair16p", prev_p)
         lib.cmtts_set_option(b"voc_xl16", prev_x)
+        lib.cmtts_set_option(b"voc_rb16", prev_r)
+    assert torch.equal(got_rb, ref), float((got_rb - ref).abs().max())
     assert torch.isfinite(got).all()
     assert torch.equal(got_x, ref), float((got_x - ref).abs().max())
     assert torch.equal(got, ref), float((got - ref).abs().max())
