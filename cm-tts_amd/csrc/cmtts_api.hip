@@ -305,6 +305,7 @@ bool g_persist_tail = true;     // skip head + post-scaling inside the persisten
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
+int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
@@ -1695,7 +1696,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             // next to its use) the pair kernel wins for every (C, k): 0.37-0.55 ms per pair against 0.60-0.64 for two launches
             // (profiles/r02_vocoder_bf16.md).  g_voc_pair16p: the persistent form with register-resident weights
             const bool pair16_pays = true;
-            const bool pair_ok = g_voc_pair && co <= 64 && v->precision != 3 &&
+            // 16-bit, C = 128 (round 2): the pair as one 8-wave workgroup with both images in LDS (151 KB) — conv_xl16 otherwise
+            // (measured, bf16: k = 3 / 7 / 11: 471 / 754 / 967 us per pair against 527 / 700 / 903 for the two launches: k = 3 only)
+            const bool pair128 = g_voc_pair128 && co == 128 && rk == 3 && (v->precision == 1 || v->precision == 2) && !g_voc_pair16p;
+            const bool pair_ok = g_voc_pair && (co <= 64 || pair128) && v->precision != 3 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
@@ -1845,6 +1849,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
         const int prev = g_ffn2_split;
         if (value == 0 || value == 1) g_ffn2_split = value;
+        return prev;
+    }
+    if (!strcmp(name, "voc_pair128")) {   // 16-bit C = 128 stage: pair kernel (1) or two X-resident convs (0); same bits
+        const int prev = g_voc_pair128;
+        if (value == 0 || value == 1) g_voc_pair128 = value;
         return prev;
     }
     if (!strcmp(name, "voc_rb16")) {      // 16-bit narrow stages: whole ResBlock per launch (1) or one launch per pair (0); same bits

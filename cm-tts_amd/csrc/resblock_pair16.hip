@@ -185,10 +185,11 @@ __device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4*
 }
 
 template <int C, int KT, int MODE>
-__global__ __launch_bounds__(256, 2) void resblock_pair16_kernel(const PairArgs a) {
+__global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kernel(const PairArgs a) {
     constexpr int RS = C + 4;
-    constexpr int NT = (C / 32) * (N1 / 32) / 4;            // 32x32 tiles per wave: one m-tile x NT n-tiles
-    constexpr int WPM = 4 / (C / 32);                       // waves per m-tile
+    constexpr int NWAVES = C == 128 ? 8 : 4;                // C = 128 (round 2): 8 waves, one 151-KB workgroup per CU
+    constexpr int NT = (C / 32) * (N1 / 32) / NWAVES;       // 32x32 tiles per wave: one m-tile x NT n-tiles
+    constexpr int WPM = NWAVES / (C / 32);                  // waves per m-tile
     constexpr int R2 = (KT - 1) / 2;
     constexpr int TT = N1 - 2 * R2;
     constexpr int XROWS = N1 + 2 * R1MAX;                   // the xt^T tile has N1 + KT - 1 rows
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair16_kernel(const PairArgs 
     // ---- stage x^T: wave w converts channel pairs w*(C/8) .. of every column; lanes run over columns (coalesced rows)
     {
         const int tbase = t0 - R2 - r1;
-        constexpr int PAIRS = C / 8;                        // channel pairs per wave: 8 / 4
+        constexpr int PAIRS = C / 2 / NWAVES;               // channel pairs per wave: 8 / 4
         constexpr int XBLK = (XROWS + 63) / 64;             // 5 column blocks
 #pragma unroll
         for (int jb = 0; jb < XBLK; ++jb) {
@@ -913,12 +914,17 @@ int launch_pair16(const PairArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((a.T + TT - 1) / TT, a.B);
-    hipLaunchKernelGGL((resblock_pair16_kernel<C, KT, MODE>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((resblock_pair16_kernel<C, KT, MODE>), grid, dim3(C == 128 ? 512 : 256), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int MODE>
 int dispatch16(const PairArgs& a, hipStream_t s) {
+    if (a.C == 128) {
+        if (a.k == 3) return launch_pair16<128, 3, MODE>(a, s);
+        if (a.k == 7) return launch_pair16<128, 7, MODE>(a, s);
+        if (a.k == 11) return launch_pair16<128, 11, MODE>(a, s);
+    }
     if (a.C == 64) {
         if (a.k == 3) return launch_pair16<64, 3, MODE>(a, s);
         if (a.k == 7) return launch_pair16<64, 7, MODE>(a, s);
