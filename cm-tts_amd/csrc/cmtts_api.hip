@@ -309,7 +309,7 @@ int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or 
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
-int g_voc_ring16 = 1;           // 16-bit HiFi-GAN convs at C >= 128: deep weight ring on iteration-order fragments (same bits); 0 = one step ahead
+int g_voc_ring16 = 0;           // 16-bit HiFi-GAN convs at C >= 128 on the CHUNKED kernel (voc_xl16 = 0): deep weight ring on iteration-order fragments (same bits, no gain: DESIGN.md §9); set before cmtts_vocoder_finalize
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
 int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
 int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
@@ -1548,7 +1548,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
-                    if (co >= 128 && co % 32 == 0) {
+                    if (g_voc_ring16 && co >= 128 && co % 32 == 0) {     // only when the (superseded) deep-ring chunked kernel is asked for before finalize
                         const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
                         CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c1fi[r][mi][mode - 1]));
                     }
@@ -1562,7 +1562,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
-                    if (co >= 128 && co % 32 == 0) {
+                    if (g_voc_ring16 && co >= 128 && co % 32 == 0) {     // only when the (superseded) deep-ring chunked kernel is asked for before finalize
                         const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
                         CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c2fi[r][mi][mode - 1]));
                     }

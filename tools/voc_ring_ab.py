@@ -10,6 +10,8 @@ from cmtts_amd.config import HifiGanConfig
 from cmtts_amd.weights import synth_hifigan_state_dict
 
 lib = _lib.load()
+lib.cmtts_set_option(b"voc_ring16", 1)     # the iteration-order fragment copies are built at finalize only when this is set
+lib.cmtts_set_option(b"voc_xl16", 0)       # the ring lives in the chunked kernel, which conv_xl16 replaced for C >= 128
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
 mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
