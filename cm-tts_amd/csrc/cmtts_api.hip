@@ -305,6 +305,7 @@ bool g_persist_tail = true;     // skip head + post-scaling inside the persisten
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
+int g_voc_ups16 = 1;            // vocoder 16-bit modes: upsampler operands in 16 bits as well (1) or fp32 upsamplers as in the first half of round 2 (0) — different numerics
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
@@ -497,6 +498,7 @@ struct cmtts_vocoder {
     PackedConv conv_pre;
     PackedConv ups[4];
     float* ups_f[4] = {nullptr, nullptr, nullptr, nullptr};   // two-tap stacked-phase weights as iteration-order fragments (convT_xl_kernel)
+    void* ups_f16[4][2] = {};                                  // the same as bf16 / fp16 fragments (convT_xl16_kernel)
     int up_rate[4] = {8, 8, 2, 2};
     int up_kernel[4] = {16, 16, 4, 4};
     int rb_kernel[3] = {3, 7, 11};
@@ -1532,7 +1534,13 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
             std::vector<float> tt;
             CHK(pack_conv_transpose(al, *uw, *ub, v->up_rate[i], &v->ups[i], &tt));
             const int mrows = v->up_rate[i] * co;
-            if (!tt.empty() && ch % 16 == 0 && mrows % 32 == 0) CHK(al.upload(to_fragment_iter_order(tt, 2, ch, mrows), &v->ups_f[i]));
+            if (!tt.empty() && ch % 16 == 0 && mrows % 32 == 0) {
+                CHK(al.upload(to_fragment_iter_order(tt, 2, ch, mrows), &v->ups_f[i]));
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(tt, 2, ch, mrows, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->ups_f16[i][mode - 1]));
+                }
+            }
         }
         for (int j = 0; j < 3; ++j) {
             const int r = i * 3 + j;
@@ -1639,7 +1647,12 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
             const PackedConv& U = v->ups[i];
             int rt = -2;
-            if (g_voc_upsT && v->ups_f[i] && K == 2 * st)      // all phases in one X-resident launch (same bits)
+            if (g_voc_ups16 && (v->precision == 1 || v->precision == 2) && v->ups_f16[i][v->precision - 1] && K == 2 * st)
+                // 16-bit modes: the upsamplers' operands are 16-bit too (since round 2; the oracle's operands16 modes follow)
+                rt = cmtts_launch_convT16(bufA, bufU, v->ups_f16[i][v->precision - 1], U.bias, (long)ch * (Ti + P), (long)co * (To + P), B, ch,
+                                          co, Ti, To, Ti + P, To + P, st, i > 0 ? 3.0f : 1.0f, 0.1f, v->precision, (void*)s);
+            if (rt == -3) return fail(CMTTS_E_HIP, "convT16 launch failed");
+            if (rt != 0 && g_voc_upsT && v->ups_f[i] && K == 2 * st)      // all phases in one X-resident launch (same bits)
                 rt = cmtts_launch_convT(bufA, bufU, v->ups_f[i], U.bias, (long)ch * (Ti + P), (long)co * (To + P), B, ch, co, Ti, To,
                                         Ti + P, To + P, st, i > 0 ? 3.0f : 1.0f, 0.1f, (void*)s);
             if (rt == -3) return fail(CMTTS_E_HIP, "convT launch failed");
@@ -1849,6 +1862,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
         const int prev = g_ffn2_split;
         if (value == 0 || value == 1) g_ffn2_split = value;
+        return prev;
+    }
+    if (!strcmp(name, "voc_ups16")) {     // 16-bit vocoder modes: 16-bit upsampler operands (1) or fp32 upsamplers (0): different numerics
+        const int prev = g_voc_ups16;
+        if (value == 0 || value == 1) g_voc_ups16 = value;
         return prev;
     }
     if (!strcmp(name, "voc_pair128")) {   // 16-bit C = 128 stage: pair kernel (1) or two X-resident convs (0); same bits

@@ -45,6 +45,9 @@ int cmtts_launch_conv_xl16(const ConvXlArgs* a, int mode, int io, void* stream);
 // 0 = launched, -2 = shape not covered (the caller runs the two layer-granular launches), -3 = HIP error
 int cmtts_launch_resblock_pair(const PairArgs* a, void* stream);
 int cmtts_launch_resblock_pair16(const PairArgs* a, int mode, void* stream);   // mode 1 = bf16, 2 = fp16
+// the upsampler with 16-bit operands (resblock_pair16.hip): wf16 = 16-bit fragments of the same two-tap stacked weights
+int cmtts_launch_convT16(const float* x, float* y, const void* wf16, const float* bias, long xbstride, long ybstride, int B, int cin,
+                         int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, int mode, void* stream);
 // a whole ResBlock (three pairs, dilations 1 / 3 / 5) of a C = 64 / 32 stage in one launch, 16-bit operands; -2 = not covered
 int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, const void* const* w2f, const float* const* b1,
                             const float* const* b2, long bstride, int B, int C, int T, int ld, int k, int accum, float slope,

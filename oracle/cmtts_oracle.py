@@ -705,7 +705,9 @@ def hifigan_generator(hsd, hcfg, mel_ct):
     nk = len(hcfg.resblock_kernel_sizes)
     for i, (u, k) in enumerate(zip(hcfg.upsample_rates, hcfg.upsample_kernel_sizes)):
         x = leaky_relu(x, hcfg.lrelu_slope)
-        x = conv_transpose1d(x, hsd[f"ups.{i}.weight"], hsd[f"ups.{i}.bias"], u, (k - u) // 2)
+        # bf16 / fp16 vocoder modes carry the upsamplers' operands in 16 bits too (convT_xl16_kernel); fp16x3 keeps them fp32
+        qu = quant16 if _OPERAND16 in ("bf16", "fp16") else (lambda a: a)
+        x = conv_transpose1d(qu(x), qu(hsd[f"ups.{i}.weight"]), hsd[f"ups.{i}.bias"], u, (k - u) // 2)
         xs = None
         for j, (rk, dils) in enumerate(zip(hcfg.resblock_kernel_sizes, hcfg.resblock_dilation_sizes)):
             r = i * nk + j

@@ -206,7 +206,9 @@ def test_precision_ladder_vocoder(golden):
                 orc[dt] = O.hifigan_generator(hsd, hcfg, mel_ct_np)
     assert np.abs(hip["fp32"] - ref64).max() < 1e-4
     for dt in ("bf16", "fp16"):
-        check_ladder("vocoder", ref64, hip["fp32"], hip[dt], orc[dt], 24, dt, golden32=g["wav"])
+        # 4 upsamplers + 24 ResBlock convs with 16-bit operands since round 2 (the upsamplers sit on the main signal path, without a
+        # residual around them: two implementations' roundings decorrelate there) -> the statistical criterion of the deep stacks
+        check_ladder("vocoder", ref64, hip["fp32"], hip[dt], orc[dt], 28, dt, golden32=g["wav"], deep=True)
     voc.set_precision("fp16x3")
     x3 = _np(voc(mel_ct))
     voc.set_precision("fp32")
@@ -298,7 +300,7 @@ def _full_config(variant, B, L, T, n_steps, den_dt, voc_dt, seed, spot, voc_fram
         report(f"DTYPE_ERR {tag} wav fp32 vocoder: max|d| vs f64 {err:.2e}")
         assert err < 1e-4, err
     else:
-        check_ladder(tag + " wav", w64, voc32_same_mel, got, w16, 24, voc_dt)
+        check_ladder(tag + " wav", w64, voc32_same_mel, got, w16, 28, voc_dt, deep=True)
 
 
 def test_config2_full_size_bf16():
