@@ -668,9 +668,14 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
     }
 }
 
+// columns per workgroup at C = 256: 128 (one 93-KB workgroup of 8 waves per CU, four n-tiles per weight fragment) beats 64 (two
+// 59-KB workgroups, two n-tiles per fragment): bf16 vocoder 16.95 -> 16.61 ms
+#ifndef XL16_BN256
+#define XL16_BN256 128
+#endif
 template <int C, int KT, int MODE, int IO>
 int launch_xl16(const ConvXlArgs& a, hipStream_t stream) {
-    constexpr int BN = C == 128 ? 128 : 64;          // C = 256: 64 columns keep two workgroups per CU (59 KB each)
+    constexpr int BN = (C == 128 || XL16_BN256 == 128) ? 128 : 64;
     constexpr int MT = 1;                            // (C = 128 with two waves of 2 x 4 tiles, conv_loop16m: same K-loop slope, slower staging: 460 / 538 vs 429 / 483 us at k = 11)
     const size_t lds = (size_t)(BN + (KT - 1) * 5) * (C + 4) * sizeof(unsigned short);
     static bool attr_set = false;
