@@ -302,6 +302,7 @@ struct Profile {
 
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
@@ -439,6 +440,7 @@ struct EncLayer {
     float* ffn1_f = nullptr;   // ffn1 as MFMA A fragments in iteration order (conv_xres.hip)
     float* qkv_f = nullptr;    // the same for the in-projection and the out-projection (round 2: LayerNorm + projection in one launch)
     float* wo_f = nullptr;
+    float* ffn2_f = nullptr;   // the FFN linear as A fragments in iteration order: conv_xres.hip's FFN fusion
     float* wvT;  // [256 c][256 d]
 };
 struct Predictor {
@@ -599,7 +601,11 @@ int finalize_model(cmtts_model* m) {
         }
         GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
         HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
-        CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2, &hp));
+            if (H == 256 && L.ffn2.cin % 128 == 0 && L.ffn2.ld == L.ffn2.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, L.ffn2.cin, H), &L.ffn2_f));
+        }
         return 0;
     };
     m->enc.resize(c.enc_layers);
@@ -1272,6 +1278,8 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
         }
+        const bool ffn2_seg = g_ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1;
+        bool ffn_fused = false;
         {   // gelu((conv_k9(LayerNorm2(x)) + b) * k^-0.5)      (model/blocks.py:539-546, 612-615)
             // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
             const bool xr = xres_cols && E.ffn1_f && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128;
@@ -1282,7 +1290,14 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             a.out[0].act = ACT_GELU_ERF;
             if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; }
             int rc = -2;
-            if (xr) rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
+            if (xr && g_ffn_fused && ffn2_seg && E.ffn2_f && E.ffn1.cout == FFN2_SEG * 128) {
+                // ... and the FFN linear's partial products in the same launch: the activated rows never leave the CU
+                a.w2frag = E.ffn2_f; a.part = w.part; a.part_zs0 = (long)FFN2_SEG * hs; a.part_zs1 = hs; a.part_ld = Lp; a.M2 = H;
+                rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
+                if (rc == 0) ffn_fused = true;
+                else { a.w2frag = nullptr; a.part = nullptr; }
+            }
+            if (xr && !ffn_fused) rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) {
                 if (ln_ffn) {
@@ -1292,7 +1307,9 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                 CHK(launch(a, EPI_PLAIN, B, s));
             }
         }
-        if (g_ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1) {
+        if (ffn_fused) {   // the partial products are in w.part already
+            k_reduce_partials(w.part, FFN2_SEG, E.ffn2.bias, w.x, src_lens, w.x, B, H, L, Lp, s);
+        } else if (ffn2_seg) {
             // x = (x + ffn_2(.)) * nonpad          (:551, :616-617) as FFN2_SEG independent partial GEMMs + one reduction
             const int kseg = E.ffn2.cin / FFN2_SEG;
             ConvArgs a = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.part, Lp, (long)FFN2_SEG * hs, L);
@@ -1848,6 +1865,11 @@ int cmtts_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
         return cmtts_persist_set_cooperative(value);
+    }
+    if (!strcmp(name, "ffn_fused")) {     // FFN linear inside the FFN conv's launch (1) or as its own K-segment launch (0); same bits
+        const int prev = g_ffn_fused;
+        if (value == 0 || value == 1) g_ffn_fused = value;
+        return prev;
     }
     if (!strcmp(name, "inproj_fused")) {  // denoiser input as one launch (1) or mel_prep + generic conv + memset (0); same bits
         const int prev = g_inproj_fused;

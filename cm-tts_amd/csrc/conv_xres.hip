@@ -229,8 +229,70 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
         }
     }
     stamp(3);
-    if (mt >= MTn) return;
     const ConvOut& o = a.out[0];
+    if (a.w2frag) {
+        // FFN fusion (model/blocks.py:539-551: w_2(gelu(w_1(x) * k^-0.5))): this workgroup's 128 activated rows are K segment `by` of the
+        // linear that follows.  They go to LDS (over the X tile) instead of HBM, and the segment's partial product W2[:, 128 by : 128 by + 128] h
+        // is formed here — two m-tiles per wave, the generic kernel's (16-row chunk, k) order over the segment => the bits of the
+        // K-segment launch it replaces (cmtts_api.hip: FFN2_SEG); reduce_partials_kernel adds the segments, bias, residual and mask as before.
+        const int MT2 = a.M2 >> 5;                       // 8
+        const float* w2 = a.w2frag + (((long)by * 16) * MT2 + 2 * w) * 256 + lane * 4;
+        f32x4 A2[16][2];                                 // the wave's whole weight slice (32 KB), requested before the tile is even written
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) A2[it][i] = *reinterpret_cast<const f32x4*>(w2 + ((long)it * MT2 + i) * 256);
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = o.bias ? o.bias[(unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf)] : 0.f;
+        __syncthreads();                                 // every wave is done with the X tile
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {               // epi_tile_simple<ACT_GELU_ERF>'s arithmetic (no residual, no mask)
+                float v = acc[j][r];
+                if (o.bias) v += bi[r];
+                v *= o.alpha;
+                v = act_apply(v, ACT_GELU_ERF);
+                xs[(w * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * X_LD + j * 32 + l31] = v;
+            }
+        __syncthreads();
+        f32x16 acc2[2][NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float b2[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b2[j] = bl[(it * 8 + 2 * kk) * X_LD + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[it][i][kk], b2[j], acc2[i][j], 0, 0, 0);
+            }
+        float* pb = a.part + z * a.part_zs0 + by * a.part_zs1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + j * 32 + l31;
+                if (n < a.N && n < o.Tout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pb[(unsigned)((2 * w + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * (unsigned)a.part_ld + (unsigned)n] = acc2[i][j][r] * 1.0f;
+                }
+            }
+        stamp(4);
+        return;
+    }
+    if (mt >= MTn) return;
 #if defined(XRES_ABL) && XRES_ABL == 2
     if (epi_simple(o)) {       // timing-only build: no activation
 #pragma unroll
@@ -269,6 +331,10 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
         a.pre_div != 1.0f || a.pre_slope != 1.0f)
         return -2;
     if (a.ln_g && (!a.ln_b || a.K != 256)) return -2;
+    if (a.w2frag) {      // FFN fusion: 128-row m-blocks = K segments of a 256-row linear, plain GELU epilogue, an LDS tile of at least 128 rows
+        const ConvOut& o = a.out[0];
+        if (!a.part || a.M2 != 256 || a.M % 128 != 0 || a.K < 128 || o.ostride != 1 || o.ooff_base || o.ooff_mul || o.row_off || o.div != 1.0f || o.accum || o.bvec || o.act != ACT_GELU_ERF || o.res || o.lens) return -2;
+    }
     static bool attr_set = false;
     const size_t lds = (size_t)a.K * X_LD * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
     if (!attr_set) {

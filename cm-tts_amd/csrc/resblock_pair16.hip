@@ -16,173 +16,10 @@
 #include "resblock_pair.h"
 #include "cvt16.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#include "conv_loop16.h"
 
 namespace {
 
-constexpr int N1 = 256;          // columns of xt per workgroup
-constexpr int RING = 8;          // A fragments in flight per wave (by hand, see conv_loop16): an L2 hit takes ~0.7 us = several groups of 2-4 MFMAs
-constexpr int R1MAX = 25;
-
-template <int MODE>
-__device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
-    if (MODE == 1)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-template <int LO, int N, int SEG, class F>
-__device__ __forceinline__ void seg_loop(F& body) {
-    constexpr int HI = LO + SEG < N ? LO + SEG : N;
-#pragma unroll
-    for (int it = LO; it < HI; ++it) body(it);
-    if constexpr (HI < N) seg_loop<HI, N, SEG>(body);
-}
-
-// acc = W * src over K = C * KT in conv_mfma16.hip's order: 32-channel chunk -> tap -> k-group of 16 within the chunk.
-// wfrag: [tap][C/16][C/32][64 lanes] u32x4 (A fragments);  src: LDS [cols][RS] 16-bit, output column c reads row c + tap*dil.
-template <int C, int KT, int NT, int MODE>
-__device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
-                                            int dil, int mt, int col0, int lane) {
-    constexpr int RS = C + 4;
-    constexpr int G = C / 16, MTn = C / 32;
-    constexpr int NG = G * KT;                      // MFMA k-groups: (chunk, tap, k-group-in-chunk)
-    const int l31 = lane & 31, khalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // the K loop is fully unrolled (NG <= 44 groups): chunk / tap / k-group and the ring slots are compile-time, the only
-    // runtime term of an operand address is tap * dil
-    auto grp = [&](int it, int& chunk, int& tap, int& kgl) {
-        chunk = it / (2 * KT);
-        const int rr = it - chunk * (2 * KT);
-        tap = rr >> 1;
-        kgl = rr & 1;
-    };
-    const unsigned short* bl = src + (col0 + l31) * RS + khalf * 8;
-    auto load_b = [&](u32x4 (&dst)[NT], int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-        const unsigned short* p = bl + (tap * dil) * RS + chunk * 32 + kgl * 16;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    // The weight stream is issued and awaited by hand (inline asm): left to the compiler, every global_load_dwordx4 of the
-    // ring was sunk next to its first use behind an s_waitcnt vmcnt(0) — no fragment in flight at all, the whole L2 latency
-    // paid per group of NT MFMAs (round 1 and the first half of round 2: 45 % of the 16-bit pipe whatever the ring depth).
-    // Loads return in order, so "at most RING-1 younger loads outstanding" is exactly "fragment `it` has landed".
-    u32x4 A[RING];
-    auto issue_a = [&](u32x4& dst, int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-        const u32x4* ptr = wfrag + ((long)(tap * G + 2 * chunk + kgl) * MTn + mt) * 64 + lane;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-    };
-#pragma unroll
-    for (int s = 0; s < RING - 1; ++s)
-        if (s < NG) issue_a(A[s], s);
-    u32x4 Bf[2][NT];
-    load_b(Bf[0], 0);
-    auto body = [&](int it) {
-        if (it + RING - 1 < NG) {
-            issue_a(A[(it + RING - 1) % RING], it + RING - 1);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RING]) : "n"(RING - 1));
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RING]));     // tail: drain
-        }
-        if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);       // the next group's B fragments
-        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // under this group's MFMAs
-    };
-    // full unrolling in segments of 44 groups: one loop of 112 / 176 groups (C = 256) exceeds the compiler's size limit for
-    // "#pragma unroll", stays a run-time loop, and the ring then lives behind s_set_gpr_idx register indexing — an asm-issued
-    // load whose destination is copied at once (memory faults and garbage: the first version of conv_xl16_kernel at C = 256)
-    seg_loop<0, NG, 44>(body);
-}
-
-// The same K loop for a wave that owns MT m-tiles x NT n-tiles (conv_xl16_kernel at C = 128: 2 x 4).  Per MFMA of 32 cycles
-// a 1 x 4 wave reads 1 KB of B fragments from LDS — 128 B/clk per CU at full rate, all the LDS delivers — and a 2 x 2 wave
-// 512 B of A fragments through the L1 (64 B/clk per CU: its limit); 2 x 4 halves both (256 B of A, 512 B of B per MFMA).
-template <int C, int KT, int MT, int NT, int MODE>
-__device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
-                                             int dil, int mt0, int col0, int lane) {
-    constexpr int RS = C + 4;
-    constexpr int G = C / 16, MTn = C / 32;
-    constexpr int NG = G * KT;
-    constexpr int RINGM = 6;
-    const int l31 = lane & 31, khalf = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto grp = [&](int it, int& chunk, int& tap, int& kgl) {
-        chunk = it / (2 * KT);
-        const int rr = it - chunk * (2 * KT);
-        tap = rr >> 1;
-        kgl = rr & 1;
-    };
-    const unsigned short* bl = src + (col0 + l31) * RS + khalf * 8;
-    auto load_b = [&](u32x4 (&dst)[NT], int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-        const unsigned short* p = bl + (tap * dil) * RS + chunk * 32 + kgl * 16;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    u32x4 A[RINGM][MT];
-    auto issue_a = [&](u32x4 (&dst)[MT], int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const u32x4* ptr = wfrag + ((long)(tap * G + 2 * chunk + kgl) * MTn + mt0 + i) * 64 + lane;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[i]) : "v"(ptr) : "memory");
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < RINGM - 1; ++s)
-        if (s < NG) issue_a(A[s], s);
-    u32x4 Bf[2][NT];
-    load_b(Bf[0], 0);
-    auto body = [&](int it) {
-        if (it + RINGM - 1 < NG) {
-            issue_a(A[(it + RINGM - 1) % RINGM], it + RINGM - 1);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RINGM][0]) : "n"((RINGM - 1) * MT));
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RINGM][0]));
-        }
-#pragma unroll
-        for (int i = 1; i < MT; ++i) asm volatile("" : "+v"(A[it % RINGM][i]));      // the other fragments of the group: same wait
-        if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][j] = mma16<MODE>(A[it % RINGM][i], Bf[it & 1][j], acc[i][j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-    };
-    seg_loop<0, NG, 22>(body);
-}
 
 template <int C, int KT, int MODE>
 __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kernel(const PairArgs a) {
@@ -541,165 +378,6 @@ int dispatch16p(const PairArgs& a, int n_cus, hipStream_t s) {
         if (a.k == 3) return launch_pair16p<32, 3, MODE>(a, n_cus, s);
         if (a.k == 7) return launch_pair16p<32, 7, MODE>(a, n_cus, s);
         if (a.k == 11) return launch_pair16p<32, 11, MODE>(a, n_cus, s);
-    }
-    return -2;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// ONE conv of a wide (C = 128 / 256) ResBlock with 16-bit operands, X-resident: the 16-bit twin of conv_xl_kernel
-// (resblock_pair.hip) and the replacement of conv_mfma16.hip's chunked kernel for these stages.  Why a new kernel: in the
-// chunked kernel the next chunk's activation loads (HBM) and the weight fragments (L2 hits) share one in-order vmcnt queue,
-// so every weight fragment issued behind an activation load waited for HBM, and the compiler had sunk the "one step ahead"
-// weight loads next to their uses anyway: the K loop ran at 45-50 % of the 16-bit pipe on top of the HBM time instead of under
-// it (profiles/r02_vocoder_bf16.md, ablation).  Here the whole x^T tile [BN + halo][C] is staged first (one HBM round trip per
-// tile, two or three workgroups per CU overlap it with the others' MFMAs), and the K loop touches only L2 (weights, hand-issued
-// ring: conv_loop16) and LDS.  IO = 1: fp32 x in -> xt out as convert(leaky_relu(xt)) in 16 bits; IO = 2: that 16-bit xt in ->
-// ((acc + b) + res) + y_old in fp32 — conv_mfma16.hip's conversions, accumulation order and epilogue => the same bits.
-template <int C, int KT, int MODE, int IO, int BN, int MT>
-__global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void conv_xl16_kernel(const ConvXlArgs a) {
-    constexpr int RS = C + 4;
-    constexpr int NWAVES = C / 32 / MT;             // MT m-tiles per wave
-    constexpr int NT = BN / 32;                     // all n-tiles of the workgroup's columns
-    constexpr int XROWS = BN + (KT - 1) * 5;        // widest halo: dilation 5
-    extern __shared__ __attribute__((aligned(16))) unsigned short xl16[];   // [XROWS][RS]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
-    const int T = a.T, dil = a.dil;
-    const int pad = dil * ((KT - 1) / 2);
-    const int xw = BN + 2 * pad;
-    const int tbase = t0 - pad;
-    constexpr int XBLK = (XROWS + 63) / 64;
-    constexpr int PAIRS = C / 2 / NWAVES;           // channel pairs per wave: 16 (32 with two m-tiles per wave)
-    constexpr int PB = 16;                          // pairs per staging batch
-    if (IO == 2) {   // 16-bit activated input (what conv1's epilogue wrote): copy, zero outside [0, T)
-        const unsigned short* xb = reinterpret_cast<const unsigned short*>(a.x) + (long)b * a.bstride;
-#pragma unroll
-        for (int jb = 0; jb < XBLK; ++jb) {
-            const int j = jb * 64 + lane;
-            const int t = tbase + j;
-            const int t_c = min(max(t, 0), T - 1);
-            const bool in = t >= 0 && t < T;
-            unsigned v[PAIRS][2];
-#pragma unroll
-            for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p) * 2 + h) * a.ld + t_c];
-            if (j < xw) {
-#pragma unroll
-                for (int p = 0; p < PAIRS; ++p)
-                    *reinterpret_cast<unsigned*>(xl16 + j * RS + (w * PAIRS + p) * 2) = in ? (v[p][0] | (v[p][1] << 16)) : 0u;
-            }
-        }
-    } else {         // fp32 input: leaky_relu, convert, transpose (conv_mfma16.hip's staging arithmetic)
-        const float* xb = a.x + (long)b * a.bstride;
-        const float slope = a.slope;
-#pragma unroll
-        for (int jb = 0; jb < XBLK; ++jb) {
-            const int j = jb * 64 + lane;
-            const int t = tbase + j;
-            const int t_c = min(max(t, 0), T - 1);
-            const bool in = t >= 0 && t < T;
-            const float fpos = in ? 1.f : 0.f, fneg = in ? slope : 0.f;
-#pragma unroll
-            for (int p0 = 0; p0 < PAIRS; p0 += PB) {         // 32 loads in flight per lane
-                float v[PB][2];
-#pragma unroll
-                for (int p = 0; p < PB; ++p)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p0 + p) * 2 + h) * a.ld + t_c];
-                if (j < xw) {
-#pragma unroll
-                    for (int p = 0; p < PB; ++p) {
-                        const float v0 = v[p][0], v1 = v[p][1];
-                        *reinterpret_cast<unsigned*>(xl16 + j * RS + (w * PAIRS + p0 + p) * 2) =
-                            pack16<MODE>(v0 * (v0 > 0.f ? fpos : fneg), v1 * (v1 > 0.f ? fpos : fneg));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc[MT][NT];
-    if constexpr (MT == 1) conv_loop16<C, KT, NT, MODE>(acc[0], (const u32x4*)a.wf, xl16, dil, w, 0, lane);
-    else conv_loop16m<C, KT, MT, NT, MODE>(acc, (const u32x4*)a.wf, xl16, dil, w * MT, 0, lane);
-
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m0 = (w * MT + i) * 32;
-        float bi[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bi[r] = a.bias[m0 + acc_row(r, lane)];
-        if (IO == 1) {
-            unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (long)b * a.bstride;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bi[r];
-                    v = v * (v > 0.f ? 1.f : a.slope);
-                    if (t < T) y16[(long)(m0 + acc_row(r, lane)) * a.ld + t] = (unsigned short)pack16<MODE>(v, 0.f);
-                }
-            }
-        } else {
-            float* yb = a.y + (long)b * a.bstride;
-            const float* rb = a.res ? a.res + (long)b * a.bstride : nullptr;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + l31;
-                const int t_c = min(t, T - 1);
-                float rv[16], yv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long off = (long)(m0 + acc_row(r, lane)) * a.ld + t_c;
-                    rv[r] = rb ? rb[off] : 0.f;
-                    yv[r] = a.accum ? yb[off] : 0.f;
-                }
-                if (t < T) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        yb[(long)(m0 + acc_row(r, lane)) * a.ld + t] = ((acc[i][j][r] + bi[r]) + rv[r]) + yv[r];
-                }
-            }
-        }
-    }
-}
-
-// columns per workgroup at C = 256: 128 (one 93-KB workgroup of 8 waves per CU, four n-tiles per weight fragment) beats 64 (two
-// 59-KB workgroups, two n-tiles per fragment): bf16 vocoder 16.95 -> 16.61 ms
-#ifndef XL16_BN256
-#define XL16_BN256 128
-#endif
-template <int C, int KT, int MODE, int IO>
-int launch_xl16(const ConvXlArgs& a, hipStream_t stream) {
-    constexpr int BN = (C == 128 || XL16_BN256 == 128) ? 128 : 64;
-    constexpr int MT = 1;                            // (C = 128 with two waves of 2 x 4 tiles, conv_loop16m: same K-loop slope, slower staging: 460 / 538 vs 429 / 483 us at k = 11)
-    const size_t lds = (size_t)(BN + (KT - 1) * 5) * (C + 4) * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl16_kernel<C, KT, MODE, IO, BN, MT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
-    dim3 grid((a.T + BN - 1) / BN, a.B);
-    hipLaunchKernelGGL((conv_xl16_kernel<C, KT, MODE, IO, BN, MT>), grid, dim3(C * 2 / MT), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-template <int MODE, int IO>
-int dispatch_xl16(const ConvXlArgs& a, hipStream_t s) {
-    if (a.C == 128) {
-        if (a.k == 3) return launch_xl16<128, 3, MODE, IO>(a, s);
-        if (a.k == 7) return launch_xl16<128, 7, MODE, IO>(a, s);
-        if (a.k == 11) return launch_xl16<128, 11, MODE, IO>(a, s);
-    } else if (a.C == 256) {
-        if (a.k == 3) return launch_xl16<256, 3, MODE, IO>(a, s);
-        if (a.k == 7) return launch_xl16<256, 7, MODE, IO>(a, s);
-        if (a.k == 11) return launch_xl16<256, 11, MODE, IO>(a, s);
     }
     return -2;
 }
@@ -1131,19 +809,6 @@ extern "C" int cmtts_launch_resblock_pair16p(const PairArgs* ap, int mode, int n
 }
 
 
-// One conv of a wide ResBlock, X-resident, 16-bit operands.  io 1: x fp32 [B][C][ld] -> y = 16-bit convert(leaky_relu(conv + b))
-// ([B][C][ld] halves, batch stride bstride in ELEMENTS of the respective type); io 2: x = that 16-bit tensor -> y fp32 =
-// ((conv + b) + res) + (accum ? y : 0).  wf: [tap][C/16][C/32][64][8] fragments (to_fragment16).  mode 1 = bf16, 2 = fp16.
-extern "C" int cmtts_launch_conv_xl16(const ConvXlArgs* ap, int mode, int io, void* stream_) {
-    const ConvXlArgs& a = *ap;
-    hipStream_t s = (hipStream_t)stream_;
-    if (a.B <= 0 || a.T <= 0) return 0;
-    if (a.dil < 1 || a.dil > 5 || (const void*)a.x == (const void*)a.y || (mode != 1 && mode != 2) || (io != 1 && io != 2) || a.cin || a.relu)
-        return -2;
-    if (io == 1 && (a.res || a.accum)) return -2;
-    if (mode == 1) return io == 1 ? dispatch_xl16<1, 1>(a, s) : dispatch_xl16<1, 2>(a, s);
-    return io == 1 ? dispatch_xl16<2, 1>(a, s) : dispatch_xl16<2, 2>(a, s);
-}
 
 // A whole ResBlock (three pairs, dilations 1, 3, 5, kernel k) of a narrow stage in one launch, 16-bit operands (resblock16_kernel).
 // w1f / w2f / b1 / b2: the three pairs' conv1 / conv2 fragments ([tap][C/16][C/32][64][8]) and biases.  x must not alias y.

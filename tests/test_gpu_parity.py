@@ -1077,6 +1077,39 @@ def test_xres_conv_bitwise(models):
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
 
 
+def test_ffn_fused_bitwise(models):
+    """conv_xres.hip's FFN fusion (the FFN linear's K-segment partial products formed from the activated rows of the k = 9 conv
+    while they are in LDS) keeps the K-segment launch's accumulation order: the text side must not change by a bit, with and
+    without the LayerNorm prologue, and a single request (generic path) still equals its row of the batch."""
+    host = _host()
+    lib = _lib.load()
+    g, cfg, sd, model = models("LJSpeech")
+    rs = np.random.RandomState(12)
+    B, L = 32, 85
+    lens = rs.randint(40, L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    prev = lib.cmtts_set_option(b"ffn_fused", 1)
+    prev_t = lib.cmtts_set_option(b"text_xres", 5)
+    try:
+        run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        outs = [("fused", run())]
+        lib.cmtts_set_option(b"text_xres", 0)
+        outs.append(("fused, separate LayerNorm", run()))
+        lib.cmtts_set_option(b"ffn_fused", 0)
+        ref = run()
+        one = model.duration_pitch_energy_net(None, torch.from_numpy(texts[:1]), torch.from_numpy(lens[:1]), max_mel_len=512)
+    finally:
+        lib.cmtts_set_option(b"ffn_fused", prev)
+        lib.cmtts_set_option(b"text_xres", prev_t)
+    torch.cuda.synchronize()
+    for k in ("enc_out", "log_d_predictions", "cond"):
+        for name, got in outs:
+            assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
+    assert torch.equal(one["enc_out"][0], outs[0][1]["enc_out"][0])
+
+
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
 def test_cond_gemm_bitwise(variant, B, T):
     """cond_gemm.hip (conditioner projections of all layers, X tile resident in LDS) keeps the generic kernel's
