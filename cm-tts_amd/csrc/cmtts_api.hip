@@ -303,6 +303,7 @@ struct Profile {
 bool g_fused_resblock = true;
 bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
+int g_pred_xres = 0;            // 1 = phoneme-level predictor convs on conv_xres.hip with the previous layer's LayerNorm as prologue (same bits, measured slower: 64 long workgroups); 0 = generic kernel + LayerNorm launches
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
@@ -894,31 +895,55 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
               const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s) {
     const float* cur = in;
     int ldc = ld_in;
+    int pend = -1;        // layer whose LayerNorm has not been applied to `cur` yet (it becomes the next conv's prologue: conv_xres.hip)
+    auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
     for (size_t li = 0; li < P.convs.size(); ++li) {
         const PackedConv& w = P.convs[li];
         int rx = -2;
-        if (g_pred_xl && P.convs_f[li] && ldc == ld && bufA != cur && (long)((T + 63) / 64) * B >= 192) {
+        float* dst = other(cur);
+        if (g_pred_xres && P.convs_f[li] && T <= 96 && B >= 16 && w.cin == 256 && w.cout == 256 && ldc == ld) {
+            // phoneme-level 256 -> 256 conv: the utterance's x tile resident in LDS, the previous layer's LayerNorm as the prologue
+            // (same accumulation order, epilogue and LayerNorm arithmetic as the separate launches => same bits)
+            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
+            a.out[0].act = ACT_RELU;
+            if (pend >= 0) { a.ln_g = P.ln_g[pend]; a.ln_b = P.ln_b[pend]; a.ln_eps = 1e-12f; a.ln_lens = ln_lens; }
+            rx = cmtts_launch_conv_xres(&a, P.convs_f[li], B, (void*)s);
+            if (rx == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+        }
+        if (rx != 0 && pend >= 0) {     // the pending LayerNorm as its own launch after all
+            k_layernorm_ct(cur, dst, P.ln_g[pend], P.ln_b[pend], 1e-12f, ln_lens, B, T, ld, s);
+            cur = dst; dst = other(cur);
+        }
+        pend = -1;
+        if (rx != 0 && g_pred_xl && P.convs_f[li] && ldc == ld && (long)((T + 63) / 64) * B >= 192) {
             // frame-level 256 -> 256 conv: whole x tile + halo resident in LDS, weights streamed as A fragments (the HiFi-GAN
             // kernel, resblock_pair.hip; same accumulation order and epilogue expressions as the generic kernel => same bits)
             ConvXlArgs xa;
             memset(&xa, 0, sizeof(xa));
-            xa.x = cur; xa.y = bufA; xa.wf = P.convs_f[li]; xa.bias = w.bias; xa.bstride = (long)w.cout * ld;
+            xa.x = cur; xa.y = dst; xa.wf = P.convs_f[li]; xa.bias = w.bias; xa.bstride = (long)w.cout * ld;
             xa.B = B; xa.C = 256; xa.T = T; xa.ld = ld; xa.k = w.taps; xa.dil = 1; xa.slope = 1.0f; xa.relu = 1;
             if (w.cin != 256) { xa.cin = w.cin; xa.xbstride = (long)w.cin * ldc; }
             rx = cmtts_launch_conv_xl(&xa, (void*)s);
             if (rx == -3) return fail(CMTTS_E_HIP, "conv_xl launch failed");
         }
         if (rx != 0) {
-            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, bufA, ld, (long)w.cout * ld, T);
+            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
             a.out[0].act = ACT_RELU;
             CHK(launch(a, EPI_PLAIN, B, s));
         }
-        if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
-            k_ln_linear(bufA, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
-            return 0;
-        k_layernorm_ct(bufA, bufB, P.ln_g[li], P.ln_b[li], 1e-12f, ln_lens, B, T, ld, s);
-        cur = bufB;
+        cur = dst;
         ldc = ld;
+        if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
+            k_ln_linear(cur, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
+            return 0;
+        if (g_pred_xres && li + 1 < P.convs.size() && P.convs_f[li + 1] && T <= 96 && B >= 16 && w.cout == 256 && P.convs[li + 1].cin == 256 &&
+            P.convs[li + 1].cout == 256) {
+            pend = (int)li;               // the next conv normalises its own tile
+            continue;
+        }
+        float* nd = other(cur);
+        k_layernorm_ct(cur, nd, P.ln_g[li], P.ln_b[li], 1e-12f, ln_lens, B, T, ld, s);
+        cur = nd;
     }
     k_chan_linear(cur, P.lin_w, P.lin_b, out, out_lens, B, P.convs.back().cout, T, ld, O, s);
     return 0;
@@ -1869,6 +1894,11 @@ int cmtts_set_option(const char* name, int value) {
     if (!strcmp(name, "ffn_fused")) {     // FFN linear inside the FFN conv's launch (1) or as its own K-segment launch (0); same bits
         const int prev = g_ffn_fused;
         if (value == 0 || value == 1) g_ffn_fused = value;
+        return prev;
+    }
+    if (!strcmp(name, "pred_xres")) {     // phoneme-level predictor convs X-resident with LayerNorm prologue (1) or generic + LayerNorm launches (0); same bits
+        const int prev = g_pred_xres;
+        if (value == 0 || value == 1) g_pred_xres = value;
         return prev;
     }
     if (!strcmp(name, "inproj_fused")) {  // denoiser input as one launch (1) or mel_prep + generic conv + memset (0); same bits

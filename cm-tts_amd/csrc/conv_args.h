@@ -60,6 +60,7 @@ struct ConvArgs {
     const float* ln_g;
     const float* ln_b;
     float ln_eps;
+    const int64_t* ln_lens;   // LayerNorm prologue: columns t >= ln_lens[z] become 0 (layernorm_ct_kernel's optional mask); nullptr = none
     // conv_xres.hip, FFN fusion: the k = 1 linear that follows (W2: [M2][M], M2 = 256) applied to this workgroup's 128 activated output rows while
     // they are on chip — its K-segment partial sum [M2][N] goes to part + z * part_zs0 + (m-block) * part_zs1 (row stride part_ld) instead of
     // the activated rows going to out[0].Y; w2frag = W2 as A fragments in iteration order [M/16][2][M2/32][64][4] (to_fragment_iter_order)

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
         // per lane half, exchanged with __shfl_xor => the same bits as the separate launch, whatever path a batch takes.
         const int c = 32 * w + l31;
         const int t = n0 - a.pad + c;
-        const bool on = c < xw && t >= 0 && t < a.Tin;
+        const bool live = c < xw && t >= 0 && t < a.Tin;
+        const bool on = live && !(a.ln_lens && (int64_t)t >= a.ln_lens[z]);      // masked columns: 0, as layernorm_ct_kernel writes them
         const float* col = xs + min(c, X_LD - 1);
         float p[4] = {0.f, 0.f, 0.f, 0.f}, q[4];
         const float* cr = col + 4 * khalf * X_LD;
@@ -180,6 +181,12 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
                     wc[k * X_LD] = __fmaf_rn((xv[e] - mean) * rstd, gv[e], bv[e]);
                 }
             }
+        } else if (live) {
+            float* wc = xs + c + 4 * khalf * X_LD;
+#pragma unroll 8
+            for (int i2 = 0; i2 < 32; ++i2)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) wc[(y + 8 * i2) * X_LD] = 0.f;
         }
         __syncthreads();
     }

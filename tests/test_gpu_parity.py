@@ -1110,6 +1110,30 @@ def test_ffn_fused_bitwise(models):
     assert torch.equal(one["enc_out"][0], outs[0][1]["enc_out"][0])
 
 
+def test_predictor_xres_bitwise(models):
+    """Phoneme-level predictor convs (duration: masked LayerNorm, energy: unmasked) on conv_xres.hip with the previous layer's
+    LayerNorm — and its length mask — as the prologue: the same bits as the generic kernel + layernorm_ct launches."""
+    lib = _lib.load()
+    g, cfg, sd, model = models("LJSpeech")
+    rs = np.random.RandomState(13)
+    B, L = 32, 85
+    lens = rs.randint(20, L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    prev = lib.cmtts_set_option(b"pred_xres", 1)
+    try:
+        run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
+        got = run()
+        lib.cmtts_set_option(b"pred_xres", 0)
+        ref = run()
+    finally:
+        lib.cmtts_set_option(b"pred_xres", prev)
+    torch.cuda.synchronize()
+    for k in ("log_d_predictions", "cond", "mel_lens"):
+        assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
+
+
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
 def test_cond_gemm_bitwise(variant, B, T):
     """cond_gemm.hip (conditioner projections of all layers, X tile resident in LDS) keeps the generic kernel's
