@@ -437,7 +437,7 @@ def main():
         d_v = timed(lambda: state.__setitem__("wav", voc(mel_v)), 5, 2, 1) / 5
         voc.set_precision("fp32")
         extras["vocoder_bf16"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
-                                  "note": "bf16 ResBlock-conv operands, fp32 upsamplers; pairs / whole ResBlocks at the HBM floor, C = 128 convs throttled to ~1.75 GHz (profiles/r02_vocoder_bf16.md)"}
+                                  "note": "bf16 operands in the ResBlock convs and the upsamplers (conv_pre / conv_post fp32); whole ResBlocks / pairs at C <= 64, X-resident convs above: a wide-stage conv costs ~bytes / 5 TB/s + its K loop, C = 128 convs throttled to ~1.7 GHz (profiles/r02_vocoder_bf16.md)"}
         # fp16x3 everywhere (residual blocks + HiFi-GAN ResBlock convs): fp32-class accuracy, exploratory
         model.set_precision("fp16x3")
         voc.set_precision("fp16x3")

@@ -98,7 +98,7 @@ open("profiles/r02_text_side.md", "w").write(cut("profiles/r02_text_side.md") + 
 {strip(rd("text_side.txt"))}```
 Since the table above: predictor heads as `ln_linear` (LayerNorm + linear, shuffle reductions: 44–59 → 8–13 µs), frame-level predictor convs on `conv_xl_kernel<256, 5, CIN>`
 (138 → 93, 73 → 52 µs), wave-parallel duration scan (20 → 4.7 µs), the generic kernel's staging (pre-activation chosen once per call, 32-bit addressing), FFN linear as
-eight K-segment partial GEMMs + reduction (60 → 44 + 9 µs; one request: 1.17 → 1.04 ms).  Generic-kernel phase counters for the FFN linear before the split
+eight K-segment partial GEMMs + reduction (60 → 44 + 9 µs; one request: 1.17 → 1.04 ms); then those partial products formed inside the FFN conv's launch from the activated rows in LDS (conv_xres FFN fusion, same bits: 139 + 44 → 146 µs per block, text side 1.65 → 1.46 ms).  Generic-kernel phase counters for the FFN linear before the split
 (`tools/conv_phases.py`, cycles per wave, 16 iterations of a 64-channel chunk): MFMA blocks 55 k (512 MFMAs in ONE dependent chain: 108 cycles each), LDS stores +
 barriers 49 k, prefetch issue 23–31 k, prologue 6 k, epilogue 13 k.
 
