@@ -20,6 +20,14 @@
 
 namespace {
 
+// bf16 epilogues store FOUR channels per LDS instruction (accumulator registers 4q .. 4q+3 = four consecutive channels of a column = 8 contiguous bytes
+// of the [column][channel] image): two packed converts + one ds_write_b64 instead of four converts + four ds_write_b16.  fp16 keeps the per-value
+// form: there the compiler fuses `leaky multiply -> convert` into a single-rounding v_fma_mixlo_f16 on the two-launch path, and no packed spelling
+// tried reproduced its bits (3e-4 on the wav; caught by test_vocoder_pair16_kernel_bitwise).
+template <int MODE>
+__device__ __forceinline__ u32x2 pack16x4(const float (&v)[4]) {
+    return (u32x2){pack16<MODE>(v[0], v[1]), pack16<MODE>(v[2], v[3])};
+}
 
 template <int C, int KT, int MODE>
 __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kernel(const PairArgs a) {
@@ -85,11 +93,25 @@ __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kerne
             const int c = col0 + j * 32 + l31;
             const int t = t0 - R2 + c;
             const bool in = t >= 0 && t < T;
+            if constexpr (MODE == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[j][r] + bi[r];
-                v = v * (v > 0.f ? 1.f : slope);
-                XTs[c * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[j][4 * q + e] + bi[4 * q + e];
+                        v[e] = v[e] * (v[e] > 0.f ? 1.f : slope);
+                    }
+                    const u32x2 pk = pack16x4<MODE>(v);
+                    *reinterpret_cast<u32x2*>(XTs + c * RS + mt * 32 + acc_row(4 * q, lane)) = in ? pk : (u32x2){0u, 0u};
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[j][r] + bi[r];
+                    v = v * (v > 0.f ? 1.f : slope);
+                    XTs[c * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+                }
             }
         }
     }
@@ -416,7 +438,9 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
     constexpr int RS = C + 4;
     constexpr int R = (KT - 1) / 2;
     constexpr int H = 12 * R;                               // (1 + 3 + 5) R for the dilated convs + 3 R for the plain ones
-    constexpr int W = 384;                                  // columns every conv is evaluated on
+    // columns every conv is evaluated on (C = 64 with 192 columns, 4 waves and two workgroups per CU — one's epilogues under the other's K loops — was
+    // tried: k = 7 1365 -> 1511 us, k = 3 739 -> 704: the recomputed halo columns cost more than the overlap gives)
+    constexpr int W = 384;
     constexpr int NOUT = W - 2 * H;                         // 264 / 312 / 360
     constexpr int MARGIN = 5 * R;                           // largest reach of one conv: rows a conv may read beyond the tile
     constexpr int ROWS = W + 2 * MARGIN;
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
     constexpr int NTHR = 64 * NWAVES;
     constexpr int WPM = 4;                                  // waves per m-tile
     constexpr int NT = (W / 32) / WPM;                      // 3 n-tiles per wave
+    static_assert(NT * WPM * 32 == W, "tile split");
     extern __shared__ __attribute__((aligned(16))) unsigned short rb16[];
     unsigned short* Xs = rb16;                              // [ROWS][RS] convert(leaky(x)),  row MARGIN + c <-> t = tb + c
     unsigned short* XTs = rb16 + ROWS * RS;                 // [ROWS][RS] convert(leaky(xt))
@@ -499,11 +524,25 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
                 const int c = col0 + j * 32 + l31;
                 const int t = tb + c;
                 const bool in = t >= 0 && t < T;
+                if constexpr (MODE == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[j][r] + bi[r];
-                    v = v * (v > 0.f ? 1.f : slope);
-                    XTs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+                    for (int q = 0; q < 4; ++q) {     // (16 two-byte stores per tile made the epilogues, not the K loops, the longest phase of this kernel)
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[j][4 * q + e] + bi[4 * q + e];
+                            v[e] = v[e] * (v[e] > 0.f ? 1.f : slope);
+                        }
+                        const u32x2 pk = pack16x4<MODE>(v);
+                        *reinterpret_cast<u32x2*>(XTs + (MARGIN + c) * RS + mt * 32 + acc_row(4 * q, lane)) = in ? pk : (u32x2){0u, 0u};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[j][r] + bi[r];
+                        v = v * (v > 0.f ? 1.f : slope);
+                        XTs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
+                    }
                 }
             }
         }
@@ -519,17 +558,36 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
                 const int c = col0 + j * 32 + l31;
                 const int t = tb + c;
                 const bool in = t >= 0 && t < T;
+                // the next pair's conv1 operand: what its staging would have made of x_new.  The product must be ROUNDED TO fp32 before the
+                // conversion, as in the staging pass of a pair launch (x_new went through HBM there): left visible, the compiler fuses multiply +
+                // convert into one v_fma_mixlo_f16 with a single rounding — rare 1-ulp fp16 differences that spread downstream
+                if constexpr (MODE == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xn = (acc[j][r] + bi[r]) + res[j][r];      // the pair kernel's (acc + b2) + x
-                    res[j][r] = in ? xn : 0.f;
-                    if (p < 2) {   // the next pair's conv1 operand: what its staging would have made of x_new
-                        float u = xn * (xn > 0.f ? 1.f : slope);
-                        // the product must be ROUNDED TO fp32 before the conversion, as in the staging pass of a pair launch
-                        // (x_new went through HBM there): left visible, the compiler fuses multiply + convert into one
-                        // v_fma_mixlo_f16 with a single rounding — rare 1-ulp fp16 differences that spread downstream
-                        asm volatile("" : "+v"(u));
-                        Xs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(u, 0.f) : (unsigned short)0;
+                    for (int q = 0; q < 4; ++q) {
+                        float u[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * q + e;
+                            const float xn = (acc[j][r] + bi[r]) + res[j][r];      // the pair kernel's (acc + b2) + x
+                            res[j][r] = in ? xn : 0.f;
+                            u[e] = xn * (xn > 0.f ? 1.f : slope);
+                            asm volatile("" : "+v"(u[e]));
+                        }
+                        if (p < 2) {
+                            const u32x2 pk = pack16x4<MODE>(u);
+                            *reinterpret_cast<u32x2*>(Xs + (MARGIN + c) * RS + mt * 32 + acc_row(4 * q, lane)) = in ? pk : (u32x2){0u, 0u};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float xn = (acc[j][r] + bi[r]) + res[j][r];
+                        res[j][r] = in ? xn : 0.f;
+                        if (p < 2) {
+                            float u = xn * (xn > 0.f ? 1.f : slope);
+                            asm volatile("" : "+v"(u));
+                            Xs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(u, 0.f) : (unsigned short)0;
+                        }
                     }
                 }
             }

@@ -8,6 +8,10 @@ O = "gpurun_out/final/"
 rd = lambda f: open(O + f).read()
 strip = lambda t: "\n".join(l for l in t.split("\n") if "amdgpu.ids" not in l)
 
+def rewrite(path, tail):
+    head = cut(path)              # read BEFORE the file is opened for writing (open(..., "w") truncates first)
+    open(path, "w").write(head + tail)
+
 def cut(path):
     s = open(path).read()
     i = s.find("\n## Final commit")
@@ -38,7 +42,7 @@ j = len(s) if j < 0 else j + 1
 s = s[:i] + f"## `python bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline` (text→mel, B=32, 80×512, T=4, fp32) — final commit {commit}\n\n" + rd("bench_mfma.md") + "\n" + s[j:]
 open("profiles/r02_pmc_mfma_busy.md", "w").write(s)
 
-open("profiles/r02_clock.md", "w").write(cut("profiles/r02_clock.md") + f"""
+rewrite("profiles/r02_clock.md", f"""
 ## Final commit {commit}
 
 ### bench, GRBM_GUI_ACTIVE + SQ_VALU_MFMA_BUSY_CYCLES in one pass
@@ -53,7 +57,7 @@ open("profiles/r02_clock.md", "w").write(cut("profiles/r02_clock.md") + f"""
 The 16-bit kernels are the ones the chip throttles hardest: the C = 128, k = 11 convs run at 1.7–1.8 GHz (profiles/r02_vocoder_bf16.md).
 """)
 ab = "\n".join(l for l in rd("voc_ab.txt").split("\n") if l.startswith(("fp32", "bf16", "fp16")))
-open("profiles/r02_vocoder_fp32.md", "w").write(cut("profiles/r02_vocoder_fp32.md") + f"""
+rewrite("profiles/r02_vocoder_fp32.md", f"""
 ## Final commit {commit} (upsamplers on `convT_xl_kernel`)
 
 ```
@@ -69,7 +73,7 @@ open("profiles/r02_vocoder_fp32.md", "w").write(cut("profiles/r02_vocoder_fp32.m
 Upsamplers: ConvTranspose1d as ONE X-resident launch over all stride phases (`convT_xl_kernel<C_in, waves>`, bitwise equal to the generic kernel run once per
 phase): 3.1 ms in the fp32 run (0.74 / 1.22 / 0.67 / 0.47), 46–73 % pipe busy, where the generic kernel took 5.06 ms (47–57 %).
 """)
-open("profiles/r02_vocoder_bf16.md", "w").write(cut("profiles/r02_vocoder_bf16.md") + f"""
+rewrite("profiles/r02_vocoder_bf16.md", f"""
 ## Final commit {commit}
 
 (see the A/B lines in profiles/r02_vocoder_fp32.md, final section; bench extras in profiles/r02_bench_default.json)
@@ -90,7 +94,7 @@ open("profiles/r02_small_batch_latency.md", "w").write(f"""# Round 2 (final, com
 {strip(rd("latency.txt"))}```
 Before the second half of the round (git history): B=1 L=25: text side 1.386 ms, T=1 text→mel 2.23 ms, to int16 wav 4.96 ms, vocoder fp32 2.46 / bf16 1.15 ms.
 """)
-open("profiles/r02_text_side.md", "w").write(cut("profiles/r02_text_side.md") + f"""
+rewrite("profiles/r02_text_side.md", f"""
 ## Final commit {commit}
 
 `python tools/text_side_bench.py`:
