@@ -1,0 +1,186 @@
+// convT_xl16_kernel: the HiFi-GAN upsamplers (ConvTranspose1d) with 16-bit operands (split out of resblock_pair16.hip).
+#include <hip/hip_runtime.h>
+#include "conv_loop16.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// HiFi-GAN upsampler with 16-bit operands: the stacked two-tap form of convT_xl_kernel (resblock_pair.hip) on the 16-bit pipe.
+// y[co][s m + r - s/2] = b[co] + sum_ci sum_{q in {0,1}} W16[ci][co][r + s q] a16(x[ci][m - q]),  a16(x) = convert(leaky_relu(x / pre_div)):
+// the x^T image [64 + 1 columns][CIN + 4] is staged once (true division, slope, convert), wave w = phase w % s of channel block w / s,
+// fp32 accumulation and bias.  Part of set_precision("bf16" | "fp16") of the vocoder since round 2 (the oracle's operands16 modes
+// quantise the same two operands: oracle/cmtts_oracle.py hifigan_generator).
+struct ConvT16Args {
+    const float* x;
+    float* y;
+    const void* wf;       // [2][CIN/16][s CO / 32][64][8] 16-bit fragments of the two-tap stacked weights (row = phase * CO + channel)
+    const float* bias;
+    long xbstride, ybstride;
+    int B, CO, Ti, To, ldx, ldy, s;
+    float pre_div, slope;
+};
+
+template <int CIN, int NT, int MODE>
+__device__ __forceinline__ void conv_loopT16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
+                                             int mt, int mtiles, int lane) {
+    constexpr int RS = CIN + 4;
+    constexpr int G = CIN / 16;
+    constexpr int NG = G * 2;                       // (32-channel chunk, tap, k-group)
+    const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    auto grp = [&](int it, int& chunk, int& tap, int& kgl) {
+        chunk = it >> 2;
+        tap = (it >> 1) & 1;
+        kgl = it & 1;
+    };
+    const unsigned short* bl = src + l31 * RS + khalf * 8;      // src = row of column c + 1 (tap 0 reads x[m], tap 1 x[m - 1])
+    auto load_b = [&](u32x4 (&dst)[NT], int it) {
+        int chunk, tap, kgl;
+        grp(it, chunk, tap, kgl);
+        const unsigned short* p = bl - tap * RS + chunk * 32 + kgl * 16;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
+            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    u32x4 A[RING];
+    auto issue_a = [&](u32x4& dst, int it) {
+        int chunk, tap, kgl;
+        grp(it, chunk, tap, kgl);
+        const u32x4* ptr = wfrag + ((long)(tap * G + 2 * chunk + kgl) * mtiles + mt) * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+    };
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s)
+        if (s < NG) issue_a(A[s], s);
+    u32x4 Bf[2][NT];
+    load_b(Bf[0], 0);
+    auto body = [&](int it) {
+        if (it + RING - 1 < NG) {
+            issue_a(A[(it + RING - 1) % RING], it + RING - 1);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RING]) : "n"(RING - 1));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RING]));
+        }
+        if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
+        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    };
+    seg_loop<0, NG, 32>(body);
+}
+
+template <int CIN, int NW, int MODE>
+__global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Args a, int mtiles) {
+    constexpr int RS = CIN + 4;
+    constexpr int BN = 64, NT = 2;
+    constexpr int XROWS = BN + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned short xt16[];   // [XROWS][RS], row j <-> m = t0 - 1 + j
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31;
+    const int b = blockIdx.y, t0 = blockIdx.x * BN;
+    const int Ti = a.Ti;
+    const float* xb = a.x + (long)b * a.xbstride;
+    {
+        constexpr int PAIRS = CIN / 2 / NW;
+        constexpr int PB = PAIRS < 16 ? PAIRS : 16;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int j = jb * 64 + lane;
+            const int m = t0 - 1 + j;
+            const int m_c = min(max(m, 0), Ti - 1);
+            const bool ok = m >= 0 && m < Ti;
+            for (int p0 = 0; p0 < PAIRS; p0 += PB) {
+                float v[PB][2];
+#pragma unroll
+                for (int p = 0; p < PB; ++p)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p0 + p) * 2 + h) * a.ldx + m_c];
+                if (j < XROWS) {
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) {
+                        float u0 = ok ? v[p][0] : 0.f, u1 = ok ? v[p][1] : 0.f;
+                        if (a.pre_div != 1.0f) { u0 = u0 / a.pre_div; u1 = u1 / a.pre_div; }
+                        u0 = u0 > 0.f ? u0 : u0 * a.slope;
+                        u1 = u1 > 0.f ? u1 : u1 * a.slope;
+                        *reinterpret_cast<unsigned*>(xt16 + j * RS + (w * PAIRS + p0 + p) * 2) = pack16<MODE>(u0, u1);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int S = a.s;
+    const int phase = w % S, cbl = w / S;
+    const int per = NW / S;
+    const int passes = (a.CO / 32) / per / gridDim.z;
+    const int pd = S / 2;
+    float* yb = a.y + (long)b * a.ybstride;
+    for (int ps = 0; ps < passes; ++ps) {
+        const int cb = (blockIdx.z * passes + ps) * per + cbl;
+        const int mt = phase * (a.CO / 32) + cb;
+        f32x16 acc[NT];
+        conv_loopT16<CIN, NT, MODE>(acc, (const u32x4*)a.wf, xt16 + RS, mt, mtiles, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * 32 + acc_row(r, lane);
+            const float bi = a.bias[co];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = t0 + j * 32 + l31;
+                const int t = n * S + phase - pd;
+                if (n <= Ti && t >= 0 && t < a.To) yb[(long)co * a.ldy + t] = acc[j][r] + bi;
+            }
+        }
+    }
+}
+
+template <int CIN, int NW, int MODE>
+int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
+    const size_t lds = (size_t)65 * (CIN + 4) * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    const int mtiles = a.s * a.CO / 32;
+    if (NW % a.s || mtiles % NW) return -2;
+    const int npass = mtiles / NW;
+    const long tiles = (long)((a.Ti + 1 + 63) / 64) * a.B;
+    int zs = 1;
+    while (tiles * zs < 4096 && zs * 2 <= npass && npass % (zs * 2) == 0) zs *= 2;
+    dim3 grid((a.Ti + 1 + 63) / 64, a.B, zs);
+    hipLaunchKernelGGL((convT_xl16_kernel<CIN, NW, MODE>), grid, dim3(64 * NW), lds, stream, a, mtiles);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int MODE>
+int dispatch_convT16(const ConvT16Args& a, int cin, hipStream_t s) {
+    const int mtiles = a.s * a.CO / 32;
+    if (cin == 512 && mtiles >= 8) return launch_convT16<512, 8, MODE>(a, s);
+    if (cin == 256 && mtiles >= 8) return launch_convT16<256, 8, MODE>(a, s);
+    if (cin == 128 && mtiles >= 4) return launch_convT16<128, 4, MODE>(a, s);
+    if (cin == 64 && mtiles >= 2) return launch_convT16<64, 2, MODE>(a, s);
+    return -2;
+}
+
+}  // namespace
+
+// HiFi-GAN upsampler with 16-bit operands (convT_xl16_kernel): arguments as cmtts_launch_convT, wf16 = to_fragment16 of the two-tap
+// stacked weights ([2][cin/16][s co / 32][64][8]), mode 1 = bf16, 2 = fp16.  0 = launched, -2 = shape not covered, -3 = HIP error.
+extern "C" int cmtts_launch_convT16(const float* x, float* y, const void* wf16, const float* bias, long xbstride, long ybstride, int B,
+                                    int cin, int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, int mode,
+                                    void* stream_) {
+    if (B <= 0 || Ti <= 0) return 0;
+    if (!wf16 || (s * co) % 32 || To != Ti * s || s < 2 || (s & 1) || (mode != 1 && mode != 2)) return -2;
+    ConvT16Args a{x, y, wf16, bias, xbstride, ybstride, B, co, Ti, To, ldx, ldy, s, pre_div, slope};
+    return mode == 1 ? dispatch_convT16<1>(a, cin, (hipStream_t)stream_) : dispatch_convT16<2>(a, cin, (hipStream_t)stream_);
+}

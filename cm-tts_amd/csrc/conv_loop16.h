@@ -184,4 +184,13 @@ __device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4*
     seg_loop<0, NG, 22>(body);
 }
 
+// bf16 epilogues store FOUR channels per LDS instruction (accumulator registers 4q .. 4q+3 = four consecutive channels of a column = 8 contiguous bytes
+// of the [column][channel] image): two packed converts + one ds_write_b64 instead of four converts + four ds_write_b16.  fp16 keeps the per-value
+// form: there the compiler fuses `leaky multiply -> convert` into a single-rounding v_fma_mixlo_f16 on the two-launch path, and no packed spelling
+// tried reproduced its bits (3e-4 on the wav; caught by test_vocoder_pair16_kernel_bitwise).
+template <int MODE>
+__device__ __forceinline__ u32x2 pack16x4(const float (&v)[4]) {
+    return (u32x2){pack16<MODE>(v[0], v[1]), pack16<MODE>(v[2], v[3])};
+}
+
 }  // namespace

@@ -20,14 +20,6 @@
 
 namespace {
 
-// bf16 epilogues store FOUR channels per LDS instruction (accumulator registers 4q .. 4q+3 = four consecutive channels of a column = 8 contiguous bytes
-// of the [column][channel] image): two packed converts + one ds_write_b64 instead of four converts + four ds_write_b16.  fp16 keeps the per-value
-// form: there the compiler fuses `leaky multiply -> convert` into a single-rounding v_fma_mixlo_f16 on the two-launch path, and no packed spelling
-// tried reproduced its bits (3e-4 on the wav; caught by test_vocoder_pair16_kernel_bitwise).
-template <int MODE>
-__device__ __forceinline__ u32x2 pack16x4(const float (&v)[4]) {
-    return (u32x2){pack16<MODE>(v[0], v[1]), pack16<MODE>(v[2], v[3])};
-}
 
 template <int C, int KT, int MODE>
 __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kernel(const PairArgs a) {
@@ -404,413 +396,6 @@ int dispatch16p(const PairArgs& a, int n_cus, hipStream_t s) {
     return -2;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// A WHOLE ResBlock (hifigan/models.py:84-109: three [leaky -> conv(k, d) -> leaky -> conv(k, 1) -> + x] iterations, d = 1, 3, 5)
-// of the narrow stages (C = 64, 32) with 16-bit operands in ONE launch: x is read once (plus the halo), the MRF sum is written
-// / accumulated once — 2 tensor passes where the three pair launches move 6 (and the layer-granular path 15).  The pairs sit
-// on the HBM floor (profiles/r02_vocoder_bf16.md), so bytes are what is left to remove.
-//
-//   * tile: 384 columns = NOUT outputs + 2 H of halo, H = 12 (k - 1) / 2 (the sum of the six convs' reaches); every conv is
-//     evaluated on all 384 columns (edge columns of a conv's output that lie beyond its valid range are computed from stale
-//     neighbours and are never read by a valid column downstream: the halo accounting guarantees it);
-//   * LDS: the 16-bit activated images of x and xt, [384 + 2 x 25 margin rows][C + 4], common row origin; conv1 of a pair reads
-//     the x image and writes the xt image, conv2 reads xt and writes leaky(x_new) back into the x image (x is dead by then);
-//   * the fp32 residual stream of a wave's own columns (one m-tile x NT n-tiles, fixed for all six convs) lives in REGISTERS in
-//     the accumulator layout: x_new = (acc + b2) + x_res replaces it pair after pair, and is what the last pair stores;
-//   * K loops = conv_loop16 (hand-issued weight ring), six per tile, a barrier after each.
-// Element by element the arithmetic is the pair kernel's (conversions, accumulation order, epilogue expressions, zero outside
-// [0, T)) => bitwise equal to three pair launches (tests/test_gpu_parity.py::test_vocoder_pair16_kernel_bitwise).
-struct Rb16Args {
-    const float* x;       // [B][C][ld]
-    float* y;             // [B][C][ld] MRF sum (y += result when accum)
-    const void* w1f[3];
-    const void* w2f[3];
-    const float* b1[3];
-    const float* b2[3];
-    long bstride;
-    int B, C, T, ld;
-    int accum;
-    float slope;
-};
-
-template <int C, int KT, int MODE>
-__global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) {      // C = 64: 8 waves (two per SIMD: one 118-KB workgroup per CU)
-    constexpr int RS = C + 4;
-    constexpr int R = (KT - 1) / 2;
-    constexpr int H = 12 * R;                               // (1 + 3 + 5) R for the dilated convs + 3 R for the plain ones
-    // columns every conv is evaluated on (C = 64 with 192 columns, 4 waves and two workgroups per CU — one's epilogues under the other's K loops — was
-    // tried: k = 7 1365 -> 1511 us, k = 3 739 -> 704: the recomputed halo columns cost more than the overlap gives)
-    constexpr int W = 384;
-    constexpr int NOUT = W - 2 * H;                         // 264 / 312 / 360
-    constexpr int MARGIN = 5 * R;                           // largest reach of one conv: rows a conv may read beyond the tile
-    constexpr int ROWS = W + 2 * MARGIN;
-    constexpr int NWAVES = C / 8;                           // 4 (C = 32) / 8 (C = 64)
-    constexpr int NTHR = 64 * NWAVES;
-    constexpr int WPM = 4;                                  // waves per m-tile
-    constexpr int NT = (W / 32) / WPM;                      // 3 n-tiles per wave
-    static_assert(NT * WPM * 32 == W, "tile split");
-    extern __shared__ __attribute__((aligned(16))) unsigned short rb16[];
-    unsigned short* Xs = rb16;                              // [ROWS][RS] convert(leaky(x)),  row MARGIN + c <-> t = tb + c
-    unsigned short* XTs = rb16 + ROWS * RS;                 // [ROWS][RS] convert(leaky(xt))
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int mt = w / WPM, nq = w % WPM;
-    const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * NOUT;
-    const int tb = t0 - H;                                  // time of tile column 0
-    const int T = a.T;
-    const float slope = a.slope;
-    const float* xb = a.x + (long)b * a.bstride;
-    const int col0 = nq * (NT * 32);
-
-    {   // stage convert(leaky(x)) for rows 0 .. ROWS-1 (t = tb - MARGIN + row): the margins hold real neighbours of the tile
-        constexpr int PAIRS = C / 2 / NWAVES;               // channel pairs per wave: 4
-        constexpr int XBLK = (ROWS + 63) / 64;
-#pragma unroll
-        for (int jb = 0; jb < XBLK; ++jb) {
-            const int j = jb * 64 + lane;
-            const int t = tb - MARGIN + j;
-            const int t_c = min(max(t, 0), T - 1);
-            const bool in = t >= 0 && t < T;
-            const float fpos = in ? 1.f : 0.f, fneg = in ? slope : 0.f;
-            float v[PAIRS][2];
-#pragma unroll
-            for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p) * 2 + h) * a.ld + t_c];
-            if (j < ROWS) {
-#pragma unroll
-                for (int p = 0; p < PAIRS; ++p) {
-                    const float v0 = v[p][0], v1 = v[p][1];
-                    *reinterpret_cast<unsigned*>(Xs + j * RS + (w * PAIRS + p) * 2) =
-                        pack16<MODE>(v0 * (v0 > 0.f ? fpos : fneg), v1 * (v1 > 0.f ? fpos : fneg));
-                }
-            }
-        }
-        // the xt image's margin rows are read by the edge columns of conv2 and never written: clear them once
-        for (int i = tid; i < 2 * MARGIN * (RS / 2); i += NTHR) {
-            const int r = i / (RS / 2), c2 = i - r * (RS / 2);
-            const int row = r < MARGIN ? r : W + r;          // rows 0 .. MARGIN-1 and MARGIN + W .. ROWS-1
-            *reinterpret_cast<unsigned*>(XTs + row * RS + 2 * c2) = 0u;
-        }
-    }
-    // fp32 residual stream of this wave's own tiles, accumulator layout (0 outside [0, T): never stored, never read as data)
-    float res[NT][16];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int t = tb + col0 + j * 32 + l31;
-        const int t_c = min(max(t, 0), T - 1);
-        const bool in = t >= 0 && t < T;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = xb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c];
-            res[j][r] = in ? v : 0.f;
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc[NT];
-    constexpr int DIL[3] = {1, 3, 5};
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        // conv1 (dilation d): output column c reads x rows (MARGIN + c) + (tap - R) d
-        conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w1f[p], Xs + (MARGIN - R * DIL[p]) * RS, DIL[p], mt, col0, lane);
-        {
-            float bi[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bi[r] = a.b1[p][mt * 32 + acc_row(r, lane)];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int c = col0 + j * 32 + l31;
-                const int t = tb + c;
-                const bool in = t >= 0 && t < T;
-                if constexpr (MODE == 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {     // (16 two-byte stores per tile made the epilogues, not the K loops, the longest phase of this kernel)
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[j][4 * q + e] + bi[4 * q + e];
-                            v[e] = v[e] * (v[e] > 0.f ? 1.f : slope);
-                        }
-                        const u32x2 pk = pack16x4<MODE>(v);
-                        *reinterpret_cast<u32x2*>(XTs + (MARGIN + c) * RS + mt * 32 + acc_row(4 * q, lane)) = in ? pk : (u32x2){0u, 0u};
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[j][r] + bi[r];
-                        v = v * (v > 0.f ? 1.f : slope);
-                        XTs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // conv2 (dilation 1): output column c reads xt rows (MARGIN + c) + (tap - R)
-        conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w2f[p], XTs + (MARGIN - R) * RS, 1, mt, col0, lane);
-        {
-            float bi[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bi[r] = a.b2[p][mt * 32 + acc_row(r, lane)];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int c = col0 + j * 32 + l31;
-                const int t = tb + c;
-                const bool in = t >= 0 && t < T;
-                // the next pair's conv1 operand: what its staging would have made of x_new.  The product must be ROUNDED TO fp32 before the
-                // conversion, as in the staging pass of a pair launch (x_new went through HBM there): left visible, the compiler fuses multiply +
-                // convert into one v_fma_mixlo_f16 with a single rounding — rare 1-ulp fp16 differences that spread downstream
-                if constexpr (MODE == 1) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float u[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * q + e;
-                            const float xn = (acc[j][r] + bi[r]) + res[j][r];      // the pair kernel's (acc + b2) + x
-                            res[j][r] = in ? xn : 0.f;
-                            u[e] = xn * (xn > 0.f ? 1.f : slope);
-                            asm volatile("" : "+v"(u[e]));
-                        }
-                        if (p < 2) {
-                            const u32x2 pk = pack16x4<MODE>(u);
-                            *reinterpret_cast<u32x2*>(Xs + (MARGIN + c) * RS + mt * 32 + acc_row(4 * q, lane)) = in ? pk : (u32x2){0u, 0u};
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float xn = (acc[j][r] + bi[r]) + res[j][r];
-                        res[j][r] = in ? xn : 0.f;
-                        if (p < 2) {
-                            float u = xn * (xn > 0.f ? 1.f : slope);
-                            asm volatile("" : "+v"(u));
-                            Xs[(MARGIN + c) * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(u, 0.f) : (unsigned short)0;
-                        }
-                    }
-                }
-            }
-        }
-        if (p < 2) __syncthreads();
-    }
-    // the block's output on the NOUT central columns: y (+)= x_3
-    float* yb = a.y + (long)b * a.bstride;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int c = col0 + j * 32 + l31;
-        const int t = tb + c;
-        const bool ok = c >= H && c < H + NOUT && t < T;     // t >= 0 follows from c >= H
-        const int t_c = min(max(t, 0), T - 1);
-        float yv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = a.accum ? yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c] : 0.f;
-        if (ok) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = res[j][r] + yv[r];
-        }
-    }
-}
-
-template <int C, int KT, int MODE>
-int launch_rb16(const Rb16Args& a, hipStream_t stream) {
-    constexpr int R = (KT - 1) / 2;
-    constexpr int NOUT = 384 - 24 * R;
-    const size_t lds = (size_t)2 * (384 + 10 * R) * (C + 4) * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, KT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
-    dim3 grid((a.T + NOUT - 1) / NOUT, a.B);
-    hipLaunchKernelGGL((resblock16_kernel<C, KT, MODE>), grid, dim3(C * 8), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-template <int MODE>
-int dispatch_rb16(const Rb16Args& a, int k, hipStream_t s) {
-    if (a.C == 64) {
-        if (k == 3) return launch_rb16<64, 3, MODE>(a, s);
-        if (k == 7) return launch_rb16<64, 7, MODE>(a, s);
-        if (k == 11) return launch_rb16<64, 11, MODE>(a, s);
-    } else if (a.C == 32) {
-        if (k == 3) return launch_rb16<32, 3, MODE>(a, s);
-        if (k == 7) return launch_rb16<32, 7, MODE>(a, s);
-        if (k == 11) return launch_rb16<32, 11, MODE>(a, s);
-    }
-    return -2;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// HiFi-GAN upsampler with 16-bit operands: the stacked two-tap form of convT_xl_kernel (resblock_pair.hip) on the 16-bit pipe.
-// y[co][s m + r - s/2] = b[co] + sum_ci sum_{q in {0,1}} W16[ci][co][r + s q] a16(x[ci][m - q]),  a16(x) = convert(leaky_relu(x / pre_div)):
-// the x^T image [64 + 1 columns][CIN + 4] is staged once (true division, slope, convert), wave w = phase w % s of channel block w / s,
-// fp32 accumulation and bias.  Part of set_precision("bf16" | "fp16") of the vocoder since round 2 (the oracle's operands16 modes
-// quantise the same two operands: oracle/cmtts_oracle.py hifigan_generator).
-struct ConvT16Args {
-    const float* x;
-    float* y;
-    const void* wf;       // [2][CIN/16][s CO / 32][64][8] 16-bit fragments of the two-tap stacked weights (row = phase * CO + channel)
-    const float* bias;
-    long xbstride, ybstride;
-    int B, CO, Ti, To, ldx, ldy, s;
-    float pre_div, slope;
-};
-
-template <int CIN, int NT, int MODE>
-__device__ __forceinline__ void conv_loopT16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
-                                             int mt, int mtiles, int lane) {
-    constexpr int RS = CIN + 4;
-    constexpr int G = CIN / 16;
-    constexpr int NG = G * 2;                       // (32-channel chunk, tap, k-group)
-    const int l31 = lane & 31, khalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    auto grp = [&](int it, int& chunk, int& tap, int& kgl) {
-        chunk = it >> 2;
-        tap = (it >> 1) & 1;
-        kgl = it & 1;
-    };
-    const unsigned short* bl = src + l31 * RS + khalf * 8;      // src = row of column c + 1 (tap 0 reads x[m], tap 1 x[m - 1])
-    auto load_b = [&](u32x4 (&dst)[NT], int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-        const unsigned short* p = bl - tap * RS + chunk * 32 + kgl * 16;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    u32x4 A[RING];
-    auto issue_a = [&](u32x4& dst, int it) {
-        int chunk, tap, kgl;
-        grp(it, chunk, tap, kgl);
-        const u32x4* ptr = wfrag + ((long)(tap * G + 2 * chunk + kgl) * mtiles + mt) * 64 + lane;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
-    };
-#pragma unroll
-    for (int s = 0; s < RING - 1; ++s)
-        if (s < NG) issue_a(A[s], s);
-    u32x4 Bf[2][NT];
-    load_b(Bf[0], 0);
-    auto body = [&](int it) {
-        if (it + RING - 1 < NG) {
-            issue_a(A[(it + RING - 1) % RING], it + RING - 1);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RING]) : "n"(RING - 1));
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RING]));
-        }
-        if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-    };
-    seg_loop<0, NG, 32>(body);
-}
-
-template <int CIN, int NW, int MODE>
-__global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Args a, int mtiles) {
-    constexpr int RS = CIN + 4;
-    constexpr int BN = 64, NT = 2;
-    constexpr int XROWS = BN + 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned short xt16[];   // [XROWS][RS], row j <-> m = t0 - 1 + j
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31;
-    const int b = blockIdx.y, t0 = blockIdx.x * BN;
-    const int Ti = a.Ti;
-    const float* xb = a.x + (long)b * a.xbstride;
-    {
-        constexpr int PAIRS = CIN / 2 / NW;
-        constexpr int PB = PAIRS < 16 ? PAIRS : 16;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const int j = jb * 64 + lane;
-            const int m = t0 - 1 + j;
-            const int m_c = min(max(m, 0), Ti - 1);
-            const bool ok = m >= 0 && m < Ti;
-            for (int p0 = 0; p0 < PAIRS; p0 += PB) {
-                float v[PB][2];
-#pragma unroll
-                for (int p = 0; p < PB; ++p)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) v[p][h] = xb[(long)((w * PAIRS + p0 + p) * 2 + h) * a.ldx + m_c];
-                if (j < XROWS) {
-#pragma unroll
-                    for (int p = 0; p < PB; ++p) {
-                        float u0 = ok ? v[p][0] : 0.f, u1 = ok ? v[p][1] : 0.f;
-                        if (a.pre_div != 1.0f) { u0 = u0 / a.pre_div; u1 = u1 / a.pre_div; }
-                        u0 = u0 > 0.f ? u0 : u0 * a.slope;
-                        u1 = u1 > 0.f ? u1 : u1 * a.slope;
-                        *reinterpret_cast<unsigned*>(xt16 + j * RS + (w * PAIRS + p0 + p) * 2) = pack16<MODE>(u0, u1);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int S = a.s;
-    const int phase = w % S, cbl = w / S;
-    const int per = NW / S;
-    const int passes = (a.CO / 32) / per / gridDim.z;
-    const int pd = S / 2;
-    float* yb = a.y + (long)b * a.ybstride;
-    for (int ps = 0; ps < passes; ++ps) {
-        const int cb = (blockIdx.z * passes + ps) * per + cbl;
-        const int mt = phase * (a.CO / 32) + cb;
-        f32x16 acc[NT];
-        conv_loopT16<CIN, NT, MODE>(acc, (const u32x4*)a.wf, xt16 + RS, mt, mtiles, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cb * 32 + acc_row(r, lane);
-            const float bi = a.bias[co];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = t0 + j * 32 + l31;
-                const int t = n * S + phase - pd;
-                if (n <= Ti && t >= 0 && t < a.To) yb[(long)co * a.ldy + t] = acc[j][r] + bi;
-            }
-        }
-    }
-}
-
-template <int CIN, int NW, int MODE>
-int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
-    const size_t lds = (size_t)65 * (CIN + 4) * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
-    const int mtiles = a.s * a.CO / 32;
-    if (NW % a.s || mtiles % NW) return -2;
-    const int npass = mtiles / NW;
-    const long tiles = (long)((a.Ti + 1 + 63) / 64) * a.B;
-    int zs = 1;
-    while (tiles * zs < 4096 && zs * 2 <= npass && npass % (zs * 2) == 0) zs *= 2;
-    dim3 grid((a.Ti + 1 + 63) / 64, a.B, zs);
-    hipLaunchKernelGGL((convT_xl16_kernel<CIN, NW, MODE>), grid, dim3(64 * NW), lds, stream, a, mtiles);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-template <int MODE>
-int dispatch_convT16(const ConvT16Args& a, int cin, hipStream_t s) {
-    const int mtiles = a.s * a.CO / 32;
-    if (cin == 512 && mtiles >= 8) return launch_convT16<512, 8, MODE>(a, s);
-    if (cin == 256 && mtiles >= 8) return launch_convT16<256, 8, MODE>(a, s);
-    if (cin == 128 && mtiles >= 4) return launch_convT16<128, 4, MODE>(a, s);
-    if (cin == 64 && mtiles >= 2) return launch_convT16<64, 2, MODE>(a, s);
-    return -2;
-}
-
 template <int C, int KT, int MODE>
 int launch_pair16(const PairArgs& a, hipStream_t stream) {
     constexpr int TT = N1 - (KT - 1);
@@ -868,27 +453,4 @@ extern "C" int cmtts_launch_resblock_pair16p(const PairArgs* ap, int mode, int n
 
 
 
-// A whole ResBlock (three pairs, dilations 1, 3, 5, kernel k) of a narrow stage in one launch, 16-bit operands (resblock16_kernel).
-// w1f / w2f / b1 / b2: the three pairs' conv1 / conv2 fragments ([tap][C/16][C/32][64][8]) and biases.  x must not alias y.
-extern "C" int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, const void* const* w2f, const float* const* b1,
-                                       const float* const* b2, long bstride, int B, int C, int T, int ld, int k, int accum, float slope,
-                                       int mode, void* stream_) {
-    if (B <= 0 || T <= 0) return 0;
-    if ((mode != 1 && mode != 2) || x == y) return -2;
-    Rb16Args a;
-    a.x = x; a.y = y;
-    for (int p = 0; p < 3; ++p) { a.w1f[p] = w1f[p]; a.w2f[p] = w2f[p]; a.b1[p] = b1[p]; a.b2[p] = b2[p]; }
-    a.bstride = bstride; a.B = B; a.C = C; a.T = T; a.ld = ld; a.accum = accum; a.slope = slope;
-    return mode == 1 ? dispatch_rb16<1>(a, k, (hipStream_t)stream_) : dispatch_rb16<2>(a, k, (hipStream_t)stream_);
-}
 
-// HiFi-GAN upsampler with 16-bit operands (convT_xl16_kernel): arguments as cmtts_launch_convT, wf16 = to_fragment16 of the two-tap
-// stacked weights ([2][cin/16][s co / 32][64][8]), mode 1 = bf16, 2 = fp16.  0 = launched, -2 = shape not covered, -3 = HIP error.
-extern "C" int cmtts_launch_convT16(const float* x, float* y, const void* wf16, const float* bias, long xbstride, long ybstride, int B,
-                                    int cin, int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, int mode,
-                                    void* stream_) {
-    if (B <= 0 || Ti <= 0) return 0;
-    if (!wf16 || (s * co) % 32 || To != Ti * s || s < 2 || (s & 1) || (mode != 1 && mode != 2)) return -2;
-    ConvT16Args a{x, y, wf16, bias, xbstride, ybstride, B, co, Ti, To, ldx, ldy, s, pre_div, slope};
-    return mode == 1 ? dispatch_convT16<1>(a, cin, (hipStream_t)stream_) : dispatch_convT16<2>(a, cin, (hipStream_t)stream_);
-}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Direct calls of cmtts_launch_conv_xl16 (resblock_pair16.hip) on synthetic buffers, one (C, k, io) per run: debugging aid."""
+"""Direct calls of cmtts_launch_conv_xl16 (conv_xl16.hip) on synthetic buffers, one (C, k, io) per run: debugging aid."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cmtts_amd

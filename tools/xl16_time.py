@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time cmtts_launch_conv_xl16 (resblock_pair16.hip) alone at the vocoder's shapes (B = 32, 512 frames): C = 128 -> 32768 columns, C = 256 -> 4096.
+"""Time cmtts_launch_conv_xl16 (conv_xl16.hip) alone at the vocoder's shapes (B = 32, 512 frames): C = 128 -> 32768 columns, C = 256 -> 4096.
 CMTTS_LIB selects an ablation build (tools/xl16_ablation.sh)."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
