@@ -122,20 +122,52 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
     const int passes = (a.CO / 32) / per / gridDim.z;
     const int pd = S / 2;
     float* yb = a.y + (long)b * a.ybstride;
+    // Output through LDS: a wave's accumulator tile is ONE stride phase of 32 output columns — written directly, every 4-byte store lands S * 4
+    // bytes from its neighbour's and each 128-byte line of y is completed by S different waves at different times (the 16-bit kernel spent most
+    // of its time there: 546 us for 0.67 GB at C_in = 256).  The waves of a workgroup hold all S phases of the same columns, so they meet in an
+    // LDS tile [rows][phase][PS] (phase-major: conflict-free writes) and the workgroup stores whole rows, consecutive lanes = consecutive samples
+    // (stride 8: 546 -> 371 us at C_in = 256, 224 -> 182 at 512; bitwise the same values).
+    constexpr int PS = 40;                               // phase stride in floats (32 columns + 8: the interleaving reads are 2-way at worst)
+    float* ot = reinterpret_cast<float*>(xt16 + ((XROWS * RS + 7) & ~7));       // [per * 32][S][PS]
+    const int lgS = __ffs(S) - 1;
+    const int rowlen = S * 32;                           // output samples per row per n-tile
     for (int ps = 0; ps < passes; ++ps) {
-        const int cb = (blockIdx.z * passes + ps) * per + cbl;
+        const int cb0 = (blockIdx.z * passes + ps) * per;
+        const int cb = cb0 + cbl;
         const int mt = phase * (a.CO / 32) + cb;
         f32x16 acc[NT];
         conv_loopT16<CIN, NT, MODE>(acc, (const u32x4*)a.wf, xt16 + RS, mt, mtiles, lane);
+        float bi[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cb * 32 + acc_row(r, lane);
-            const float bi = a.bias[co];
+        for (int r = 0; r < 16; ++r) bi[r] = a.bias[cb * 32 + acc_row(r, lane)];
+        if (S < 4) {      // two phases: neighbouring stores are 8 bytes apart and the direct form is (slightly) faster: 374 / 326 vs 389 / 334 us
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = t0 + j * 32 + l31;
-                const int t = n * S + phase - pd;
-                if (n <= Ti && t >= 0 && t < a.To) yb[(long)co * a.ldy + t] = acc[j][r] + bi;
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + acc_row(r, lane);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = t0 + j * 32 + l31;
+                    const int t = n * S + phase - pd;
+                    if (n <= Ti && t >= 0 && t < a.To) yb[(long)co * a.ldy + t] = acc[j][r] + bi[r];
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            __syncthreads();                             // the tile is free (previous n-tile stored)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[((cbl * 32 + acc_row(r, lane)) * S + phase) * PS + l31] = acc[j][r] + bi[r];
+            __syncthreads();
+            const int tb = (t0 + j * 32) * S - pd;       // time of the tile's first sample
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {               // per * 32 rows x S * 32 samples = 16 per thread
+                const int idx = q * (64 * NW) + tid;
+                const int row = idx >> (lgS + 5), c = idx & (rowlen - 1);
+                const int m = c >> lgS, ph = c & (S - 1);
+                const int t = tb + c;
+                const float v = ot[(row * S + ph) * PS + m];
+                if (t0 + j * 32 + m <= Ti && t >= 0 && t < a.To) yb[(long)(cb0 * 32 + row) * a.ldy + t] = v;
             }
         }
     }
@@ -143,13 +175,14 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
 
 template <int CIN, int NW, int MODE>
 int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
-    const size_t lds = (size_t)65 * (CIN + 4) * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (a.s & (a.s - 1)) return -2;                    // the output tile's interleave uses shifts
+    const size_t lds = (((size_t)65 * (CIN + 4) + 7) & ~(size_t)7) * sizeof(unsigned short) + (a.s >= 4 ? (size_t)(NW / a.s) * 32 * a.s * 40 * sizeof(float) : 0);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return -3;
-        attr_set = true;
+        attr_lds = lds;
     }
     const int mtiles = a.s * a.CO / 32;
     if (NW % a.s || mtiles % NW) return -2;
