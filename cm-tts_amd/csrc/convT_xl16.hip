@@ -1,5 +1,6 @@
 // convT_xl16_kernel: the HiFi-GAN upsamplers (ConvTranspose1d) with 16-bit operands (split out of resblock_pair16.hip).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "conv_loop16.h"
 
 namespace {
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
         for (int jb = 0; jb < 2; ++jb) {
             const int j = jb * 64 + lane;
             const int m = t0 - 1 + j;
-            const int m_c = min(max(m, 0), Ti - 1);
+            // lanes past the image's last row (all but one of the second block) re-read that row's column: same cache line, no traffic — clamped
+            // to Ti - 1 only, they fetched the NEXT tile's 63 columns as well: twice the input bytes (374 -> 2xx us at C_in = 128)
+            const int m_c = min(max(t0 - 1 + min(j, XROWS - 1), 0), Ti - 1);
             const bool ok = m >= 0 && m < Ti;
             for (int p0 = 0; p0 < PAIRS; p0 += PB) {
                 float v[PB][2];
@@ -189,7 +192,13 @@ int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
     const int npass = mtiles / NW;
     const long tiles = (long)((a.Ti + 1 + 63) / 64) * a.B;
     int zs = 1;
-    while (tiles * zs < 4096 && zs * 2 <= npass && npass % (zs * 2) == 0) zs *= 2;
+    // channel-block split of the grid: only until every CU has two workgroups — each split stages the x tile again, and staging is what this
+    // kernel waits for (C_in = 256: 336 / 402 / 500 us with 1 / 2 / 4 splits; C_in = 512, 288 tiles: 180 / 158 / 160 / 184 with 1 / 2 / 4 / 8)
+    while (tiles * zs < 512 && zs * 2 <= npass && npass % (zs * 2) == 0) zs *= 2;
+    {   // CMTTS_CONVT_ZS=<n>: channel-block split of the grid, for experiments (tools/)
+        static const char* e = getenv("CMTTS_CONVT_ZS");
+        if (e && atoi(e) > 0 && npass % atoi(e) == 0) zs = atoi(e);
+    }
     dim3 grid((a.Ti + 1 + 63) / 64, a.B, zs);
     hipLaunchKernelGGL((convT_xl16_kernel<CIN, NW, MODE>), grid, dim3(64 * NW), lds, stream, a, mtiles);
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, CIN >= 512 ? 2 : (NW >= 8 ? 4 : 2)) void c
             float v[2][16];
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-                const int m_c = min(max(t0 - 1 + jcol[jb], 0), Ti - 1);
+                const int m_c = min(max(t0 - 1 + min(jcol[jb], XL_BN), 0), Ti - 1);      // lanes past the last column re-read it (no traffic) instead of the next tile's columns
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[jb][q] = xb[(long)(w * ROWS + h + q) * a.ldx + m_c];
             }
