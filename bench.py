@@ -19,6 +19,11 @@ import os
 import sys
 import time
 
+# CPU-baseline hygiene: OpenMP worker i stays on core i for the whole run (set before torch creates
+# its thread pool), so the host-side timing does not depend on where the scheduler happens to move the workers
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 import torch
 
@@ -108,25 +113,27 @@ def cpu_baseline(cfg, sd):
             d = time.perf_counter() - t0
             if best is None or d < best:
                 best, best_threads = d, nt
-    # then the GPU step's own workload (full batch) at the best thread count, best of 3 passes (~5-15 s of CPU work)
+    # then the GPU step's own workload (full batch) at the best thread count: 5 passes (~5-20 s of CPU work), best AND median
     Bf = BATCH
     texts_f = rs.randint(1, cfg.n_symbols, size=(Bf, PHONEMES)).astype(np.int64)
     lens_f = np.full((Bf,), PHONEMES, np.int64)
     noise_f = [rs.standard_normal(size=(Bf, 1, FRAMES_PAD, cfg.n_mels)).astype(np.float32) for _ in range(N_STEPS + 1)]
     torch.set_num_threads(best_threads)
-    full = None
-    for _ in range(3):
+    runs = []
+    for _ in range(5):
         t0 = time.perf_counter()
         mel, mel_len, _ = O.synthesize(sd, cfg, texts_f, lens_f, None, N_STEPS, noise_f, max_mel_len=FRAMES_PAD, torch_sampler=True)
-        d = time.perf_counter() - t0
-        full = d if full is None or d < full else full
+        runs.append(time.perf_counter() - t0)
     torch.set_num_threads(threads)
-    dt, threads, B = full, best_threads, Bf
+    dt, med, threads, B = min(runs), float(np.median(runs)), best_threads, Bf
     O.set_backend("numpy")
     return {"value": round(float(mel_len.sum()) / dt, 1), "unit": "mel-frames/s", "cores": int(threads),
+            "median_value": round(float(mel_len.sum()) / med, 1), "runs_s": [round(r, 3) for r in runs],
+            "pinning": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
             "kind": "port", "threads_tried": sorted({min(all_threads, n) for n in (16, 32, 64, all_threads)}),
             "sample": f"oracle graph in stock torch-CPU ops (oneDNN/MKL; sampler end-to-end in torch), text->mel, B={B} x {PHONEMES * DUR} frames (padded {FRAMES_PAD}), "
-                      f"T={N_STEPS} (the GPU step's own batch), thread count chosen on B=8 from {{16,32,64,all}}, best of 3 passes = {dt:.2f} s"}
+                      f"T={N_STEPS} (the GPU step's own batch), OpenMP workers pinned one per core, thread count chosen on B=8 from {{16,32,64,all}}, "
+                      f"`value` = best of 5 passes ({dt:.2f} s), `median_value` = their median ({med:.2f} s)"}
 
 
 def host_info():
@@ -174,6 +181,110 @@ def cpu_baseline_small(cfg, sd, hcfg, hsd, threads):
             "vocoder_b1": {"value": round(frames / best_v, 1), "unit": "mel-frames/s", "seconds": round(best_v, 4),
                            "rtf": round(best_v / audio, 5), "cores": threads,
                            "sample": f"HiFi-GAN generator, B=1 x {frames} frames (614.1 MFLOP/frame), best of 3"}}
+
+
+def ragged_groups(lcfg, rank, world, device, per_bucket=8):
+    """BASELINE.json configs[3] through shard.plan_shards: a GLOBAL ragged batch of world x 32 utterances (per_bucket x world
+    per static frame bucket, lengths ~ U[0.5, 1] x bucket as SURVEY.md §8d prescribes, durations forced to 6 frames per
+    phoneme) is bucketed and dealt over the ranks by length; returns this rank's bucket groups
+    [(texts, src_lens, spk, noise, bucket, valid_frames)], the plan, the global frame counts and the utterance ids per group."""
+    rs = np.random.RandomState(40)
+    n_frames, phon = [], []
+    for bucket in shard.FRAME_BUCKETS:
+        Lmax = bucket // DUR
+        prev = shard.FRAME_BUCKETS[shard.FRAME_BUCKETS.index(bucket) - 1] // DUR if bucket != shard.FRAME_BUCKETS[0] else 0
+        ln = np.maximum((rs.uniform(0.5, 1.0, size=per_bucket * world) * Lmax).astype(np.int64), prev + 1)   # stays in ITS bucket
+        phon += [int(v) for v in ln]
+        n_frames += [int(v) * DUR for v in ln]
+    plan = shard.plan_shards(n_frames, world)
+    groups, ids = [], []
+    for bucket, ranks in plan.items():
+        mine = [i if i >= 0 else ranks[rank][0] for i in ranks[rank]]
+        Lmax = bucket // DUR
+        ln = np.asarray([phon[i] for i in mine], np.int64)
+        tx = np.zeros((len(mine), Lmax), np.int64)
+        for r, i in enumerate(mine):
+            tx[r, :ln[r]] = np.random.RandomState(1000 + i).randint(1, lcfg.n_symbols, size=ln[r])
+        gen = torch.Generator(device="cpu").manual_seed(7000 + bucket + rank)
+        spk = torch.randn(len(mine), lcfg.external_speaker_dim, generator=gen)
+        nz = torch.randn(N_STEPS + 1, len(mine), 1, bucket, lcfg.n_mels, generator=gen)
+        valid = int(sum(n_frames[i] for i in ranks[rank] if i >= 0))
+        groups.append((torch.from_numpy(tx).to(device), torch.from_numpy(ln).to(device), spk.to(device), nz.to(device), bucket, valid))
+        ids.append(mine)
+    return groups, plan, n_frames, ids
+
+
+def multi_gpu_extras(args, cfg, model, step, timed_w, state, frames_rank, audio_s, rank, world, device, gather):
+    """The per-config numbers an N-GPU run must carry (VERDICT r02 missing #2): T = 1 / 2 rates and RTF on the headline
+    workload, BASELINE.json configs[3] (ragged LibriTTS shard: plan_shards -> bucket groups -> ONE all-gather of all buckets ->
+    restore_order) and configs[4] (fp16 residual blocks + fp32 HiFi-GAN -> int16 PCM -> one all-gather of the PCM block).
+    Every rank runs them (the timed regions hold barriers); all values are whole-job aggregates over the N ranks."""
+    extras = {}
+    for n in (1, 2):
+        k = max(4, args.steps // 2)
+        d = timed_w(lambda: step(n), k, 2)
+        extras[f"frames_per_s_T{n}"] = round(frames_rank * world * k / d, 1)
+        extras[f"rtf_mel_only_T{n}"] = round((d / k) / audio_s, 6)
+    # ---- configs[3]
+    lcfg = get_config("LibriTTS")
+    lmodel = host.CMTotalTTS(lcfg, device).load_state_dict(synth_cmtts_state_dict(lcfg, seed=1, dur_frames=float(DUR), dur_spread=0.0))
+    groups, plan, n_frames, ids = ragged_groups(lcfg, rank, world, device)
+    bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4)
+
+    def step_cfg3():
+        outs = bsyn.run([g[:5] for g in groups])
+        local = {g[4]: o for g, o in zip(groups, outs)}
+        state["cfg3"] = shard.allgather_buckets(local, force=gather)
+
+    step_cfg3()
+    torch.cuda.synchronize()
+    host.check_async_error()
+    utts = shard.restore_order(state["cfg3"], plan, len(n_frames))
+    assert [int(u.shape[0]) for u in utts] == n_frames, "configs[3]: restored utterance lengths differ from the plan"
+    assert all(bool(torch.isfinite(u).all()) for u in utts[:: max(1, len(utts) // 8)])
+    k = max(4, args.steps // 2)
+    d = timed_w(step_cfg3, k, 2)
+    extras["configs3_ragged_bucketed"] = {
+        "frames_per_s": round(sum(n_frames) * k / d, 1), "ms_per_step": round(d / k * 1e3, 3),
+        "rtf_mel_only": round((d / k) / (sum(n_frames) * lcfg.hop_length / lcfg.sampling_rate), 6),
+        "workload": f"LibriTTS model, {len(n_frames)} utterances ({len(n_frames) // world} per GPU), lengths ~ U[0.5,1] x bucket clipped to the bucket's own range, static frame "
+                    f"buckets {list(shard.FRAME_BUCKETS)}, T=4, fp32; plan_shards -> bucket groups -> one all-gather of all buckets -> restore_order",
+        "valid_frames": int(sum(n_frames))}
+    del bsyn, groups, lmodel
+    # ---- configs[4]: end-to-end wav, fp16 residual blocks + fp32 vocoder, 16 utterances x 1024 frames per GPU
+    B5, L5, T5 = 16, 170, 1024
+    zmodel = host.CMTotalTTS(lcfg, device).load_state_dict(synth_cmtts_state_dict(lcfg, seed=2, dur_frames=float(DUR), dur_spread=0.0))
+    zmodel.set_precision("fp16")
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, device).load_state_dict(synth_hifigan_state_dict(hcfg, seed=0))
+    rs5 = np.random.RandomState(50 + rank)
+    tx5 = torch.from_numpy(rs5.randint(1, lcfg.n_symbols, size=(B5, L5)).astype(np.int64)).to(device)
+    ln5 = torch.full((B5,), L5, dtype=torch.int64, device=device)
+    spk5 = torch.randn(B5, lcfg.external_speaker_dim, generator=torch.Generator().manual_seed(60 + rank)).to(device)
+
+    def step_cfg4():
+        o = zmodel.duration_pitch_energy_net(None, tx5, ln5, spker_embeds=spk5, max_mel_len=T5)
+        nz = torch.randn(N_STEPS + 1, B5, 1, T5, lcfg.n_mels, device=device)
+        mel = host.sample_with_cond(zmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz)
+        pcm = host.vocoder_infer_device(mel.transpose(1, 2).contiguous(), voc)
+        state["cfg4"] = shard.allgather_pcm(pcm, o["mel_lens"] * lcfg.hop_length, force=gather)
+        state["cfg4_local"] = pcm
+
+    step_cfg4()
+    torch.cuda.synchronize()
+    host.check_async_error()
+    g_pcm, g_len = state["cfg4"]
+    assert g_pcm.shape == (world * B5, T5 * lcfg.hop_length) and (g_len == L5 * DUR * lcfg.hop_length).all()
+    assert torch.equal(g_pcm[rank * B5:(rank + 1) * B5], state["cfg4_local"])
+    k = 3
+    d = timed_w(step_cfg4, k, 1)
+    f5 = B5 * L5 * DUR * world
+    extras["configs4_end_to_end_wav"] = {
+        "frames_per_s": round(f5 * k / d, 1), "ms_per_step": round(d / k * 1e3, 3),
+        "rtf_end_to_end": round((d / k) / (f5 * lcfg.hop_length / lcfg.sampling_rate), 6),
+        "workload": f"LibriTTS-trained model with external speaker vectors (zero-shot input), {B5} utterances x {L5 * DUR} frames (padded {T5}) "
+                    "per GPU, T=4, fp16 residual-block operands, fp32 HiFi-GAN, int16 PCM collated by one all-gather (shard.allgather_pcm)"}
+    return extras
 
 
 def main():
@@ -314,8 +425,13 @@ def main():
                      "flops_per_launch": flops_launch},
     }
 
+    if (world > 1 or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:
+        # every rank takes part: T = 1 / 2, configs[3] and configs[4] with their collectives (whole-job aggregates)
+        result["extras"] = multi_gpu_extras(args, cfg, model, step, lambda f, k, w: timed(f, k, w, world, flush=flush), state,
+                                            frames_rank, audio_s, rank, world, device, gather)
+        flush()
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = {}
+        extras = result.get("extras", {})
         for n in (1, 2):
             k = max(4, args.steps // 2)
             d = timed(lambda: step(n), k, 2, 1)

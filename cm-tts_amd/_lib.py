@@ -1,7 +1,7 @@
-"""Binding of libcmtts_hip.so (the C ABI in include/cmtts_hip.h): cffi in ABI mode when the module is importable
-(BASELINE.json north_star: "a thin C-ABI cffi layer"; declarations parsed from the header itself), ctypes otherwise —
-``cffi`` is not installed in this image, so ctypes is what runs here and what the tests exercise;
-both bind the same symbols with the same signatures behind the same call sites (``CMTTS_FFI=ctypes|cffi`` forces one).
+"""Binding of libcmtts_hip.so (the C ABI in include/cmtts_hip.h): ctypes by default; cffi in ABI mode
+(BASELINE.json north_star: "a thin C-ABI cffi layer"; declarations parsed from the header itself) with ``CMTTS_FFI=cffi`` —
+``cffi`` is not installed in this image, so ctypes is what runs here and what the tests exercise, and the
+cffi adapter stays opt-in until it has run somewhere; both bind the same symbols with the same signatures behind the same call sites.
 There is NO compute fallback: if the shared library is missing or a symbol is absent the import of the compute path
 fails loudly.
 """
@@ -34,6 +34,7 @@ _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "cmtts_last_error": (C.c_char_p, []),
     "cmtts_version": (C.c_char_p, []),
+    "cmtts_abi_version": (_i, []),
     "cmtts_create": (_i, [C.POINTER(CMTTSConfigStruct), C.POINTER(_vp)]),
     "cmtts_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "cmtts_finalize": (_i, [_vp]),
@@ -73,12 +74,15 @@ SIGNATURES = {
     "cmtts_comm_destroy": (_i, [_vp]),
     "cmtts_allgather_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "cmtts_allgather_mels": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_allgather_pcm_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "cmtts_allgather_pcm": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_transpose": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "cmtts_pack_conv_weight": (_i, [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i)]),
     "cmtts_free_device": (None, [_vp]),
     "cmtts_conv1d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
+ABI_VERSION = 3          # include/cmtts_hip.h: CMTTS_ABI_VERSION
 _lib = None
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cmtts_hip.h")
 
@@ -173,17 +177,20 @@ def load():
     # that HIP runtime (same SONAME) and shares torch's device context and streams.  Loaded the other way round, the
     # process ends up with /opt/rocm's runtime under torch and "no ROCm-capable device is detected".
     import torch  # noqa: F401
-    want = os.environ.get("CMTTS_FFI", "")
-    lib = None
-    if want != "ctypes":
-        try:
-            import cffi  # noqa: F401
-            lib = _CffiLib(LIB_PATH)
-        except ImportError:
-            if want == "cffi":
-                raise
-    if lib is None:
+    # ctypes is the default binding: it is the one every test in this image exercises.  The cffi ABI-mode binding is opt-in
+    # (CMTTS_FFI=cffi) until a CI leg with cffi installed has run tests/test_cabi.py and a GPU smoke through it.
+    want = os.environ.get("CMTTS_FFI", "ctypes")
+    if want == "cffi":
+        import cffi  # noqa: F401  (ImportError: the caller asked for a binding this environment does not have)
+        lib = _CffiLib(LIB_PATH)
+    elif want == "ctypes":
         lib = _load_ctypes()
+    else:
+        raise RuntimeError(f"CMTTS_FFI={want!r}: expected 'ctypes' or 'cffi'")
+    got = lib.cmtts_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI revision {got}, this binding was written for {ABI_VERSION} "
+                           "(include/cmtts_hip.h: CMTTS_ABI_VERSION): rebuild the library")
     _lib = lib
     return lib
 

@@ -1167,7 +1167,8 @@ extern "C" {
 
 const char* cmtts_last_error(void) { return g_err.c_str(); }
 int cmtts_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : "?"); }     // for the other translation units (rccl_gather.hip)
-const char* cmtts_version(void) { return "cmtts_hip 0.1 (gfx950)"; }
+const char* cmtts_version(void) { return "cmtts_hip 0.3 (gfx950)"; }
+int cmtts_abi_version(void) { return CMTTS_ABI_VERSION; }
 
 int cmtts_create(const cmtts_config* cfg, cmtts_model** out) {
     if (!cfg || !out) return fail(CMTTS_E_INVALID, "cmtts_create: null argument");
@@ -1888,8 +1889,13 @@ int cmtts_set_option(const char* name, int value) {
         if (value == 0 || value == 1) g_persist_tail = value != 0;
         return prev;
     }
-    if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel
-        return cmtts_persist_set_cooperative(value);
+    if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel: 0 never, 1 always, 2 = automatic
+        // (default): once the process has a communicator / process group ("process_group"), i.e. RCCL kernels may share the GPU
+        const int prev = cmtts_persist_set_cooperative(value == 2 ? -1 : (value == 0 || value == 1) ? value : -2);
+        return prev < 0 ? 2 : prev;
+    }
+    if (!strcmp(name, "process_group")) {        // the host tells the library that a process group exists (torch.distributed initialised)
+        return cmtts_persist_note_process_group(value);
     }
     if (!strcmp(name, "ffn_fused")) {     // FFN linear inside the FFN conv's launch (1) or as its own K-segment launch (0); same bits
         const int prev = g_ffn_fused;

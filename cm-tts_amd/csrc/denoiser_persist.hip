@@ -403,12 +403,16 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 }
 
 long long* g_pdbg = nullptr;
-int g_coop = 0;
+// -1 = automatic (default): cooperative launches (the runtime checks that the whole grid is co-resident) once the process has
+// a communicator — RCCL's kernels then share the GPU with the persistent grid — plain launches otherwise; 0 / 1 = forced
+int g_coop = -1;
+int g_process_group = 0;
 
 }  // namespace
 
-extern "C" int cmtts_persist_set_cooperative(int on) { const int p = g_coop; if (on == 0 || on == 1) g_coop = on; return p; }
-extern "C" int cmtts_persist_cooperative(void) { return g_coop; }
+extern "C" int cmtts_persist_set_cooperative(int on) { const int p = g_coop; if (on >= -1 && on <= 1) g_coop = on; return p; }
+extern "C" int cmtts_persist_cooperative(void) { return g_coop < 0 ? g_process_group : g_coop; }
+extern "C" int cmtts_persist_note_process_group(int on) { const int p = g_process_group; if (on == 0 || on == 1) g_process_group = on; return p; }
 
 extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
 
@@ -482,7 +486,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.out = a.out + off;
         }
         if (a.dbg) hipLaunchKernelGGL(denoiser_persist_kernel<true>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-        else if (g_coop) {
+        else if (cmtts_persist_cooperative()) {
             void* params[] = {(void*)&c};
             if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false>), dim3(tiles, nb),
                                            dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;

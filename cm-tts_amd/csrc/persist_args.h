@@ -51,8 +51,10 @@ int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call m
 void cmtts_persist_set_debug(long long* dbg);
 // 1: launch through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident and dispatches it
 // with the cooperative-queue guarantee); 0: plain launch, grid <= CU count by construction.  Returns the previous value.
+// -1 (default) = automatic: cooperative once a process group / communicator exists in the process (cmtts_persist_note_process_group).
 int cmtts_persist_set_cooperative(int on);
-int cmtts_persist_cooperative(void);
+int cmtts_persist_cooperative(void);            // the effective setting (0 / 1)
+int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
 }
 #endif

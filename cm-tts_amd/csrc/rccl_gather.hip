@@ -73,11 +73,27 @@ __global__ void unpack_kernel(const float* __restrict__ in, float* __restrict__ 
     if (i == 0) mel_len[b] = (int64_t)rintf(in[(long)b * (row + 1) + row]);
 }
 
+// int16 PCM rows (vocoder_infer's output, utils/model.py:187-205): [Bl][N] samples + [Bl] sample counts -> [Bl][rowp] int16 with
+// the int64 count in the last four slots (rowp = N rounded up to a multiple of 4, + 4: the count sits 8-byte aligned)
+__global__ void pack_pcm_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ len, int16_t* __restrict__ out, long N, long rowp) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < rowp - 4) out[(long)b * rowp + i] = i < N ? pcm[(long)b * N + i] : (int16_t)0;
+    if (i == 0) *reinterpret_cast<int64_t*>(out + (long)b * rowp + rowp - 4) = len[b];
+}
+__global__ void unpack_pcm_kernel(const int16_t* __restrict__ in, int16_t* __restrict__ pcm, int64_t* __restrict__ len, long N, long rowp) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) pcm[(long)b * N + i] = in[(long)b * rowp + i];
+    if (i == 0) len[b] = *reinterpret_cast<const int64_t*>(in + (long)b * rowp + rowp - 4);
+}
+
 }  // namespace
 
 
 // cmtts_api.hip owns cmtts_last_error(); these entry points report through it
 extern "C" int cmtts_internal_fail(int code, const char* msg);
+extern "C" int cmtts_persist_note_process_group(int on);      // denoiser_persist.hip: persistent launches become cooperative
 
 extern "C" {
 
@@ -96,6 +112,7 @@ int cmtts_comm_init_rank(void** comm, int world, int rank, const void* id128_hos
     __builtin_memcpy(&id, id128_host, sizeof(id));
     const int r = g_rccl.comm_init_rank(comm, world, id, rank);
     if (r != 0) return cmtts_internal_fail(CMTTS_E_HIP, g_rccl.error_string ? g_rccl.error_string(r) : "ncclCommInitRank failed");
+    cmtts_persist_note_process_group(1);     // RCCL kernels now share the GPU with the persistent grid: residency is checked by the runtime
     return 0;
 }
 
@@ -132,6 +149,35 @@ int cmtts_allgather_mels(void* comm, int world, const float* mel, const int64_t*
     }
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((row + 255) / 256), world * Bl), dim3(256), 0, s, gathered, out_mel, out_len, row);
     if (hipGetLastError() != hipSuccess) return cmtts_internal_fail(CMTTS_E_HIP, "all-gather pack/unpack launch failed");
+    return 0;
+}
+
+static long pcm_row(int64_t N) { return ((N + 3) / 4) * 4 + 4; }
+
+size_t cmtts_allgather_pcm_workspace_bytes(int world, int Bl, int64_t N) {
+    return ((size_t)Bl + (size_t)world * Bl) * (size_t)pcm_row(N) * sizeof(int16_t) + 512;
+}
+
+int cmtts_allgather_pcm(void* comm, int world, const int16_t* pcm, const int64_t* wav_len, int Bl, int64_t N,
+                        int16_t* out_pcm, int64_t* out_len, void* ws, size_t ws_bytes, void* stream) {
+    if (!pcm || !wav_len || !out_pcm || !out_len || !ws || world < 1 || Bl <= 0 || N <= 0)
+        return cmtts_internal_fail(CMTTS_E_INVALID, "cmtts_allgather_pcm: bad argument");
+    if (ws_bytes < cmtts_allgather_pcm_workspace_bytes(world, Bl, N)) return cmtts_internal_fail(CMTTS_E_WORKSPACE, "pcm all-gather workspace too small");
+    if (world > 1 && !comm) return cmtts_internal_fail(CMTTS_E_INVALID, "cmtts_allgather_pcm: a communicator is required for world > 1");
+    hipStream_t s = (hipStream_t)stream;
+    const long rowp = pcm_row(N);
+    int16_t* send = (int16_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    int16_t* recv = send + (size_t)Bl * rowp;
+    hipLaunchKernelGGL(pack_pcm_kernel, dim3((unsigned)((rowp + 255) / 256), Bl), dim3(256), 0, s, pcm, wav_len, send, N, rowp);
+    const int16_t* gathered = send;
+    if (comm) {       // bytes on the wire (RCCL has no int16 type): ncclInt8, count in bytes
+        if (!rccl_open()) return cmtts_internal_fail(CMTTS_E_UNSUPPORTED, "librccl.so could not be opened (dlopen)");
+        const int r = g_rccl.all_gather(send, recv, (size_t)Bl * rowp * sizeof(int16_t), /*ncclInt8*/ 0, comm, s);
+        if (r != 0) return cmtts_internal_fail(CMTTS_E_HIP, g_rccl.error_string ? g_rccl.error_string(r) : "ncclAllGather failed");
+        gathered = recv;
+    }
+    hipLaunchKernelGGL(unpack_pcm_kernel, dim3((unsigned)((N + 255) / 256), world * Bl), dim3(256), 0, s, gathered, out_pcm, out_len, N, rowp);
+    if (hipGetLastError() != hipSuccess) return cmtts_internal_fail(CMTTS_E_HIP, "pcm all-gather pack/unpack launch failed");
     return 0;
 }
 

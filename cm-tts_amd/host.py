@@ -49,6 +49,19 @@ def _push_state_dict(lib, setter, handle, sd):
         _lib.check(setter(handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
 
 
+_PG_NOTED = False
+
+
+def _note_process_group(lib):
+    """Once torch.distributed is initialised RCCL's kernels may share the GPU with the persistent denoiser grid, whose
+    hand-offs need every workgroup resident: tell the library, which then launches that grid cooperatively (the runtime
+    checks residency and fails the launch instead of letting it spin; cmtts_set_option("cooperative_launch", 0|1|2))."""
+    global _PG_NOTED
+    if not _PG_NOTED and torch.distributed.is_available() and torch.distributed.is_initialized():
+        lib.cmtts_set_option(b"process_group", 1)
+        _PG_NOTED = True
+
+
 def _norm_device(device):
     """torch.device with an explicit index ("cuda" -> "cuda:<current>"): tensors report indexed devices, so an
     un-indexed one never compares equal to a buffer's and every workspace lookup would reallocate."""
@@ -146,6 +159,7 @@ class CMTotalTTS(torch.nn.Module):
         return self
 
     def _require(self):
+        _note_process_group(self.lib)
         if not self._ready and getattr(self, "_pending", False):
             if not torch.cuda.is_available():
                 raise RuntimeError("CMTotalTTS: no GPU — cmtts_amd has no CPU fallback (the weights are loaded, the kernels cannot run)")
@@ -222,8 +236,11 @@ class DurationPitchSpeakerNet(torch.nn.Module):
         if table:
             if speakers is None:
                 raise AssertionError("speakers (ids into the speaker_emb table) should not be None")
-            if not speakers.is_cuda and (int(speakers.min()) < 0 or int(speakers.max()) >= cfg.n_speaker):
-                raise IndexError("index out of range in self")          # what nn.Embedding raises (model/cmtts.py:78)
+            # what nn.Embedding raises (model/cmtts.py:78), also for ids that already live on the device (the reference's
+            # to_device has moved them): one tiny min/max read-back — the text path synchronises for mel_len anyway, and a
+            # clamped id would silently synthesise another speaker
+            if speakers.numel() and (int(speakers.min()) < 0 or int(speakers.max()) >= cfg.n_speaker):
+                raise IndexError("index out of range in self")
             spk_ids = _i64(speakers, dev)
         H = cfg.hidden
         with torch.cuda.device(dev):
@@ -671,19 +688,54 @@ class Generator(torch.nn.Module):
         return wav
 
 
-def vocoder_infer(mels, vocoder, model_config=None, preprocess_config=None, lengths=None, max_wav_value=32768.0):
-    """utils/model.py:187-205: mels [B,80,T] -> list of int16 numpy arrays trimmed to `lengths`."""
-    if preprocess_config is not None:
-        max_wav_value = preprocess_config["preprocessing"]["audio"]["max_wav_value"]
+def vocoder_infer_device(mels, vocoder, max_wav_value=32768.0):
+    """The device half of vocoder_infer (utils/model.py:187-198): mels [B,80,T] -> int16 PCM [B, T*hop] still on the GPU
+    (what shard.allgather_pcm collates across ranks before anything crosses PCIe)."""
     wavs = vocoder(mels).squeeze(1)
     pcm = torch.empty(wavs.shape, dtype=torch.int16, device=wavs.device)
     with torch.cuda.device(wavs.device):
         _lib.check(vocoder.lib.cmtts_wav_to_int16(_ptr(wavs), _ptr(pcm), wavs.numel(), float(max_wav_value), _stream()))
+    return pcm
+
+
+def vocoder_infer(mels, vocoder, model_config=None, preprocess_config=None, lengths=None, max_wav_value=32768.0):
+    """utils/model.py:187-205: mels [B,80,T] -> list of int16 numpy arrays trimmed to `lengths`."""
+    if preprocess_config is not None:
+        max_wav_value = preprocess_config["preprocessing"]["audio"]["max_wav_value"]
+    pcm = vocoder_infer_device(mels, vocoder, max_wav_value)
     out = [w for w in pcm.cpu().numpy()]
     check_async_error()          # the D2H copy synchronised: a timeout in the launches that produced `mels` is raised here
     if lengths is not None:
         out = [w[: int(lengths[i])] for i, w in enumerate(out)]
     return out
+
+
+def synth_samples(args, targets, predictions, vocoder, model_config, preprocess_config, path, diffusion=None):
+    """utils/tools.py:566-607 (same argument list), the part that is on the inference path: mel -> vocoder_infer -> one int16
+    .wav per utterance at the dataset's sampling rate (22 050 Hz), written to <path>/<args.restore_step>/ under the
+    reference's names: "<basename>_<speaker_id><tag>.wav" for a multi-speaker model in single mode, "<basename><tag>.wav"
+    otherwise (tag = "_teacher_forced" when args.teacher_forced).  `targets` is the synthesize batch (ids first),
+    `predictions` the out_put list of CMTotalTTSSynthesize.synthesize (mel [B,T,80] in slot 0, mel_lens in slot 11).  The
+    mel-spectrogram PNGs of :573-594 are matplotlib host work and are not produced.  Returns the paths written."""
+    import os
+    from scipy.io import wavfile
+    multi_speaker = model_config["multi_speaker"]
+    tag = "_teacher_forced" if getattr(args, "teacher_forced", False) else ""
+    basenames = targets[0]
+    mel_predictions = predictions[0].transpose(1, 2)            # [B,80,T]
+    lengths = predictions[11] * preprocess_config["preprocessing"]["stft"]["hop_length"]
+    wav_predictions = vocoder_infer(mel_predictions, vocoder, model_config, preprocess_config, lengths=lengths.tolist())
+    sampling_rate = preprocess_config["preprocessing"]["audio"]["sampling_rate"]
+    out_dir = os.path.join(path, str(getattr(args, "restore_step", "")))
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for wav, basename in zip(wav_predictions, basenames):
+        single = multi_speaker and getattr(args, "mode", None) == "single"
+        name = "{}_{}{}.wav".format(basename, args.speaker_id, tag) if single else "{}{}.wav".format(basename, tag)
+        out = os.path.join(out_dir, name)
+        wavfile.write(out, sampling_rate, wav)
+        written.append(out)
+    return written
 
 
 def transpose_last2(x):

@@ -137,6 +137,56 @@ def allgather_mels_async(mel: torch.Tensor, mel_len: torch.Tensor, group=None, f
     return PendingGather(work, out, T, M, buf)
 
 
+def pack_pcm(pcm: torch.Tensor, wav_len: torch.Tensor) -> torch.Tensor:
+    """int16 [Bl,N] + int64 [Bl] -> one int16 buffer [Bl, N4 + 4] (N4 = N rounded up to a multiple of 4): the sample count
+    rides behind each row as an int64 in four int16 slots — the layout of cmtts_allgather_pcm (csrc/rccl_gather.hip)."""
+    Bl, N = pcm.shape
+    n4 = (N + 3) // 4 * 4
+    buf = torch.zeros(Bl, n4 + 4, dtype=torch.int16, device=pcm.device)
+    buf[:, :N] = pcm
+    buf[:, n4:].view(torch.int64)[:, 0] = wav_len.to(torch.int64)
+    return buf
+
+
+def unpack_pcm(buf: torch.Tensor, N: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    n4 = buf.shape[1] - 4
+    return buf[:, :N], buf[:, n4:].contiguous().view(torch.int64)[:, 0]
+
+
+def allgather_pcm(pcm: torch.Tensor, wav_len: torch.Tensor, group=None, force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """End-to-end wav jobs (BASELINE.json configs[4]; SURVEY.md §8e: "cfg5 gathers int16 wav [16, 1024*256] = 8.4 MB/rank
+    instead"): what is collated is vocoder_infer's output (utils/model.py:187-205) — every rank contributes its padded int16
+    block pcm [Bl,N] and the valid sample counts wav_len [Bl] (= mel_len * hop) and receives [world*Bl, N] + [world*Bl] in
+    rank order: ONE all-gather of bytes (neither RCCL nor gloo moves int16 natively).  `force` runs the collective on a
+    1-rank group too (single-GPU check of the RCCL call sequence)."""
+    assert pcm.dtype == torch.int16 and pcm.dim() == 2
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return pcm, wav_len.to(torch.int64)
+    world = dist.get_world_size(group)
+    Bl, N = pcm.shape
+    buf = pack_pcm(pcm, wav_len)
+    send = buf.view(torch.uint8).reshape(-1)
+    out = torch.empty(world, send.numel(), dtype=torch.uint8, device=buf.device)
+    if dist.get_backend(group) == "gloo":
+        dist.all_gather(list(out.unbind(0)), send, group=group)
+    else:
+        dist.all_gather_into_tensor(out.reshape(-1), send, group=group)
+    return unpack_pcm(out.view(torch.int16).reshape(world * Bl, buf.shape[1]), N)
+
+
+def restore_pcm_order(pcm: torch.Tensor, wav_len: torch.Tensor, deal: Sequence[Sequence[int]], n_items: int):
+    """Gathered rows (rank-major, rank r's rows in the order of deal[r]; -1 = filler) -> list of per-utterance int16 tensors
+    trimmed to their sample counts, in the ORIGINAL utterance order (the list vocoder_infer returns, utils/model.py:199-205)."""
+    out = [None] * n_items
+    flat = [i for r in deal for i in r]
+    assert pcm.shape[0] == len(flat), (pcm.shape, len(flat))
+    for row, i in enumerate(flat):
+        if i >= 0:
+            out[i] = pcm[row, : int(wav_len[row])]
+    assert all(o is not None for o in out)
+    return out
+
+
 def allgather_buckets(mels, group=None, force: bool = False):
     """configs[3]: every bucket of a ragged shard in ONE all-gather.  mels: {bucket: (mel [n_b, bucket, M], mel_len
     [n_b])} with the same n_b on every rank (plan_shards guarantees it).  The blocks are packed back to back (each as

@@ -52,6 +52,12 @@ typedef struct cmtts_config {
 
 const char* cmtts_last_error(void);
 const char* cmtts_version(void);
+/* Binary-interface revision of this header: bumped whenever a struct layout or an existing signature changes (round 2
+ * inserted cmtts_config.n_speaker and the `speakers` parameter of cmtts_text_forward: revision 2; round 3 adds entry
+ * points only but starts the counter: 3).  A host compares cmtts_abi_version() with the CMTTS_ABI_VERSION it was built
+ * against before it passes a struct (cmtts_amd/_lib.py does at load time). */
+#define CMTTS_ABI_VERSION 3
+int cmtts_abi_version(void);
 
 /* ---- weight import: replaces torch.load + load_state_dict (synthesize.py:79-83).
  * cmtts_set_tensor takes one entry of CMTotalTTS.state_dict() under its original key and in its
@@ -228,6 +234,14 @@ int cmtts_comm_destroy(void* comm);
 size_t cmtts_allgather_workspace_bytes(int world, int Bl, int T, int M);
 int cmtts_allgather_mels(void* comm, int world, const float* mel, const int64_t* mel_len, int Bl, int T, int M,
                          float* out_mel, int64_t* out_len, void* ws, size_t ws_bytes, void* stream);
+/* The same exchange for end-to-end wav jobs (BASELINE.json configs[4]; SURVEY.md §8e: "cfg5 gathers int16 wav [16, 1024*256]"):
+ * what it collates is vocoder_infer's output (utils/model.py:187-205) — pcm int16 [Bl,N] (N = padded frames * hop) and the
+ * valid sample count wav_len int64 [Bl] = mel_len * hop (device) -> out_pcm int16 [world*Bl,N], out_len int64 [world*Bl] in
+ * rank order.  The count rides in the same buffer (four int16 slots after each row), so it is ONE ncclAllGather of bytes.
+ * ws = device scratch of cmtts_allgather_pcm_workspace_bytes(world, Bl, N) bytes. */
+size_t cmtts_allgather_pcm_workspace_bytes(int world, int Bl, int64_t N);
+int cmtts_allgather_pcm(void* comm, int world, const int16_t* pcm, const int64_t* wav_len, int Bl, int64_t N,
+                        int16_t* out_pcm, int64_t* out_len, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- get_mask_from_lengths (utils/tools.py:275-283): mask[b][t] = (t >= lens[b]) as one byte per element
  * (True = padding), lens int64 [B], mask [B,W]. */

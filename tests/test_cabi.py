@@ -32,6 +32,13 @@ def test_loader_binds_and_reports_errors():
     assert lib.cmtts_create(None, None) == -1
     assert b"null" in lib.cmtts_last_error()
     assert lib.cmtts_profile_begin(0, 1) == -1
+    assert lib.cmtts_abi_version() == _lib.ABI_VERSION
+    text = open(os.path.join(ROOT, "include", "cmtts_hip.h")).read()
+    assert int(re.search(r"#define CMTTS_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION
+    # unknown option names fail (and say so); known ones return their previous value
+    assert lib.cmtts_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.cmtts_last_error()
+    assert lib.cmtts_set_option(None, 1) == -1
+    assert lib.cmtts_set_option(b"cooperative_launch", -1) == 2      # default: automatic
 
 
 def test_config_struct_matches_header():

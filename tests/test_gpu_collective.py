@@ -112,3 +112,53 @@ def test_c_abi_allgather_on_a_one_rank_communicator():
                                         mel.data_ptr(), 1 << 30, None) < 0            # world > 1 needs a communicator
     finally:
         _lib.check(lib.cmtts_comm_destroy(comm))
+
+
+def test_pcm_gather_torch_and_c_abi_one_rank(nccl_group):
+    """SURVEY.md §8e, BASELINE.json configs[4]: the int16 wav collation of end-to-end jobs.  shard.allgather_pcm on a 1-rank
+    RCCL group (force) and cmtts_allgather_pcm on a 1-rank communicator / without one must both return the producer's PCM
+    and sample counts bit for bit, including a row length that is not a multiple of 4 (the count is packed behind the row)."""
+    import ctypes as C
+    lib = _lib.load()
+    for N in (4 * 256, 1021):
+        Bl = 3
+        pcm = torch.randint(-32768, 32768, (Bl, N), dtype=torch.int32, generator=torch.Generator().manual_seed(N)).to(torch.int16).to(DEV)
+        wav_len = torch.tensor([N, 256, 1], dtype=torch.int64, device=DEV)
+        g_pcm, g_len = shard.allgather_pcm(pcm, wav_len, force=True)
+        assert torch.equal(g_pcm, pcm) and torch.equal(g_len, wav_len)
+        uid = (C.c_char * 128)()
+        _lib.check(lib.cmtts_comm_unique_id(C.cast(uid, C.c_void_p)))
+        comm = C.c_void_p()
+        _lib.check(lib.cmtts_comm_init_rank(C.byref(comm), 1, 0, C.cast(uid, C.c_void_p)))
+        try:
+            for use_comm in (True, False):
+                out_pcm = torch.full((Bl, N), 77, dtype=torch.int16, device=DEV)
+                out_len = torch.zeros(Bl, dtype=torch.int64, device=DEV)
+                nb = lib.cmtts_allgather_pcm_workspace_bytes(1, Bl, N)
+                ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+                _lib.check(lib.cmtts_allgather_pcm(comm if use_comm else None, 1, pcm.data_ptr(), wav_len.data_ptr(), Bl, N,
+                                                   out_pcm.data_ptr(), out_len.data_ptr(), ws.data_ptr(), nb,
+                                                   torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                assert torch.equal(out_pcm, pcm) and torch.equal(out_len, wav_len)
+            assert lib.cmtts_allgather_pcm(None, 2, pcm.data_ptr(), wav_len.data_ptr(), Bl, N, pcm.data_ptr(), wav_len.data_ptr(),
+                                           pcm.data_ptr(), 1 << 30, None) < 0            # world > 1 needs a communicator
+        finally:
+            _lib.check(lib.cmtts_comm_destroy(comm))
+
+
+def test_cooperative_launch_is_automatic_with_a_process_group(nccl_group):
+    """with a process group in the process the persistent denoiser is launched cooperatively by default
+    (option value 2 = automatic); 0 / 1 force it; the previous value comes back."""
+    from cmtts_amd import host
+    lib = _lib.load()
+    cfg = get_config("LJSpeech")
+    host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=0, dur_frames=6.0, dur_spread=0.0))._require()
+    assert lib.cmtts_set_option(b"process_group", -1) == 1           # the host layer told the library (torch.distributed is up)
+    prev = lib.cmtts_set_option(b"cooperative_launch", 2)
+    try:
+        assert lib.cmtts_set_option(b"cooperative_launch", 0) == 2
+        assert lib.cmtts_set_option(b"cooperative_launch", 1) == 0
+        assert lib.cmtts_set_option(b"cooperative_launch", 2) == 1
+    finally:
+        lib.cmtts_set_option(b"cooperative_launch", prev)

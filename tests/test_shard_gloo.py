@@ -34,6 +34,20 @@ def _worker(rank, world, port, q):
     src.zero_()
     a_mel, a_len = pend.wait()
     assert torch.equal(a_mel, all_mel) and torch.equal(a_len, all_len)
+    # end-to-end wav jobs (BASELINE.json configs[4]): the int16 PCM block + sample counts in ONE all-gather of bytes
+    N = 517                                           # not a multiple of 4: the packed row pads before the int64 count
+    gp = torch.Generator().manual_seed(500 + rank)
+    pcm = torch.randint(-32768, 32768, (Bl, N), generator=gp, dtype=torch.int32).to(torch.int16)
+    wav_len = torch.tensor([N, 256 * (rank + 1), 1], dtype=torch.int64)
+    all_pcm, all_wl = shard.allgather_pcm(pcm, wav_len)
+    assert all_pcm.dtype == torch.int16 and all_pcm.shape == (world * Bl, N) and all_wl.dtype == torch.int64
+    for r in range(world):
+        gr = torch.Generator().manual_seed(500 + r)
+        ref = torch.randint(-32768, 32768, (Bl, N), generator=gr, dtype=torch.int32).to(torch.int16)
+        assert torch.equal(all_pcm[r * Bl:(r + 1) * Bl], ref)
+        assert all_wl[r * Bl:(r + 1) * Bl].tolist() == [N, 256 * (r + 1), 1]
+    utts = shard.restore_pcm_order(all_pcm, all_wl, [[4, 0, -1], [1, 3, 2]], 5)      # rank-major deal, -1 = filler row
+    assert [u.numel() for u in utts] == [256, N, 1, 512, N]
     q.put((rank, all_mel.numpy(), all_len.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -75,6 +89,15 @@ def test_shard_arithmetic():
     mel = torch.arange(2 * 4 * 80, dtype=torch.float32).reshape(2, 4, 80)
     m2, l2 = shard.unpack_mels(shard.pack_mels(mel, torch.tensor([4, 3])), 4, 80)
     assert torch.equal(m2, mel) and l2.tolist() == [4, 3]
+    for N in (8, 9, 10, 11, 1024):
+        pcm = (torch.arange(3 * N, dtype=torch.int32).reshape(3, N) * 37 - 20000).to(torch.int16)
+        wl = torch.tensor([N, 2 ** 40 + 5, 0], dtype=torch.int64)          # the count travels as a full int64
+        buf = shard.pack_pcm(pcm, wl)
+        assert buf.shape == (3, (N + 3) // 4 * 4 + 4) and buf.dtype == torch.int16
+        p2, w2 = shard.unpack_pcm(buf, N)
+        assert torch.equal(p2, pcm) and torch.equal(w2, wl)
+    p1, w1 = shard.allgather_pcm(pcm, wl)                                    # no process group: identity
+    assert torch.equal(p1, pcm) and torch.equal(w1, wl)
 
 
 FRAMES = [900, 100, 500, 510, 20, 1000, 30, 700, 255, 257, 600]     # 11 utterances: 3 / 3 / 2 / 3 per bucket
