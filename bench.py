@@ -320,6 +320,8 @@ def main():
         lib.cmtts_set_persistent_denoiser(0)
     if args.tile:
         _lib.check(lib.cmtts_set_resblock_tile(args.tile))
+    if os.environ.get("CMTTS_COOPERATIVE") in ("0", "1", "2"):    # A/B: persistent launches plain / cooperative / automatic (default)
+        lib.cmtts_set_option(b"cooperative_launch", int(os.environ["CMTTS_COOPERATIVE"]))
     if os.environ.get("CMTTS_BRANCH_STREAMS") in ("0", "1"):      # A/B of the library's side streams
         lib.cmtts_set_option(b"branch_streams", int(os.environ["CMTTS_BRANCH_STREAMS"]))
     state = {}

@@ -61,6 +61,8 @@ SIGNATURES = {
     "cmtts_set_persistent_denoiser": (_i, [_i]),
     "cmtts_poll_error": (_i, []),
     "cmtts_set_option": (_i, [C.c_char_p, _i]),
+    "cmtts_model_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "cmtts_vocoder_set_option": (_i, [_vp, C.c_char_p, _i]),
     "cmtts_set_resblock_tile": (_i, [_i]),
     "cmtts_set_precision": (_i, [_vp, _i]),
     "cmtts_vocoder_set_precision": (_i, [_vp, _i]),
@@ -193,6 +195,20 @@ def load():
                            "(include/cmtts_hip.h: CMTTS_ABI_VERSION): rebuild the library")
     _lib = lib
     return lib
+
+
+_internal = None
+
+
+def internal_set(name, value):
+    """csrc/internal_hooks.h: flip one of the A/B switches between a fused kernel and the path it replaces (bitwise equal
+    pairs; tests/ and tools/ only — not part of the C ABI, hence bound here and not in SIGNATURES).  Returns the previous value."""
+    global _internal
+    load()
+    if _internal is None:
+        _internal = C.CDLL(LIB_PATH).cmtts_internal_set
+        _internal.restype, _internal.argtypes = _i, [C.c_char_p, _i]
+    return _internal(name if isinstance(name, bytes) else name.encode(), int(value))
 
 
 def backend():

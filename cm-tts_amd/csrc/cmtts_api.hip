@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/cmtts_hip.h"
+#include "internal_hooks.h"
 #include "conv_args.h"
 #include "kernels.h"
 #include "resblock_args.h"
@@ -301,26 +302,21 @@ struct Profile {
 } g_prof;
 
 bool g_fused_resblock = true;
-bool g_persist_tail = true;     // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
+int g_persist_tail = 1;      // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
-int g_pred_xres = 0;            // 1 = phoneme-level predictor convs on conv_xres.hip with the previous layer's LayerNorm as prologue (same bits, measured slower: 64 long workgroups); 0 = generic kernel + LayerNorm launches
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
-int g_ffn2_split = 1;           // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (changes the fp32 summation order: set BEFORE comparing runs); 0 = one launch
-int g_voc_ups16 = 1;            // vocoder 16-bit modes: upsampler operands in 16 bits as well (1) or fp32 upsamplers as in the first half of round 2 (0) — different numerics
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
-int g_voc_ring16 = 0;           // 16-bit HiFi-GAN convs at C >= 128 on the CHUNKED kernel (voc_xl16 = 0): deep weight ring on iteration-order fragments (same bits, no gain: DESIGN.md §9); set before cmtts_vocoder_finalize
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
 int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
 int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip) when L <= 192: 0 = three-launch path
-int g_voc_pair16p = 0;          // 16-bit ResBlock pairs through the persistent register-resident-weight kernel (resblock_pair16.hip): measured slower (one wave per SIMD serialises its staging / epilogue work, profiles/r02_vocoder_bf16.md): off
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
-bool g_ffn_xres = true;         // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
+int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
@@ -379,7 +375,7 @@ int persist_launched(hipStream_t s, int blocks) {
 // Independent branches of the text side (duration / energy predictors, ...) are short launches that cannot fill the chip:
 // a branch runs on a side stream forked from and joined back into the caller's stream with events, so the two overlap.
 // One side stream per caller stream (callers that run bucket groups on several streams keep their concurrency).
-bool g_branch_streams = true;
+int g_branch_streams = 1;
 struct SideStream {
     hipStream_t user, side;
     hipEvent_t fork, join;
@@ -465,6 +461,7 @@ struct cmtts_model {
     std::map<std::string, HostTensor> host;
     bool finalized = false;
     int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
+    int ffn2_split = 1;    // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (another fp32 summation order than one launch: a property of the model handle, cmtts_model_set_option)
     cmtts_variance_controls vc = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Allocs al;
     float *embed = nullptr, *omega_h = nullptr, *omega_cwt = nullptr, *omega_res = nullptr;
@@ -508,9 +505,9 @@ struct cmtts_vocoder {
     int rb_dil[3] = {1, 3, 5};
     PackedConv c1[12][3], c2[12][3];
     void *c1f[12][3][3] = {}, *c2f[12][3][3] = {};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies of the ResBlock convs
-    void *c1fi[12][3][2] = {}, *c2fi[12][3][2] = {};  // bf16 / fp16 once more in iteration order: wide stages (C >= 128), deep-ring kernel
     float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
+    int ups16 = 1;                                    // 16-bit modes: upsampler operands in 16 bits as well (cmtts_vocoder_set_option "ups16"; 0 = fp32 upsamplers, different numerics)
     float *post_w = nullptr, *post_b = nullptr;
     int post_cin = 32, post_k = 7;
 };
@@ -895,26 +892,11 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
               const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s) {
     const float* cur = in;
     int ldc = ld_in;
-    int pend = -1;        // layer whose LayerNorm has not been applied to `cur` yet (it becomes the next conv's prologue: conv_xres.hip)
     auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
     for (size_t li = 0; li < P.convs.size(); ++li) {
         const PackedConv& w = P.convs[li];
         int rx = -2;
         float* dst = other(cur);
-        if (g_pred_xres && P.convs_f[li] && T <= 96 && B >= 16 && w.cin == 256 && w.cout == 256 && ldc == ld) {
-            // phoneme-level 256 -> 256 conv: the utterance's x tile resident in LDS, the previous layer's LayerNorm as the prologue
-            // (same accumulation order, epilogue and LayerNorm arithmetic as the separate launches => same bits)
-            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
-            a.out[0].act = ACT_RELU;
-            if (pend >= 0) { a.ln_g = P.ln_g[pend]; a.ln_b = P.ln_b[pend]; a.ln_eps = 1e-12f; a.ln_lens = ln_lens; }
-            rx = cmtts_launch_conv_xres(&a, P.convs_f[li], B, (void*)s);
-            if (rx == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
-        }
-        if (rx != 0 && pend >= 0) {     // the pending LayerNorm as its own launch after all
-            k_layernorm_ct(cur, dst, P.ln_g[pend], P.ln_b[pend], 1e-12f, ln_lens, B, T, ld, s);
-            cur = dst; dst = other(cur);
-        }
-        pend = -1;
         if (rx != 0 && g_pred_xl && P.convs_f[li] && ldc == ld && (long)((T + 63) / 64) * B >= 192) {
             // frame-level 256 -> 256 conv: whole x tile + halo resident in LDS, weights streamed as A fragments (the HiFi-GAN
             // kernel, resblock_pair.hip; same accumulation order and epilogue expressions as the generic kernel => same bits)
@@ -936,11 +918,6 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
             k_ln_linear(cur, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
             return 0;
-        if (g_pred_xres && li + 1 < P.convs.size() && P.convs_f[li + 1] && T <= 96 && B >= 16 && w.cout == 256 && P.convs[li + 1].cin == 256 &&
-            P.convs[li + 1].cout == 256) {
-            pend = (int)li;               // the next conv normalises its own tile
-            continue;
-        }
         float* nd = other(cur);
         k_layernorm_ct(cur, nd, P.ln_g[li], P.ln_b[li], 1e-12f, ln_lens, B, T, ld, s);
         cur = nd;
@@ -1304,7 +1281,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
         }
-        const bool ffn2_seg = g_ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1;
+        const bool ffn2_seg = m->ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1;
         bool ffn_fused = false;
         {   // gelu((conv_k9(LayerNorm2(x)) + b) * k^-0.5)      (model/blocks.py:539-546, 612-615)
             // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
@@ -1599,10 +1576,6 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
-                    if (g_voc_ring16 && co >= 128 && co % 32 == 0) {     // only when the (superseded) deep-ring chunked kernel is asked for before finalize
-                        const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
-                        CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c1fi[r][mi][mode - 1]));
-                    }
                 }
                 {
                     const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
@@ -1613,10 +1586,6 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
-                    if (g_voc_ring16 && co >= 128 && co % 32 == 0) {     // only when the (superseded) deep-ring chunked kernel is asked for before finalize
-                        const std::vector<unsigned short> fi = to_fragment16_iter(hp, v->rb_kernel[j], co, co, mode);
-                        CHK(al.upload_bytes(fi.data(), fi.size() * 2, &v->c2fi[r][mi][mode - 1]));
-                    }
                 }
                 {
                     const std::vector<unsigned short> fs = to_fragment16_split(hp, v->rb_kernel[j], co, co);
@@ -1690,7 +1659,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
             const PackedConv& U = v->ups[i];
             int rt = -2;
-            if (g_voc_ups16 && (v->precision == 1 || v->precision == 2) && v->ups_f16[i][v->precision - 1] && K == 2 * st)
+            if (v->ups16 && (v->precision == 1 || v->precision == 2) && v->ups_f16[i][v->precision - 1] && K == 2 * st)
                 // 16-bit modes: the upsamplers' operands are 16-bit too (since round 2; the oracle's operands16 modes follow)
                 rt = cmtts_launch_convT16(bufA, bufU, v->ups_f16[i][v->precision - 1], U.bias, (long)ch * (Ti + P), (long)co * (To + P), B, ch,
                                           co, Ti, To, Ti + P, To + P, st, i > 0 ? 3.0f : 1.0f, 0.1f, v->precision, (void*)s);
@@ -1750,11 +1719,11 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             // (resblock_pair.hip; the pair's output must not alias its input, so the chain ping-pongs bR / bT)
             // 16-bit operands: with the weight ring issued by hand (resblock_pair16.hip: the compiler had sunk every fragment load
             // next to its use) the pair kernel wins for every (C, k): 0.37-0.55 ms per pair against 0.60-0.64 for two launches
-            // (profiles/r02_vocoder_bf16.md).  g_voc_pair16p: the persistent form with register-resident weights
+            // (profiles/r02_vocoder_bf16.md)
             const bool pair16_pays = true;
             // 16-bit, C = 128 (round 2): the pair as one 8-wave workgroup with both images in LDS (151 KB) — conv_xl16 otherwise
             // (measured, bf16: k = 3 / 7 / 11: 471 / 754 / 967 us per pair against 527 / 700 / 903 for the two launches: k = 3 only)
-            const bool pair128 = g_voc_pair128 && co == 128 && rk == 3 && (v->precision == 1 || v->precision == 2) && !g_voc_pair16p;
+            const bool pair128 = g_voc_pair128 && co == 128 && rk == 3 && (v->precision == 1 || v->precision == 2);
             const bool pair_ok = g_voc_pair && (co <= 64 || pair128) && v->precision != 3 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
@@ -1770,7 +1739,6 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 pa.accum = lastm && j > 0; pa.slope = 0.1f;
                 int prc;
                 if (!v->precision) prc = cmtts_launch_resblock_pair(&pa, (void*)q);
-                else if (g_voc_pair16p) prc = cmtts_launch_resblock_pair16p(&pa, v->precision, persist_blocks(), (void*)q);
                 else prc = cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q);
                 if (prc != 0) return fail(CMTTS_E_HIP, "resblock_pair launch failed");
                 if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
@@ -1823,7 +1791,6 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else if (v->precision) {
                     a.y16 = 1; a.y16_slope = 0.1f;        // xt crosses HBM as convert(leaky_relu(xt)) in 16 bits
-                    if (g_voc_ring16) a.wfrag_iter = v->c1fi[r][mi][v->precision - 1];
                     if (cmtts_launch_conv16(&a, v->c1f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
@@ -1841,7 +1808,6 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else if (v->precision) {
                     b.x16 = 1;
-                    if (g_voc_ring16) b.wfrag_iter = v->c2fi[r][mi][v->precision - 1];
                     if (cmtts_launch_conv16(&b, v->c2f[r][mi][v->precision - 1], v->precision, B, (void*)q) != 0)
                         return fail(CMTTS_E_HIP, "conv16 launch failed");
                 } else {
@@ -1867,132 +1833,93 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
     return 0;
 }
 
+// ---- options.  Three tiers:
+//   cmtts_set_option            process-wide SCHEDULING knobs of the public ABI: they never change a result bit
+//   cmtts_model_set_option /    per-handle NUMERICS choices (another fp32 summation order / another operand precision):
+//   cmtts_vocoder_set_option    properties of a model, not of the process
+//   cmtts_internal_set          A/B switches between a fused kernel and the path it replaces (bitwise equal, used by tests/ and
+//                               tools/ for cross-checks and measurements); declared in csrc/internal_hooks.h, NOT part of the ABI
+struct Knob { const char* name; int* var; int lo, hi; };
+static int knob_set(const Knob* tab, size_t n, const char* name, int value, bool* found) {
+    for (size_t i = 0; i < n; ++i)
+        if (!strcmp(name, tab[i].name)) {
+            *found = true;
+            const int prev = *tab[i].var;
+            if (value >= tab[i].lo && value <= tab[i].hi) *tab[i].var = value;
+            return prev;
+        }
+    *found = false;
+    return 0;
+}
+
 int cmtts_set_option(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_set_option: null name");
-    if (!strcmp(name, "cond_gemm")) {       // 0 never, 1 when it pays (>= 128 frame tiles), 2 whenever supported
-        const int prev = g_cond_gemm;
-        if (value >= 0 && value <= 2) g_cond_gemm = value;
-        return prev;
-    }
-    if (!strcmp(name, "resblock_split")) {   // 0 never, 1 small batches, 2 always (fp32 per-layer path)
-        const int prev = g_split_resblock;
-        if (value >= 0 && value <= 2) g_split_resblock = value;
-        return prev;
-    }
-    if (!strcmp(name, "branch_streams")) {
-        const int prev = g_branch_streams ? 1 : 0;
-        if (value == 0 || value == 1) g_branch_streams = value != 0;
-        return prev;
-    }
-    if (!strcmp(name, "persist_tail")) {
-        const int prev = g_persist_tail ? 1 : 0;
-        if (value == 0 || value == 1) g_persist_tail = value != 0;
-        return prev;
-    }
     if (!strcmp(name, "cooperative_launch")) {   // persistent denoiser through hipLaunchCooperativeKernel: 0 never, 1 always, 2 = automatic
-        // (default): once the process has a communicator / process group ("process_group"), i.e. RCCL kernels may share the GPU
+        // (default): with a communicator / process group in the process ("process_group") the first launch of every grid shape is
+        // cooperative (the runtime validates co-residency), later ones plain (a cooperative launch drains every queue: +24 % per step)
         const int prev = cmtts_persist_set_cooperative(value == 2 ? -1 : (value == 0 || value == 1) ? value : -2);
         return prev < 0 ? 2 : prev;
     }
     if (!strcmp(name, "process_group")) {        // the host tells the library that a process group exists (torch.distributed initialised)
         return cmtts_persist_note_process_group(value);
     }
-    if (!strcmp(name, "ffn_fused")) {     // FFN linear inside the FFN conv's launch (1) or as its own K-segment launch (0); same bits
-        const int prev = g_ffn_fused;
-        if (value == 0 || value == 1) g_ffn_fused = value;
-        return prev;
-    }
-    if (!strcmp(name, "pred_xres")) {     // phoneme-level predictor convs X-resident with LayerNorm prologue (1) or generic + LayerNorm launches (0); same bits
-        const int prev = g_pred_xres;
-        if (value == 0 || value == 1) g_pred_xres = value;
-        return prev;
-    }
-    if (!strcmp(name, "inproj_fused")) {  // denoiser input as one launch (1) or mel_prep + generic conv + memset (0); same bits
-        const int prev = g_inproj_fused;
-        if (value == 0 || value == 1) g_inproj_fused = value;
-        return prev;
-    }
-    if (!strcmp(name, "step_cache")) {    // cmtts_sample: cached step-embedding rows (1) or recomputed per call (0); same bits
-        const int prev = g_step_cache;
-        if (value == 0 || value == 1) g_step_cache = value;
-        return prev;
-    }
-    if (!strcmp(name, "ffn2_split")) {    // FFN linear of the FFT blocks as K-segment partial GEMMs + reduction (1) or one launch (0): another fp32 summation order
-        const int prev = g_ffn2_split;
-        if (value == 0 || value == 1) g_ffn2_split = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_ups16")) {     // 16-bit vocoder modes: 16-bit upsampler operands (1) or fp32 upsamplers (0): different numerics
-        const int prev = g_voc_ups16;
-        if (value == 0 || value == 1) g_voc_ups16 = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_pair128")) {   // 16-bit C = 128 stage: pair kernel (1) or two X-resident convs (0); same bits
-        const int prev = g_voc_pair128;
-        if (value == 0 || value == 1) g_voc_pair128 = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_rb16")) {      // 16-bit narrow stages: whole ResBlock per launch (1) or one launch per pair (0); same bits
-        const int prev = g_voc_rb16;
-        if (value >= 0 && value <= 2) g_voc_rb16 = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_upsT")) {      // upsampling transposed convs on convT_xl_kernel (1) or the generic kernel (0); same bits
-        const int prev = g_voc_upsT;
-        if (value == 0 || value == 1) g_voc_upsT = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_xl16")) {      // 16-bit wide ResBlock convs: X-resident kernel (1) or the chunked one (0); same bits
-        const int prev = g_voc_xl16;
-        if (value == 0 || value == 1) g_voc_xl16 = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_ring16")) {    // 16-bit wide ResBlock convs: deep weight ring (1) or one step ahead (0); same bits
-        const int prev = g_voc_ring16;
-        if (value == 0 || value == 1) g_voc_ring16 = value;
-        return prev;
-    }
-    if (!strcmp(name, "pred_xl")) {       // frame-level predictor convs on conv_xl_kernel (1) or the generic kernel (0); same bits
-        const int prev = g_pred_xl;
-        if (value == 0 || value == 1) g_pred_xl = value;
-        return prev;
-    }
-    if (!strcmp(name, "pred_head")) {     // predictors: last LayerNorm + linear head in one launch (1) or as two (0)
-        const int prev = g_pred_head;
-        if (value == 0 || value == 1) g_pred_head = value;
-        return prev;
-    }
-    if (!strcmp(name, "text_xres")) {     // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection, 2 = out-projection, 4 = LayerNorm2 + FFN conv on the X-resident kernel
-        const int prev = g_text_xres;
-        if (value >= 0 && value <= 15) g_text_xres = value;
-        return prev;
-    }
-    if (!strcmp(name, "attn_fused")) {    // FFT-block attention: 1 = QKV projection + one fused kernel (L <= 192), 0 = three launches
-        const int prev = g_attn_fused;
-        if (value == 0 || value == 1) g_attn_fused = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_pair16p")) {   // 16-bit pairs: persistent kernel with register-resident weights (1) or the per-tile streamed form (0)
-        const int prev = g_voc_pair16p;
-        if (value == 0 || value == 1) g_voc_pair16p = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_xl")) {        // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel
-        const int prev = g_voc_xl;
-        if (value == 0 || value == 1) g_voc_xl = value;
-        return prev;
-    }
-    if (!strcmp(name, "voc_pair")) {      // HiFi-GAN ResBlock pairs of the C <= 64 stages fused into one launch
-        const int prev = g_voc_pair;
-        if (value >= 0 && value <= 2) g_voc_pair = value;
-        return prev;
-    }
-    if (!strcmp(name, "ffn_xres")) {
-        const int prev = g_ffn_xres ? 1 : 0;
-        if (value == 0 || value == 1) g_ffn_xres = value != 0;
-        return prev;
-    }
+    static const Knob tab[] = {
+        {"branch_streams", &g_branch_streams, 0, 1},     // independent branches of a call on library-owned side streams
+        {"resblock_split", &g_split_resblock, 0, 2},     // fp32 residual block as two launches over 4x the CUs: 0 never, 1 small batches, 2 always
+        {"step_cache", &g_step_cache, 0, 1},             // cmtts_sample: keep the timestep-only step-embedding rows on the device
+    };
+    bool found;
+    const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
+    if (found) return prev;
     return fail(CMTTS_E_INVALID, "cmtts_set_option: unknown option");
+}
+
+int cmtts_model_set_option(cmtts_model* m, const char* name, int value) {
+    if (!m || !name) return fail(CMTTS_E_INVALID, "cmtts_model_set_option: null argument");
+    const Knob tab[] = {
+        {"ffn2_split", &m->ffn2_split, 0, 1},            // FFN linear of the FFT blocks as 8 K-segment partial GEMMs + one reduction (1) or one launch (0)
+    };
+    bool found;
+    const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
+    if (found) return prev;
+    return fail(CMTTS_E_INVALID, "cmtts_model_set_option: unknown option");
+}
+
+int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
+    if (!v || !name) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_option: null argument");
+    const Knob tab[] = {
+        {"ups16", &v->ups16, 0, 1},                      // 16-bit modes: 16-bit operands in the upsamplers too (1) or fp32 upsamplers (0)
+    };
+    bool found;
+    const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
+    if (found) return prev;
+    return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_option: unknown option");
+}
+
+// csrc/internal_hooks.h — fused kernel vs the path it replaces; every pair is bitwise equal (tests/test_gpu_parity.py)
+int cmtts_internal_set(const char* name, int value) {
+    if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
+    static const Knob tab[] = {
+        {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
+        {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
+        {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
+        {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
+        {"ffn_fused", &g_ffn_fused, 0, 1},         // FFN linear's partial products inside the FFN conv's launch
+        {"text_xres", &g_text_xres, 0, 15},        // bit mask: 1 LN1 + in-projection, 2 out-projection, 4 LN2 + FFN conv on conv_xres.hip
+        {"attn_fused", &g_attn_fused, 0, 1},       // fused attention kernel vs three launches
+        {"pred_xl", &g_pred_xl, 0, 1},             // frame-level predictor convs on conv_xl
+        {"pred_head", &g_pred_head, 0, 1},         // LayerNorm + linear head in one launch
+        {"voc_pair", &g_voc_pair, 0, 2},           // HiFi-GAN ResBlock pairs (C <= 64) as one launch
+        {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel
+        {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
+        {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
+        {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
+        {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
+    };
+    bool found;
+    const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
+    if (found) return prev;
+    return fail(CMTTS_E_INVALID, "cmtts_internal_set: unknown switch");
 }
 
 int cmtts_poll_error(void) {

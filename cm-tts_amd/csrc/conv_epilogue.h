@@ -115,10 +115,6 @@ __device__ __forceinline__ void epi_tile_simple(const ConvOut& o, const f32x16& 
         v = act_apply(v, ACT);
         if (rb) v += rv[r];
         if (!keep) v = 0.f;
-#if defined(XRES_ABL) && XRES_ABL == 1
-        if (ok_n && m < M && v == 12345.678f) yb[(unsigned)m * (unsigned)o.ldy + (unsigned)n] = v;     // timing-only build: no stores
-#else
         if (ok_n && m < M) yb[(unsigned)m * (unsigned)o.ldy + (unsigned)n] = v;
-#endif
     }
 }

@@ -13,9 +13,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-#ifndef X16_ABL
-#define X16_ABL 0                // timing-only ablation builds (tools/xl16_ablation.sh; results are WRONG): bit 0 no weight stream, bit 1 no LDS operand
-#endif                           // reads in the K loop, bit 2 no staging loads (conv_xl16), bit 3 no epilogue loads / stores (conv_xl16)
 constexpr int N1 = 256;          // columns of xt per workgroup
 constexpr int RING = 8;          // A fragments in flight per wave (by hand, see conv_loop16): an L2 hit takes ~0.7 us = several groups of 2-4 MFMAs
 constexpr int R1MAX = 25;
@@ -88,23 +85,15 @@ __device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __re
     u32x4 Bf[2][NT];
     load_b(Bf[0], 0);
     auto body = [&](int it) {
-#if X16_ABL & 1
-        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]));
-#else
         if (it + RING - 1 < NG) {
             issue_a(A[(it + RING - 1) % RING], it + RING - 1);
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RING]) : "n"(RING - 1));
         } else {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RING]));     // tail: drain
         }
-#endif
-#if X16_ABL & 2
-        if (it == 0) load_b(Bf[1], 1);
-#else
         if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
-#endif
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[(X16_ABL & 1) ? it % (RING - 1) : it % RING], Bf[it & 1][j], acc[j]);
+        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
         if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);       // the next group's B fragments
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // under this group's MFMAs
     };

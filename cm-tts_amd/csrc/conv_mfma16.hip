@@ -27,10 +27,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Activations stream through once per launch while every workgroup re-reads the same few hundred KB of weights: the
 // streams are marked non-temporal so that they do not push the weights out of the 4-MB L2 of an XCD (CONV16_NT=0: plain)
-// Timing-only ablation builds (tools/conv16_ablation.sh; results are WRONG): 1 = no weight stream, 2 = no LDS operand reads, 3 = both
-#ifndef C16_ABL
-#define C16_ABL 0
-#endif
 #ifndef CONV16_NT
 #define CONV16_NT 0
 #endif
@@ -61,13 +57,8 @@ __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f3
 // MODE 3 ("fp16x3", IO 0 only): operands carried as hi = fp16(v), lo = fp16(v - hi) — two LDS images of the X tile, two
 // fragment sets of the weights (lo follows hi) — and every product as three fp16 MFMAs (a_lo b_hi + a_hi b_lo + a_hi b_hi,
 // fp32 accumulate): fp32-class results at 3/16 of the fp32 matrix cost.
-// RING > 0 (round 2, wide convs): the weights come in ITERATION order ([32-channel chunk][tap][k-group][m-tile][lane][8]: the
-// stream is one linear walk over the steps (chunk, tap, k-group)) through a register ring RING steps deep that runs across
-// chunk boundaries and barriers.  With MT x NT = 2 x 2 tiles per wave an A fragment (1 KB per wave) feeds only two MFMAs of 32
-// cycles: 64 B/clk per CU for a full pipe, so the kernel lives on how many bytes a wave keeps in flight against the ~0.7 us
-// an L2 hit takes; one step ahead (RING == 0, round 1) had every wave waiting on each fragment.
-template <int BM, int BN, int WM, int WN, int MODE, int IO, int RING = 0>
-__global__ __launch_bounds__(256, (BN > 128 || MODE == 3 || RING > 0) ? 2 : 3) void conv1d_mfma16_kernel(const ConvArgs a, const u32x4* __restrict__ wfrag) {
+template <int BM, int BN, int WM, int WN, int MODE, int IO>
+__global__ __launch_bounds__(256, (BN > 128 || MODE == 3) ? 2 : 3) void conv1d_mfma16_kernel(const ConvArgs a, const u32x4* __restrict__ wfrag) {
     constexpr int MT = BM / (WM * 32);
     constexpr int NT = BN / (WN * 32);
     constexpr int MM = MODE == 3 ? 2 : MODE;              // MFMA element type
@@ -180,49 +171,6 @@ __global__ __launch_bounds__(256, (BN > 128 || MODE == 3 || RING > 0) ? 2 : 3) v
     store_x(0);
     __syncthreads();
     const int nq = a.taps * 2;                     // (tap, k-group-in-chunk) pairs per chunk
-    if constexpr (RING > 0) {
-        static_assert(NT == 2 && NS == 1, "ring variant: 2 n-tiles per wave, one operand set");
-        const int S = nchunks * nq;                // steps; a multiple of RING (checked by the launcher)
-        int mto[MT];                               // this wave's m-tiles (clamped: idle rows load valid memory)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) mto[i] = min(m0 / 32 + wm * MT + i, MTn - 1) * 64 + lane;
-        auto load_ai = [&](u32x4 (&dst)[MT], int it) {
-            const u32x4* pw = wfrag + (long)min(it, S - 1) * MTn * 64;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) dst[i] = pw[mto[i]];
-        };
-        u32x4 A[RING][MT], Bf[2][NS];
-#pragma unroll
-        for (int s = 0; s < RING - 1; ++s) load_ai(A[s], s);
-        int chunk = 0, q = 0;
-        const unsigned short* xb = xs;
-#pragma unroll 1
-        for (int it0 = 0; it0 < S; it0 += RING) {
-#pragma unroll
-            for (int s = 0; s < RING; ++s) {
-                if (q == 0) {                      // chunk start (wave-uniform): next chunk's global loads, this chunk's first B
-                    if (chunk + 1 < nchunks) load_x(chunk + 1);
-                    xb = xs + (chunk & 1) * NS * IMG;
-                    load_b(Bf[0], xb, 0, 0);
-                }
-                load_ai(A[(s + RING - 1) % RING], it0 + s + RING - 1);
-                const int qn = min(q + 1, nq - 1);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (j + 1 < NT) load_b(Bf[(j + 1) & 1], xb, q, j + 1);
-                    else load_b(Bf[0], xb, qn, 0);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][j] = mma16<MM>(A[s][i], Bf[j & 1][0], acc[i][j]);
-                }
-                if (++q == nq) {                   // chunk end: publish the next chunk's tile
-                    if (chunk + 1 < nchunks) store_x((chunk + 1) & 1);
-                    __syncthreads();
-                    q = 0;
-                    ++chunk;
-                }
-            }
-        }
-    } else
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool has_next = chunk + 1 < nchunks;
         if (has_next) load_x(chunk + 1);
@@ -236,21 +184,12 @@ __global__ __launch_bounds__(256, (BN > 128 || MODE == 3 || RING > 0) ? 2 : 3) v
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int qn = min(q + s + 1, nq - 1);
-#if C16_ABL == 1 || C16_ABL == 3
-                A[(s + 1) & 1][0][0] = A[s][0][0];        // timing-only build: no weight stream
-                if (MT > 1) A[(s + 1) & 1][0][MT - 1] = A[s][0][MT - 1];
-#else
                 load_a(A[(s + 1) & 1], qn >> 1, chunk * 2 + (qn & 1));
-#endif
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                                     const int cur = (s * NT + j) & 1;
-#if C16_ABL == 2 || C16_ABL == 3
-                    Bf[cur ^ 1][0] = Bf[cur][0];          // timing-only build: no LDS operand reads
-#else
                     if (j + 1 < NT) load_b(Bf[cur ^ 1], xb, q + s, j + 1);
                     else load_b(Bf[cur ^ 1], xb, qn, 0);
-#endif
                     // a chunk whose second k-group lies beyond K contributes zeros (X rows are zero-filled)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
@@ -319,7 +258,6 @@ __global__ __launch_bounds__(256, (BN > 128 || MODE == 3 || RING > 0) ? 2 : 3) v
     }
 }
 
-constexpr int WRING = 8;     // steps of weights in flight per wave in the ring variant (7 x 2 KB)
 
 template <int BM, int BN, int WM, int WN>
 int launch16(const ConvArgs& a, const void* wfrag, int mode, int nbatch, hipStream_t stream) {
@@ -329,17 +267,6 @@ int launch16(const ConvArgs& a, const void* wfrag, int mode, int nbatch, hipStre
     const size_t lds = (size_t)(mode == 3 ? 2 : 1) * 2 * (BN + 64) * RSX * sizeof(unsigned short);
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch);
     const int io = a.y16 ? 1 : (a.x16 ? 2 : 0);
-    if constexpr (BM == 128 && BN == 128 && WN == 2) {
-        // wide convs with an iteration-order copy of the weights: deep weight ring (same MFMA order => same bits)
-        if (a.wfrag_iter && mode != 3 && a.dil > 0 && ((a.K / KC) * a.taps * 2) % WRING == 0) {
-            const u32x4* wi = (const u32x4*)a.wfrag_iter;
-#define CMTTS_L16R(M_, IO_) hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, M_, IO_, WRING>), grid, dim3(256), lds, stream, a, wi)
-            if (mode == 1) { if (io == 1) CMTTS_L16R(1, 1); else if (io == 2) CMTTS_L16R(1, 2); else CMTTS_L16R(1, 0); }
-            else { if (io == 1) CMTTS_L16R(2, 1); else if (io == 2) CMTTS_L16R(2, 2); else CMTTS_L16R(2, 0); }
-#undef CMTTS_L16R
-            return hipGetLastError() == hipSuccess ? 0 : -3;
-        }
-    }
     if (mode == 3) {
         if (io != 0) return -2;
         hipLaunchKernelGGL((conv1d_mfma16_kernel<BM, BN, WM, WN, 3, 0>), grid, dim3(256), lds, stream, a, (const u32x4*)wfrag);

@@ -33,15 +33,6 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
     const int tbase = t0 - pad;
     constexpr int XBLK = (XROWS + 63) / 64;
     constexpr int PAIRS = C / 2 / NWAVES;           // channel pairs per wave: 16 (32 with two m-tiles per wave)
-#if defined(XL16_STAGGER)
-    {   // experiment: the workgroups of the first wave start 0-7 x 4 us apart, so that co-resident workgroups are in different phases
-        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if (lin < (unsigned)XL16_STAGGER) {
-            const int n = (int)((lin * 2654435761u) >> 29);
-            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
     // Staging: ALL loads of the tile are issued before the first LDS store — one HBM round trip per workgroup instead of one per
     // 64-column block.  It matters beyond this workgroup: the CU's vector-memory path returns in order across waves, so while a
     // staging batch is waiting for HBM the co-resident workgroups' weight fragments (L2 hits) queue behind it and their K loops
@@ -56,7 +47,7 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
 #pragma unroll
             for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) v[jb][p][h] = (X16_ABL & 4) ? (unsigned)(p + h) : (xb + (long)((w * PAIRS + p) * 2 + h) * a.ld)[t_c];
+                for (int h = 0; h < 2; ++h) v[jb][p][h] = (xb + (long)((w * PAIRS + p) * 2 + h) * a.ld)[t_c];
         }
 #pragma unroll
         for (int jb = 0; jb < XBLK; ++jb) {
@@ -79,7 +70,7 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
 #pragma unroll
             for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) v[jb][p][h] = (X16_ABL & 4) ? (float)(p + h) : (xb + (long)((w * PAIRS + p) * 2 + h) * a.ld)[t_c];
+                for (int h = 0; h < 2; ++h) v[jb][p][h] = (xb + (long)((w * PAIRS + p) * 2 + h) * a.ld)[t_c];
         }
 #pragma unroll
         for (int jb = 0; jb < XBLK; ++jb) {
@@ -118,7 +109,7 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][j][r] + bi[r];
                     v = v * (v > 0.f ? 1.f : a.slope);
-                    if (t < T && (!(X16_ABL & 8) || v == 12345.678f)) y16[(long)(m0 + acc_row(r, lane)) * a.ld + t] = (unsigned short)pack16<MODE>(v, 0.f);
+                    if (t < T) y16[(long)(m0 + acc_row(r, lane)) * a.ld + t] = (unsigned short)pack16<MODE>(v, 0.f);
                 }
             }
         } else {
@@ -139,14 +130,14 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
                         const unsigned t_c = (unsigned)min(t0 + (j0 + jj) * 32 + l31, T - 1);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            rv[jj][r] = rb && !(X16_ABL & 8) ? rb[rowoff[r] + t_c] : 0.f;
-                            if (ACC) yv[jj][r] = !(X16_ABL & 8) ? yb[rowoff[r] + t_c] : 0.f;
+                            rv[jj][r] = rb ? rb[rowoff[r] + t_c] : 0.f;
+                            if (ACC) yv[jj][r] = yb[rowoff[r] + t_c];
                         }
                     }
 #pragma unroll
                     for (int jj = 0; jj < JB; ++jj) {
                         const int t = t0 + (j0 + jj) * 32 + l31;
-                        if (t < T && (!(X16_ABL & 8) || acc[i][j0 + jj][0] == 12345.678f)) {
+                        if (t < T) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
                                 yb[rowoff[r] + (unsigned)t] = ((acc[i][j0 + jj][r] + bi[r]) + rv[jj][r]) + (ACC ? yv[jj][r] : 0.f);

@@ -300,12 +300,6 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
         return;
     }
     if (mt >= MTn) return;
-#if defined(XRES_ABL) && XRES_ABL == 2
-    if (epi_simple(o)) {       // timing-only build: no activation
-#pragma unroll
-        for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_NONE>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);
-    } else
-#endif
     if (epi_simple(o) && o.act == ACT_GELU_ERF) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) epi_tile_simple<ACT_GELU_ERF>(o, acc[j], mt * 32, 4 * khalf, n0 + j * 32 + l31, a.M, a.N, z);

@@ -431,7 +431,7 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        if (cmtts_persist_cooperative()) {
+        if (cmtts_persist_cooperative(MODE, tiles, nb)) {
             void* params[] = {(void*)&c};
             if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>), dim3(tiles, nb),
                                            dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;

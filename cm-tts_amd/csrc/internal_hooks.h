@@ -1,0 +1,15 @@
+// NOT part of the C ABI (include/cmtts_hip.h): A/B switches between a fused kernel and the path it replaces, for the bitwise
+// cross-check tests (tests/test_gpu_parity.py) and the measurement tools (tools/).  Every pair produces identical bits; the
+// switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
+// (cmtts_amd/_lib.py: internal_set).
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
+// Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
+// voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT (cmtts_api.hip: cmtts_internal_set).
+int cmtts_internal_set(const char* name, int value);
+#ifdef __cplusplus
+}
+#endif

@@ -51,9 +51,10 @@ int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call m
 void cmtts_persist_set_debug(long long* dbg);
 // 1: launch through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident and dispatches it
 // with the cooperative-queue guarantee); 0: plain launch, grid <= CU count by construction.  Returns the previous value.
-// -1 (default) = automatic: cooperative once a process group / communicator exists in the process (cmtts_persist_note_process_group).
+// -1 (default) = automatic: once a process group / communicator exists in the process (cmtts_persist_note_process_group) the first
+// launch of every (variant, grid) is cooperative — the runtime validates co-residency — and later ones are plain (denoiser_persist.hip).
 int cmtts_persist_set_cooperative(int on);
-int cmtts_persist_cooperative(void);            // the effective setting (0 / 1)
+int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant 0 = fp32, 1..3 = 16-bit modes)
 int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
 }

@@ -33,8 +33,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Ablation builds (tools/pair_ablation.sh; results are WRONG, timing only): 1 = no weight stream (A loaded once),
-// 2 = no LDS operand reads in the K loops, 3 = no LeakyReLU on conv1's operand, 4 = no x staging / no output stores
+// -DPAIR_DBG=5 (tools/pair_phases.py): every wave stamps the cycle counter at its phase boundaries; results are unchanged
 #ifndef PAIR_DBG
 #define PAIR_DBG 0
 #endif
@@ -103,19 +102,17 @@ __device__ __forceinline__ void conv_loop(f32x16 (&acc)[NT], const float* __rest
             advance();                                   // -> offset of group it + s + 1 (past the end: harmless, in-bounds reads)
             const int off_n = min(boff, (CIN - 8) * ld + (KT - 1) * max(dil, 0));   // past-the-end prefetch: harmless in-bounds read
             const float* bs = bl + off_n;
-            if (PAIR_DBG != 1) load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+            load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (PAIR_DBG != 2) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * ld + j * 32];
-                }
+                for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * ld + j * 32];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
                 }
-                if (PAIR_DBG != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read2_b32 (next group's k-step kk) ...
-                if (kk == 0 && PAIR_DBG != 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... the A load of a later group ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one ds_read2_b32 (next group's k-step kk) ...
+                if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... the A load of a later group ...
                 __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);     // ... under this k-step's MFMAs
             }
         }
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairArgs a)
             const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
 #pragma unroll
             for (int q = 0; q < ROWS_PER_WAVE; ++q)
-                v[jb][q] = PAIR_DBG == 4 ? (float)t_c : xb[(long)(w * ROWS_PER_WAVE + q) * a.ld + t_c];
+                v[jb][q] = xb[(long)(w * ROWS_PER_WAVE + q) * a.ld + t_c];
         }
 #pragma unroll
         for (int jb = 0; jb < XBLK; ++jb) {
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairArgs a)
         for (int j = 0; j < NT; ++j) {
             const int o = col0 + j * 32 + l31;
             const int t = t0 + o;
-            const bool ok = o < TT && t < T && !(PAIR_DBG == 4 && a.slope != -12345.f);
+            const bool ok = o < TT && t < T;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * 32 + acc_row(r, lane);

@@ -137,265 +137,6 @@ __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kerne
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent form with REGISTER-RESIDENT weights.  The kernel above streams both convs' weights per 246-column tile (C = 64,
-// k = 11: 2 x 90 KB per tile and per m-tile-sharing wave): at 16-bit MFMA rates that stream, not the tensor passes, sets
-// the time of the k >= 7 pairs (0.83 ms per k = 11 pair vs 0.64 for the two-launch path).  Here a workgroup of 4 waves — one
-// per SIMD, the whole 512-entry register file each — loads its A fragments of BOTH convs once (one m-tile x all of K:
-// 2 * (C/16) * k fragments = 88 ... 352 registers) and then walks over a contiguous range of tiles:
-//
-//   * steady state touches HBM/L2 only for activations: the next tile's raw x arrives by LDS-DMA (global_load_lds_dword,
-//     no registers) in a double-buffered fp32 staging area while the current tile is multiplied; a convert pass
-//     (LeakyReLU, zero padding, v_cvt_pk, transpose) turns it into the 16-bit x^T image the MFMAs read;
-//   * three raw s_barriers per tile (lgkmcnt only: a __syncthreads would drain the DMA in flight), one vmcnt(0) per tile
-//     just before the barrier that publishes the landed DMA;
-//   * fully unrolled K loops with compile-time fragment indices, B fragments one group ahead.
-// Same conversions, accumulation order and epilogue as above => bitwise equal to it and to the two-launch path.
-template <int C> struct P16 {
-    static constexpr int N1 = C == 64 ? 128 : 256;         // 8 accumulator tiles per workgroup either way
-    static constexpr int NT = 2;
-    static constexpr int XROWS = N1 + 2 * R1MAX;
-    static constexpr int XWF = (XROWS + 63) / 64 * 64;     // fp32 staging row stride: whole 64-lane DMA blocks
-};
-
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int C, int KT, int MODE>
-__global__ __launch_bounds__(256, 1) void resblock_pair16p_kernel(const PairArgs a, int tiles_per_utt, int total_tiles) {
-    using P = P16<C>;
-    constexpr int N1 = P::N1, NT = P::NT, XROWS = P::XROWS, XWF = P::XWF;
-    constexpr int RS = C + 4;
-    constexpr int G = C / 16, MTn = C / 32, NG = G * KT;
-    constexpr int WPM = 4 / MTn;
-    constexpr int R2 = (KT - 1) / 2;
-    constexpr int TT = N1 - 2 * R2;
-    constexpr int NBLK = XWF / 64;
-    constexpr bool RES_PREFETCH = 2 * NG * 4 <= 256;        // C = 64, k = 11 keeps 352 registers of weights: residual loaded late
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
-    float* Xf = reinterpret_cast<float*>(smem_p);                                   // [2][C][XWF] raw x (LDS-DMA target)
-    unsigned short* Xs = reinterpret_cast<unsigned short*>(smem_p + (size_t)2 * C * XWF * 4);   // [XROWS][RS]
-    unsigned short* XTs = Xs + XROWS * RS;                                           // [XTROWS][RS]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int mt = w / WPM, nq = w % WPM;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int T = a.T, dil = a.dil;
-    const int r1 = dil * R2;
-    const int xw = N1 + 2 * r1;
-    const float slope = a.slope;
-    const int col0 = nq * (NT * 32);
-
-    // ---- this workgroup's contiguous tile range
-    const int G_ = gridDim.x, g = blockIdx.x;
-    const int tile_lo = (int)((long)total_tiles * g / G_), tile_hi = (int)((long)total_tiles * (g + 1) / G_);
-    if (tile_lo >= tile_hi) return;
-
-    // ---- resident weights: A fragments of this wave's m-tile for every (chunk, tap, k-group) of both convs
-    u32x4 A1[NG], A2[NG];
-    {
-        const u32x4* w1 = (const u32x4*)a.w1f;
-        const u32x4* w2 = (const u32x4*)a.w2f;
-#pragma unroll
-        for (int it = 0; it < NG; ++it) {
-            const int chunk = it / (2 * KT), rr = it - chunk * (2 * KT), tap = rr >> 1, kgl = rr & 1;
-            const long idx = ((long)(tap * G + 2 * chunk + kgl) * MTn + mt) * 64 + lane;
-            A1[it] = w1[idx];
-            A2[it] = w2[idx];
-        }
-    }
-    float b1r[16], b2r[16];         // biases: resident unless the weights leave no room (then re-read per tile: L1/L2 hits)
-    if (RES_PREFETCH) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { b1r[r] = a.b1[mt * 32 + acc_row(r, lane)]; b2r[r] = a.b2[mt * 32 + acc_row(r, lane)]; }
-    }
-
-    // LDS-DMA of one tile's raw x rows into staging buffer `buf`: wave w moves rows w, w+4, ...; a wave-instruction moves 64
-    // consecutive columns of a row (clamped addresses: out-of-sequence columns are zeroed by the convert pass)
-    auto dma_tile = [&](int tile, int buf) {
-        const int b = tile / tiles_per_utt, ti = tile - b * tiles_per_utt;
-        const int tbase = ti * TT - R2 - r1;
-        const float* xb = a.x + (long)b * a.bstride;
-#pragma unroll 1
-        for (int c = w; c < C; c += 4) {
-            const float* xrow = xb + (long)c * a.ld;
-#pragma unroll
-            for (int jb = 0; jb < NBLK; ++jb) {
-                const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xrow + t_c),
-                                                 (__attribute__((address_space(3))) void*)(Xf + ((size_t)buf * C + c) * XWF + jb * 64), 4, 0, 0);
-            }
-        }
-    };
-    auto load_b = [&](u32x4 (&dst)[NT], const unsigned short* src, int it, int dl) {
-        const int chunk = it / (2 * KT), rr = it - chunk * (2 * KT), tap = rr >> 1, kgl = rr & 1;
-        const unsigned short* p = src + (col0 + l31 + tap * dl) * RS + khalf * 8 + chunk * 32 + kgl * 16;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-
-    dma_tile(tile_lo, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int buf = (tile - tile_lo) & 1;
-        const int b = tile / tiles_per_utt, ti = tile - b * tiles_per_utt;
-        const int t0 = ti * TT;
-        const float* xb = a.x + (long)b * a.bstride;
-        float* yb = a.y + (long)b * a.bstride;
-        if (tile + 1 < tile_hi) dma_tile(tile + 1, buf ^ 1);          // lands while this tile is multiplied
-
-        // ---- convert pass: staging (fp32, [C][XWF]) -> x^T image (16-bit, [col][C]), LeakyReLU + zero padding applied
-        {
-            const float* xf = Xf + (size_t)buf * C * XWF;
-            const int tbase = t0 - R2 - r1;
-#pragma unroll 1
-            for (int p = w; p < C / 2; p += 4) {
-#pragma unroll
-                for (int jb = 0; jb < NBLK; ++jb) {
-                    const int j = jb * 64 + lane;
-                    const int t = tbase + j;
-                    const bool in = t >= 0 && t < T;
-                    const float fpos = in ? 1.f : 0.f, fneg = in ? slope : 0.f;
-                    const float v0 = xf[(2 * p) * XWF + j], v1 = xf[(2 * p + 1) * XWF + j];
-                    const unsigned pk = pack16<MODE>(v0 * (v0 > 0.f ? fpos : fneg), v1 * (v1 > 0.f ? fpos : fneg));
-                    if (j < xw) *reinterpret_cast<unsigned*>(Xs + j * RS + 2 * p) = pk;
-                }
-            }
-        }
-        lds_barrier();
-
-        f32x16 acc[NT];
-        // ---- conv1 on the x^T image
-        {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            u32x4 Bf[2][NT];
-            load_b(Bf[0], Xs, 0, dil);
-#pragma unroll
-            for (int it = 0; it < NG; ++it) {
-                if (it + 1 < NG) load_b(Bf[(it + 1) & 1], Xs, it + 1, dil);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A1[it], Bf[it & 1][j], acc[j]);
-                if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-            }
-            if (!RES_PREFETCH) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) b1r[r] = a.b1[mt * 32 + acc_row(r, lane)];
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int c = col0 + j * 32 + l31;
-                const int t = t0 - R2 + c;
-                const bool in = t >= 0 && t < T;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[j][r] + b1r[r];
-                    v = v * (v > 0.f ? 1.f : slope);
-                    XTs[c * RS + mt * 32 + acc_row(r, lane)] = in ? (unsigned short)pack16<MODE>(v, 0.f) : (unsigned short)0;
-                }
-            }
-        }
-        lds_barrier();
-
-        // ---- conv2 on the xt^T image; the residual operand is requested first and arrives under the K loop
-        float rv[NT][16];
-        if (RES_PREFETCH) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t_c = min(t0 + col0 + j * 32 + l31, T - 1);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[j][r] = xb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c];
-            }
-        }
-        {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            u32x4 Bf[2][NT];
-            load_b(Bf[0], XTs, 0, 1);
-#pragma unroll
-            for (int it = 0; it < NG; ++it) {
-                if (it + 1 < NG) load_b(Bf[(it + 1) & 1], XTs, it + 1, 1);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A2[it], Bf[it & 1][j], acc[j]);
-                if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-            }
-        }
-        // ---- epilogue: ((acc + b2) + x) + y_old
-        if (!RES_PREFETCH) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) b2r[r] = a.b2[mt * 32 + acc_row(r, lane)];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int o = col0 + j * 32 + l31;
-            const int t = t0 + o;
-            const bool ok = o < TT && t < T;
-            const int t_c = min(t, T - 1);
-            float yv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long off = (long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c;
-                if (!RES_PREFETCH) rv[j][r] = xb[off];
-                yv[r] = a.accum ? yb[off] : 0.f;
-            }
-            if (ok) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = ((acc[j][r] + b2r[r]) + rv[j][r]) + yv[r];
-            }
-        }
-        // the next tile's DMA must have landed (every wave's share) before anyone converts it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-    }
-}
-
-template <int C, int KT, int MODE>
-int launch_pair16p(const PairArgs& a, int n_cus, hipStream_t stream) {
-    using P = P16<C>;
-    constexpr int TT = P::N1 - (KT - 1);
-    const size_t lds = (size_t)2 * C * P::XWF * 4 + (size_t)(P::XROWS + P::N1 + KT - 1) * (C + 4) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_pair16p_kernel<C, KT, MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
-        attr_set = true;
-    }
-    const int tiles_per_utt = (a.T + TT - 1) / TT;
-    const long total = (long)tiles_per_utt * a.B;
-    if (total >= (1L << 30)) return -2;
-    const int grid = (int)(total < n_cus ? total : n_cus);
-    hipLaunchKernelGGL((resblock_pair16p_kernel<C, KT, MODE>), dim3(grid), dim3(256), lds, stream, a, tiles_per_utt, (int)total);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-template <int MODE>
-int dispatch16p(const PairArgs& a, int n_cus, hipStream_t s) {
-    if (a.C == 64) {
-        if (a.k == 3) return launch_pair16p<64, 3, MODE>(a, n_cus, s);
-        if (a.k == 7) return launch_pair16p<64, 7, MODE>(a, n_cus, s);
-        if (a.k == 11) return launch_pair16p<64, 11, MODE>(a, n_cus, s);
-    } else if (a.C == 32) {
-        if (a.k == 3) return launch_pair16p<32, 3, MODE>(a, n_cus, s);
-        if (a.k == 7) return launch_pair16p<32, 7, MODE>(a, n_cus, s);
-        if (a.k == 11) return launch_pair16p<32, 11, MODE>(a, n_cus, s);
-    }
-    return -2;
-}
-
 template <int C, int KT, int MODE>
 int launch_pair16(const PairArgs& a, hipStream_t stream) {
     constexpr int TT = N1 - (KT - 1);
@@ -441,16 +182,3 @@ extern "C" int cmtts_launch_resblock_pair16(const PairArgs* ap, int mode, void* 
     if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y || (mode != 1 && mode != 2)) return -2;
     return mode == 1 ? dispatch16<1>(a, s) : dispatch16<2>(a, s);
 }
-
-// Persistent form (register-resident weights, LDS-DMA staging): one workgroup per CU walks a contiguous range of tiles.
-extern "C" int cmtts_launch_resblock_pair16p(const PairArgs* ap, int mode, int n_cus, void* stream_) {
-    const PairArgs& a = *ap;
-    hipStream_t s = (hipStream_t)stream_;
-    if (a.B <= 0 || a.T <= 0) return 0;
-    if (a.dil * (a.k - 1) / 2 > R1MAX || a.x == a.y || (mode != 1 && mode != 2) || n_cus < 1) return -2;
-    return mode == 1 ? dispatch16p<1>(a, n_cus, s) : dispatch16p<2>(a, n_cus, s);
-}
-
-
-
-

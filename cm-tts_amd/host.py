@@ -158,6 +158,14 @@ class CMTotalTTS(torch.nn.Module):
         _lib.check(self.lib.cmtts_set_precision(self._h, mode))
         return self
 
+    def set_option(self, name, value):
+        """Per-model numerics option (cmtts_model_set_option): "ffn2_split" 1 (default) | 0 — the FFN linear of the FFT blocks as
+        eight K-segment partial GEMMs + one reduction, or as one launch (another fp32 summation order).  Returns the previous value."""
+        prev = self.lib.cmtts_model_set_option(self._h, name.encode() if isinstance(name, str) else name, int(value))
+        if prev < 0:
+            _lib.check(prev)
+        return prev
+
     def _require(self):
         _note_process_group(self.lib)
         if not self._ready and getattr(self, "_pending", False):
@@ -665,6 +673,14 @@ class Generator(torch.nn.Module):
         mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2, "fp16x3": 3}[dtype]
         _lib.check(self.lib.cmtts_vocoder_set_precision(self._h, mode))
         return self
+
+    def set_option(self, name, value):
+        """Per-vocoder numerics option (cmtts_vocoder_set_option): "ups16" 1 (default) | 0 — in the 16-bit modes the upsamplers
+        take 16-bit operands too, or stay fp32.  Returns the previous value."""
+        prev = self.lib.cmtts_vocoder_set_option(self._h, name.encode() if isinstance(name, str) else name, int(value))
+        if prev < 0:
+            _lib.check(prev)
+        return prev
 
     def eval(self):
         return self

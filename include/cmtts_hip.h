@@ -35,6 +35,9 @@ extern "C" {
 #define CMTTS_E_HIP (-3)          /* HIP runtime error */
 #define CMTTS_E_WORKSPACE (-4)    /* workspace too small */
 
+/* Supported shapes: the kernels are specialised for what the reference's three configs use — hidden = res_channels = 256,
+ * 2 attention heads of 128 channels, 80 mel bins (<= 96), <= 32 residual layers, HiFi-GAN V1 (hifigan/config.json).  Anything
+ * else returns CMTTS_E_UNSUPPORTED from cmtts_create / cmtts_finalize / the forward calls — never a silent fallback. */
 typedef struct cmtts_model cmtts_model;      /* CMTotalTTS weights, packed for the kernels */
 typedef struct cmtts_vocoder cmtts_vocoder;  /* hifigan.Generator weights */
 
@@ -181,14 +184,30 @@ int cmtts_set_persistent_denoiser(int mode);
  * The next denoiser call also checks the word before it launches.  There is no counterpart in the reference (its
  * errors are Python exceptions). */
 int cmtts_poll_error(void);
-/* A/B switches that do not change results (bitwise, tested).  "cond_gemm": 1 (default) = the stacked conditioner
- * projections of all residual layers through the X-resident kernel (cond_gemm.hip), 0 = through the generic conv
- * kernel.  "ffn_xres": 1 (default) = the k=9 FFN conv of the FFT blocks through the X-resident kernel
- * (conv_xres.hip) when the batch fills the chip, 0 = always the generic kernel.  "persist_tail": 1 (default) = the
- * skip head (skip_projection, ReLU, output_projection) and the sampler's post-scaling run inside the persistent
- * denoiser launch, 0 = as separate launches.  Returns the previous value (any
- * other value only queries), or a negative status for an unknown name. */
+/* Process-wide scheduling options.  None of them changes a result bit (tested); they are per process, not per model or
+ * stream.  Returns the previous value (a value outside the option's range only queries) or CMTTS_E_INVALID for an
+ * unknown name.
+ *   "branch_streams"      1 (default) / 0: independent branches of a call on library-owned side streams / all on `stream`
+ *   "resblock_split"      fp32 residual block as two launches over 4x the CUs: 0 never, 1 (default) small batches, 2 always
+ *   "step_cache"          1 (default) / 0: cmtts_sample keeps the timestep-only rows of the step embedding on the device
+ *   "cooperative_launch"  persistent denoiser through hipLaunchCooperativeKernel: 0 never, 1 every launch, 2 (default)
+ *                         automatic — once "process_group" is set the first launch of every (variant, grid) is cooperative
+ *                         (the runtime validates that the grid is co-resident and fails the launch otherwise), later launches
+ *                         of a validated shape are plain (every cooperative launch drains all queues of the device: +24 % per
+ *                         step next to RCCL, profiles/r03_cooperative.md)
+ *   "process_group"       1: a communicator / process group exists in this process (set by cmtts_comm_init_rank and by the
+ *                         Python host once torch.distributed is initialised)
+ * (The switches between a fused kernel and the path it replaces that the bitwise tests flip are not part of the ABI:
+ * csrc/internal_hooks.h.) */
 int cmtts_set_option(const char* name, int value);
+/* Per-handle numerics options: choices that change low-order bits belong to a model, not to the process.
+ *   cmtts_model_set_option(m, "ffn2_split", 1 (default) | 0): the FFN linear of the FFT blocks (model/blocks.py:547-551) as
+ *       eight K-segment partial GEMMs added in ascending order, or as one launch — two fp32 summation orders.
+ *   cmtts_vocoder_set_option(v, "ups16", 1 (default) | 0): in the 16-bit precision modes the ConvTranspose1d upsamplers take
+ *       16-bit operands as well, or stay fp32.
+ * Same return convention as cmtts_set_option. */
+int cmtts_model_set_option(cmtts_model* m, const char* name, int value);
+int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
  * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4].
@@ -197,8 +216,11 @@ int cmtts_set_option(const char* name, int value);
  * kernels', tests/test_gpu_precision.py) at 3/16 of the fp32 matrix cost; used by the persistent stack (large
  * batches), other shapes run the exact fp32 kernels. */
 int cmtts_set_precision(cmtts_model* m, int mode);
-/* Same switch for the HiFi-GAN ResBlock convs (94 % of the generator's FLOPs); conv_pre, the transposed
- * convs, conv_post and all activations in HBM stay fp32.  Mode 3 = fp16x3 as above (fp32-class). */
+/* Same switch for the HiFi-GAN generator.  Modes 1 / 2 (bf16 / fp16 operands, fp32 accumulate): the 72 ResBlock convs (94 %
+ * of the generator's FLOPs) AND, by default, the four ConvTranspose1d upsamplers take 16-bit operands
+ * (cmtts_vocoder_set_option(v, "ups16", 0) keeps the upsamplers fp32); inside a ResBlock pair the intermediate xt crosses HBM
+ * (or stays in LDS) as convert(leaky_relu(xt)) in 16 bits; the stage tensors (residual stream, MRF sum), conv_pre and conv_post
+ * stay fp32.  Mode 3 = fp16x3 as above (fp32-class): ResBlock convs only, upsamplers and every HBM tensor fp32. */
 int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode);
 
 /* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still

@@ -39,6 +39,16 @@ def test_loader_binds_and_reports_errors():
     assert lib.cmtts_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.cmtts_last_error()
     assert lib.cmtts_set_option(None, 1) == -1
     assert lib.cmtts_set_option(b"cooperative_launch", -1) == 2      # default: automatic
+    # the public table is short (<= 10 documented knobs); A/B switches are internal hooks, not ABI
+    api = open(os.path.join(ROOT, "cm-tts_amd", "csrc", "cmtts_api.hip")).read()
+    body = api[api.index("int cmtts_set_option(const char* name, int value) {"):api.index("int cmtts_model_set_option(")]
+    public = set(re.findall(r'\{"([a-z_0-9]+)", &', body)) | set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', body))
+    assert public == {"branch_streams", "resblock_split", "step_cache", "cooperative_launch", "process_group"}
+    for n in public:
+        assert n in text, f"option {n} is not documented in include/cmtts_hip.h"
+    assert lib.cmtts_set_option(b"voc_pair", 1) == -1                # internal switches are not reachable through the ABI
+    assert _lib.internal_set(b"voc_pair", -1) in (0, 1, 2) and _lib.internal_set(b"nope", 1) == -1
+    assert lib.cmtts_model_set_option(None, b"ffn2_split", 1) == -1 and lib.cmtts_vocoder_set_option(None, b"ups16", 1) == -1
 
 
 def test_config_struct_matches_header():

@@ -4,6 +4,8 @@ seeded inputs.  Tolerances: bit-exact for integer/index work; |delta mel| < 1e-3
 bound) for floating point, tighter where the stage is short."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -325,6 +327,48 @@ def test_synthesizer_reference_constructor_end_to_end(models, tmp_path):
         syn.model.to("cpu")
 
 
+def test_synth_samples_writes_the_reference_wav_files(models, tmp_path):
+    """utils/tools.py:566-607: the synthesize flow ends in one 22 050 Hz int16 .wav per utterance under
+    <path>/<restore_step>/ with the reference's file names; the samples are vocoder_infer's, trimmed to mel_len * hop."""
+    import argparse
+    from scipy.io import wavfile
+    from test_host_module_cpu import _reference_configs
+    host = _host()
+    g, cfg, sd, model = models("VCTK")
+    pre, mod, tr = _reference_configs()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=2))
+    texts, lens, spk = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"]), torch.from_numpy(g["spker_embeds"])
+    B = texts.shape[0]
+    ids = [f"utt{i}" for i in range(B)]
+    batch = (ids, ["x"] * B, torch.zeros(B, dtype=torch.long), texts, lens, int(lens.max()), spk)
+    out = host.CMTotalTTSSynthesize.from_model(model, T=2).synthesize(batch)
+    ref = host.vocoder_infer(out[0].transpose(1, 2), voc, mod, pre, lengths=(out[11] * cfg.hop_length).tolist())
+    for mode, names in (("batch", [f"{i}.wav" for i in ids]), ("single", [f"{i}_p225.wav" for i in ids])):
+        args = argparse.Namespace(restore_step=300, mode=mode, speaker_id="p225", teacher_forced=False)
+        written = host.synth_samples(args, batch, out, voc, mod, pre, str(tmp_path), None)
+        assert [os.path.relpath(w, tmp_path) for w in written] == [os.path.join("300", n) for n in names]
+        for w, r, n in zip(written, ref, _np(out[11])):
+            rate, data = wavfile.read(w)
+            assert rate == 22050 and data.dtype == np.int16 and data.shape[0] == int(n) * cfg.hop_length
+            assert np.array_equal(data, r)
+
+
+def test_speaker_table_ids_are_checked_on_the_device():
+    """ids into the speaker_emb table that already live on the GPU (the reference's to_device moved them) must
+    raise like nn.Embedding does (model/cmtts.py:78), not be clamped to another speaker."""
+    host = _host()
+    cfg = get_config("VCTK_table")
+    sd = synth_cmtts_state_dict(cfg, seed=1, dur_frames=3.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    texts = torch.randint(1, cfg.n_symbols, (2, 6))
+    lens = torch.tensor([6, 6])
+    model.duration_pitch_energy_net(torch.tensor([0, cfg.n_speaker - 1], device=DEV), texts, lens)
+    for bad in ([0, cfg.n_speaker], [-1, 0]):
+        with pytest.raises(IndexError):
+            model.duration_pitch_energy_net(torch.tensor(bad, device=DEV), texts, lens)
+
+
 def test_generic_denoise_path_matches_fused_sampler(models):
     """KarrasDenoiser.denoise around CMTotalTTS.forward (which re-runs the duration net on every call,
     tts_net.py:132-147) must give the onestep sample the fused cmtts_sample path gives."""
@@ -608,15 +652,15 @@ def test_fused_attention_matches_three_launch_path(variant, B, L):
     texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
-    prev = lib.cmtts_set_option(b"attn_fused", 0)
+    prev = _lib.internal_set(b"attn_fused", 0)
     try:
         ref = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
-        lib.cmtts_set_option(b"attn_fused", 1)
+        _lib.internal_set(b"attn_fused", 1)
         got = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
         again = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"attn_fused", prev)
+        _lib.internal_set(b"attn_fused", prev)
     assert torch.isfinite(got["enc_out"]).all()
     err = float((got["enc_out"] - ref["enc_out"]).abs().max())
     assert err < 2e-5, err
@@ -644,15 +688,15 @@ def test_fused_input_projection_bitwise(B, T):
     gen = torch.Generator(device="cpu").manual_seed(T)
     cond = torch.randn(B, cfg.hidden, T, generator=gen).to(DEV)
     noise = torch.randn(5, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
-    prev = lib.cmtts_set_option(b"inproj_fused", 0)
+    prev = _lib.internal_set(b"inproj_fused", 0)
     try:
         ref = host.sample_with_cond(model, cond, None, 4, noise).clone()
-        lib.cmtts_set_option(b"inproj_fused", 1)
+        _lib.internal_set(b"inproj_fused", 1)
         got = host.sample_with_cond(model, cond, None, 4, noise).clone()
         again = host.sample_with_cond(model, cond, None, 4, noise).clone()
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"inproj_fused", prev)
+        _lib.internal_set(b"inproj_fused", prev)
     assert torch.isfinite(ref).all()
     assert torch.equal(got, ref), float((got - ref).abs().max())
     assert torch.equal(again, ref)
@@ -707,14 +751,14 @@ def test_predictor_conv_xl_bitwise(models):
     texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
-    prev = lib.cmtts_set_option(b"pred_xl", 1)
+    prev = _lib.internal_set(b"pred_xl", 1)
     try:
         one = run()
-        lib.cmtts_set_option(b"pred_xl", 0)
+        _lib.internal_set(b"pred_xl", 0)
         ref = run()
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"pred_xl", prev)
+        _lib.internal_set(b"pred_xl", prev)
     assert torch.equal(one["p_predictions"]["cwt"], ref["p_predictions"]["cwt"])
     assert torch.equal(one["cond"], ref["cond"]) and torch.equal(one["p_predictions"]["p_idx"], ref["p_predictions"]["p_idx"])
 
@@ -737,15 +781,15 @@ def test_predictor_head_fused_matches_two_launch_path(variant, B, L):
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
     run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
-    prev = lib.cmtts_set_option(b"pred_head", 0)
+    prev = _lib.internal_set(b"pred_head", 0)
     try:
         ref = run()
-        lib.cmtts_set_option(b"pred_head", 1)
+        _lib.internal_set(b"pred_head", 1)
         got = run()
         again = run()
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"pred_head", prev)
+        _lib.internal_set(b"pred_head", prev)
     for k in ("log_d_predictions", "e_predictions"):
         err = float((got[k] - ref[k]).abs().max())
         assert err < 1e-5, (k, err)
@@ -1057,20 +1101,20 @@ def test_xres_conv_bitwise(models):
     lens[0] = L
     texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
-    prev = lib.cmtts_set_option(b"ffn_xres", 1)
-    prev_t = lib.cmtts_set_option(b"text_xres", 0)
+    prev = _lib.internal_set(b"ffn_xres", 1)
+    prev_t = _lib.internal_set(b"text_xres", 0)
     try:
         run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
         one = run()                                   # X-resident k=9 conv, separate LayerNorm launches
         outs = []
         for bits in (9, 1, 2, 4, 7):                     # LayerNorm1 + in-projection | out-projection | LayerNorm2 + FFN conv | all
-            lib.cmtts_set_option(b"text_xres", bits)
+            _lib.internal_set(b"text_xres", bits)
             outs.append((f"text_xres={bits}", run()))
-        lib.cmtts_set_option(b"ffn_xres", 0)
+        _lib.internal_set(b"ffn_xres", 0)
         ref = run()
     finally:
-        lib.cmtts_set_option(b"ffn_xres", prev)
-        lib.cmtts_set_option(b"text_xres", prev_t)
+        _lib.internal_set(b"ffn_xres", prev)
+        _lib.internal_set(b"text_xres", prev_t)
     torch.cuda.synchronize()
     for k in ("enc_out", "log_d_predictions", "cond"):
         for name, got in [("xres", one)] + outs:
@@ -1090,48 +1134,24 @@ def test_ffn_fused_bitwise(models):
     lens[0] = L
     texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
-    prev = lib.cmtts_set_option(b"ffn_fused", 1)
-    prev_t = lib.cmtts_set_option(b"text_xres", 5)
+    prev = _lib.internal_set(b"ffn_fused", 1)
+    prev_t = _lib.internal_set(b"text_xres", 5)
     try:
         run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
         outs = [("fused", run())]
-        lib.cmtts_set_option(b"text_xres", 0)
+        _lib.internal_set(b"text_xres", 0)
         outs.append(("fused, separate LayerNorm", run()))
-        lib.cmtts_set_option(b"ffn_fused", 0)
+        _lib.internal_set(b"ffn_fused", 0)
         ref = run()
         one = model.duration_pitch_energy_net(None, torch.from_numpy(texts[:1]), torch.from_numpy(lens[:1]), max_mel_len=512)
     finally:
-        lib.cmtts_set_option(b"ffn_fused", prev)
-        lib.cmtts_set_option(b"text_xres", prev_t)
+        _lib.internal_set(b"ffn_fused", prev)
+        _lib.internal_set(b"text_xres", prev_t)
     torch.cuda.synchronize()
     for k in ("enc_out", "log_d_predictions", "cond"):
         for name, got in outs:
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
     assert torch.equal(one["enc_out"][0], outs[0][1]["enc_out"][0])
-
-
-def test_predictor_xres_bitwise(models):
-    """Phoneme-level predictor convs (duration: masked LayerNorm, energy: unmasked) on conv_xres.hip with the previous layer's
-    LayerNorm — and its length mask — as the prologue: the same bits as the generic kernel + layernorm_ct launches."""
-    lib = _lib.load()
-    g, cfg, sd, model = models("LJSpeech")
-    rs = np.random.RandomState(13)
-    B, L = 32, 85
-    lens = rs.randint(20, L + 1, size=B).astype(np.int64)
-    lens[0] = L
-    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
-    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
-    prev = lib.cmtts_set_option(b"pred_xres", 1)
-    try:
-        run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
-        got = run()
-        lib.cmtts_set_option(b"pred_xres", 0)
-        ref = run()
-    finally:
-        lib.cmtts_set_option(b"pred_xres", prev)
-    torch.cuda.synchronize()
-    for k in ("log_d_predictions", "cond", "mel_lens"):
-        assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
 
 
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
@@ -1147,13 +1167,13 @@ def test_cond_gemm_bitwise(variant, B, T):
     x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
     spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
     t = torch.full((B,), 1095.5)
-    prev = lib.cmtts_set_option(b"cond_gemm", 2)          # 2 = take the kernel at every size (1 leaves small batches to the generic kernel)
+    prev = _lib.internal_set(b"cond_gemm", 2)          # 2 = take the kernel at every size (1 leaves small batches to the generic kernel)
     try:
         one = model.net(x, t, cond, spk)
-        lib.cmtts_set_option(b"cond_gemm", 0)
+        _lib.internal_set(b"cond_gemm", 0)
         ref = model.net(x, t, cond, spk)
     finally:
-        lib.cmtts_set_option(b"cond_gemm", prev)
+        _lib.internal_set(b"cond_gemm", prev)
     torch.cuda.synchronize()
     assert lib.cmtts_set_option(b"no_such_option", 0) < 0
     assert torch.isfinite(one).all()
@@ -1346,34 +1366,28 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=6))
     voc.set_precision(dtype)
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
-    prev = lib.cmtts_set_option(b"voc_pair", 0)
-    prev_x = lib.cmtts_set_option(b"voc_xl16", 0)
-    prev_r = lib.cmtts_set_option(b"voc_rb16", 2)      # 2 = for every (C, k) of the narrow stages
+    prev = _lib.internal_set(b"voc_pair", 0)
+    prev_x = _lib.internal_set(b"voc_xl16", 0)
+    prev_r = _lib.internal_set(b"voc_rb16", 2)      # 2 = for every (C, k) of the narrow stages
     try:
-        prev_p = lib.cmtts_set_option(b"voc_pair16p", 0)
         got_rb = voc(mel).clone()                     # C = 64 / 32 stages: a whole ResBlock (three pairs) per launch
-        lib.cmtts_set_option(b"voc_rb16", 0)
+        _lib.internal_set(b"voc_rb16", 0)
         ref = voc(mel).clone()                        # every ResBlock conv on the chunked conv_mfma16 kernel
-        lib.cmtts_set_option(b"voc_xl16", 1)          # C = 128 / 256 stages on the X-resident conv_xl16 kernel
+        _lib.internal_set(b"voc_xl16", 1)          # C = 128 / 256 stages on the X-resident conv_xl16 kernel
         got_x = voc(mel).clone()
-        lib.cmtts_set_option(b"voc_pair", 2)          # 2 = every (C, k) through the per-tile streamed pair kernel
+        _lib.internal_set(b"voc_pair", 2)          # 2 = every (C, k) through the per-tile streamed pair kernel
         got = voc(mel).clone()
-        lib.cmtts_set_option(b"voc_pair", 1)
-        lib.cmtts_set_option(b"voc_pair16p", 1)       # persistent form: register-resident weights, LDS-DMA staging
-        got_p = voc(mel).clone()
-        got_p2 = voc(mel).clone()                     # back to back: stale LDS / staging state must not leak
+        got2 = voc(mel).clone()                       # back to back: stale LDS / staging state must not leak
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"voc_pair", prev)
-        lib.cmtts_set_option(b"voc_pair16p", prev_p)
-        lib.cmtts_set_option(b"voc_xl16", prev_x)
-        lib.cmtts_set_option(b"voc_rb16", prev_r)
+        _lib.internal_set(b"voc_pair", prev)
+        _lib.internal_set(b"voc_xl16", prev_x)
+        _lib.internal_set(b"voc_rb16", prev_r)
     assert torch.equal(got_rb, ref), float((got_rb - ref).abs().max())
     assert torch.isfinite(got).all()
     assert torch.equal(got_x, ref), float((got_x - ref).abs().max())
     assert torch.equal(got, ref), float((got - ref).abs().max())
-    assert torch.equal(got_p, ref), float((got_p - ref).abs().max())
-    assert torch.equal(got_p2, ref)
+    assert torch.equal(got2, ref)
 
 
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
@@ -1387,14 +1401,14 @@ def test_vocoder_upsampler_kernel_bitwise(B, T):
     hcfg = HifiGanConfig()
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=8))
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(50 + T)) * 1.5 - 4).to(DEV)
-    prev = lib.cmtts_set_option(b"voc_upsT", 0)
+    prev = _lib.internal_set(b"voc_upsT", 0)
     try:
         ref = voc(mel).clone()
-        lib.cmtts_set_option(b"voc_upsT", 1)
+        _lib.internal_set(b"voc_upsT", 1)
         got = voc(mel).clone()
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"voc_upsT", prev)
+        _lib.internal_set(b"voc_upsT", prev)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref), float((got - ref).abs().max())
 
@@ -1411,20 +1425,20 @@ def test_vocoder_pair_kernel_bitwise(B, T):
     hsd = synth_hifigan_state_dict(hcfg, seed=6)
     voc = host.Generator(hcfg, DEV).load_state_dict(hsd)
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T)) * 1.5 - 4).to(DEV)
-    prev = lib.cmtts_set_option(b"voc_pair", 0)
-    prev_x = lib.cmtts_set_option(b"voc_xl", 0)
+    prev = _lib.internal_set(b"voc_pair", 0)
+    prev_x = _lib.internal_set(b"voc_xl", 0)
     prev_b = lib.cmtts_set_option(b"branch_streams", 0)
     try:
         ref = voc(mel).clone()
-        lib.cmtts_set_option(b"voc_pair", 1)
-        lib.cmtts_set_option(b"voc_xl", 1)        # C = 128 / 256 stages: X-resident single convs (conv_xl_kernel)
+        _lib.internal_set(b"voc_pair", 1)
+        _lib.internal_set(b"voc_xl", 1)        # C = 128 / 256 stages: X-resident single convs (conv_xl_kernel)
         got = voc(mel).clone()
         lib.cmtts_set_option(b"branch_streams", 1)       # the three ResBlock chains of a stage on three streams
         got_s = voc(mel).clone()
         torch.cuda.synchronize()
     finally:
-        lib.cmtts_set_option(b"voc_pair", prev)
-        lib.cmtts_set_option(b"voc_xl", prev_x)
+        _lib.internal_set(b"voc_pair", prev)
+        _lib.internal_set(b"voc_xl", prev_x)
         lib.cmtts_set_option(b"branch_streams", prev_b)
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref), float((got - ref).abs().max())

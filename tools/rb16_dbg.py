@@ -10,8 +10,8 @@ voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_st
 for prec in ("bf16", "fp16"):
     voc.set_precision(prec)
     mel = (torch.randn(2, 80, 61, generator=torch.Generator().manual_seed(61)) * 1.5 - 4).cuda()
-    lib.cmtts_set_option(b"voc_rb16", 0); ref = voc(mel).clone()
-    lib.cmtts_set_option(b"voc_rb16", 1); got = voc(mel).clone()
+    _lib.internal_set(b"voc_rb16", 0); ref = voc(mel).clone()
+    _lib.internal_set(b"voc_rb16", 1); got = voc(mel).clone()
     torch.cuda.synchronize()
     d = (got - ref).abs()[0, 0].cpu().numpy()
     idx = np.nonzero(d)[0]

@@ -32,10 +32,10 @@ for B, L in ((32, 85), (1, 25)):
     noise = torch.randn(2, B, 1, 6 * L, cfg.n_mels, device="cuda")
     for attn in (0, 1):
         for bs in (0, 1):
-            lib.cmtts_set_option(b"attn_fused", attn)
+            _lib.internal_set(b"attn_fused", attn)
             lib.cmtts_set_option(b"branch_streams", bs)
             t_text = med(lambda: m.duration_pitch_energy_net(None, tx, ln, max_mel_len=6 * L))
             o = m.duration_pitch_energy_net(None, tx, ln, max_mel_len=6 * L)
             t_all = med(lambda: host.sample_with_cond(m, m.duration_pitch_energy_net(None, tx, ln, max_mel_len=6 * L)["cond_ct"], None, 1, noise))
             print(f"B={B:2d} L={L:3d} attn_fused={attn} branch_streams={bs}: text side {t_text:.3f} ms, text->mel T=1 {t_all:.3f} ms", flush=True)
-lib.cmtts_set_option(b"attn_fused", 1); lib.cmtts_set_option(b"branch_streams", 1)
+_lib.internal_set(b"attn_fused", 1); lib.cmtts_set_option(b"branch_streams", 1)

@@ -19,6 +19,6 @@ for B, L in ((32, 85), (1, 25)):
     tx = torch.from_numpy(rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)).cuda()
     ln = torch.full((B,), L, dtype=torch.int64, device="cuda")
     for tx_opt in (0, 1, 4, 5, 7):
-        lib.cmtts_set_option(b"text_xres", tx_opt)
+        _lib.internal_set(b"text_xres", tx_opt)
         t = med(lambda: m.duration_pitch_energy_net(None, tx, ln, max_mel_len=6 * L))
         print(f"B={B} L={L} text_xres={tx_opt}: text side {t:.3f} ms", flush=True)

@@ -12,13 +12,12 @@ lib = _lib.load()
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
 mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
-lib.cmtts_set_option(b"voc_pair16p", int(os.environ.get("VP16P", 0)))
 for prec in os.environ.get("VP", "fp32").split(","):
     voc.set_precision(prec)
     outs = []
     for vp in (0, 1):
-        lib.cmtts_set_option(b"voc_pair", vp)
-        lib.cmtts_set_option(b"voc_xl", vp)
+        _lib.internal_set(b"voc_pair", vp)
+        _lib.internal_set(b"voc_xl", vp)
         for _ in range(2):
             w = voc(mel)
         torch.cuda.synchronize()

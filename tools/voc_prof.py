@@ -11,12 +11,10 @@ from cmtts_amd.weights import synth_hifigan_state_dict
 
 lib = _lib.load()
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
-lib.cmtts_set_option(b"voc_pair", int(os.environ.get("VPAIR", 1)))
-lib.cmtts_set_option(b"voc_pair16p", int(os.environ.get("VP16P", 0)))
-lib.cmtts_set_option(b"voc_xl", int(os.environ.get("VXL", os.environ.get("VPAIR", 1))))
+_lib.internal_set(b"voc_pair", int(os.environ.get("VPAIR", 1)))
+_lib.internal_set(b"voc_xl", int(os.environ.get("VXL", os.environ.get("VPAIR", 1))))
 lib.cmtts_set_option(b"branch_streams", int(os.environ.get("VSTREAMS", 1)))      # 0: the three ResBlock chains in line (clean per-kernel times)
-lib.cmtts_set_option(b"voc_ring16", int(os.environ.get("VRING", 1)))
-lib.cmtts_set_option(b"voc_rb16", int(os.environ.get("VRB", 1)))       # 2 = whole-ResBlock kernel for every (C, k) of the narrow stages
+_lib.internal_set(b"voc_rb16", int(os.environ.get("VRB", 1)))       # 2 = whole-ResBlock kernel for every (C, k) of the narrow stages
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
 voc.set_precision(os.environ.get("VP", "fp32"))
 mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
