@@ -502,12 +502,20 @@ def main():
         k = max(4, args.steps // 2)
         d = timed(step_bucketed, k, 2, 1)
         extras["frames_per_s_T4_libritts_bucketed_shard"] = round(sum(g[5] for g in groups) * k / d, 1)   # valid frames only
-        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4)      # one HIP stream per bucket group
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="streams")      # one HIP stream per bucket group
 
         def step_bucketed_streams():
             state["mel_b"] = bsyn.run([g[:5] for g in groups])
         d = timed(step_bucketed_streams, k, 2, 1)
         extras["frames_per_s_T4_libritts_bucketed_shard_4_streams"] = round(sum(g[5] for g in groups) * k / d, 1)
+        # round 3: the text side of the groups on four streams, then ALL groups' residual layers in one persistent launch per
+        # evaluation (cmtts_sample_ragged), utterances trimmed to mel_len + 16 frames + the sampler's receptive field
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", tail_frames=16)
+        d = timed(step_bucketed_streams, k, 2, 1)
+        extras["frames_per_s_T4_libritts_bucketed_shard_one_launch"] = round(sum(g[5] for g in groups) * k / d, 1)
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", trim=False)
+        d = timed(step_bucketed_streams, k, 2, 1)
+        extras["frames_per_s_T4_libritts_bucketed_shard_one_launch_untrimmed"] = round(sum(g[5] for g in groups) * k / d, 1)
         del bsyn
         del groups, lmodel
         # end to end with the HiFi-GAN generator (fp32), T=4

@@ -28,6 +28,12 @@ class VarianceControlsStruct(C.Structure):
                 ("cwt_spec", C.c_void_p), ("f0_mean", C.c_void_p), ("f0_std", C.c_void_p), ("uv", C.c_void_p)]
 
 
+class SampleGroupStruct(C.Structure):
+    """struct cmtts_sample_group (include/cmtts_hip.h)."""
+    _fields_ = [("noise", C.c_void_p), ("cond_ct", C.c_void_p), ("speaker_emb", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32),
+                ("active_frames", C.c_void_p), ("mel", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes); must list every symbol include/cmtts_hip.h declares
@@ -49,6 +55,7 @@ SIGNATURES = {
     "cmtts_denoiser_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_schedule": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmtts_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp]),
+    "cmtts_sample_ragged": (_i, [_vp, C.POINTER(SampleGroupStruct), _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _vp]),
     "cmtts_vocoder_create": (_i, [C.POINTER(_vp)]),
     "cmtts_vocoder_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "cmtts_vocoder_finalize": (_i, [_vp]),

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -306,6 +307,7 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
+int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
 int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTranspose1d in one X-resident launch (same bits); 0 = generic kernel, one z per phase
@@ -1000,6 +1002,36 @@ struct MelPost {
     float* out;
 };
 
+// The part of an evaluation in front of the residual layers: c_in scaling + transpose + input projection (+ clearing of the persistent
+// kernel's halo granules) and the step embedding.  *halo_zeroed: the granules of this (B, T) batch have been cleared on `s`.
+int denoiser_prologue(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps, const float* spk, int B,
+                      int T, hipStream_t s, bool embed, float t_host, bool* halo_zeroed) {
+    const cmtts_config& c = m->cfg;
+    const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
+    const long cs = (long)C * T;
+    *halo_zeroed = false;
+    int rin = -2;
+    if (g_inproj_fused && m->in_proj_f) {   // c_in scaling + transpose + input projection (+ halo clearing) in one launch: same bits
+        InProjArgs ia;
+        memset(&ia, 0, sizeof(ia));
+        ia.x = x_src; ia.scale = in_scale; ia.wf = m->in_proj_f; ia.bias = m->in_proj.bias; ia.h = w.h;
+        ia.B = B; ia.T = T; ia.M = M; ia.C = C;
+        const bool persist_path = g_fused_resblock && g_persist && NL <= PERSIST_MAX_LAYERS;
+        if (persist_path) { ia.zero = w.halo; ia.zero_f4 = (long)(cmtts_persist_halo_bytes(B, T) / 16); }
+        rin = cmtts_launch_inproj(&ia, (void*)s);
+        if (rin == -3) return fail(CMTTS_E_HIP, "inproj launch failed");
+        *halo_zeroed = rin == 0 && persist_path && cmtts_persist_halo_bytes(B, T) % 16 == 0;
+    }
+    if (rin != 0) {
+        k_mel_prep(x_src, nullptr, in_scale, w.hin, B, T, M, s);
+        ConvArgs a = conv_args(m->in_proj, w.hin, T, T, (long)M * T, w.h, T, cs, T);
+        a.out[0].act = ACT_RELU;   // relu(relu(.)) == relu(.), model/modules.py:575-577,624
+        CHK(launch(a, EPI_PLAIN, B, s));
+    }
+    if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s, t_host));
+    return 0;
+}
+
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
                   const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
                   SideStream* pending = nullptr, float t_host = NAN) {   // pending: a side branch (the conditioner GEMM) to join before the layers
@@ -1011,25 +1043,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
     bool halo_zeroed = false;
-    int rin = -2;
-    if (g_inproj_fused && m->in_proj_f) {   // c_in scaling + transpose + input projection (+ halo clearing) in one launch: same bits
-        InProjArgs ia;
-        memset(&ia, 0, sizeof(ia));
-        ia.x = x_src; ia.scale = in_scale; ia.wf = m->in_proj_f; ia.bias = m->in_proj.bias; ia.h = w.h;
-        ia.B = B; ia.T = T; ia.M = M; ia.C = C;
-        const bool persist_path = g_fused_resblock && g_persist && NL <= PERSIST_MAX_LAYERS;
-        if (persist_path) { ia.zero = w.halo; ia.zero_f4 = (long)(cmtts_persist_halo_bytes(B, T) / 16); }
-        rin = cmtts_launch_inproj(&ia, (void*)s);
-        if (rin == -3) return fail(CMTTS_E_HIP, "inproj launch failed");
-        halo_zeroed = rin == 0 && persist_path && cmtts_persist_halo_bytes(B, T) % 16 == 0;
-    }
-    if (rin != 0) {
-        k_mel_prep(x_src, nullptr, in_scale, w.hin, B, T, M, s);
-        ConvArgs a = conv_args(m->in_proj, w.hin, T, T, (long)M * T, w.h, T, cs, T);
-        a.out[0].act = ACT_RELU;   // relu(relu(.)) == relu(.), model/modules.py:575-577,624
-        CHK(launch(a, EPI_PLAIN, B, s));
-    }
-    if (embed) CHK(step_embedding(m, w, timesteps, spk, B, s, t_host));
+    CHK(denoiser_prologue(m, w, x_src, in_scale, timesteps, spk, B, T, s, embed, t_host, &halo_zeroed));
     if (pending) CHK(branch_join(pending));
     const float* dp = m->cfg.multi_speaker ? w.dp : w.dproj;
     const bool unfused = !g_fused_resblock;   // three-launch form of the residual block (A/B and bitwise tests)
@@ -1526,6 +1540,140 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
     return 0;
 }
 
+// karras_sample_tts for a RAGGED shard (BASELINE.json configs[3]: utterances dealt into static frame buckets): every group is a
+// padded (B, T) batch with its own buffers — results are defined per padded bucket (model/modules.py:429-430 via model/cmtts.py:61-62)
+// — but the residual layers of ALL groups run in ONE persistent launch per evaluation (denoiser_persist.hip, RAGGED instance), so that
+// small buckets fill the chip together instead of one after the other.
+int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_groups, int n_steps, const float* sigmas,
+                        const float* renoise_std, int tail_frames, void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!groups || n_groups < 1 || n_steps < 1 || !sigmas || !renoise_std || tail_frames < 0)
+        return fail(CMTTS_E_INVALID, "cmtts_sample_ragged: bad argument");
+    const cmtts_config& c = m->cfg;
+    const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
+    hipStream_t s = (hipStream_t)stream;
+    long padded_tiles = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const cmtts_sample_group& G = groups[g];
+        if (!G.noise || !G.cond_ct || !G.mel || !G.ws || G.B <= 0 || G.T <= 0) return fail(CMTTS_E_INVALID, "cmtts_sample_ragged: bad group");
+        if (c.multi_speaker && !G.speaker_emb) return fail(CMTTS_E_INVALID, "speaker_emb is required for a multi-speaker model");
+        if (G.ws_bytes < carve_den(c, G.B, G.T, nullptr).bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
+        padded_tiles += (long)G.B * ((G.T + 63) / 64);
+    }
+    // the one-launch form needs the fp32 persistent kernel with its in-kernel tail; anything else (16-bit modes, switches off, more
+    // groups / longer utterances than a descriptor holds, too little work to beat the per-layer kernels) runs group after group
+    bool one_launch = m->precision == 0 && g_fused_resblock && g_persist && g_persist_tail && g_inproj_fused && m->skip_f && m->outp_f &&
+                      m->in_proj_f && NL <= PERSIST_MAX_LAYERS && n_groups <= PERSIST_MAX_GROUPS && padded_tiles * 2 > persist_blocks();
+    for (int g = 0; g < n_groups && one_launch; ++g)
+        if ((groups[g].T + 63) / 64 > 127 || groups[g].B > 1023 || (long)C * groups[g].T >= (1L << 30) ||
+            cmtts_persist_halo_bytes(groups[g].B, groups[g].T) % 16 != 0)
+            one_launch = false;
+    if (!one_launch) {
+        for (int g = 0; g < n_groups; ++g) {
+            const cmtts_sample_group& G = groups[g];
+            const int rc = cmtts_sample(m, G.noise, G.cond_ct, G.speaker_emb, G.B, G.T, n_steps, sigmas, renoise_std, G.mel, G.ws, G.ws_bytes, stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
+        *(volatile unsigned*)g_tmo_host = 0;
+        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
+    }
+    std::vector<DenWs> ws(n_groups);
+    SideStream* ss = side_for(s);
+    if (ss) CHK(branch_fork(ss));
+    bool trimmed = false;
+    for (int g = 0; g < n_groups; ++g) {
+        const cmtts_sample_group& G = groups[g];
+        ws[g] = carve_den(c, G.B, G.T, G.ws);
+        CHK(cond_projections(m, ws[g], G.cond_ct, G.B, G.T, ss ? ss->side : s));      // once for all evaluations, beside the first prologues
+        k_scale(G.noise, ws[g].xcur, (long)G.B * G.T * M, c.sigma_max, s);            // x_T = randn * sigma_max (karras_diffusion.py:534)
+        trimmed = trimmed || G.active_frames != nullptr;
+        if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)G.B * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
+    }
+    const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
+    const int cap = std::min(persist_blocks(), PERSIST_MAX_WG);
+    PersistArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.vec_stride = (long)NL * C; pa.tmo = g_tmo_host; pa.NL = NL; pa.halo_zeroed = 1;
+    pa.tail = 1;
+    pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
+    pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;
+    for (int l = 0; l < NL; ++l) {
+        pa.W3f[l] = m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
+    }
+    pa.n_groups = n_groups;
+    for (int i = 0; i < n_steps; ++i) {
+        // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
+        const float sg = sigmas[i];
+        const float dm = sg - smin;
+        const float c_skip = sd2 / (dm * dm + sd2);
+        const float rt = sqrtf(sg * sg + sd2);
+        const float c_out = dm * c.sigma_data / rt;
+        const float c_in = 1.0f / rt;
+        const float t_resc = 250.0f * logf(sg + 1e-44f);
+        const bool new_sigma = i == 0 || sigmas[i] != sigmas[i - 1];
+        const bool last = i + 1 == n_steps;
+        const bool renoise = renoise_std[i] >= 0.0f;
+        // an output frame depends on NL frames of input to either side (NL k = 3 layers): evaluation i must be exact on every frame the
+        // later evaluations and the caller's `tail_frames` reach, so it is computed NL * (n_steps - i) frames beyond that
+        const long reach = (long)tail_frames + (long)NL * (n_steps - i);
+        struct Utt { int g, b, act; };
+        std::vector<Utt> utts;
+        long total = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            const cmtts_sample_group& G = groups[g];
+            const DenWs& w = ws[g];
+            if (new_sigma) k_fill_float(w.tbuf, t_resc, G.B, s);
+            bool hz = false;
+            CHK(denoiser_prologue(m, w, w.xcur, c_in, w.tbuf, G.speaker_emb, G.B, G.T, s, new_sigma, t_resc, &hz));
+            if (!hz) HIPCHK(hipMemsetAsync(w.halo, 0, cmtts_persist_halo_bytes(G.B, G.T), s));
+            const int tiles = (G.T + 63) / 64;
+            PersistGroup& pg = pa.grp[g];
+            pg.x0 = w.h; pg.cp = w.cp; pg.cp_bstride = (long)NL * C * G.T;
+            pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.halo = w.halo;
+            pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
+            pg.B = G.B; pg.T = G.T; pg.tiles = tiles;
+            for (int b = 0; b < G.B; ++b) {
+                int act = tiles;
+                if (G.active_frames) {
+                    const long need = (long)G.active_frames[b] + reach;
+                    act = (int)std::min<long>(tiles, std::max<long>(1, (need + 63) / 64));
+                }
+                utts.push_back({g, b, act});
+                total += act;
+            }
+        }
+        if (i == 0 && ss) CHK(branch_join(ss));
+        pa.c_out = c_out; pa.c_skip = c_skip; pa.nstd = renoise ? renoise_std[i] : 0.0f;
+        // rounds: every workgroup of a launch must be resident, so a shard with more active tiles than CUs runs as balanced rounds of
+        // whole utterances (tiles of one utterance exchange their edge columns and must share a launch)
+        const int nrounds = (int)((total + cap - 1) / cap);
+        const long target = (total + nrounds - 1) / nrounds;
+        size_t u = 0;
+        while (u < utts.size()) {
+            int n = 0;
+            while (u < utts.size() && n + utts[u].act <= cap && (n == 0 || n + utts[u].act <= target + 8)) {
+                for (int t = 0; t < utts[u].act; ++t)
+                    pa.desc[n++] = (unsigned)utts[u].g | ((unsigned)utts[u].b << 3) | ((unsigned)t << 13) | ((unsigned)utts[u].act << 20);
+                ++u;
+            }
+            if (n == 0) return fail(CMTTS_E_UNSUPPORTED, "cmtts_sample_ragged: an utterance has more 64-frame tiles than the GPU has CUs");
+            pa.n_wg = n;
+            const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            CHK(persist_admit(s, n, persist_blocks()));
+            if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+            const int rc = cmtts_launch_denoiser_persist_ragged(&pa, (void*)s);
+            if (rc != 0) return fail(rc == -2 ? CMTTS_E_UNSUPPORTED : CMTTS_E_HIP, "ragged persistent denoiser launch failed");
+            CHK(persist_launched(s, n));
+            if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ vocoder
 int cmtts_vocoder_create(cmtts_vocoder** out) {
     if (!out) return fail(CMTTS_E_INVALID, "cmtts_vocoder_create: null argument");
@@ -1724,7 +1872,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             // 16-bit, C = 128 (round 2): the pair as one 8-wave workgroup with both images in LDS (151 KB) — conv_xl16 otherwise
             // (measured, bf16: k = 3 / 7 / 11: 471 / 754 / 967 us per pair against 527 / 700 / 903 for the two launches: k = 3 only)
             const bool pair128 = g_voc_pair128 && co == 128 && rk == 3 && (v->precision == 1 || v->precision == 2);
-            const bool pair_ok = g_voc_pair && (co <= 64 || pair128) && v->precision != 3 &&
+            // 16-bit, C = 128 (round 3): the pair in ONE launch with a single in-place image (81 KB: two workgroups per CU, 2 x 4 tiles per wave)
+            const bool pairw = g_voc_pairw && co == 128 && (v->precision == 1 || v->precision == 2);
+            bool pair_ok = g_voc_pair && (co <= 64 || pair128 || pairw) && v->precision != 3 &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
@@ -1739,7 +1889,12 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 pa.accum = lastm && j > 0; pa.slope = 0.1f;
                 int prc;
                 if (!v->precision) prc = cmtts_launch_resblock_pair(&pa, (void*)q);
+                else if (pairw) prc = cmtts_launch_resblock_pairw16(&pa, v->precision, (void*)q);
                 else prc = cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q);
+                if (prc == -2 && mi == 0) {      // this (C, k, dilation) is not covered by the pair kernels: the per-conv path below
+                    pair_ok = false;            // (nothing has been launched for this ResBlock yet)
+                    break;
+                }
                 if (prc != 0) return fail(CMTTS_E_HIP, "resblock_pair launch failed");
                 if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                 xr = pa.y;
@@ -1910,7 +2065,8 @@ int cmtts_internal_set(const char* name, int value) {
         {"pred_xl", &g_pred_xl, 0, 1},             // frame-level predictor convs on conv_xl
         {"pred_head", &g_pred_head, 0, 1},         // LayerNorm + linear head in one launch
         {"voc_pair", &g_voc_pair, 0, 2},           // HiFi-GAN ResBlock pairs (C <= 64) as one launch
-        {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel
+        {"voc_pairw", &g_voc_pairw, 0, 1},         // 16-bit C = 128 pairs: one launch, one in-place LDS image (resblock_pairw16.hip)
+        {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel (two images, one workgroup per CU; only when voc_pairw = 0)
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16

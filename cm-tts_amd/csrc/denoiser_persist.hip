@@ -59,23 +59,45 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool DBG>     // DBG: cycle stamps of the middle layer (tools/persist_timing.py); the production instance has none
+// DBG: cycle stamps of the middle layer (tools/persist_timing.py); the production instance has none.
+// RAGGED (round 3, BASELINE.json configs[3]): a 1-D grid over a tile-descriptor list — the utterances of SEVERAL frame buckets
+// (groups: own buffers, own padded T) fill the chip together, and an utterance may be TRIMMED to its first `active` tiles:
+// frames at and beyond Tc = active * 64 behave exactly like frames beyond T (u = 0 there, no neighbour, nothing stored).  Frames
+// closer than NL to Tc differ from the untrimmed result; the caller keeps Tc far enough beyond the frames it uses
+// (cmtts_api.hip: sample_ragged).  The arithmetic of a computed frame is unchanged: every value is bit-identical to the uniform
+// launch of its own bucket as long as no trimmed frame lies within its receptive field.
+template <bool DBG, bool RAGGED>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int tile = blockIdx.x, b = blockIdx.y;
+    int tile_, b_, T_, Tc_, gi = 0;
+    if (RAGGED) {
+        const unsigned d = a.desc[blockIdx.x];
+        gi = d & 7;
+        b_ = (d >> 3) & 1023;
+        tile_ = (d >> 13) & 127;
+        T_ = a.grp[gi].T;
+        Tc_ = min(T_, (int)((d >> 20) & 255) * FN);
+    } else {
+        tile_ = blockIdx.x; b_ = blockIdx.y; T_ = a.T; Tc_ = a.T;
+    }
+    const int tile = tile_, b = b_;
     const int t0 = tile * FN;
-    const int T = a.T;
+    const int T = T_;                                  // row stride / address clamp
+    const int Tc = Tc_;                                // frames that exist for this launch (== T unless trimmed)
     const int l31 = lane & 31, khalf = lane >> 5;
-    const float* cp_b = a.cp + (long)b * a.cp_bstride;
-    const float* dp_b = a.dp + (long)b * a.vec_stride;
-    const float* dv_b = a.d + (long)b * a.vec_stride;
+    const float* x0_b = (RAGGED ? a.grp[gi].x0 : a.x0) + (long)b * C * T;
+    const float* cp_b = (RAGGED ? a.grp[gi].cp + (long)b * a.grp[gi].cp_bstride : a.cp + (long)b * a.cp_bstride);
+    const float* dp_b = (RAGGED ? a.grp[gi].dp : a.dp) + (long)b * a.vec_stride;
+    const float* dv_b = (RAGGED ? a.grp[gi].d : a.d) + (long)b * a.vec_stride;
+    unsigned long long* halo_g = RAGGED ? a.grp[gi].halo : a.halo;
+    const int B_g = RAGGED ? a.grp[gi].B : a.B, tiles_g = RAGGED ? a.grp[gi].tiles : a.tiles;
     const int mrow0 = w * 32;                          // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
 
 
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
     {
-        const float* xin = a.x0 + (long)b * C * T;
+        const float* xin = x0_b;
         const int t = t0 + lane;
         const int t_c = min(t, T - 1);
         constexpr int ROWS_PER_WAVE = C / NW;
@@ -93,7 +115,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             for (int q = 0; q < 8; ++q) {
                 const int m = w * ROWS_PER_WAVE + i + q;
                 const float uv = cv[q] + (xv[q] + dq[q]);
-                smem[m * U_LD + 1 + lane] = t < T ? uv : 0.f;
+                smem[m * U_LD + 1 + lane] = t < Tc ? uv : 0.f;
             }
         }
         if (tid < 2 * C) {
@@ -102,14 +124,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const int th = right ? t0 + FN : t0 - 1;
             const int thc = min(max(th, 0), T - 1);
             const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
-            smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < T) ? uh : 0.f;
+            smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < Tc) ? uh : 0.f;
         }
     }
     // resident state: st[0] = this wave's 32 rows of x, st[1] = its 32 rows of the skip sum; MFMA C layout: [j][r] = row
     // acc_row(r), frame j*32 + l31
     f32x16 st[MT][NT];
     {
-        const float* xin = a.x0 + (long)b * C * T;
+        const float* xin = x0_b;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // ---- hand the edge columns of x' to the neighbouring tiles first (their latency is what the neighbours wait for)
         const float* dpn = dp_b + (long)(l + 1) * C;
         const unsigned tag = (unsigned)l + 1;
-        unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;    // [parity][b][tile][side][C]
+        unsigned long long* hbase = halo_g + ((((long)(l & 1) * B_g + b) * tiles_g) * 2) * C;    // [parity][b][tile][side][C]
         {
             const int ln = opaque(lane), c31 = ln & 31;
             // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1)
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int r = 0; r < 16; ++r) {
                     const int m = mrow0 + acc_row(r, ln);
                     const float uv = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
-                    u_lds[m * U_LD + 1 + j * 32 + c31] = t < T ? uv : 0.f;
+                    u_lds[m * U_LD + 1 + j * 32 + c31] = t < Tc ? uv : 0.f;
                 }
             }
         }
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             // the last two waves also fetch the left / right halo column: x' of the neighbour's edge + dp + cp
             const bool right = w == NW - 1;
             const int th = right ? t0 + FN : t0 - 1;
-            const bool inside = th >= 0 && th < T;
+            const bool inside = th >= 0 && th < Tc;
             const int thc = min(max(th, 0), T - 1);
             const int ntile = right ? tile + 1 : tile - 1;
             const float* cpn = cp_b + (long)(l + 1) * C * T;
@@ -389,15 +411,16 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     }
 
     if (a.tail) {   // skip head + post-scaling in-kernel (persist_tail.h); the u buffer is free since barrier (3), z after barrier (A) inside
-        persist_tail::run(a, smem, smem + C * U_LD, st[1], w, lane, b, t0, T);
+        persist_tail::run(a, smem, smem + C * U_LD, st[1], w, lane, b, t0, T, RAGGED ? a.grp[gi].xold : a.xold,
+                          RAGGED ? a.grp[gi].noise : a.noise, RAGGED ? a.grp[gi].out : a.out, Tc);
     } else {   // ---- the skip sum leaves the chip once
-        float* skip = a.skip + (long)b * C * T;
+        float* skip = (RAGGED ? a.grp[gi].skip : a.skip) + (long)b * C * T;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int t = t0 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t < T) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
+                if (t < Tc) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
         }
     }
 }
@@ -471,9 +494,9 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
@@ -501,13 +524,37 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        if (a.dbg) hipLaunchKernelGGL(denoiser_persist_kernel<true>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        if (a.dbg) hipLaunchKernelGGL((denoiser_persist_kernel<true, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         else if (cmtts_persist_cooperative(0, tiles, nb)) {
             void* params[] = {(void*)&c};
-            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false>), dim3(tiles, nb),
+            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>), dim3(tiles, nb),
                                            dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
-        } else hipLaunchKernelGGL(denoiser_persist_kernel<false>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        } else hipLaunchKernelGGL((denoiser_persist_kernel<false, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;
+}
+
+// Ragged form: one workgroup per descriptor (persist_args.h).  The caller has cleared every group's halo granules on `stream`.
+extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, void* stream_) {
+    const PersistArgs& a = *a_in;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || a.n_groups < 1 || a.n_groups > PERSIST_MAX_GROUPS || a.n_wg < 1 || a.n_wg > PERSIST_MAX_WG)
+        return -2;
+    for (int g = 0; g < a.n_groups; ++g)
+        if ((long)C * a.grp[g].T >= (1L << 30) || a.grp[g].tiles > 127 || a.grp[g].B > 1023) return -2;
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    if (cmtts_persist_cooperative(0, a.n_wg, -1)) {
+        void* params[] = {(void*)a_in};
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW),
+                                       params, (unsigned)lds, stream) != hipSuccess) return -3;
+    } else hipLaunchKernelGGL((denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -8,7 +8,7 @@ extern "C" {
 #endif
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
-// voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT (cmtts_api.hip: cmtts_internal_set).
+// voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 #ifdef __cplusplus
 }

@@ -3,6 +3,23 @@
 #include <stddef.h>
 
 #define PERSIST_MAX_LAYERS 32
+#define PERSIST_MAX_GROUPS 8      // utterance groups (frame buckets) one ragged launch may mix
+#define PERSIST_MAX_WG 256        // workgroups of a ragged launch (= the CU count of an MI355X; larger shards run in rounds)
+
+// One utterance group of a ragged launch (denoiser_persist.hip, RAGGED instance): the buffers cmtts_sample carves for a (B, T) batch
+struct PersistGroup {
+    const float* x0;      // [B][256][T]
+    const float* cp;      // [B][NL*256][T]
+    const float* dp;      // [B][vec_stride]
+    const float* d;       // [B][vec_stride]
+    float* skip;          // [B][256][T] (tail == 0 only)
+    unsigned long long* halo;   // [2][B][tiles][2][256] granules of THIS group
+    const float* xold;    // tail: [B][T][n_mels] or null
+    const float* noise;   // tail: [B][T][n_mels] or null
+    float* out;           // tail: [B][T][n_mels]
+    long cp_bstride;
+    int B, T, tiles, pad_;
+};
 
 struct PersistArgs {
     const float* x0;      // [B][256][T] input of layer 0 (input projection output)
@@ -35,6 +52,14 @@ struct PersistArgs {
     float* out;           // [B][T][n_mels]
     int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
+    // ---- ragged launches (round 3; fp32 kernel): a 1-D grid of n_wg workgroups, workgroup i works on tile (desc >> 13 & 127) of
+    // utterance (desc >> 3 & 1023) of group (desc & 7); (desc >> 20 & 255) = ACTIVE tiles of that utterance: frames at and beyond
+    // active * 64 are treated like frames beyond T (never computed, never read).  x0 / cp / dp / d / skip / halo / xold / noise / out /
+    // cp_bstride / B / T / tiles above are ignored; everything else (weights, NL, tail constants, tmo) is shared by all groups.
+    int n_groups;         // 0 = the uniform (tile, b) grid
+    int n_wg;
+    PersistGroup grp[PERSIST_MAX_GROUPS];
+    unsigned desc[PERSIST_MAX_WG];
 };
 
 #ifdef __cplusplus
@@ -46,6 +71,9 @@ size_t cmtts_persist_halo_bytes(int B, int T);
 int cmtts_launch_denoiser_persist(const PersistArgs* a, int max_blocks, int force, void* stream);
 // 16-bit operand variant (denoiser_persist_lp.hip): mode 1 = bf16, 2 = fp16; W3f / Wof = 16-bit fragment-order weights.
 int cmtts_launch_denoiser_persist_lp(const PersistArgs* a, int mode, int max_blocks, int force, void* stream);
+// Ragged form: a->n_groups, a->grp[], a->n_wg, a->desc[] filled by the caller (cmtts_api.hip: sample_ragged); the halo granules of every
+// group must already be cleared on `stream`.  0 = launched, -2 = not supported, -3 = HIP error.
+int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a, void* stream);
 int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int force);   // resident workgroups of the largest launch (0 = path not taken)
 int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
 void cmtts_persist_set_debug(long long* dbg);

@@ -20,8 +20,10 @@ __device__ __forceinline__ float pt_ldg(const float* base, unsigned idx) {
 }
 __device__ __forceinline__ int pt_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// xold / noise / out: the utterance batch's [B][T][n_mels] tensors (a.xold / a.noise / a.out, or a ragged group's); Tc: frames at and
+// beyond Tc are not stored (Tc = T unless the utterance is trimmed)
 __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z_lds, const f32x16 (&skip)[PT_NT], int w, int lane,
-                                    int b, int t0, int T) {
+                                    int b, int t0, int T, const float* xold, const float* noise, float* out, int Tc) {
     constexpr int C = PT_C, NT = PT_NT, U_LD = PT_LD, RING = PT_RING;
     const int l31 = lane & 31, khalf = lane >> 5;
     const int mrow0 = w * 32;
@@ -106,13 +108,13 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int t = t0 + j * 32 + c31;
-                if (m < M && t < T) {
+                if (m < M && t < Tc) {
                     const long o = ((long)b * T + t) * M + m;
                     const float F = h[j][r] + bi;
                     float v = a.c_out * F;
-                    if (a.xold) v = __builtin_fmaf(a.c_skip, a.xold[o], v);
-                    if (a.noise) v = __builtin_fmaf(a.noise[o] * a.nstd, 0.85f, v);
-                    a.out[o] = v;
+                    if (xold) v = __builtin_fmaf(a.c_skip, xold[o], v);
+                    if (noise) v = __builtin_fmaf(noise[o] * a.nstd, 0.85f, v);
+                    out[o] = v;
                 }
             }
         }

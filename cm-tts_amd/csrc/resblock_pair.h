@@ -52,7 +52,8 @@ int cmtts_launch_convT16(const float* x, float* y, const void* wf16, const float
 int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, const void* const* w2f, const float* const* b1,
                             const float* const* b2, long bstride, int B, int C, int T, int ld, int k, int accum, float slope,
                             int mode, void* stream);
-int cmtts_launch_resblock_pair16p(const PairArgs* a, int mode, int n_cus, void* stream);   // persistent, register-resident weights
+// wide stages (C = 128): the pair in one launch with ONE in-place 16-bit image, two workgroups per CU (resblock_pairw16.hip)
+int cmtts_launch_resblock_pairw16(const PairArgs* a, int mode, void* stream);
 void cmtts_pair_set_debug(long long* dbg);
 #ifdef __cplusplus
 }

@@ -1,0 +1,3 @@
+// resblock_pairw16.inc instantiated for kernel size 3 (bf16 and fp16): see that file.
+#define PW16_KT 3
+#include "resblock_pairw16.inc"

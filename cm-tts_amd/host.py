@@ -448,6 +448,43 @@ def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
     return mel
 
 
+def sample_ragged(model: CMTotalTTS, groups, n_steps, tail_frames=0):
+    """cmtts_sample_ragged: T-step consistency sampling of a RAGGED shard — every group a padded (B, T) batch with its own
+    conditioning, results those of sample_with_cond on that batch — with the residual layers of ALL groups in one persistent
+    launch per evaluation (buckets too small to fill the chip fill it together).
+    groups: iterable of (cond_ct [B,H,T], speaker_emb [B,H] | None, noise [n_noise,B,1,T,80], active_frames | None);
+    active_frames = host sequence of B ints (mel_len): the utterance is then only computed as far as those frames (+ tail_frames
+    + the sampler's receptive field) need — they come out bit-identical, frames beyond the computed range are zeros.
+    Returns the list of mels [B,T,80]."""
+    model._require()
+    lib, dev, cfg = model.lib, model.device, model.config
+    n_noise = 1 if n_steps == 1 else n_steps + 1
+    sig = (C.c_float * n_steps)()
+    std = (C.c_float * n_steps)()
+    _lib.check(lib.cmtts_schedule(model._h, n_steps, sig, std))
+    groups = list(groups)
+    arr = (_lib.SampleGroupStruct * len(groups))()
+    mels, keep = [], []
+    with torch.cuda.device(dev):
+        for gi, (cond_ct, spk, noise, active) in enumerate(groups):
+            B, H, T = cond_ct.shape
+            assert noise.shape[0] >= n_noise and tuple(noise.shape[1:]) == (B, 1, T, cfg.n_mels)
+            mel = torch.empty(B, T, cfg.n_mels, dtype=torch.float32, device=dev)
+            nb = lib.cmtts_denoiser_workspace_bytes(model._h, B, T)
+            ws = model._ws.get(("den_ragged", gi), nb, dev)
+            g = arr[gi]
+            g.noise, g.cond_ct, g.speaker_emb = noise.data_ptr(), cond_ct.data_ptr(), (spk.data_ptr() if spk is not None else None)
+            g.B, g.T, g.mel, g.ws, g.ws_bytes = B, T, mel.data_ptr(), ws.data_ptr(), nb
+            if active is not None:
+                act = (C.c_int64 * B)(*[int(v) for v in active])
+                keep.append(act)
+                g.active_frames = C.cast(act, C.c_void_p).value
+            mels.append(mel)
+            keep += [cond_ct, spk, noise, ws]
+        _lib.check(lib.cmtts_sample_ragged(model._h, arr, len(groups), n_steps, sig, std, int(tail_frames), _stream()))
+    return mels
+
+
 def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, progress=False, callback=None,
                       model_kwargs=None, device=None, sigma_min=0.002, sigma_max=80, rho=7.0, sampler="onestep",
                       generator=None, ts=None, **unused):
@@ -802,18 +839,20 @@ class StreamPipelinedSynthesizer:
 
 class BucketedSynthesizer:
     """BASELINE.json configs[3] on one rank: a shard of ragged utterances dealt into static frame buckets
-    (cmtts_amd.shard.frame_bucket).  A bucket group alone cannot fill 256 CUs, so every group runs on its own HIP
-    stream (own workspaces) and the groups overlap on the chip.  Same kernels and the same results per group as running
-    them one after the other; only the issue order across groups changes."""
+    (cmtts_amd.shard.frame_bucket).  A bucket group alone cannot fill 256 CUs.  mode "ragged" (default): the text side of every
+    group runs on its own HIP stream (short launches that overlap), then ONE cmtts_sample_ragged call runs the residual layers of
+    all groups in one persistent launch per evaluation, each utterance trimmed to the frames its mel_len (+ tail_frames) needs
+    — the one host read-back of the shard (the reference's length regulator reads back per phoneme, model/modules.py:439-441).
+    mode "streams": every group end to end on its own stream (round 2).  Either way each group's valid frames are those of
+    running the group alone."""
 
-    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None):
-        """persistent: denoiser mode while the groups run (cmtts_set_persistent_denoiser; None = leave the process
-        setting alone, the default: a group takes the persistent stack when it alone has more than 128 tiles).
-        2 = every group takes it (the library admits persistent launches of different streams side by side while their
-        workgroups fit the chip) — measured slower for the 4 x 8-utterance shard of tools/bucketed_bench.py (41 vs 27
-        ms): each group then pays 20 x 128 us per evaluation whatever its size, and HIP maps the streams onto 3-4
-        hardware queues."""
-        self.model, self.n_steps, self.persistent = model, n_steps, persistent
+    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None, mode="ragged", tail_frames=16, trim=True):
+        """persistent: denoiser mode while the groups run in "streams" mode (cmtts_set_persistent_denoiser; None = leave the
+        process setting alone).  tail_frames: frames beyond mel_len that must be exact in the padded mel (16 covers HiFi-GAN's
+        receptive field; the frames beyond the computed range are zeros instead of denoised padding).  trim=False computes
+        every padded frame (bit-identical to the per-group launches everywhere)."""
+        self.model, self.n_steps, self.persistent, self.mode = model, n_steps, persistent, mode
+        self.tail_frames, self.trim = int(tail_frames), bool(trim)
         self.streams = [torch.cuda.Stream(device=model.device) for _ in range(n_streams)]
 
     def run(self, groups):
@@ -823,24 +862,40 @@ class BucketedSynthesizer:
         main = torch.cuda.current_stream(dev)
         out = []
         lib = self.model.lib
-        prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None else None
+        prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None and self.mode != "ragged" else None
         # the groups already overlap across streams; the library's own side streams (independent branches of one group)
         # would only add streams competing for the few hardware queues HIP maps them onto (25 -> 31-39 ms measured)
         prev_branch = lib.cmtts_set_option(b"branch_streams", 0)
+        groups = list(groups)
         try:
+            conds = []
             for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
                 st = self.streams[i % len(self.streams)]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
-                    mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
-                out.append((mel, o["mel_lens"]))
+                    if self.mode != "ragged":
+                        mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
+                        out.append((mel, o["mel_lens"]))
+                conds.append(o)
         finally:
             lib.cmtts_set_option(b"branch_streams", prev_branch)
             if prev is not None:
                 lib.cmtts_set_persistent_denoiser(prev)
         for st in self.streams:
             main.wait_stream(st)
+        if self.mode == "ragged":
+            lens = [o["mel_lens"] for o in conds]
+            active = [None] * len(conds)
+            if self.trim:      # one device -> host copy for the whole shard
+                flat = torch.cat(lens).cpu().tolist()
+                k = 0
+                for gi, l in enumerate(lens):
+                    active[gi] = flat[k:k + l.numel()]
+                    k += l.numel()
+            mels = sample_ragged(self.model, [(o["cond_ct"], o["speaker_emb"], g[3], a) for o, g, a in zip(conds, groups, active)],
+                                 self.n_steps, self.tail_frames)
+            out = list(zip(mels, lens))
         return out
 
 

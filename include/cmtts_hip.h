@@ -145,6 +145,35 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
                  int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
                  float* mel, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the same sampler for a RAGGED shard (BASELINE.json configs[3]: variable-length utterances dealt into static frame buckets;
+ * new work — the reference synthesizes one padded batch at a time, synthesize.py:195-227).  Every group is one padded (B, T) batch
+ * with its own noise / conditioning / output / workspace (cmtts_denoiser_workspace_bytes(m, B, T)) exactly as cmtts_sample takes
+ * them, and its results are those of cmtts_sample on that batch (outputs are defined per padded bucket: model/modules.py:429-430
+ * via model/cmtts.py:61-62); but the residual layers of ALL groups run in ONE persistent launch per evaluation, so that
+ * buckets too small to fill 256 CUs fill them together.
+ *   active_frames: optional HOST int64 [B] (NULL = every frame of the padded batch): the frames of each utterance the caller
+ *   will use (its mel_len).  With it the utterance is only computed on its first
+ *   ceil((active_frames + tail_frames + res_layers * (n_steps - i)) / 64) 64-frame tiles in evaluation i — an output frame
+ *   depends on res_layers frames of input to either side, so every frame below active_frames + tail_frames comes out
+ *   BIT-IDENTICAL to the untrimmed result; frames beyond the computed range are unspecified padding — zeros in the one-launch
+ *   form, the untrimmed values when the call falls back to cmtts_sample per group (the reference fills them with denoised
+ *   padding that every caller slices off: utils/tools.py:575-576, utils/model.py:199-203).
+ *   tail_frames: frames beyond active_frames that must still be exact (the receptive field of whatever consumes the padded
+ *   mel: 16 covers hifigan.Generator; 0 for mel-only use).
+ * Falls back to one cmtts_sample per group when the one-launch form does not apply (16-bit precision modes, tiny shards). */
+typedef struct cmtts_sample_group {
+    const float* noise;          /* [n_noise,B,1,T,80] */
+    const float* cond_ct;        /* [B,hidden,T] */
+    const float* speaker_emb;    /* [B,hidden] or NULL */
+    int32_t B, T;
+    const int64_t* active_frames;/* HOST [B] or NULL */
+    float* mel;                  /* out [B,T,80] */
+    void* ws;
+    size_t ws_bytes;
+} cmtts_sample_group;
+int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_groups, int n_steps,
+                        const float* sigmas_host, const float* renoise_std_host, int tail_frames, void* stream);
+
 /* ---- hifigan.Generator (hifigan/models.py:112-174) + get_vocoder weight handling
  * (utils/model.py:155-184; weights with weight-norm already folded). */
 int cmtts_vocoder_create(cmtts_vocoder** out);

@@ -1203,10 +1203,73 @@ def test_bucketed_synthesizer_streams_match_sequential():
         o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
         seq.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], 2, nz), o["mel_lens"]))
     torch.cuda.synchronize()
-    par = host.BucketedSynthesizer(model, n_steps=2, n_streams=3).run(groups)
+    par = host.BucketedSynthesizer(model, n_steps=2, n_streams=3, mode="streams").run(groups)
     torch.cuda.synchronize()
     for (m0, l0), (m1, l1) in zip(seq, par):
         assert torch.equal(l0, l1) and torch.equal(m0, m1)
+
+
+@pytest.mark.parametrize("n_steps", [1, 4])
+def test_ragged_one_launch_shard_bitwise(n_steps):
+    """VERDICT r02 next #2, BASELINE.json configs[3]: all bucket groups of a ragged shard through ONE persistent launch per
+    evaluation (cmtts_sample_ragged, tile-descriptor list).  (a) untrimmed: every frame of every padded group is bit-identical
+    to running the group alone (parity is defined per padded bucket, model/modules.py:429-430); (b) trimmed to mel_len + 16
+    frames (+ the sampler's receptive field): every frame below mel_len + 16 is still bit-identical, frames beyond the computed
+    range are zeros; (c) a shard with more active tiles than CUs runs in rounds and stays bit-identical."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("LibriTTS")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=12, dur_frames=4.0, dur_spread=0.0))
+    rs = np.random.RandomState(6)
+
+    def make(buckets, n):
+        groups = []
+        for bucket in buckets:
+            Lmax = bucket // 4
+            ln = np.maximum((rs.uniform(0.3, 1.0, size=n) * Lmax).astype(np.int64), 1)
+            ln[0] = Lmax
+            tx = rs.randint(1, cfg.n_symbols, size=(n, Lmax)).astype(np.int64)
+            tx[np.arange(Lmax)[None, :] >= ln[:, None]] = 0
+            gen = torch.Generator().manual_seed(bucket + n)
+            groups.append((torch.from_numpy(tx).to(DEV), torch.from_numpy(ln).to(DEV),
+                           torch.randn(n, cfg.external_speaker_dim, generator=gen).to(DEV),
+                           torch.randn(n_steps + 1, n, 1, bucket, cfg.n_mels, generator=gen).to(DEV), bucket))
+        return groups
+
+    def alone(groups):
+        prev = lib.cmtts_set_persistent_denoiser(2)       # the same persistent kernel, one uniform launch per group
+        try:
+            seq = []
+            for tx, ln, spk, nz, bucket in groups:
+                o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
+                seq.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], n_steps, nz), o["mel_lens"]))
+            host.synchronize()
+            return seq
+        finally:
+            lib.cmtts_set_persistent_denoiser(prev)
+
+    groups = make((128, 256, 512, 384), 8)                 # 8 * (2 + 4 + 8 + 6) = 160 padded tiles: enough for the one-launch form
+    seq = alone(groups)
+    full = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, trim=False).run(groups)
+    trim = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, tail_frames=16).run(groups)
+    host.synchronize()
+    saved = 0
+    for (m0, l0), (m1, l1), (m2, l2) in zip(seq, full, trim):
+        assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        assert torch.equal(m0, m1), float((m0 - m1).abs().max())
+        for b, n in enumerate(l0.tolist()):
+            keep = min(n + 16, m0.shape[1])
+            assert torch.equal(m2[b, :keep], m0[b, :keep]), (b, n, float((m2[b, :keep] - m0[b, :keep]).abs().max()))
+            cut = min(m0.shape[1], (n + 16 + cfg.res_layers + 63) // 64 * 64)      # the last evaluation's computed range
+            assert not m2[b, cut:].any()
+            saved += m0.shape[1] - cut
+    assert saved > 0, "the shard has nothing to trim: the test is vacuous"
+    big = make((512, 1024), 14)                            # 14 * (8 + 16) = 336 padded tiles > 256 CUs: rounds of whole utterances
+    seq = alone(big)
+    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(big)
+    host.synchronize()
+    for (m0, l0), (m1, l1) in zip(seq, got):
+        assert torch.equal(l0, l1) and torch.equal(m0, m1), float((m0 - m1).abs().max())
 
 
 def test_two_persistent_launches_on_two_streams():

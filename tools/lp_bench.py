@@ -13,7 +13,7 @@ model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cf
 B, T = 32, 512
 cond = torch.randn(B, 256, T, device="cuda"); noise = torch.randn(5, B, 1, T, 80, device="cuda")
 ref = None
-for dt in ("fp32", "bf16", "fp16"):
+for dt in os.environ.get("LP", "fp32,bf16,fp16,fp16x3").split(","):
     model.set_precision(dt)
     for _ in range(2):
         mel = host.sample_with_cond(model, cond, None, 4, noise)
