@@ -563,7 +563,8 @@ def main():
         d_v = timed(lambda: state.__setitem__("wav", voc(mel_v)), 5, 2, 1) / 5
         voc.set_precision("fp32")
         extras["vocoder_bf16"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
-                                  "note": "bf16 operands in the ResBlock convs and the upsamplers (conv_pre / conv_post fp32); whole ResBlocks / pairs at C <= 64, X-resident convs above: a wide-stage conv costs ~bytes / 5 TB/s + its K loop, C = 128 convs throttled to ~1.7 GHz (profiles/r02_vocoder_bf16.md)"}
+                                  "frac_of_bf16_mfma_peak": round(vflops / d_v / 1e12 / 2500.0, 4),
+                                  "note": "bf16 operands in the ResBlock convs and the upsamplers (conv_pre / conv_post fp32); whole ResBlocks / pairs at C <= 64, one-launch in-place pairs at C = 128 (round 3), X-resident convs at C = 256 (profiles/r03_16bit_paths.md)"}
         # fp16x3 everywhere (residual blocks + HiFi-GAN ResBlock convs): fp32-class accuracy, exploratory
         model.set_precision("fp16x3")
         voc.set_precision("fp16x3")
@@ -576,6 +577,38 @@ def main():
         extras["vocoder_fp16x3"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
                                     "note": "fp16 hi + lo operands, three MFMAs per product (fp32-class; tests/test_gpu_precision.py)"}
         state["hifigan"] = (hcfg, synth_hifigan_state_dict(hcfg, seed=0))
+        # ---- second roofline block: the 16-bit paths against the 2.5 PFLOP/s dense bf16 MFMA peak.  (a) the persistent
+        # denoiser stack with bf16 operands: HIP events around its launches, like the headline's; (b) the bf16 HiFi-GAN generator as a
+        # whole (its time is spread over ~40 kernel shapes: profiles/r03_16bit_paths.md has the per-kernel tables)
+        BF16_PEAK = 2500.0
+        model.set_precision("bf16")
+        k = max(4, args.steps // 2)
+        d_lp = timed(step, k, 2, 1, before=lambda: _lib.check(lib.cmtts_profile_begin(k * N_STEPS * cfg.res_layers, 1)))
+        tms, nl = C.c_double(), C.c_int()
+        _lib.check(lib.cmtts_profile_end(C.byref(tms), C.byref(nl)))
+        model.set_precision("fp32")
+        lp_us = tms.value / max(nl.value, 1) * 1e3
+        lp_flops = (2.0 * (2 * C_) * (3 * C_ + C_) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
+        try:
+            pj2 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pj2 = {}
+        lp_ach = lp_flops / (lp_us * 1e-6) / 1e12 if nl.value else 0.0
+        vb = extras["vocoder_bf16"]
+        result["roofline_16bit"] = [
+            {"bound": "mfma", "kernel": "denoiser_persist_lp_kernel<bf16> (20 residual layers, bf16 operands, fp32 state / accumulate / tail)",
+             "achieved": round(lp_ach, 1), "peak": BF16_PEAK, "unit": "TFLOP/s", "frac": round(lp_ach / BF16_PEAK, 4),
+             "launches": nl.value, "avg_launch_us": round(lp_us, 2), "flops_per_launch": lp_flops,
+             "traffic": pj2.get("denoiser_persist_lp_kernel", {}).get("bytes_per_launch"),
+             "note": "bound in practice by the per-XCD L2 -> CU weight delivery (1.05 MB per workgroup per layer), not by the matrix pipe "
+                     "(26 % MFMA-busy) or HBM (1.7 TB/s at the fabric): profiles/r03_16bit_paths.md"},
+            {"bound": "mfma", "kernel": "HiFi-GAN generator, bf16 operands (whole forward: ~40 kernel shapes)",
+             "achieved": vb["achieved_tflops"], "peak": BF16_PEAK, "unit": "TFLOP/s", "frac": round(vb["achieved_tflops"] / BF16_PEAK, 4),
+             "ms_per_batch": vb["ms_per_batch"], "flops_per_batch": vflops,
+             "traffic": pj2.get("vocoder_bf16", {}).get("bytes_per_batch"),
+             "note": "fabric-side bytes per 32 x 512-frame batch from separate --pmc FETCH_SIZE / WRITE_SIZE passes (calibrated); the "
+                     "C = 128 pairs sit at the bf16 ridge (451 FLOP/B at k = 11 against 2.5 PF / 5 TB/s = 500), the narrow stages are "
+                     "bound by per-conv fixed costs: profiles/r03_16bit_paths.md"}]
         result["extras"] = extras
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd)

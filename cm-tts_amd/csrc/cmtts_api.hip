@@ -387,6 +387,7 @@ struct SideStream {
 std::vector<SideStream> g_sides;
 SideStream* side_for(hipStream_t s) {
     if (!g_branch_streams) return nullptr;
+    if (g_sides.capacity() < 16) g_sides.reserve(16);      // callers keep SideStream pointers across nested side_for() calls: never reallocate (only grows while empty)
     for (auto& x : g_sides)
         if (x.user == s) return &x;
     if (g_sides.size() >= 16) return nullptr;          // more caller streams than that: branches run in line
@@ -1580,20 +1581,74 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
     }
+    // ---- which groups share the persistent launch.  Every workgroup of that launch must be resident, so a shard with more active
+    // tiles than CUs needs a second ROUND of 20 layers (2.7 ms per evaluation whatever its size).  When leaving out a few SMALL groups
+    // (<= 64 active tiles together: the range where the per-layer / split kernels take < 1 ms per evaluation, tools/split_crossover.py)
+    // makes the rest fit one round, those groups go through cmtts_sample on the side stream instead: 2.7 + ~0.9 ms per evaluation
+    // where two rounds cost 5.4.
+    const int cap_all = std::min(persist_blocks(), PERSIST_MAX_WG);
+    auto active_tiles = [&](const cmtts_sample_group& G, int eval) {
+        const int tiles = (G.T + 63) / 64;
+        if (!G.active_frames) return (long)tiles * G.B;
+        long n = 0;
+        for (int b = 0; b < G.B; ++b) {
+            const long need = (long)G.active_frames[b] + tail_frames + (long)NL * (n_steps - eval);
+            n += std::min<long>(tiles, std::max<long>(1, (need + 63) / 64));
+        }
+        return n;
+    };
+    std::vector<char> aside(n_groups, 0);
+    {
+        long total = 0;
+        std::vector<long> at(n_groups);
+        for (int g = 0; g < n_groups; ++g) { at[g] = active_tiles(groups[g], 0); total += at[g]; }
+        if (total > cap_all) {
+            std::vector<int> order(n_groups);
+            for (int g = 0; g < n_groups; ++g) order[g] = g;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return at[x] < at[y]; });
+            long out = 0, rest = total;
+            std::vector<int> pick;
+            for (int g : order) {
+                if (rest <= cap_all) break;
+                out += at[g]; rest -= at[g]; pick.push_back(g);
+            }
+            if (rest <= cap_all && rest > 0 && out <= 64)
+                for (int g : pick) aside[g] = 1;
+        }
+    }
     std::vector<DenWs> ws(n_groups);
     SideStream* ss = side_for(s);
     if (ss) CHK(branch_fork(ss));
     bool trimmed = false;
+    bool any_aside = false;
     for (int g = 0; g < n_groups; ++g) {
         const cmtts_sample_group& G = groups[g];
+        if (aside[g]) { any_aside = true; continue; }
         ws[g] = carve_den(c, G.B, G.T, G.ws);
         CHK(cond_projections(m, ws[g], G.cond_ct, G.B, G.T, ss ? ss->side : s));      // once for all evaluations, beside the first prologues
         k_scale(G.noise, ws[g].xcur, (long)G.B * G.T * M, c.sigma_max, s);            // x_T = randn * sigma_max (karras_diffusion.py:534)
         trimmed = trimmed || G.active_frames != nullptr;
         if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)G.B * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
     }
+    if (ss) CHK(branch_join(ss));          // the conditioner projections; the side stream then carries the set-aside groups
+    if (any_aside) {
+        // the small groups: the ordinary sampler (per-layer / split kernels), queued on the side stream so that its launches fill the
+        // gaps of the main stream (prologues, launch boundaries) and whatever CUs the persistent grid leaves free
+        hipStream_t q = ss ? ss->side : s;
+        if (ss) CHK(branch_fork(ss));
+        const int prev_persist = g_persist;
+        g_persist = 0;
+        int rc = 0;
+        for (int g = 0; g < n_groups && rc == 0; ++g)
+            if (aside[g]) {
+                const cmtts_sample_group& G = groups[g];
+                rc = cmtts_sample(m, G.noise, G.cond_ct, G.speaker_emb, G.B, G.T, n_steps, sigmas, renoise_std, G.mel, G.ws, G.ws_bytes, (void*)q);
+            }
+        g_persist = prev_persist;
+        if (rc != 0) return rc;
+    }
     const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
-    const int cap = std::min(persist_blocks(), PERSIST_MAX_WG);
+    const int cap = cap_all;
     PersistArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.vec_stride = (long)NL * C; pa.tmo = g_tmo_host; pa.NL = NL; pa.halo_zeroed = 1;
@@ -1624,6 +1679,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         long total = 0;
         for (int g = 0; g < n_groups; ++g) {
             const cmtts_sample_group& G = groups[g];
+            if (aside[g]) continue;
             const DenWs& w = ws[g];
             if (new_sigma) k_fill_float(w.tbuf, t_resc, G.B, s);
             bool hz = false;
@@ -1645,7 +1701,6 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
                 total += act;
             }
         }
-        if (i == 0 && ss) CHK(branch_join(ss));
         pa.c_out = c_out; pa.c_skip = c_skip; pa.nstd = renoise ? renoise_std[i] : 0.0f;
         // rounds: every workgroup of a launch must be resident, so a shard with more active tiles than CUs runs as balanced rounds of
         // whole utterances (tiles of one utterance exchange their edge columns and must share a launch)
@@ -1670,6 +1725,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
         }
     }
+    if (any_aside && ss) CHK(branch_join(ss));
     HIPCHK(hipGetLastError());
     return 0;
 }

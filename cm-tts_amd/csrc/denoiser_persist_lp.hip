@@ -206,35 +206,11 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
 #pragma unroll
         for (int s = 0; s < RINGM - 1; ++s) load_a(A[s], a.W3f[l], s);         // the weight stream does not depend on u
         __syncthreads();   // (1) u^T of layer l complete
-        // ---- L2 warm-up for layer l + 1, one dword per 128-B line, results never read (round 3).
-        //  * the next layer's cp tile (as before), and
-        //  * the next layer's WEIGHTS: the 20 layers' 16-bit weight sets (21 MB) do not stay in an XCD's 4-MB L2, so the first workgroup
-        //    to reach a layer fetched every line from the Infinity Cache / HBM and — the workgroups of an XCD walking the layers
-        //    almost in lock-step — all of them waited for those fetches: the ring ran at one memory latency (~2 us) per five k-groups,
-        //    30 us per layer against 7 us of MFMAs.  Every workgroup now touches its 1/n-th slice of layer l + 1's lines (n = workgroups
-        //    on its XCD; workgroup i runs on XCD i % 8) a whole layer ahead: when the ring asks for them they are L2 hits.
-        // The touches are issued by hand and their destination is kept live until the K loop's own waits have passed them (loads return
-        // in order): a plain C++ load would be waited for right here (vmcnt(0): the cp fetch from HBM AND the whole weight ring).
-        unsigned touch = 0;
-        if (more) {
+        if (more) {        // pull the next layer's cp tile towards L2: one dword per 128-B line
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int tl = opaque(tid);
-            const float* pc = cpn + (unsigned)((tl >> 1) * T + min(t0 + (tl & 1) * 32, T - 1));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(pc) : "memory");
-            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
-            const unsigned nsl = (nwg + 7u) / 8u, sl = (lin / 8u) % nsl;
-            constexpr unsigned L3 = NS * 3u * (C / 16) * (2 * C / 32) * 64 * 16 / 128, LO = NS * (C / 16) * (2 * C / 32) * 64 * 16 / 128;   // 128-B lines
-            const unsigned per3 = (L3 + nsl - 1) / nsl, pero = (LO + nsl - 1) / nsl;
-            const char* w3n = reinterpret_cast<const char*>(a.W3f[l + 1]);
-            const char* won = reinterpret_cast<const char*>(a.Wof[l + 1]);
-            for (unsigned i = tl; i < per3; i += 64 * NW) {
-                const char* pw = w3n + (size_t)min(sl * per3 + i, L3 - 1) * 128;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(pw) : "memory");
-            }
-            for (unsigned i = tl; i < pero; i += 64 * NW) {
-                const char* pw = won + (size_t)min(sl * pero + i, LO - 1) * 128;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(touch) : "v"(pw) : "memory");
-            }
+            const float warm = cpn[(unsigned)((tl >> 1) * T + min(t0 + (tl & 1) * 32, T - 1))];
+            asm volatile("" ::"v"(warm));
         }
 
         // =========================================================== phase B: gated k=3 conv, 48 k-groups
@@ -255,7 +231,6 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 }
             }
         }
-        asm volatile("" : "+v"(touch));      // the K loop's waits have covered the warm-up loads: their register may die now
 #pragma unroll
         for (int s = 0; s < RINGM - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
         {   // gate -> z^T (own buffer: no barrier between the conv and the gate)

@@ -867,35 +867,67 @@ class BucketedSynthesizer:
         # would only add streams competing for the few hardware queues HIP maps them onto (25 -> 31-39 ms measured)
         prev_branch = lib.cmtts_set_option(b"branch_streams", 0)
         groups = list(groups)
+        # "ragged": a shard whose padded tiles exceed the CU count needs a second round of the persistent launch unless a few SMALL
+        # groups are left out (cmtts_sample_ragged sets them aside itself once the lengths are known).  When the padded sizes already
+        # say so, those groups run END TO END on their own stream right away — their sampler (per-layer kernels) then overlaps the
+        # text side of the large groups instead of following it.  The guess only moves work between streams: results are per group.
+        early = set()
+        if self.mode == "ragged" and self.trim:
+            cap = torch.cuda.get_device_properties(dev).multi_processor_count
+            tiles = [int(g[0].shape[0]) * ((int(g[4]) + 63) // 64) for g in groups]
+            order = sorted(range(len(groups)), key=lambda i: tiles[i])
+            rest, gone = sum(tiles), 0
+            for i in order:
+                if rest <= cap or gone + tiles[i] > 64:
+                    break
+                early.add(i); rest -= tiles[i]; gone += tiles[i]
+            if not (rest * 0.92 <= cap):       # would not fit one round even after trimming: let the library decide
+                early = set()
         try:
             conds = []
-            for i, (texts, src_lens, spk, noise, bucket) in enumerate(groups):
+            done = {}
+            for i in sorted(range(len(groups)), key=lambda i: i not in early):      # the early groups are queued first
+                texts, src_lens, spk, noise, bucket = groups[i]
                 st = self.streams[i % len(self.streams)]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
-                    if self.mode != "ragged":
+                    if self.mode != "ragged" or i in early:
+                        prev_p = lib.cmtts_set_persistent_denoiser(0) if i in early else None
                         mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
-                        out.append((mel, o["mel_lens"]))
-                conds.append(o)
+                        if prev_p is not None:
+                            lib.cmtts_set_persistent_denoiser(prev_p)
+                        done[i] = (mel, o["mel_lens"])
+                conds.append((i, o))
+            conds = [o for _, o in sorted(conds, key=lambda t: t[0])]
+            if self.mode != "ragged":
+                out = [done[i] for i in range(len(groups))]
         finally:
             lib.cmtts_set_option(b"branch_streams", prev_branch)
             if prev is not None:
                 lib.cmtts_set_persistent_denoiser(prev)
+        early_streams = {id(self.streams[i % len(self.streams)]) for i in early}
         for st in self.streams:
-            main.wait_stream(st)
+            if id(st) not in early_streams:      # the early groups' streams are joined after the persistent launches are queued
+                main.wait_stream(st)
         if self.mode == "ragged":
-            lens = [o["mel_lens"] for o in conds]
-            active = [None] * len(conds)
-            if self.trim:      # one device -> host copy for the whole shard
+            late = [i for i in range(len(groups)) if i not in early]
+            lens = [conds[i]["mel_lens"] for i in late]
+            active = [None] * len(late)
+            if self.trim and late:      # one device -> host copy for the whole shard
                 flat = torch.cat(lens).cpu().tolist()
                 k = 0
                 for gi, l in enumerate(lens):
                     active[gi] = flat[k:k + l.numel()]
                     k += l.numel()
-            mels = sample_ragged(self.model, [(o["cond_ct"], o["speaker_emb"], g[3], a) for o, g, a in zip(conds, groups, active)],
-                                 self.n_steps, self.tail_frames)
-            out = list(zip(mels, lens))
+            mels = sample_ragged(self.model, [(conds[i]["cond_ct"], conds[i]["speaker_emb"], groups[i][3], a) for i, a in zip(late, active)],
+                                 self.n_steps, self.tail_frames) if late else []
+            for i, mel, l in zip(late, mels, lens):
+                done[i] = (mel, l)
+            out = [done[i] for i in range(len(groups))]
+        for st in self.streams:
+            if id(st) in early_streams:
+                main.wait_stream(st)
         return out
 
 

@@ -1264,6 +1264,14 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
             assert not m2[b, cut:].any()
             saved += m0.shape[1] - cut
     assert saved > 0, "the shard has nothing to trim: the test is vacuous"
+    # (d) 15 x 16 + 8 x 4 = 272 padded tiles: leaving the small group out fits one round — it is set aside for the ordinary sampler
+    # (per-layer kernels on the side stream) while the large one takes the persistent launch
+    mixed = make((1024,), 15) + make((256,), 8)
+    seq = alone(mixed)
+    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(mixed)
+    host.synchronize()
+    for (m0, l0), (m1, l1) in zip(seq, got):
+        assert torch.equal(l0, l1) and torch.equal(m0, m1), float((m0 - m1).abs().max())
     big = make((512, 1024), 14)                            # 14 * (8 + 16) = 336 padded tiles > 256 CUs: rounds of whole utterances
     seq = alone(big)
     got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(big)
