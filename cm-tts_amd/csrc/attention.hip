@@ -180,14 +180,167 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long sequences (L > 192: the FastspeechDecoder over the frame axis, texts up to max_seq_len = 1000 — config/LJSpeech/model.yaml:55;
+// round 3, VERDICT r02 missing #5): the same attention with the keys walked in 64-key chunks and an ONLINE softmax, so that neither
+// the scores nor the probabilities of a query ever exist in full.  Workgroup = (utterance, head, block of NWQ x 32 queries): the grid
+// also splits the QUERIES, not only the heads (B H ceil(L / 128) workgroups).  Per chunk:
+//   S = K_c^T Q (two 32-key accumulators)  ->  m' = max(m, max_keys S), alpha = exp(m - m'), P = exp(S - m') (0 on padded keys),
+//   l = l alpha + sum_keys P,  O = O alpha + V_c P^T  (P fed from the accumulator registers exactly as above);  finally O / l.
+// K and V chunks have their own LDS tiles (65 KB together: two barriers per chunk); chunks that lie wholly beyond the utterance's
+// length are skipped.  Same operations as the two-pass softmax up to the order of roundings (fp32, ~1e-7 relative).
+template <int NWQ>
+__global__ __launch_bounds__(64 * NWQ) void attention_long_kernel(const AttnArgs a) {
+    constexpr int NTHREADS = 64 * NWQ;
+    extern __shared__ __attribute__((aligned(16))) float ltile[];
+    float* Ks = ltile;                       // [DH][KB]
+    float* Vs = ltile + DH * KB;             // [DH][VLD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int z = blockIdx.x, b = z / a.H, h = z - b * a.H;
+    const int L = a.L, ld = a.ld;
+    const int len = min((int)a.lens[b], L);
+    const int q0 = blockIdx.y * (32 * NWQ) + 32 * w;
+    const float* qb = a.qkv + (long)b * a.bstride + (long)(h * DH) * ld;
+    const float* kb = a.qkv + (long)b * a.bstride + (long)(a.H * DH + h * DH) * ld;
+    const float* vb = a.qkv + (long)b * a.bstride + (long)(2 * a.H * DH + h * DH) * ld;
+
+    float Qr[DH / 2];
+    {
+        const int i_c = min(q0 + l31, L - 1);
+#pragma unroll
+        for (int kk = 0; kk < DH / 2; ++kk) Qr[kk] = qb[(long)(2 * kk + khalf) * ld + i_c];
+    }
+    f32x16 O[DH / 32];
+#pragma unroll
+    for (int mt = 0; mt < DH / 32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[mt][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    constexpr int NV = DH * (KB / 4);
+    constexpr int PER = (NV + NTHREADS - 1) / NTHREADS;
+    const int nch = (len + KB - 1) / KB;
+    for (int c = 0; c < nch; ++c) {
+        const int key0 = c * KB;
+        {   // stage K_c and V_c: all loads (unconditional, clamped addresses) before the first LDS write
+            f32x4 kv[PER], vv[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int idx = min(tid + u * NTHREADS, NV - 1);
+                const int d = idx / (KB / 4), c4 = idx - d * (KB / 4);
+                const int j = min(key0 + 4 * c4, ld - 4);
+                kv[u] = *reinterpret_cast<const f32x4*>(kb + (long)d * ld + j);
+                vv[u] = *reinterpret_cast<const f32x4*>(vb + (long)d * ld + j);
+            }
+            if (c > 0) __syncthreads();          // every wave has finished the previous chunk's MFMAs
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int idx = tid + u * NTHREADS;
+                if (idx < NV) {
+                    const int d = idx / (KB / 4), c4 = idx - d * (KB / 4);
+                    const int j = key0 + 4 * c4;
+                    const bool in = j <= ld - 4;
+                    float* pk = Ks + d * KB + 4 * c4;
+                    float* pv = Vs + d * VLD + 4 * c4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = in && j + e < L;
+                        pk[e] = ok ? kv[u][e] : 0.f;
+                        pv[e] = ok ? vv[u][e] : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        f32x16 S[2];
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[mtl][r] = 0.f;
+            const float* ks = Ks + khalf * KB + mtl * 32 + l31;
+            float av = ks[0];
+#pragma unroll
+            for (int kk = 0; kk < DH / 2; ++kk) {
+                const float nav = kk + 1 < DH / 2 ? ks[(kk + 1) * 2 * KB] : 0.f;
+                S[mtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Qr[kk], S[mtl], 0, 0, 0);
+                av = nav;
+            }
+        }
+        // online softmax update of this lane's query column (both lane halves hold the same queries, different keys)
+        float cmx = -INFINITY;
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 32 * mtl + acc_row(r, lane);
+                const float v = S[mtl][r] * a.scale;
+                S[mtl][r] = v;
+                if (key < len) cmx = fmaxf(cmx, v);
+            }
+        cmx = fmaxf(cmx, __shfl_xor(cmx, 32));
+        const float mnew = fmaxf(mrun, cmx);                  // finite: chunk c < nch holds at least one valid key
+        const float alpha = expf(mrun - mnew);                // first chunk: exp(-inf) = 0 on O = 0, l = 0
+        float csum = 0.f;
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 32 * mtl + acc_row(r, lane);
+                const float e = key < len ? expf(S[mtl][r] - mnew) : 0.f;
+                S[mtl][r] = e;
+                csum += e;
+            }
+        csum += __shfl_xor(csum, 32);
+        lrun = lrun * alpha + csum;
+        mrun = mnew;
+#pragma unroll
+        for (int mt = 0; mt < DH / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[mt][r] *= alpha;
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = mtl * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+#pragma unroll
+                for (int mt = 0; mt < DH / 32; ++mt)
+                    O[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(mt * 32 + l31) * VLD + kl], S[mtl][r], O[mt], 0, 0, 0);
+            }
+    }
+    float* ob = a.out + (long)b * a.obstride + (long)(h * DH) * ld;
+    const int i = q0 + l31;
+    if (i < L) {
+        const float inv = lrun > 0.f ? lrun : 1.f;            // len == 0: all probabilities 0
+#pragma unroll
+        for (int mt = 0; mt < DH / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long)(mt * 32 + acc_row(r, lane)) * ld + i] = O[mt][r] / inv;
+    }
+}
+
 }  // namespace
 
-// 0 = launched, -2 = shape not covered (L > 192 or head_dim != 128: the caller runs the three-launch path), -3 = HIP error
+// 0 = launched, -2 = shape not covered (head_dim != 128, unaligned rows: the caller runs the three-launch path), -3 = HIP error
 extern "C" int cmtts_launch_attention(const AttnArgs* ap, void* stream_) {
     const AttnArgs& a = *ap;
     hipStream_t s = (hipStream_t)stream_;
     if (a.B <= 0 || a.L <= 0) return 0;
-    if (a.dh != DH || a.L > 192 || (a.ld & 3)) return -2;
+    if (a.dh != DH || (a.ld & 3)) return -2;
+    if (a.L > 192) {          // key-chunked online softmax, queries split over workgroups
+        constexpr int NWQ = 4;
+        const size_t lds = (size_t)(DH * KB + DH * VLD) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_long_kernel<NWQ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return -3;
+            attr_set = true;
+        }
+        dim3 grid(a.B * a.H, (a.L + 32 * NWQ - 1) / (32 * NWQ));
+        hipLaunchKernelGGL(attention_long_kernel<NWQ>, grid, dim3(64 * NWQ), lds, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     const int nmt = (a.L + 31) / 32;
     dim3 grid(a.B * a.H);
     switch (nmt) {

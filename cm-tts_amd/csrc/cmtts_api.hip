@@ -315,7 +315,7 @@ int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-re
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
 int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
 int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
-int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip) when L <= 192: 0 = three-launch path
+int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip; key-chunked with an online softmax above L = 192): 0 = three-launch path
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
@@ -1209,7 +1209,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
     const bool xres_cols = g_ffn_xres && t96 * 96 <= t64 * 64;
     for (size_t i = 0; i < layers.size(); ++i) {
         const EncLayer& E = layers[i];
-        const bool fused_attn = g_attn_fused && dh == 128 && L <= 192;
+        const bool fused_attn = g_attn_fused && dh == 128;      // L <= 192: all keys in registers; longer: key-chunked online softmax (attention.hip)
         // LayerNorm1 as the prologue of the in-projection: one launch, no normalised copy in HBM
         const bool ln_qkv = fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && (long)t96 * (3 * H / 128) * B >= 128;
         if (!ln_qkv) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);

@@ -588,6 +588,13 @@ def test_fastspeech_decoder_golden_and_long(golden):
     ref = O.fastspeech_decoder(dsd, cfg, xl, padl)
     y = model.decoder(torch.from_numpy(xl), torch.from_numpy(padl))
     np.testing.assert_allclose(_np(y), ref, atol=1e-4)
+    prev = _lib.internal_set(b"attn_fused", 0)          # T = 700 takes the fused (key-chunked) attention kernel since round 3
+    try:
+        y3 = model.decoder(torch.from_numpy(xl), torch.from_numpy(padl))
+    finally:
+        _lib.internal_set(b"attn_fused", prev)
+    d = float((y3 - y).abs().max())
+    assert 0 < d < 5e-5, d
     # a model without decoder.* tensors refuses loudly
     plain = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=2))
     with pytest.raises(RuntimeError):
@@ -635,12 +642,14 @@ def test_branch_streams_bitwise(variant, B, L):
         lib.cmtts_set_option(b"branch_streams", prev)
 
 
-@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 171), ("VCTK", 4, 33), ("LJSpeech", 2, 1), ("LJSpeech", 2, 192)])
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 171), ("VCTK", 4, 33), ("LJSpeech", 2, 1), ("LJSpeech", 2, 192),
+                                         ("LJSpeech", 3, 193), ("VCTK", 2, 640), ("LJSpeech", 1, 1000)])
 def test_fused_attention_matches_three_launch_path(variant, B, L):
     """attention.hip (QKV projection as one contraction + softmax(q k^T / sqrt(dh) + key mask) v in one launch, scores in
     registers) against the three-launch path (K^T Q GEMM -> softmax_cols -> V P^T GEMM): the same operations in a
     different fp32 summation order -> encoder output within 2e-5, integer stages identical; ragged lengths exercise the
-    key mask, L = 171 / 192 the six-wave form, L = 1 the degenerate one."""
+    key mask, L = 171 / 192 the six-wave form, L = 1 the degenerate one; L > 192 (up to max_seq_len = 1000,
+    config/LJSpeech/model.yaml:55) the key-chunked online-softmax kernel with the queries split over workgroups."""
     host = _host()
     lib = _lib.load()
     cfg = get_config(variant)
