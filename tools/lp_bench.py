@@ -10,7 +10,8 @@ from cmtts_amd.weights import synth_cmtts_state_dict
 
 cfg = get_config("LJSpeech")
 model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cfg, seed=0))
-B, T = 32, 512
+B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
+
 cond = torch.randn(B, 256, T, device="cuda"); noise = torch.randn(5, B, 1, T, 80, device="cuda")
 ref = None
 for dt in os.environ.get("LP", "fp32,bf16,fp16,fp16x3").split(","):
