@@ -1503,16 +1503,13 @@ int cmtts_schedule(const cmtts_model* m, int n_steps, float* sigmas, float* reno
     return 0;
 }
 
-int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
-                 int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
-                 void* stream) {
-    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
-    if (!noise || !cond_ct || !mel || !ws || !sigmas || !renoise_std || B <= 0 || T <= 0 || n_steps < 1)
-        return fail(CMTTS_E_INVALID, "cmtts_sample: bad argument");
+}  // extern "C" (reopened below)
+namespace {
+// The sampler on one padded (B, T) batch whose workspace is already carved.  noise_stride = elements between consecutive noise tensors
+// (B * T * n_mels for a whole batch; a sub-batch [b0, b0 + B) of a larger batch keeps the larger batch's stride).
+int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_stride, const float* cond_ct, const float* speaker_emb, int B,
+                int T, int n_steps, const float* sigmas, const float* renoise_std, float* mel, hipStream_t s) {
     const cmtts_config& c = m->cfg;
-    DenWs w = carve_den(c, B, T, ws);
-    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
-    hipStream_t s = (hipStream_t)stream;
     const long nel = (long)B * T * c.n_mels;
     // once for all n_steps evaluations, on the side stream: joined before the first residual layer of the first evaluation
     SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
@@ -1533,12 +1530,37 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
         if (new_sigma) k_fill_float(w.tbuf, t_resc, B, s);
         const bool last = i + 1 == n_steps;
         const bool renoise = renoise_std[i] >= 0.0f;
-        const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * nel : nullptr, c_out, c_skip,
+        const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * noise_stride : nullptr, c_out, c_skip,
                               renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
         CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr, t_resc));
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// The workspace of utterances [b0, B) of a batch carved for (B, T): every buffer is batch-major, so a sub-batch is a pointer offset
+// (the halo granules are the persistent kernel's and are not used by the sub-batch path).
+DenWs den_slice(const cmtts_config& c, const DenWs& w, int b0, int T) {
+    const long C = c.res_channels, NL = c.res_layers, M = c.n_mels;
+    DenWs v = w;
+    v.hin += (long)b0 * M * T; v.h += b0 * C * T; v.u += b0 * C * T; v.zb += b0 * C * T; v.skip += b0 * C * T;
+    v.emb += b0 * C; v.e1 += b0 * 4 * C; v.e2 += b0 * C; v.dproj += b0 * NL * C; v.sproj += b0 * NL * C; v.dp += b0 * NL * C;
+    v.tbuf += b0; v.xcur += (long)b0 * T * M; v.cp += (long)b0 * NL * C * T;
+    return v;
+}
+}  // namespace
+extern "C" {
+
+int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
+                 int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
+                 void* stream) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!noise || !cond_ct || !mel || !ws || !sigmas || !renoise_std || B <= 0 || T <= 0 || n_steps < 1)
+        return fail(CMTTS_E_INVALID, "cmtts_sample: bad argument");
+    const cmtts_config& c = m->cfg;
+    DenWs w = carve_den(c, B, T, ws);
+    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
+    return sample_core(m, w, noise, (long)B * T * c.n_mels, cond_ct, speaker_emb, B, T, n_steps, sigmas, renoise_std, mel, (hipStream_t)stream);
 }
 
 // karras_sample_tts for a RAGGED shard (BASELINE.json configs[3]: utterances dealt into static frame buckets): every group is a
@@ -1581,54 +1603,53 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
     }
-    // ---- which groups share the persistent launch.  Every workgroup of that launch must be resident, so a shard with more active
-    // tiles than CUs needs a second ROUND of 20 layers (2.7 ms per evaluation whatever its size).  When leaving out a few SMALL groups
-    // (<= 64 active tiles together: the range where the per-layer / split kernels take < 1 ms per evaluation, tools/split_crossover.py)
-    // makes the rest fit one round, those groups go through cmtts_sample on the side stream instead: 2.7 + ~0.9 ms per evaluation
-    // where two rounds cost 5.4.
+    // ---- which utterances share the persistent launch.  Every workgroup of that launch must be resident, so a shard with more active
+    // tiles than CUs needs a second ROUND of 20 layers (2.7 ms per evaluation whatever its size).  When leaving out a few SMALL
+    // utterances (<= 64 active tiles together: the range where the per-layer / split kernels take < 1 ms per evaluation,
+    // tools/split_crossover.py) makes the rest fit one round, those go through the ordinary sampler on the side stream instead: 2.7 +
+    // ~0.9 ms per evaluation where two rounds cost 5.4.  They are taken from the END of the groups with the shortest padded length
+    // (a sub-batch [b0, B) of a group is a pointer offset: every buffer is batch-major); keep[g] = utterances of group g that stay.
     const int cap_all = std::min(persist_blocks(), PERSIST_MAX_WG);
-    auto active_tiles = [&](const cmtts_sample_group& G, int eval) {
+    auto utt_tiles = [&](const cmtts_sample_group& G, int b, int eval) {
         const int tiles = (G.T + 63) / 64;
-        if (!G.active_frames) return (long)tiles * G.B;
-        long n = 0;
-        for (int b = 0; b < G.B; ++b) {
-            const long need = (long)G.active_frames[b] + tail_frames + (long)NL * (n_steps - eval);
-            n += std::min<long>(tiles, std::max<long>(1, (need + 63) / 64));
-        }
-        return n;
+        if (!G.active_frames) return (long)tiles;
+        const long need = (long)G.active_frames[b] + tail_frames + (long)NL * (n_steps - eval);
+        return std::min<long>(tiles, std::max<long>(1, (need + 63) / 64));
     };
-    std::vector<char> aside(n_groups, 0);
+    std::vector<int> keep(n_groups);
     {
         long total = 0;
-        std::vector<long> at(n_groups);
-        for (int g = 0; g < n_groups; ++g) { at[g] = active_tiles(groups[g], 0); total += at[g]; }
+        for (int g = 0; g < n_groups; ++g) {
+            keep[g] = groups[g].B;
+            for (int b = 0; b < groups[g].B; ++b) total += utt_tiles(groups[g], b, 0);
+        }
         if (total > cap_all) {
-            std::vector<int> order(n_groups);
+            std::vector<int> order(n_groups), k2 = keep;
             for (int g = 0; g < n_groups; ++g) order[g] = g;
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return at[x] < at[y]; });
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return groups[x].T < groups[y].T; });
             long out = 0, rest = total;
-            std::vector<int> pick;
             for (int g : order) {
+                while (rest > cap_all && k2[g] > 0) {
+                    const long t = utt_tiles(groups[g], k2[g] - 1, 0);
+                    out += t; rest -= t; --k2[g];
+                }
                 if (rest <= cap_all) break;
-                out += at[g]; rest -= at[g]; pick.push_back(g);
             }
-            if (rest <= cap_all && rest > 0 && out <= 64)
-                for (int g : pick) aside[g] = 1;
+            if (rest <= cap_all && rest > 0 && out <= 64) keep = k2;
         }
     }
     std::vector<DenWs> ws(n_groups);
     SideStream* ss = side_for(s);
     if (ss) CHK(branch_fork(ss));
-    bool trimmed = false;
     bool any_aside = false;
     for (int g = 0; g < n_groups; ++g) {
         const cmtts_sample_group& G = groups[g];
-        if (aside[g]) { any_aside = true; continue; }
         ws[g] = carve_den(c, G.B, G.T, G.ws);
-        CHK(cond_projections(m, ws[g], G.cond_ct, G.B, G.T, ss ? ss->side : s));      // once for all evaluations, beside the first prologues
-        k_scale(G.noise, ws[g].xcur, (long)G.B * G.T * M, c.sigma_max, s);            // x_T = randn * sigma_max (karras_diffusion.py:534)
-        trimmed = trimmed || G.active_frames != nullptr;
-        if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)G.B * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
+        if (keep[g] < G.B) any_aside = true;
+        if (keep[g] == 0) continue;
+        CHK(cond_projections(m, ws[g], G.cond_ct, keep[g], G.T, ss ? ss->side : s));   // once for all evaluations, beside the first prologues
+        k_scale(G.noise, ws[g].xcur, (long)keep[g] * G.T * M, c.sigma_max, s);         // x_T = randn * sigma_max (karras_diffusion.py:534)
+        if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)keep[g] * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
     }
     if (ss) CHK(branch_join(ss));          // the conditioner projections; the side stream then carries the set-aside groups
     if (any_aside) {
@@ -1640,9 +1661,13 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         g_persist = 0;
         int rc = 0;
         for (int g = 0; g < n_groups && rc == 0; ++g)
-            if (aside[g]) {
+            if (keep[g] < groups[g].B) {
                 const cmtts_sample_group& G = groups[g];
-                rc = cmtts_sample(m, G.noise, G.cond_ct, G.speaker_emb, G.B, G.T, n_steps, sigmas, renoise_std, G.mel, G.ws, G.ws_bytes, (void*)q);
+                const int b0 = keep[g], nb = G.B - b0;
+                const long per = (long)G.T * M;
+                rc = sample_core(m, den_slice(c, ws[g], b0, G.T), G.noise + b0 * per, (long)G.B * per, G.cond_ct + (long)b0 * c.hidden * G.T,
+                                 G.speaker_emb ? G.speaker_emb + (long)b0 * c.hidden : nullptr, nb, G.T, n_steps, sigmas, renoise_std,
+                                 G.mel + b0 * per, q);
             }
         g_persist = prev_persist;
         if (rc != 0) return rc;
@@ -1673,30 +1698,26 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         const bool renoise = renoise_std[i] >= 0.0f;
         // an output frame depends on NL frames of input to either side (NL k = 3 layers): evaluation i must be exact on every frame the
         // later evaluations and the caller's `tail_frames` reach, so it is computed NL * (n_steps - i) frames beyond that
-        const long reach = (long)tail_frames + (long)NL * (n_steps - i);
         struct Utt { int g, b, act; };
         std::vector<Utt> utts;
         long total = 0;
         for (int g = 0; g < n_groups; ++g) {
             const cmtts_sample_group& G = groups[g];
-            if (aside[g]) continue;
+            const int Bk = keep[g];
+            if (Bk == 0) continue;
             const DenWs& w = ws[g];
-            if (new_sigma) k_fill_float(w.tbuf, t_resc, G.B, s);
+            if (new_sigma) k_fill_float(w.tbuf, t_resc, Bk, s);
             bool hz = false;
-            CHK(denoiser_prologue(m, w, w.xcur, c_in, w.tbuf, G.speaker_emb, G.B, G.T, s, new_sigma, t_resc, &hz));
-            if (!hz) HIPCHK(hipMemsetAsync(w.halo, 0, cmtts_persist_halo_bytes(G.B, G.T), s));
+            CHK(denoiser_prologue(m, w, w.xcur, c_in, w.tbuf, G.speaker_emb, Bk, G.T, s, new_sigma, t_resc, &hz));
+            if (!hz) HIPCHK(hipMemsetAsync(w.halo, 0, cmtts_persist_halo_bytes(Bk, G.T), s));
             const int tiles = (G.T + 63) / 64;
             PersistGroup& pg = pa.grp[g];
             pg.x0 = w.h; pg.cp = w.cp; pg.cp_bstride = (long)NL * C * G.T;
             pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.halo = w.halo;
             pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
-            pg.B = G.B; pg.T = G.T; pg.tiles = tiles;
-            for (int b = 0; b < G.B; ++b) {
-                int act = tiles;
-                if (G.active_frames) {
-                    const long need = (long)G.active_frames[b] + reach;
-                    act = (int)std::min<long>(tiles, std::max<long>(1, (need + 63) / 64));
-                }
+            pg.B = Bk; pg.T = G.T; pg.tiles = tiles;
+            for (int b = 0; b < Bk; ++b) {
+                const int act = (int)utt_tiles(G, b, i);
                 utts.push_back({g, b, act});
                 total += act;
             }
