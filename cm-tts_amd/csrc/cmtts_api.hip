@@ -1836,7 +1836,10 @@ void cmtts_vocoder_destroy(cmtts_vocoder* v) {
 }
 // Row padding of the stage buffers (floats).  Power-of-two row strides were suspected of HBM channel
 // camping; padding by 256 B or 4 KB + 128 B changed the vocoder time by < 2 %, so rows stay dense.
-static int voc_row_pad() { return 0; }
+static int voc_row_pad() {      // extra floats per row of the stage buffers (experiment switch CMTTS_VOC_PAD: power-of-two row strides put every channel row of a column block on the same HBM channel)
+    static const int p = [] { const char* e = getenv("CMTTS_VOC_PAD"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 4096 ? v & ~3 : 0; }();
+    return p;
+}
 // The three ResBlocks of an MRF stage are independent until their sum: they run on three streams (own xt / residual
 // buffers, + 4 stage buffers of workspace).  Small batches, whose convs cannot fill the chip (stage 2 has B*T/2
 // workgroups), gain most — one 150-frame utterance 4.1 -> 2.7 ms — and 32 x 512 frames still 1 % (tails of one ResBlock's

@@ -21,6 +21,12 @@ namespace {
 //   * K loops = conv_loop16 (hand-issued weight ring), six per tile, a barrier after each.
 // Element by element the arithmetic is the pair kernel's (conversions, accumulation order, epilogue expressions, zero outside
 // [0, T)) => bitwise equal to three pair launches (tests/test_gpu_parity.py::test_vocoder_pair16_kernel_bitwise).
+// -DRB16_STAMP (tools/rb16_exp.sh, tools/rb16_phases.py): every wave stamps the cycle counter at its phase boundaries; results unchanged
+#ifndef RB16_STAMP
+#define RB16_STAMP 0
+#endif
+long long* g_rb16_dbg = nullptr;
+
 struct Rb16Args {
     const float* x;       // [B][C][ld]
     float* y;             // [B][C][ld] MRF sum (y += result when accum)
@@ -32,6 +38,7 @@ struct Rb16Args {
     int B, C, T, ld;
     int accum;
     float slope;
+    long long* dbg;       // RB16_STAMP builds: [grid][waves][16] cycle stamps
 };
 
 template <int C, int KT, int MODE>
@@ -63,6 +70,11 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
     const float slope = a.slope;
     const float* xb = a.x + (long)b * a.bstride;
     const int col0 = nq * (NT * 32);
+    auto stamp = [&](int slot) {
+        if (RB16_STAMP && a.dbg && lane == 0)
+            a.dbg[(((long)b * gridDim.x + blockIdx.x) * NWAVES + w) * 16 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    stamp(0);
 
     {   // stage convert(leaky(x)) for rows 0 .. ROWS-1 (t = tb - MARGIN + row): the margins hold real neighbours of the tile
         constexpr int PAIRS = C / 2 / NWAVES;               // channel pairs per wave: 4
@@ -108,7 +120,9 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
             res[j][r] = in ? v : 0.f;
         }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     f32x16 acc[NT];
     constexpr int DIL[3] = {1, 3, 5};
@@ -116,6 +130,7 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
     for (int p = 0; p < 3; ++p) {
         // conv1 (dilation d): output column c reads x rows (MARGIN + c) + (tap - R) d
         conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w1f[p], Xs + (MARGIN - R * DIL[p]) * RS, DIL[p], mt, col0, lane);
+        stamp(3 + 4 * p);
         {
             float bi[16];
 #pragma unroll
@@ -148,8 +163,10 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
             }
         }
         __syncthreads();
+        stamp(4 + 4 * p);
         // conv2 (dilation 1): output column c reads xt rows (MARGIN + c) + (tap - R)
         conv_loop16<C, KT, NT, MODE>(acc, (const u32x4*)a.w2f[p], XTs + (MARGIN - R) * RS, 1, mt, col0, lane);
+        stamp(5 + 4 * p);
         {
             float bi[16];
 #pragma unroll
@@ -194,23 +211,39 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
             }
         }
         if (p < 2) __syncthreads();
+        stamp(6 + 4 * p);
     }
-    // the block's output on the NOUT central columns: y (+)= x_3
+    // the block's output on the NOUT central columns: y (+)= x_3; the old sum of all tiles is requested before the first store
     float* yb = a.y + (long)b * a.bstride;
+    if (a.accum) {
+        float yv[NT][16];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int c = col0 + j * 32 + l31;
-        const int t = tb + c;
-        const bool ok = c >= H && c < H + NOUT && t < T;     // t >= 0 follows from c >= H
-        const int t_c = min(max(t, 0), T - 1);
-        float yv[16];
+        for (int j = 0; j < NT; ++j) {
+            const int t_c = min(max(tb + col0 + j * 32 + l31, 0), T - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) yv[r] = a.accum ? yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c] : 0.f;
-        if (ok) {
+            for (int r = 0; r < 16; ++r) yv[j][r] = yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c];
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = res[j][r] + yv[r];
+        for (int j = 0; j < NT; ++j) {
+            const int c = col0 + j * 32 + l31;
+            const int t = tb + c;
+            if (c >= H && c < H + NOUT && t < T) {     // t >= 0 follows from c >= H
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = res[j][r] + yv[j][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = col0 + j * 32 + l31;
+            const int t = tb + c;
+            if (c >= H && c < H + NOUT && t < T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = res[j][r] + 0.f;
+            }
         }
     }
+    stamp(15);
 }
 
 template <int C, int KT, int MODE>
@@ -226,12 +259,18 @@ int launch_rb16(const Rb16Args& a, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((a.T + NOUT - 1) / NOUT, a.B);
-    hipLaunchKernelGGL((resblock16_kernel<C, KT, MODE>), grid, dim3(C * 8), lds, stream, a);
+    Rb16Args c = a;
+    c.dbg = g_rb16_dbg;
+    hipLaunchKernelGGL((resblock16_kernel<C, KT, MODE>), grid, dim3(C * 8), lds, stream, c);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int MODE>
 int dispatch_rb16(const Rb16Args& a, int k, hipStream_t s) {
+#ifdef RB16_DEV               // quick experimental builds: ONE bf16 instance (-DRB16_DEV_C=64 -DRB16_DEV_K=7), everything else returns -2
+    if (MODE == 1 && a.C == RB16_DEV_C && k == RB16_DEV_K) return launch_rb16<RB16_DEV_C, RB16_DEV_K, 1>(a, s);
+    return -2;
+#endif
     if (a.C == 64) {
         if (k == 3) return launch_rb16<64, 3, MODE>(a, s);
         if (k == 7) return launch_rb16<64, 7, MODE>(a, s);
@@ -246,6 +285,8 @@ int dispatch_rb16(const Rb16Args& a, int k, hipStream_t s) {
 
 }  // namespace
 
+extern "C" void cmtts_rb16_set_debug(long long* dbg) { g_rb16_dbg = dbg; }
+
 // A whole ResBlock (three pairs, dilations 1, 3, 5, kernel k) of a narrow stage in one launch, 16-bit operands (resblock16_kernel).
 // w1f / w2f / b1 / b2: the three pairs' conv1 / conv2 fragments ([tap][C/16][C/32][64][8]) and biases.  x must not alias y.
 extern "C" int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, const void* const* w2f, const float* const* b1,
@@ -256,6 +297,6 @@ extern "C" int cmtts_launch_resblock16(const float* x, float* y, const void* con
     Rb16Args a;
     a.x = x; a.y = y;
     for (int p = 0; p < 3; ++p) { a.w1f[p] = w1f[p]; a.w2f[p] = w2f[p]; a.b1[p] = b1[p]; a.b2[p] = b2[p]; }
-    a.bstride = bstride; a.B = B; a.C = C; a.T = T; a.ld = ld; a.accum = accum; a.slope = slope;
+    a.bstride = bstride; a.B = B; a.C = C; a.T = T; a.ld = ld; a.accum = accum; a.slope = slope; a.dbg = nullptr;
     return mode == 1 ? dispatch_rb16<1>(a, k, (hipStream_t)stream_) : dispatch_rb16<2>(a, k, (hipStream_t)stream_);
 }
