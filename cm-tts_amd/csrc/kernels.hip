@@ -74,13 +74,17 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* texts,
 
 // ---- LayerNorm over the 256 channels of a channel-major tensor (model/blocks.py:88-107 eps 1e-12,
 // model/modules.py:74 eps 1e-5); optional zeroing of columns >= lens[b].
+// Reductions by WAVE SHUFFLES (round 3; BASELINE.json north_star): a wave = 8 columns x 8 channel phases (lane = 8 y + x), a lane sums the 32
+// channels y + 8 i of its column, and the eight partial sums of a column — lanes x, 8 + x, ..., 56 + x — are added in the order y = 0..7 with
+// eight __shfl: the SAME association as the LDS reduction it replaces and as conv_xres.hip's fused LayerNorm prologue (bit-identical), without
+// LDS and without the three workgroup barriers.
 __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, float* out, const float* gamma,
                                                            const float* beta, float eps, const int64_t* lens,
                                                            int T, int ld) {
     constexpr int C = 256;
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + tx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int tx = lane & 7, ty = lane >> 3;
+    const int t = blockIdx.x * 32 + w * 8 + tx;
     const int b = blockIdx.y;
     const bool ok = t < T;
     float v[32];
@@ -91,21 +95,16 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float* in, floa
         v[i] = ok ? in[((long)b * C + c) * ld + t] : 0.f;
         sum += v[i];
     }
-    red[ty][tx] = sum;
-    __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) tot += red[y][tx];
+    for (int y = 0; y < 8; ++y) tot += __shfl(sum, y * 8 + tx);
     const float mean = tot / (float)C;
-    __syncthreads();
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; sq = __fmaf_rn(d, d, sq); }   // explicit: conv_xres.hip's fused LayerNorm repeats exactly this sequence
-    red[ty][tx] = sq;
-    __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) var += red[y][tx];
+    for (int y = 0; y < 8; ++y) var += __shfl(sq, y * 8 + tx);
     var = var / (float)C;
     const float rstd = 1.0f / sqrtf(var + eps);
     const bool keep = !(lens && (int64_t)t >= lens[b]);
