@@ -14,7 +14,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int N1 = 256;          // columns of xt per workgroup
-constexpr int RING = 8;          // A fragments in flight per wave (by hand, see conv_loop16): an L2 hit takes ~0.7 us = several groups of 2-4 MFMAs
+#ifndef CL16_RING
+#define CL16_RING 8
+#endif
+constexpr int RING = CL16_RING;  // A fragments in flight per wave (by hand, see conv_loop16): an L2 hit takes ~0.7 us = several groups of 2-4 MFMAs
 constexpr int R1MAX = 25;
 
 template <int MODE>
