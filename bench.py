@@ -21,8 +21,10 @@ import time
 
 # CPU-baseline hygiene: OpenMP worker i stays on core i for the whole run (set before torch creates
 # its thread pool), so the host-side timing does not depend on where the scheduler happens to move the workers
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# — single-process runs only: under torch.distributed.run every rank would bind its initial thread to the same first core.
+if os.environ.get("WORLD_SIZE", "1") == "1":
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 import torch
