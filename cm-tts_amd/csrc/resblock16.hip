@@ -3,6 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "conv_loop16.h"
 
+#ifndef RB16_W
+#define RB16_W 384
+#endif
+#ifndef RB16_OCC
+#define RB16_OCC 2
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -42,13 +49,13 @@ struct Rb16Args {
 };
 
 template <int C, int KT, int MODE>
-__global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) {      // C = 64: 8 waves (two per SIMD: one 118-KB workgroup per CU)
+__global__ __launch_bounds__(C * 8, RB16_OCC) void resblock16_kernel(const Rb16Args a) {      // C = 64: 8 waves (two per SIMD: one 118-KB workgroup per CU)
     constexpr int RS = C + 4;
     constexpr int R = (KT - 1) / 2;
     constexpr int H = 12 * R;                               // (1 + 3 + 5) R for the dilated convs + 3 R for the plain ones
     // columns every conv is evaluated on (C = 64 with 192 columns, 4 waves and two workgroups per CU — one's epilogues under the other's K loops — was
     // tried: k = 7 1365 -> 1511 us, k = 3 739 -> 704: the recomputed halo columns cost more than the overlap gives)
-    constexpr int W = 384;
+    constexpr int W = RB16_W;
     constexpr int NOUT = W - 2 * H;                         // 264 / 312 / 360
     constexpr int MARGIN = 5 * R;                           // largest reach of one conv: rows a conv may read beyond the tile
     constexpr int ROWS = W + 2 * MARGIN;
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(C * 8, 2) void resblock16_kernel(const Rb16Args a) 
 template <int C, int KT, int MODE>
 int launch_rb16(const Rb16Args& a, hipStream_t stream) {
     constexpr int R = (KT - 1) / 2;
-    constexpr int NOUT = 384 - 24 * R;
-    const size_t lds = (size_t)2 * (384 + 10 * R) * (C + 4) * sizeof(unsigned short);
+    constexpr int NOUT = RB16_W - 24 * R;
+    const size_t lds = (size_t)2 * (RB16_W + 10 * R) * (C + 4) * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, KT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
