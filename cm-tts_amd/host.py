@@ -156,6 +156,7 @@ class CMTotalTTS(torch.nn.Module):
         results at a fraction of the fp32 matrix cost (large batches: the persistent stack; others run exact fp32)."""
         mode = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2, "fp16x3": 3}[dtype]
         _lib.check(self.lib.cmtts_set_precision(self._h, mode))
+        self._precision_mode = mode
         return self
 
     def set_option(self, name, value):
@@ -862,17 +863,20 @@ class BucketedSynthesizer:
         main = torch.cuda.current_stream(dev)
         out = []
         lib = self.model.lib
-        prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None and self.mode != "ragged" else None
+        prev = lib.cmtts_set_persistent_denoiser(self.persistent) if self.persistent is not None and (self.mode != "ragged" or getattr(self.model, "_precision_mode", 0) != 0) else None
         # the groups already overlap across streams; the library's own side streams (independent branches of one group)
         # would only add streams competing for the few hardware queues HIP maps them onto (25 -> 31-39 ms measured)
         prev_branch = lib.cmtts_set_option(b"branch_streams", 0)
         groups = list(groups)
+        mode = self.mode
+        if mode == "ragged" and getattr(self.model, "_precision_mode", 0) != 0:
+            mode = "streams"      # the one-launch form is the fp32 persistent kernel's: 16-bit models keep one stream per bucket group
         # "ragged": a shard whose padded tiles exceed the CU count needs a second round of the persistent launch unless a few SMALL
         # groups are left out (cmtts_sample_ragged sets them aside itself once the lengths are known).  When the padded sizes already
         # say so, those groups run END TO END on their own stream right away — their sampler (per-layer kernels) then overlaps the
         # text side of the large groups instead of following it.  The guess only moves work between streams: results are per group.
         early = set()
-        if self.mode == "ragged" and self.trim:
+        if mode == "ragged" and self.trim:
             cap = torch.cuda.get_device_properties(dev).multi_processor_count
             tiles = [int(g[0].shape[0]) * ((int(g[4]) + 63) // 64) for g in groups]
             order = sorted(range(len(groups)), key=lambda i: tiles[i])
@@ -892,7 +896,7 @@ class BucketedSynthesizer:
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
-                    if self.mode != "ragged" or i in early:
+                    if mode != "ragged" or i in early:
                         prev_p = lib.cmtts_set_persistent_denoiser(0) if i in early else None
                         mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
                         if prev_p is not None:
@@ -900,7 +904,7 @@ class BucketedSynthesizer:
                         done[i] = (mel, o["mel_lens"])
                 conds.append((i, o))
             conds = [o for _, o in sorted(conds, key=lambda t: t[0])]
-            if self.mode != "ragged":
+            if mode != "ragged":
                 out = [done[i] for i in range(len(groups))]
         finally:
             lib.cmtts_set_option(b"branch_streams", prev_branch)
@@ -910,7 +914,7 @@ class BucketedSynthesizer:
         for st in self.streams:
             if id(st) not in early_streams:      # the early groups' streams are joined after the persistent launches are queued
                 main.wait_stream(st)
-        if self.mode == "ragged":
+        if mode == "ragged":
             late = [i for i in range(len(groups)) if i not in early]
             lens = [conds[i]["mel_lens"] for i in late]
             active = [None] * len(late)

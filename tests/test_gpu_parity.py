@@ -1216,6 +1216,19 @@ def test_bucketed_synthesizer_streams_match_sequential():
     torch.cuda.synchronize()
     for (m0, l0), (m1, l1) in zip(seq, par):
         assert torch.equal(l0, l1) and torch.equal(m0, m1)
+    # a 16-bit model: the default ("ragged") mode keeps one stream per group (the one-launch form is the fp32 persistent kernel's)
+    model.set_precision("bf16")
+    try:
+        seq16 = []
+        for tx, ln, spk, nz, bucket in groups:
+            o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
+            seq16.append(host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], 2, nz))
+        par16 = host.BucketedSynthesizer(model, n_steps=2, n_streams=3).run(groups)
+        host.synchronize()
+    finally:
+        model.set_precision("fp32")
+    for m0, (m1, _) in zip(seq16, par16):
+        assert torch.equal(m0, m1)
 
 
 @pytest.mark.parametrize("n_steps", [1, 4])
