@@ -429,7 +429,7 @@ def main():
                      "flops_per_launch": flops_launch},
     }
 
-    if (world > 1 or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:
+    if (world > 1 or gather or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:      # gather: CMTTS_FORCE_COLLECTIVE=1 on one GPU
         # every rank takes part: T = 1 / 2, configs[3] and configs[4] with their collectives (whole-job aggregates)
         result["extras"] = multi_gpu_extras(args, cfg, model, step, lambda f, k, w: timed(f, k, w, world, flush=flush), state,
                                             frames_rank, audio_s, rank, world, device, gather)
