@@ -1286,6 +1286,16 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
             assert not m2[b, cut:].any()
             saved += m0.shape[1] - cut
     assert saved > 0, "the shard has nothing to trim: the test is vacuous"
+    if n_steps == 1:
+        # tail_frames = 16 covers HiFi-GAN's receptive field (conv_pre 3 frames + the k = 11 ResBlock of the first stage 7.5 + ...): the
+        # int16 wav of every utterance, cut to mel_len * hop as vocoder_infer does, is the same from the trimmed and the full mel
+        hcfg = HifiGanConfig()
+        voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=3))
+        for (m0, l0), (m2, _) in zip(seq[:2], trim[:2]):
+            lens_w = (l0 * cfg.hop_length).tolist()
+            w_full = host.vocoder_infer(m0.transpose(1, 2).contiguous(), voc, lengths=lens_w)
+            w_trim = host.vocoder_infer(m2.transpose(1, 2).contiguous(), voc, lengths=lens_w)
+            assert all(np.array_equal(a, b) for a, b in zip(w_full, w_trim))
     # (d) 15 x 16 + 8 x 4 = 272 padded tiles: leaving the small group out fits one round — it is set aside for the ordinary sampler
     # (per-layer kernels on the side stream) while the large one takes the persistent launch
     mixed = make((1024,), 15) + make((256,), 8)
