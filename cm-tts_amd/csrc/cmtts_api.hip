@@ -307,6 +307,7 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
+int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
 int g_voc_rb16 = 1;             // 16-bit HiFi-GAN, C <= 64: a whole ResBlock (three pairs) per launch (same bits); 0 = one launch per pair
@@ -1954,7 +1955,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             const bool pair128 = g_voc_pair128 && co == 128 && rk == 3 && (v->precision == 1 || v->precision == 2);
             // 16-bit, C = 128 (round 3): the pair in ONE launch with a single in-place image (81 KB: two workgroups per CU, 2 x 4 tiles per wave)
             const bool pairw = g_voc_pairw && co == 128 && (v->precision == 1 || v->precision == 2);
-            bool pair_ok = g_voc_pair && (co <= 64 || pair128 || pairw) && v->precision != 3 &&
+            // fp16x3 (round 3): the pair X-resident with (hi, lo) images, C <= 128 (resblock_pair16x3.hip; same bits as the two conv16 launches)
+            const bool pair3 = g_voc_pair3 && v->precision == 3 && co <= 128;
+            bool pair_ok = g_voc_pair && (co <= 64 || pair128 || pairw || pair3) && (v->precision != 3 || pair3) &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
@@ -1969,6 +1972,7 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 pa.accum = lastm && j > 0; pa.slope = 0.1f;
                 int prc;
                 if (!v->precision) prc = cmtts_launch_resblock_pair(&pa, (void*)q);
+                else if (pair3) prc = cmtts_launch_resblock_pair16x3(&pa, (void*)q);
                 else if (pairw) prc = cmtts_launch_resblock_pairw16(&pa, v->precision, (void*)q);
                 else prc = cmtts_launch_resblock_pair16(&pa, v->precision, (void*)q);
                 if (prc == -2 && mi == 0) {      // this (C, k, dilation) is not covered by the pair kernels: the per-conv path below
@@ -2014,6 +2018,24 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = (const float*)v->c2f[r][mi][v->precision - 1];
                         xa.bias = v->c2[r][mi].bias; xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
                         if (cmtts_launch_conv_xl16(&xa, v->precision, 2, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xl16 launch failed");
+                        if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                        xr = bR;
+                        continue;
+                    }
+                }
+                if (g_voc_pair3 && v->precision == 3 && co == 256 && v->c1f[r][mi][2]) {
+                    // fp16x3, C = 256: X-resident single convs with (hi, lo) images (conv_xl16x3_kernel); xt crosses HBM in fp32
+                    ConvXlArgs xa;
+                    memset(&xa, 0, sizeof(xa));
+                    xa.x = xr; xa.y = bT; xa.wf = (const float*)v->c1f[r][mi][2]; xa.bias = v->c1[r][mi].bias;
+                    xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f;
+                    const int rc1 = cmtts_launch_conv_xl16x3(&xa, (void*)q);
+                    if (rc1 == -3) return fail(CMTTS_E_HIP, "conv_xl16x3 launch failed");
+                    if (rc1 == 0) {
+                        if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                        xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = (const float*)v->c2f[r][mi][2];
+                        xa.bias = v->c2[r][mi].bias; xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
+                        if (cmtts_launch_conv_xl16x3(&xa, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xl16x3 launch failed");
                         if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                         xr = bR;
                         continue;
@@ -2145,6 +2167,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"pred_xl", &g_pred_xl, 0, 1},             // frame-level predictor convs on conv_xl
         {"pred_head", &g_pred_head, 0, 1},         // LayerNorm + linear head in one launch
         {"voc_pair", &g_voc_pair, 0, 2},           // HiFi-GAN ResBlock pairs (C <= 64) as one launch
+        {"voc_pair3", &g_voc_pair3, 0, 1},         // fp16x3 pairs: one X-resident launch (resblock_pair16x3.hip)
         {"voc_pairw", &g_voc_pairw, 0, 1},         // 16-bit C = 128 pairs: one launch, one in-place LDS image (resblock_pairw16.hip)
         {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel (two images, one workgroup per CU; only when voc_pairw = 0)
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always

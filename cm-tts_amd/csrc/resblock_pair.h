@@ -54,6 +54,10 @@ int cmtts_launch_resblock16(const float* x, float* y, const void* const* w1f, co
                             int mode, void* stream);
 // wide stages (C = 128): the pair in one launch with ONE in-place 16-bit image, two workgroups per CU (resblock_pairw16.hip)
 int cmtts_launch_resblock_pairw16(const PairArgs* a, int mode, void* stream);
+// the pair with fp16x3 operands (resblock_pair16x3.hip): w1f / w2f = hi fragment set followed by the lo set; C = 32 / 64 / 128
+int cmtts_launch_resblock_pair16x3(const PairArgs* a, void* stream);
+// one conv of the C = 256 stage, fp16x3 operands, fp32 in / out (same file)
+int cmtts_launch_conv_xl16x3(const ConvXlArgs* a, void* stream);
 void cmtts_pair_set_debug(long long* dbg);
 #ifdef __cplusplus
 }

@@ -1496,6 +1496,31 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
 
 
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
+def test_vocoder_pair16x3_bitwise(B, T):
+    """resblock_pair16x3.hip (fp16x3 operands: one X-resident launch per ResBlock pair of the C = 128 / 64 / 32 stages, (hi, lo) LDS
+    images of x and xt) keeps conv_mfma16.hip MODE 3's split arithmetic, (chunk, tap, k-group) order with the small terms first and
+    its epilogue expressions: the wav must not change by a bit against two chunked launches per pair.  T = 1 / 7: tiles that are all
+    halo; 61 / 130: ragged last tiles at every stage (x 8, x 64, x 128, x 256 frames)."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=9))
+    voc.set_precision("fp16x3")
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(70 + T)) * 1.5 - 4).to(DEV)
+    prev = _lib.internal_set(b"voc_pair3", 0)
+    try:
+        ref = voc(mel).clone()
+        _lib.internal_set(b"voc_pair3", 1)
+        got = voc(mel).clone()
+        got2 = voc(mel).clone()
+        torch.cuda.synchronize()
+    finally:
+        _lib.internal_set(b"voc_pair3", prev)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert torch.equal(got2, ref)
+
+
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
 def test_vocoder_upsampler_kernel_bitwise(B, T):
     """convT_xl_kernel (all stride phases of a HiFi-GAN ConvTranspose1d in one X-resident launch: a two-tap conv with s * C_out
     stacked rows and a phase-interleaving store) against the generic kernel run once per phase: same staging arithmetic (x / 3,
