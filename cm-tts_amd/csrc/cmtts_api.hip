@@ -502,7 +502,7 @@ struct cmtts_vocoder {
     PackedConv conv_pre;
     PackedConv ups[4];
     float* ups_f[4] = {nullptr, nullptr, nullptr, nullptr};   // two-tap stacked-phase weights as iteration-order fragments (convT_xl_kernel)
-    void* ups_f16[4][2] = {};                                  // the same as bf16 / fp16 fragments (convT_xl16_kernel)
+    void* ups_f16[4][3] = {};                                  // the same as bf16 / fp16 / fp16x3 (hi | lo) fragments (convT_xl16_kernel)
     int up_rate[4] = {8, 8, 2, 2};
     int up_kernel[4] = {16, 16, 4, 4};
     int rb_kernel[3] = {3, 7, 11};
@@ -1786,6 +1786,8 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                     const std::vector<unsigned short> f16 = to_fragment16(tt, 2, ch, mrows, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->ups_f16[i][mode - 1]));
                 }
+                const std::vector<unsigned short> fs = to_fragment16_split(tt, 2, ch, mrows);
+                CHK(al.upload_bytes(fs.data(), fs.size() * 2, &v->ups_f16[i][2]));
             }
         }
         for (int j = 0; j < 3; ++j) {
@@ -1888,8 +1890,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
         {   // x = ups[i](leaky_relu(x, 0.1)) as `st` polyphase sub-convolutions (hifigan/models.py:152-153)
             const PackedConv& U = v->ups[i];
             int rt = -2;
-            if (v->ups16 && (v->precision == 1 || v->precision == 2) && v->ups_f16[i][v->precision - 1] && K == 2 * st)
-                // 16-bit modes: the upsamplers' operands are 16-bit too (since round 2; the oracle's operands16 modes follow)
+            if (v->ups16 && v->precision >= 1 && v->precision <= 3 && v->ups_f16[i][v->precision - 1] && K == 2 * st)
+                // 16-bit modes: the upsamplers' operands are 16-bit too (since round 2; the oracle's operands16 modes follow); fp16x3 (round 3):
+                // (hi, lo) operand pairs like the ResBlock convs
                 rt = cmtts_launch_convT16(bufA, bufU, v->ups_f16[i][v->precision - 1], U.bias, (long)ch * (Ti + P), (long)co * (To + P), B, ch,
                                           co, Ti, To, Ti + P, To + P, st, i > 0 ? 3.0f : 1.0f, 0.1f, v->precision, (void*)s);
             if (rt == -3) return fail(CMTTS_E_HIP, "convT16 launch failed");

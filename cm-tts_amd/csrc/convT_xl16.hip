@@ -21,10 +21,15 @@ struct ConvT16Args {
     float pre_div, slope;
 };
 
+// MODE 3 ("fp16x3", round 3): `src` is the hi image with the lo image `img` elements further, `wfrag` the hi fragment set with the lo set `wset`
+// fragments further; every product is three fp16 MFMAs, small terms first (resblock_pair16x3.inc).
 template <int CIN, int NT, int MODE>
 __device__ __forceinline__ void conv_loopT16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
-                                             int mt, int mtiles, int lane) {
+                                             int mt, int mtiles, int lane, int img = 0, long wset = 0) {
     constexpr int RS = CIN + 4;
+    constexpr int NS = MODE == 3 ? 2 : 1;
+    constexpr int MM = MODE == 3 ? 2 : MODE;
+    constexpr int RINGT = MODE == 3 ? 4 : RING;
     constexpr int G = CIN / 16;
     constexpr int NG = G * 2;                       // (32-channel chunk, tap, k-group)
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -38,41 +43,54 @@ __device__ __forceinline__ void conv_loopT16(f32x16 (&acc)[NT], const u32x4* __r
         kgl = it & 1;
     };
     const unsigned short* bl = src + l31 * RS + khalf * 8;      // src = row of column c + 1 (tap 0 reads x[m], tap 1 x[m - 1])
-    auto load_b = [&](u32x4 (&dst)[NT], int it) {
+    auto load_b = [&](u32x4 (&dst)[NT][NS], int it) {
         int chunk, tap, kgl;
         grp(it, chunk, tap, kgl);
         const unsigned short* p = bl - tap * RS + chunk * 32 + kgl * 16;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
-            dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-        }
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(p + q * img + j * 32 * RS);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(p + q * img + j * 32 * RS + 4);
+                dst[j][q] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
     };
-    u32x4 A[RING];
-    auto issue_a = [&](u32x4& dst, int it) {
+    u32x4 A[RINGT][NS];
+    auto issue_a = [&](u32x4 (&dst)[NS], int it) {
         int chunk, tap, kgl;
         grp(it, chunk, tap, kgl);
         const u32x4* ptr = wfrag + ((long)(tap * G + 2 * chunk + kgl) * mtiles + mt) * 64 + lane;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(ptr) : "memory");
+        if (NS == 2) {
+            const u32x4* ptr2 = ptr + wset;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[NS - 1]) : "v"(ptr2) : "memory");
+        }
     };
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s)
+    for (int s = 0; s < RINGT - 1; ++s)
         if (s < NG) issue_a(A[s], s);
-    u32x4 Bf[2][NT];
+    u32x4 Bf[2][NT][NS];
     load_b(Bf[0], 0);
     auto body = [&](int it) {
-        if (it + RING - 1 < NG) {
-            issue_a(A[(it + RING - 1) % RING], it + RING - 1);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RING]) : "n"(RING - 1));
+        if (it + RINGT - 1 < NG) {
+            issue_a(A[(it + RINGT - 1) % RINGT], it + RINGT - 1);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A[it % RINGT][0]) : "n"((RINGT - 1) * NS));
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RING]));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A[it % RINGT][0]));
         }
+        if (NS == 2) asm volatile("" : "+v"(A[it % RINGT][NS - 1]));        // the lo fragment of the pair: same wait
         if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
+        if (NS == 2) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            for (int j = 0; j < NT; ++j) acc[j] = mma16<MM>(A[it % RINGT][NS - 1], Bf[it & 1][j][0], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = mma16<MM>(A[it % RINGT][0], Bf[it & 1][j][NS - 1], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = mma16<MM>(A[it % RINGT][0], Bf[it & 1][j][0], acc[j]);
+        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT * NS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT * (NS == 2 ? 3 : 1), 0);
     };
     seg_loop<0, NG, 32>(body);
 }
@@ -82,7 +100,10 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
     constexpr int RS = CIN + 4;
     constexpr int BN = 64, NT = 2;
     constexpr int XROWS = BN + 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned short xt16[];   // [XROWS][RS], row j <-> m = t0 - 1 + j
+    constexpr int NS = MODE == 3 ? 2 : 1;                                   // fp16x3: (hi, lo) images
+    constexpr int MM = MODE == 3 ? 2 : MODE;
+    constexpr int XIMG = (XROWS * RS + 7) & ~7;
+    extern __shared__ __attribute__((aligned(16))) unsigned short xt16[];   // [NS][XROWS][RS], row j <-> m = t0 - 1 + j
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31;
     const int b = blockIdx.y, t0 = blockIdx.x * BN;
@@ -112,7 +133,12 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
                         if (a.pre_div != 1.0f) { u0 = u0 / a.pre_div; u1 = u1 / a.pre_div; }
                         u0 = u0 > 0.f ? u0 : u0 * a.slope;
                         u1 = u1 > 0.f ? u1 : u1 * a.slope;
-                        *reinterpret_cast<unsigned*>(xt16 + j * RS + (w * PAIRS + p0 + p) * 2) = pack16<MODE>(u0, u1);
+                        const unsigned hi = pack16<MM>(u0, u1);
+                        *reinterpret_cast<unsigned*>(xt16 + j * RS + (w * PAIRS + p0 + p) * 2) = hi;
+                        if (MODE == 3) {
+                            const cvt_f16x2 h = __builtin_bit_cast(cvt_f16x2, hi);
+                            *reinterpret_cast<unsigned*>(xt16 + XIMG + j * RS + (w * PAIRS + p0 + p) * 2) = pack16<2>(u0 - (float)h[0], u1 - (float)h[1]);
+                        }
                     }
                 }
             }
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
     // LDS tile [rows][phase][PS] (phase-major: conflict-free writes) and the workgroup stores whole rows, consecutive lanes = consecutive samples
     // (stride 8: 546 -> 371 us at C_in = 256, 224 -> 182 at 512; bitwise the same values).
     constexpr int PS = 40;                               // phase stride in floats (32 columns + 8: the interleaving reads are 2-way at worst)
-    float* ot = reinterpret_cast<float*>(xt16 + ((XROWS * RS + 7) & ~7));       // [per * 32][S][PS]
+    float* ot = reinterpret_cast<float*>(xt16 + NS * XIMG);       // [per * 32][S][PS]
     const int lgS = __ffs(S) - 1;
     const int rowlen = S * 32;                           // output samples per row per n-tile
     for (int ps = 0; ps < passes; ++ps) {
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
         const int cb = cb0 + cbl;
         const int mt = phase * (a.CO / 32) + cb;
         f32x16 acc[NT];
-        conv_loopT16<CIN, NT, MODE>(acc, (const u32x4*)a.wf, xt16 + RS, mt, mtiles, lane);
+        conv_loopT16<CIN, NT, MODE>(acc, (const u32x4*)a.wf, xt16 + RS, mt, mtiles, lane, XIMG, (long)2 * (CIN / 16) * mtiles * 64);
         float bi[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) bi[r] = a.bias[cb * 32 + acc_row(r, lane)];
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
 template <int CIN, int NW, int MODE>
 int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
     if (a.s & (a.s - 1)) return -2;                    // the output tile's interleave uses shifts
-    const size_t lds = (((size_t)65 * (CIN + 4) + 7) & ~(size_t)7) * sizeof(unsigned short) + (a.s >= 4 ? (size_t)(NW / a.s) * 32 * a.s * 40 * sizeof(float) : 0);
+    const size_t lds = (MODE == 3 ? 2 : 1) * (((size_t)65 * (CIN + 4) + 7) & ~(size_t)7) * sizeof(unsigned short) + (a.s >= 4 ? (size_t)(NW / a.s) * 32 * a.s * 40 * sizeof(float) : 0);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -207,7 +233,10 @@ int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
 template <int MODE>
 int dispatch_convT16(const ConvT16Args& a, int cin, hipStream_t s) {
     const int mtiles = a.s * a.CO / 32;
-    if (cin == 512 && mtiles >= 8) return launch_convT16<512, 8, MODE>(a, s);
+    if (cin == 512 && mtiles >= 8) {
+        if constexpr (MODE == 3) return -2;             // two 512-channel images + the output tile exceed the LDS: the fp32 upsampler runs this stage
+        else return launch_convT16<512, 8, MODE>(a, s);
+    }
     if (cin == 256 && mtiles >= 8) return launch_convT16<256, 8, MODE>(a, s);
     if (cin == 128 && mtiles >= 4) return launch_convT16<128, 4, MODE>(a, s);
     if (cin == 64 && mtiles >= 2) return launch_convT16<64, 2, MODE>(a, s);
@@ -217,12 +246,13 @@ int dispatch_convT16(const ConvT16Args& a, int cin, hipStream_t s) {
 }  // namespace
 
 // HiFi-GAN upsampler with 16-bit operands (convT_xl16_kernel): arguments as cmtts_launch_convT, wf16 = to_fragment16 of the two-tap
-// stacked weights ([2][cin/16][s co / 32][64][8]), mode 1 = bf16, 2 = fp16.  0 = launched, -2 = shape not covered, -3 = HIP error.
+// stacked weights ([2][cin/16][s co / 32][64][8]), mode 1 = bf16, 2 = fp16, 3 = fp16x3 (the hi fragment set followed by the lo set).  0 = launched, -2 = shape not covered, -3 = HIP error.
 extern "C" int cmtts_launch_convT16(const float* x, float* y, const void* wf16, const float* bias, long xbstride, long ybstride, int B,
                                     int cin, int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, int mode,
                                     void* stream_) {
     if (B <= 0 || Ti <= 0) return 0;
-    if (!wf16 || (s * co) % 32 || To != Ti * s || s < 2 || (s & 1) || (mode != 1 && mode != 2)) return -2;
+    if (!wf16 || (s * co) % 32 || To != Ti * s || s < 2 || (s & 1) || mode < 1 || mode > 3) return -2;
     ConvT16Args a{x, y, wf16, bias, xbstride, ybstride, B, co, Ti, To, ldx, ldy, s, pre_div, slope};
+    if (mode == 3) return dispatch_convT16<3>(a, cin, (hipStream_t)stream_);
     return mode == 1 ? dispatch_convT16<1>(a, cin, (hipStream_t)stream_) : dispatch_convT16<2>(a, cin, (hipStream_t)stream_);
 }

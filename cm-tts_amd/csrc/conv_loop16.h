@@ -19,6 +19,11 @@ constexpr int N1 = 256;          // columns of xt per workgroup
 #endif
 constexpr int RING = CL16_RING;  // A fragments in flight per wave (by hand, see conv_loop16): an L2 hit takes ~0.7 us = several groups of 2-4 MFMAs
 constexpr int R1MAX = 25;
+// padding of an LDS image row [column][C + CL16_PAD] in 16-bit elements: 4 = a B fragment is two conflict-free ds_read_b64; 8 (rows a multiple of
+// 16 bytes) = one ds_read_b128.  Every kernel that includes this header lays its images out with the same constant.
+#ifndef CL16_PAD
+#define CL16_PAD 4
+#endif
 
 template <int MODE>
 __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -43,7 +48,7 @@ __device__ __forceinline__ void seg_loop(F& body) {
 template <int C, int KT, int NT, int MODE>
 __device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
                                             int dil, int mt, int col0, int lane) {
-    constexpr int RS = C + 4;
+    constexpr int RS = C + CL16_PAD;
     constexpr int G = C / 16, MTn = C / 32;
     constexpr int NG = G * KT;                      // MFMA k-groups: (chunk, tap, k-group-in-chunk)
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -66,6 +71,10 @@ __device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __re
         const unsigned short* p = bl + (tap * dil) * RS + chunk * 32 + kgl * 16;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            if (CL16_PAD == 8) {
+                dst[j] = *reinterpret_cast<const u32x4*>(p + j * 32 * RS);
+                continue;
+            }
             const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
             dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
@@ -97,7 +106,7 @@ __device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __re
         if (it + 1 < NG) load_b(Bf[(it + 1) & 1], it + 1);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = mma16<MODE>(A[it % RING], Bf[it & 1][j], acc[j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);       // the next group's B fragments
+        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, (CL16_PAD == 8 ? 1 : 2) * NT, 0);       // the next group's B fragments
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // under this group's MFMAs
     };
     // full unrolling in segments of 44 groups: one loop of 112 / 176 groups (C = 256) exceeds the compiler's size limit for
@@ -112,7 +121,7 @@ __device__ __forceinline__ void conv_loop16(f32x16 (&acc)[NT], const u32x4* __re
 template <int C, int KT, int MT, int NT, int MODE>
 __device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4* __restrict__ wfrag, const unsigned short* __restrict__ src,
                                              int dil, int mt0, int col0, int lane) {
-    constexpr int RS = C + 4;
+    constexpr int RS = C + CL16_PAD;
     constexpr int G = C / 16, MTn = C / 32;
     constexpr int NG = G * KT;
     constexpr int RINGM = 6;
@@ -136,6 +145,10 @@ __device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4*
         const unsigned short* p = bl + (tap * dil) * RS + chunk * 32 + kgl * 16;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            if (CL16_PAD == 8) {
+                dst[j] = *reinterpret_cast<const u32x4*>(p + j * 32 * RS);
+                continue;
+            }
             const u32x2 lo = *reinterpret_cast<const u32x2*>(p + j * 32 * RS);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(p + j * 32 * RS + 4);
             dst[j] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
@@ -170,7 +183,7 @@ __device__ __forceinline__ void conv_loop16m(f32x16 (&acc)[MT][NT], const u32x4*
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i) acc[i][j] = mma16<MODE>(A[it % RINGM][i], Bf[it & 1][j], acc[i][j]);
-        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
+        if (it + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, (CL16_PAD == 8 ? 1 : 2) * NT, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
     };
     seg_loop<0, NG, 22>(body);

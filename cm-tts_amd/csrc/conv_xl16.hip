@@ -1,6 +1,7 @@
 // conv_xl16_kernel: ONE conv of a wide (C = 128 / 256) HiFi-GAN ResBlock with 16-bit operands, X-resident (split out of
 // resblock_pair16.hip: a translation unit of its own compiles in minutes instead of nine).
 #include <hip/hip_runtime.h>
+#define CL16_PAD 8          // image rows a multiple of 16 bytes: a B fragment is one ds_read_b128 (bf16 vocoder 14.93 -> 14.80 ms; no gain in the pair kernels)
 #include "conv_loop16.h"
 #include <type_traits>
 
@@ -18,7 +19,7 @@ namespace {
 // ((acc + b) + res) + y_old in fp32 — conv_mfma16.hip's conversions, accumulation order and epilogue => the same bits.
 template <int C, int KT, int MODE, int IO, int BN, int MT>
 __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void conv_xl16_kernel(const ConvXlArgs a) {
-    constexpr int RS = C + 4;
+    constexpr int RS = C + CL16_PAD;
     constexpr int NWAVES = C / 32 / MT;             // MT m-tiles per wave
     constexpr int NT = BN / 32;                     // all n-tiles of the workgroup's columns
     constexpr int XROWS = BN + (KT - 1) * 5;        // widest halo: dilation 5
@@ -162,7 +163,7 @@ template <int C, int KT, int MODE, int IO>
 int launch_xl16(const ConvXlArgs& a, hipStream_t stream) {
     constexpr int BN = (C == 128 || XL16_BN256 == 128) ? 128 : 64;
     constexpr int MT = 1;                            // (C = 128 with two waves of 2 x 4 tiles, conv_loop16m: same K-loop slope, slower staging: 460 / 538 vs 429 / 483 us at k = 11)
-    const size_t lds = (size_t)(BN + (KT - 1) * 5) * (C + 4) * sizeof(unsigned short);
+    const size_t lds = (size_t)(BN + (KT - 1) * 5) * (C + CL16_PAD) * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl16_kernel<C, KT, MODE, IO, BN, MT>),

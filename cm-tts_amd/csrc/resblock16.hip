@@ -50,7 +50,7 @@ struct Rb16Args {
 
 template <int C, int KT, int MODE>
 __global__ __launch_bounds__(C * 8, RB16_OCC) void resblock16_kernel(const Rb16Args a) {      // C = 64: 8 waves (two per SIMD: one 118-KB workgroup per CU)
-    constexpr int RS = C + 4;
+    constexpr int RS = C + CL16_PAD;
     constexpr int R = (KT - 1) / 2;
     constexpr int H = 12 * R;                               // (1 + 3 + 5) R for the dilated convs + 3 R for the plain ones
     // columns every conv is evaluated on (C = 64 with 192 columns, 4 waves and two workgroups per CU — one's epilogues under the other's K loops — was
@@ -257,7 +257,7 @@ template <int C, int KT, int MODE>
 int launch_rb16(const Rb16Args& a, hipStream_t stream) {
     constexpr int R = (KT - 1) / 2;
     constexpr int NOUT = RB16_W - 24 * R;
-    const size_t lds = (size_t)2 * (RB16_W + 10 * R) * (C + 4) * sizeof(unsigned short);
+    const size_t lds = (size_t)2 * (RB16_W + 10 * R) * (C + CL16_PAD) * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, KT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,

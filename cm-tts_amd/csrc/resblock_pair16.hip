@@ -23,7 +23,7 @@ namespace {
 
 template <int C, int KT, int MODE>
 __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kernel(const PairArgs a) {
-    constexpr int RS = C + 4;
+    constexpr int RS = C + CL16_PAD;
     constexpr int NWAVES = C == 128 ? 8 : 4;                // C = 128 (round 2): 8 waves, one 151-KB workgroup per CU
     constexpr int NT = (C / 32) * (N1 / 32) / NWAVES;       // 32x32 tiles per wave: one m-tile x NT n-tiles
     constexpr int WPM = NWAVES / (C / 32);                  // waves per m-tile
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kerne
 template <int C, int KT, int MODE>
 int launch_pair16(const PairArgs& a, hipStream_t stream) {
     constexpr int TT = N1 - (KT - 1);
-    const size_t lds = (size_t)(N1 + 2 * R1MAX + N1 + KT - 1) * (C + 4) * sizeof(unsigned short);
+    const size_t lds = (size_t)(N1 + 2 * R1MAX + N1 + KT - 1) * (C + CL16_PAD) * sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_pair16_kernel<C, KT, MODE>),

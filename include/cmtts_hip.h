@@ -249,7 +249,8 @@ int cmtts_set_precision(cmtts_model* m, int mode);
  * of the generator's FLOPs) AND, by default, the four ConvTranspose1d upsamplers take 16-bit operands
  * (cmtts_vocoder_set_option(v, "ups16", 0) keeps the upsamplers fp32); inside a ResBlock pair the intermediate xt crosses HBM
  * (or stays in LDS) as convert(leaky_relu(xt)) in 16 bits; the stage tensors (residual stream, MRF sum), conv_pre and conv_post
- * stay fp32.  Mode 3 = fp16x3 as above (fp32-class): ResBlock convs only, upsamplers and every HBM tensor fp32. */
+ * stay fp32.  Mode 3 = fp16x3 as above (fp32-class): ResBlock convs and ("ups16", default) upsamplers with (hi, lo) operand pairs,
+ * every HBM tensor fp32. */
 int cmtts_vocoder_set_precision(cmtts_vocoder* v, int mode);
 
 /* Tuning knob of the fused residual block: frames per workgroup (0 = automatic: 64 when that still

@@ -1520,6 +1520,31 @@ def test_vocoder_pair16x3_bitwise(B, T):
     assert torch.equal(got2, ref)
 
 
+@pytest.mark.parametrize("B,T", [(2, 61), (3, 130), (1, 1)])
+def test_vocoder_fp16x3_upsamplers(B, T):
+    """fp16x3 upsamplers (convT_xl16_kernel MODE 3: (hi, lo) images and fragment sets, three fp16 MFMAs per product) against the fp32
+    upsamplers of the same precision mode ("ups16" = 0) and against the all-fp32 generator: fp32-class agreement, not the same bits."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=10))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(90 + T)) * 1.5 - 4).to(DEV)
+    ref32 = voc(mel).clone()
+    voc.set_precision("fp16x3")
+    got = voc(mel).clone()
+    prev = voc.set_option("ups16", 0)
+    try:
+        ref = voc(mel).clone()
+    finally:
+        voc.set_option("ups16", prev)
+    again = voc(mel).clone()
+    torch.cuda.synchronize()
+    scale = float(ref32.abs().max())
+    assert torch.isfinite(got).all() and torch.equal(again, got)
+    assert not torch.equal(got, ref)
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1.0), (float((got - ref).abs().max()), scale)
+    assert float((got - ref32).abs().max()) <= 2e-5 * max(scale, 1.0), (float((got - ref32).abs().max()), scale)
+
+
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
 def test_vocoder_upsampler_kernel_bitwise(B, T):
     """convT_xl_kernel (all stride phases of a HiFi-GAN ConvTranspose1d in one X-resident launch: a two-tap conv with s * C_out
