@@ -2177,6 +2177,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
+        {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);

