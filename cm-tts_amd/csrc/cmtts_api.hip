@@ -321,6 +321,7 @@ int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stage
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
+int g_cond_gemm16 = 1;          // bf16 / fp16 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
@@ -485,6 +486,7 @@ struct cmtts_model {
     float *skip_f = nullptr, *outp_f = nullptr;   // skip / output projection in fragment order (persistent kernel's tail)
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
+    void* cond_all_f16[2] = {nullptr, nullptr};   // bf16 / fp16 fragment-order copies (cond_gemm16.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
     // Step-embedding cache (round 2): the DiffusionEmbedding -> MLP -> 20 stacked diffusion projections of a timestep depend
@@ -769,6 +771,11 @@ int finalize_model(cmtts_model* m) {
         CHK(pack_conv(al, W, &Bv, nullptr, &m->cond_all, &hp));
         if (H % 8 == 0 && (NL * C) % 32 == 0 && m->cond_all.ld == NL * C)
             CHK(al.upload(to_fragment_order(hp, 1, H, NL * C), &m->cond_all_f));
+        if (H % 16 == 0 && (NL * C) % 32 == 0 && m->cond_all.ld == NL * C)
+            for (int mode = 1; mode <= 2; ++mode) {
+                const std::vector<unsigned short> f16 = to_fragment16(hp, 1, H, NL * C, mode);
+                CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->cond_all_f16[mode - 1]));
+            }
     }
     CHK(al.upload(dproj, &m->dproj_wt));
     if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
@@ -934,6 +941,16 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
 // cp[b][l*C + m][t] = conditioner_projection_l(cond)[m][t] + bias: one stacked GEMM, reused by every step
 int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B, int T, hipStream_t s) {
     const cmtts_config& c = m->cfg;
+    if (g_cond_gemm16 && (m->precision == 1 || m->precision == 2) && m->cond_all_f16[m->precision - 1]) {
+        // bf16 / fp16 models: the conditioner projections are residual-block contractions too — 16-bit operands, fp32 accumulate and output
+        // (round 3; the oracle's operands16 modes quantise the same operands).  Shapes the kernel does not take run the fp32 kernels below.
+        CondGemmArgs g;
+        g.X = cond_ct; g.Wf = nullptr; g.bias = m->cond_all.bias; g.Y = w.cp;
+        g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = 1;      // every shape: the numerics of a 16-bit model do not depend on the batch
+        const int r = cmtts_launch_cond_gemm16(&g, m->cond_all_f16[m->precision - 1], m->precision, (void*)s);
+        if (r == 0) return 0;
+        if (r != -2) return fail(CMTTS_E_HIP, "cond_gemm16 launch failed");
+    }
     if (m->cond_all_f) {   // X tile resident in LDS, one walk over all 20 x 256 rows (bitwise equal to the generic kernel)
         CondGemmArgs g;
         g.X = cond_ct; g.Wf = m->cond_all_f; g.bias = m->cond_all.bias; g.Y = w.cp;
@@ -2160,6 +2177,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
@@ -2183,6 +2201,14 @@ int cmtts_internal_set(const char* name, int value) {
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
     if (found) return prev;
     return fail(CMTTS_E_INVALID, "cmtts_internal_set: unknown switch");
+}
+
+int cmtts_internal_cond_projections(cmtts_model* m, const float* cond_ct, int B, int T, float* cp, void* stream) {
+    if (!m || !cond_ct || !cp || B <= 0 || T <= 0) return fail(CMTTS_E_INVALID, "cmtts_internal_cond_projections: bad argument");
+    DenWs w;
+    memset(&w, 0, sizeof(w));
+    w.cp = cp;
+    return cond_projections(m, w, cond_ct, B, T, (hipStream_t)stream);
 }
 
 int cmtts_poll_error(void) {

@@ -14,6 +14,8 @@ struct CondGemmArgs {
 extern "C" {
 #endif
 int cmtts_launch_cond_gemm(const CondGemmArgs* a, void* stream);   // 0, -2 (unsupported shape), -3 (HIP error)
+// the same GEMM with 16-bit operands (cond_gemm16.hip): wf16 = to_fragment16 of the stacked weights, mode 1 = bf16, 2 = fp16
+int cmtts_launch_cond_gemm16(const CondGemmArgs* a, const void* wf16, int mode, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -50,8 +50,8 @@ _OPERAND16 = None          # None | "bf16" | "fp16": see operands16
 
 class operands16:
     """``with operands16("bf16"):`` restates the library's reduced-precision scheme (BASELINE.json configs[2]/[4];
-    the reference has no such mode): the MFMA operands of the denoiser's residual-block convs (u, z and the two weight
-    sets) and of the HiFi-GAN ResBlock convs (leaky_relu(x), leaky_relu(xt), weights) are rounded to 16 bits
+    the reference has no such mode): the MFMA operands of the denoiser's residual-block convs (u, z, the conditioner input and the three
+    weight sets) and of the HiFi-GAN ResBlock convs (leaky_relu(x), leaky_relu(xt), weights) are rounded to 16 bits
     (round-to-nearest-even from their fp32 value), products and sums stay in the working precision, and everything
     else (biases, gate, residual arithmetic, conv_pre / transposed convs / conv_post) is untouched."""
 
@@ -487,7 +487,10 @@ def denoiser_forward(sd, cfg, x, t, cond, speaker_emb):
     for i in range(cfg.res_layers):
         p = f"net.residual_layers.{i}."
         d = linear(e, sd[p + "diffusion_projection.linear.weight"])[:, :, None]
-        cp = conv1d(c, sd[p + "conditioner_projection.conv.weight"], sd[p + "conditioner_projection.conv.bias"])
+        # 16-bit modes (round 3): the conditioner projection takes 16-bit operands like the block's other two contractions (csrc/cond_gemm16.hip);
+        # fp16x3 keeps it in fp32 on the device
+        qc = quant16 if _OPERAND16 in ("bf16", "fp16") else (lambda a: a)
+        cp = conv1d(qc(c.astype(F32)), qc(sd[p + "conditioner_projection.conv.weight"]), sd[p + "conditioner_projection.conv.bias"])
         r = (h + d).astype(F32)
         u = r + cp
         if cfg.multi_speaker:
