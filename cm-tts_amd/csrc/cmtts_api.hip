@@ -321,7 +321,7 @@ int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stage
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
-int g_cond_gemm16 = 1;          // bf16 / fp16 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
+int g_cond_gemm16 = 1;          // bf16 / fp16 / fp16x3 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
@@ -486,7 +486,7 @@ struct cmtts_model {
     float *skip_f = nullptr, *outp_f = nullptr;   // skip / output projection in fragment order (persistent kernel's tail)
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
-    void* cond_all_f16[2] = {nullptr, nullptr};   // bf16 / fp16 fragment-order copies (cond_gemm16.hip)
+    void* cond_all_f16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies (cond_gemm16.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
     // Step-embedding cache (round 2): the DiffusionEmbedding -> MLP -> 20 stacked diffusion projections of a timestep depend
@@ -776,6 +776,10 @@ int finalize_model(cmtts_model* m) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 1, H, NL * C, mode);
                 CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->cond_all_f16[mode - 1]));
             }
+        if (H % 16 == 0 && (NL * C) % 32 == 0 && m->cond_all.ld == NL * C) {
+            const std::vector<unsigned short> fs = to_fragment16_split(hp, 1, H, NL * C);
+            CHK(al.upload_bytes(fs.data(), fs.size() * 2, &m->cond_all_f16[2]));
+        }
     }
     CHK(al.upload(dproj, &m->dproj_wt));
     if (c.multi_speaker) CHK(al.upload(sproj, &m->sproj_wt));
@@ -941,8 +945,8 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
 // cp[b][l*C + m][t] = conditioner_projection_l(cond)[m][t] + bias: one stacked GEMM, reused by every step
 int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B, int T, hipStream_t s) {
     const cmtts_config& c = m->cfg;
-    if (g_cond_gemm16 && (m->precision == 1 || m->precision == 2) && m->cond_all_f16[m->precision - 1]) {
-        // bf16 / fp16 models: the conditioner projections are residual-block contractions too — 16-bit operands, fp32 accumulate and output
+    if (g_cond_gemm16 && m->precision >= 1 && m->precision <= 3 && m->cond_all_f16[m->precision - 1]) {
+        // bf16 / fp16 / fp16x3 models: the conditioner projections are residual-block contractions too — 16-bit operands (pairs), fp32 accumulate and output
         // (round 3; the oracle's operands16 modes quantise the same operands).  Shapes the kernel does not take run the fp32 kernels below.
         CondGemmArgs g;
         g.X = cond_ct; g.Wf = nullptr; g.bias = m->cond_all.bias; g.Y = w.cp;

@@ -240,7 +240,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value);
 /* Operand precision of the denoiser's residual-block contractions (93 % of its FLOPs): 0 = fp32 (default,
  * the reference's only inference precision), 1 = bf16, 2 = fp16 MFMA operands with fp32 accumulation;
  * activations in HBM, biases, gate and residual arithmetic stay fp32.  BASELINE.json configs[2]/[4].  In modes 1 / 2 the blocks'
- * conditioner projections take 16-bit operands as well (since round 3, every batch shape; mode 3 keeps them fp32).
+ * conditioner projections take 16-bit operands as well (since round 3, every batch shape; mode 3: (hi, lo) pairs).
  * 3 = "fp16x3": every operand carried as hi = fp16(v), lo = fp16(v - hi) and every product as three fp16 MFMAs
  * (a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulate): fp32-class accuracy (error vs float64 within 2x of the fp32
  * kernels', tests/test_gpu_precision.py) at 3/16 of the fp32 matrix cost; used by the persistent stack (large

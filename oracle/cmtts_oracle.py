@@ -487,10 +487,8 @@ def denoiser_forward(sd, cfg, x, t, cond, speaker_emb):
     for i in range(cfg.res_layers):
         p = f"net.residual_layers.{i}."
         d = linear(e, sd[p + "diffusion_projection.linear.weight"])[:, :, None]
-        # 16-bit modes (round 3): the conditioner projection takes 16-bit operands like the block's other two contractions (csrc/cond_gemm16.hip);
-        # fp16x3 keeps it in fp32 on the device
-        qc = quant16 if _OPERAND16 in ("bf16", "fp16") else (lambda a: a)
-        cp = conv1d(qc(c.astype(F32)), qc(sd[p + "conditioner_projection.conv.weight"]), sd[p + "conditioner_projection.conv.bias"])
+        # 16-bit modes (round 3): the conditioner projection takes 16-bit operands like the block's other two contractions (csrc/cond_gemm16.hip)
+        cp = conv1d(quant16(c.astype(F32)), quant16(sd[p + "conditioner_projection.conv.weight"]), sd[p + "conditioner_projection.conv.bias"])
         r = (h + d).astype(F32)
         u = r + cp
         if cfg.multi_speaker:

@@ -1189,12 +1189,12 @@ def test_cond_gemm_bitwise(variant, B, T):
     assert torch.equal(one, ref), float((one - ref).abs().max())
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16", "fp16x3"])
 @pytest.mark.parametrize("variant,B,T,layers", [("LJSpeech", 3, 200, 20), ("VCTK", 2, 77, 20), ("LJSpeech", 32, 512, 20), ("LJSpeech", 2, 200, 1)])
 def test_cond_projections_operands(variant, B, T, layers, dtype):
     """The stacked conditioner projections on their own (csrc/internal_hooks.h: cmtts_internal_cond_projections): fp32 models multiply fp32
-    operands (cond_gemm.hip / the generic kernel), bf16 / fp16 models operands rounded to 16 bits with fp32 accumulation (cond_gemm16.hip,
-    round 3) at EVERY shape — the numerics of a 16-bit model must not depend on the batch.  Against float64 products of the same operands:
+    operands (cond_gemm.hip / the generic kernel), bf16 / fp16 models operands rounded to 16 bits and fp16x3 models (hi, lo) fp16 pairs, with fp32
+    accumulation (cond_gemm16.hip, round 3) at EVERY shape — the numerics of a 16-bit model must not depend on the batch.  Against float64 products of the same operands:
     what is left is fp32 accumulation error.  T = 77 / 200: ragged last tile; one layer: waves without rows in the only pass."""
     import ctypes as C
     import dataclasses
@@ -1213,13 +1213,17 @@ def test_cond_projections_operands(variant, B, T, layers, dtype):
     cp = torch.full((B, NL * Cc, T), float("nan"), device=DEV)
     assert raw.cmtts_internal_cond_projections(model._h, C.c_void_p(cd.data_ptr()), B, T, C.c_void_p(cp.data_ptr()), None) == 0
     torch.cuda.synchronize()
-    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
-    ref = torch.einsum("mk,bkt->bmt", W.to(tdt).double(), cond.to(tdt).double()) + bias.double()[None, :, None]
+    def q(a):                  # the operand the device multiplies, as a float64 tensor
+        if dtype == "fp16x3":  # hi + lo fp16 pair (the dropped lo * lo term is 2^-22 relative)
+            hi = a.half().float()
+            return hi.double() + (a - hi).half().double()
+        return a.to({"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]).double()
+    ref = torch.einsum("mk,bkt->bmt", q(W), q(cond)) + bias.double()[None, :, None]
     got = cp.cpu().double()
     assert torch.isfinite(got).all()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 2e-6 * scale, (float((got - ref).abs().max()), scale)
-    if dtype != "fp32":      # and the operands really were rounded: far from the fp32-operand products
+    if dtype in ("bf16", "fp16"):      # and the operands really were rounded: far from the fp32-operand products
         ref32 = torch.einsum("mk,bkt->bmt", W.double(), cond.double()) + bias.double()[None, :, None]
         assert float((got - ref32).abs().max()) > 50e-6 * scale
     model.set_precision("fp32")
