@@ -1535,12 +1535,13 @@ def test_vocoder_pair16_kernel_bitwise(B, T, dtype):
     assert torch.equal(got2, ref)
 
 
-@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1)])
+@pytest.mark.parametrize("B,T", [(2, 61), (1, 7), (3, 130), (1, 1), (5, 300)])
 def test_vocoder_pair16x3_bitwise(B, T):
     """resblock_pair16x3.hip (fp16x3 operands: one X-resident launch per ResBlock pair of the C = 128 / 64 / 32 stages, (hi, lo) LDS
     images of x and xt) keeps conv_mfma16.hip MODE 3's split arithmetic, (chunk, tap, k-group) order with the small terms first and
     its epilogue expressions: the wav must not change by a bit against two chunked launches per pair.  T = 1 / 7: tiles that are all
-    halo; 61 / 130: ragged last tiles at every stage (x 8, x 64, x 128, x 256 frames)."""
+    halo; 61 / 130: ragged last tiles at every stage (x 8, x 64, x 128, x 256 frames); 5 x 300: thousands of tiles per launch, workgroup counts that
+    are not multiples of 8 (the XCD-aware tile order must stay a bijection)."""
     host = _host()
     hcfg = HifiGanConfig()
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=9))
