@@ -95,10 +95,11 @@ __device__ __forceinline__ void conv_loopT16(f32x16 (&acc)[NT], const u32x4* __r
     seg_loop<0, NG, 32>(body);
 }
 
-template <int CIN, int NW, int MODE>
+// BN = input columns per workgroup: 64; 32 for the fp16x3 C_in = 512 stage, whose two 512-channel images of 65 rows plus the output tile exceed the LDS
+template <int CIN, int NW, int MODE, int BN = 64>
 __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Args a, int mtiles) {
     constexpr int RS = CIN + 4;
-    constexpr int BN = 64, NT = 2;
+    constexpr int NT = BN / 32;
     constexpr int XROWS = BN + 1;
     constexpr int NS = MODE == 3 ? 2 : 1;                                   // fp16x3: (hi, lo) images
     constexpr int MM = MODE == 3 ? 2 : MODE;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
         constexpr int PAIRS = CIN / 2 / NW;
         constexpr int PB = PAIRS < 16 ? PAIRS : 16;
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+        for (int jb = 0; jb < (XROWS + 63) / 64; ++jb) {
             const int j = jb * 64 + lane;
             const int m = t0 - 1 + j;
             // lanes past the image's last row (all but one of the second block) re-read that row's column: same cache line, no traffic — clamped
@@ -202,13 +203,13 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
     }
 }
 
-template <int CIN, int NW, int MODE>
+template <int CIN, int NW, int MODE, int BN = 64>
 int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
     if (a.s & (a.s - 1)) return -2;                    // the output tile's interleave uses shifts
-    const size_t lds = (MODE == 3 ? 2 : 1) * (((size_t)65 * (CIN + 4) + 7) & ~(size_t)7) * sizeof(unsigned short) + (a.s >= 4 ? (size_t)(NW / a.s) * 32 * a.s * 40 * sizeof(float) : 0);
+    const size_t lds = (MODE == 3 ? 2 : 1) * (((size_t)(BN + 1) * (CIN + 4) + 7) & ~(size_t)7) * sizeof(unsigned short) + (a.s >= 4 ? (size_t)(NW / a.s) * 32 * a.s * 40 * sizeof(float) : 0);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(convT_xl16_kernel<CIN, NW, MODE, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return -3;
         attr_lds = lds;
@@ -216,7 +217,7 @@ int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
     const int mtiles = a.s * a.CO / 32;
     if (NW % a.s || mtiles % NW) return -2;
     const int npass = mtiles / NW;
-    const long tiles = (long)((a.Ti + 1 + 63) / 64) * a.B;
+    const long tiles = (long)((a.Ti + 1 + BN - 1) / BN) * a.B;
     int zs = 1;
     // channel-block split of the grid: only until every CU has two workgroups — each split stages the x tile again, and staging is what this
     // kernel waits for (C_in = 256: 336 / 402 / 500 us with 1 / 2 / 4 splits; C_in = 512, 288 tiles: 180 / 158 / 160 / 184 with 1 / 2 / 4 / 8)
@@ -225,8 +226,8 @@ int launch_convT16(const ConvT16Args& a, hipStream_t stream) {
         static const char* e = getenv("CMTTS_CONVT_ZS");
         if (e && atoi(e) > 0 && npass % atoi(e) == 0) zs = atoi(e);
     }
-    dim3 grid((a.Ti + 1 + 63) / 64, a.B, zs);
-    hipLaunchKernelGGL((convT_xl16_kernel<CIN, NW, MODE>), grid, dim3(64 * NW), lds, stream, a, mtiles);
+    dim3 grid((a.Ti + 1 + BN - 1) / BN, a.B, zs);
+    hipLaunchKernelGGL((convT_xl16_kernel<CIN, NW, MODE, BN>), grid, dim3(64 * NW), lds, stream, a, mtiles);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -234,7 +235,7 @@ template <int MODE>
 int dispatch_convT16(const ConvT16Args& a, int cin, hipStream_t s) {
     const int mtiles = a.s * a.CO / 32;
     if (cin == 512 && mtiles >= 8) {
-        if constexpr (MODE == 3) return -2;             // two 512-channel images + the output tile exceed the LDS: the fp32 upsampler runs this stage
+        if constexpr (MODE == 3) return launch_convT16<512, 8, MODE, 32>(a, s);       // 32-column tiles: two 512-channel images + the output tile fit (109 KB)
         else return launch_convT16<512, 8, MODE>(a, s);
     }
     if (cin == 256 && mtiles >= 8) return launch_convT16<256, 8, MODE>(a, s);
