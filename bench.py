@@ -461,6 +461,11 @@ def main():
             k = max(4, args.steps // 2)
             d = timed(step, k, 2, 1)
             extras[f"frames_per_s_T4_{dt}_resblocks"] = round(frames_rank * k / d, 1)
+            if dt != "fp16x3":     # + the opt-in 16-bit FFN contractions of the text encoder (set_option("text16", 1): the integer stages then depend on the mode)
+                model.set_option("text16", 1)
+                d = timed(step, k, 2, 1)
+                model.set_option("text16", 0)
+                extras[f"frames_per_s_T4_{dt}_resblocks_text16"] = round(frames_rank * k / d, 1)
         model.set_precision("fp32")
         extras["fp16x3_note"] = ("residual-block operands as hi + lo fp16 pairs (22 bits), three fp16 MFMAs per product, fp32 accumulate: "
                                  "fp32-class accuracy (tests/test_gpu_precision.py: error vs float64 within 2x of the exact-fp32 kernels'); "

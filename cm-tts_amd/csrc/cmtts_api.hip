@@ -443,6 +443,10 @@ struct EncLayer {
     float* qkv_f = nullptr;    // the same for the in-projection and the out-projection (round 2: LayerNorm + projection in one launch)
     float* wo_f = nullptr;
     float* ffn2_f = nullptr;   // the FFN linear as A fragments in iteration order: conv_xres.hip's FFN fusion
+    void* ffn1_f16[2] = {nullptr, nullptr};   // bf16 / fp16 fragment-order copies of the two FFN contractions (conv_mfma16.hip; the opt-in "text16")
+    void* ffn2_f16[2] = {nullptr, nullptr};
+    void* qkv_f16[2] = {nullptr, nullptr};    // ... and of the in- / out-projection of the self-attention
+    void* wo_f16[2] = {nullptr, nullptr};
     float* wvT;  // [256 c][256 d]
 };
 struct Predictor {
@@ -466,6 +470,7 @@ struct cmtts_model {
     std::map<std::string, HostTensor> host;
     bool finalized = false;
     int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
+    int text16 = 0;        // 16-bit models (precision 1 / 2): the FFN contractions of the FFT blocks with 16-bit operands too (opt-in: the text side feeds the integer stages — durations, pitch buckets, lengths — which then depend on the precision mode; cmtts_model_set_option)
     int ffn2_split = 1;    // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (another fp32 summation order than one launch: a property of the model handle, cmtts_model_set_option)
     cmtts_variance_controls vc = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Allocs al;
@@ -587,6 +592,11 @@ int finalize_model(cmtts_model* m) {
             std::vector<float> hp;
             CHK(pack_conv(al, qkv, nullptr, nullptr, &L.qkv, &hp));
             if (H % 32 == 0 && L.qkv.ld == L.qkv.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, H, 3 * H), &L.qkv_f));
+            if (H % 32 == 0 && L.qkv.ld == L.qkv.cout)
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, 1, H, 3 * H, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &L.qkv_f16[mode - 1]));
+                }
         }
         CHK(al.upload(transpose2d(inw->data.data() + (size_t)2 * H * H, H, H), &L.wvT));
         GET(ow, p + "self_attn.out_proj.weight", H, H);
@@ -595,6 +605,11 @@ int finalize_model(cmtts_model* m) {
             std::vector<float> hp;
             CHK(pack_conv(al, ow3, nullptr, nullptr, &L.wo, &hp));
             if (H % 32 == 0 && L.wo.ld == L.wo.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, H, H), &L.wo_f));
+            if (H % 32 == 0 && L.wo.ld == L.wo.cout)
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, 1, H, H, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &L.wo_f16[mode - 1]));
+                }
         }
         GET(f1w, p + "ffn.ffn_1.weight", 4 * H, H, c.ffn_kernel); GET(f1b, p + "ffn.ffn_1.bias", 4 * H);
         {
@@ -602,6 +617,11 @@ int finalize_model(cmtts_model* m) {
             CHK(pack_conv(al, *f1w, f1b, nullptr, &L.ffn1, &hp));
             if (L.ffn1.cin % 32 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
                 CHK(al.upload(to_fragment_iter_order(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_f));
+            if (L.ffn1.cin % 32 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &L.ffn1_f16[mode - 1]));
+                }
         }
         GET(f2w, p + "ffn.ffn_2.weight", H, 4 * H); GET(f2b, p + "ffn.ffn_2.bias", H);
         HostTensor f2 = *f2w; f2.shape = {H, 4 * H, 1};
@@ -609,6 +629,11 @@ int finalize_model(cmtts_model* m) {
             std::vector<float> hp;
             CHK(pack_conv(al, f2, f2b, nullptr, &L.ffn2, &hp));
             if (H == 256 && L.ffn2.cin % 128 == 0 && L.ffn2.ld == L.ffn2.cout) CHK(al.upload(to_fragment_iter_order(hp, 1, L.ffn2.cin, H), &L.ffn2_f));
+            if (L.ffn2.cin % 32 == 0 && H % 32 == 0 && L.ffn2.ld == L.ffn2.cout)
+                for (int mode = 1; mode <= 2; ++mode) {
+                    const std::vector<unsigned short> f16 = to_fragment16(hp, 1, L.ffn2.cin, H, mode);
+                    CHK(al.upload_bytes(f16.data(), f16.size() * 2, &L.ffn2_f16[mode - 1]));
+                }
         }
         return 0;
     };
@@ -1233,7 +1258,11 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
         const EncLayer& E = layers[i];
         const bool fused_attn = g_attn_fused && dh == 128;      // L <= 192: all keys in registers; longer: key-chunked online softmax (attention.hip)
         // LayerNorm1 as the prologue of the in-projection: one launch, no normalised copy in HBM
-        const bool ln_qkv = fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && (long)t96 * (3 * H / 128) * B >= 128;
+        // opt-in ("text16", cmtts_model_set_option; bf16 / fp16 models): the block's four K = 256 / 1024 contractions (in-projection, out-projection, FFN
+        // conv, FFN linear) with 16-bit MFMA operands and fp32 accumulate on conv_mfma16.hip; LayerNorm, softmax, bias, scale, GELU, residuals, masks fp32
+        const int pm = m->precision;
+        const bool t16 = m->text16 && (pm == 1 || pm == 2) && E.ffn1_f16[pm - 1] && E.ffn2_f16[pm - 1] && E.qkv_f16[pm - 1] && E.wo_f16[pm - 1];
+        const bool ln_qkv = !t16 && fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && (long)t96 * (3 * H / 128) * B >= 128;
         if (!ln_qkv) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
         bool attn_done = false;
         if (fused_attn) {
@@ -1250,6 +1279,12 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                 rq = cmtts_launch_conv_xres(&a, E.qkv_f, B, (void*)s);
                 if (rq == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
                 if (rq != 0) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
+            }
+            if (rq != 0 && t16) {
+                ConvArgs a = conv_args(E.qkv, w.h, L, Lp, hs, w.qk, Lp, 3 * hs, L);
+                a.text_epi = 1;
+                rq = cmtts_launch_conv16(&a, E.qkv_f16[pm - 1], pm, B, (void*)s);
+                if (rq == -3) return fail(CMTTS_E_HIP, "text16: in-projection launch failed");
             }
             if (rq != 0) {
                 ConvArgs a = conv_args(E.qkv, w.h, L, Lp, hs, w.qk, Lp, 3 * hs, L);
@@ -1313,10 +1348,32 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             ConvArgs a = conv_args(E.wo, w.o, L, Lp, hs, w.x, Lp, hs, L);
             a.out[0].res = w.x; a.out[0].r_zs0 = hs; a.out[0].ldr = Lp; a.out[0].lens = src_lens;
             int rc = -2;
-            if ((g_text_xres & 2) && E.wo_f && xres_cols && (long)t96 * (H / 128) * B >= 64)
+            if (t16) {
+                a.text_epi = 1;
+                rc = cmtts_launch_conv16(&a, E.wo_f16[pm - 1], pm, B, (void*)s);
+                if (rc == -3) return fail(CMTTS_E_HIP, "text16: out-projection launch failed");
+                a.text_epi = 0;
+            } else if ((g_text_xres & 2) && E.wo_f && xres_cols && (long)t96 * (H / 128) * B >= 64)
                 rc = cmtts_launch_conv_xres(&a, E.wo_f, B, (void*)s);
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
+        }
+        if (t16) {      // LayerNorm2, FFN conv (+ k^-0.5, GELU), FFN linear (+ residual, mask): three launches instead of two
+            k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+            ConvArgs a = conv_args(E.ffn1, w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
+            a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
+            a.out[0].act = ACT_GELU_ERF;
+            a.text_epi = 1;
+            int rc = cmtts_launch_conv16(&a, E.ffn1_f16[pm - 1], pm, B, (void*)s);
+            if (rc == 0) {
+                ConvArgs b = conv_args(E.ffn2, w.f, L, Lp, 4 * hs, w.x, Lp, hs, L);
+                b.out[0].res = w.x; b.out[0].r_zs0 = hs; b.out[0].ldr = Lp; b.out[0].lens = src_lens;
+                b.text_epi = 1;
+                rc = cmtts_launch_conv16(&b, E.ffn2_f16[pm - 1], pm, B, (void*)s);
+                if (rc != 0) return fail(CMTTS_E_HIP, "text16: FFN linear launch failed");
+                continue;
+            }
+            if (rc != -2) return fail(CMTTS_E_HIP, "text16: FFN conv launch failed");
         }
         const bool ffn2_seg = m->ffn2_split && E.ffn2.cin % FFN2_SEG == 0 && E.ffn2.taps == 1;
         bool ffn_fused = false;
@@ -2159,6 +2216,7 @@ int cmtts_model_set_option(cmtts_model* m, const char* name, int value) {
     if (!m || !name) return fail(CMTTS_E_INVALID, "cmtts_model_set_option: null argument");
     const Knob tab[] = {
         {"ffn2_split", &m->ffn2_split, 0, 1},            // FFN linear of the FFT blocks as 8 K-segment partial GEMMs + one reduction (1) or one launch (0)
+        {"text16", &m->text16, 0, 1},                    // bf16 / fp16 models: 16-bit operands in the FFT blocks' FFN contractions as well (default 0)
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);

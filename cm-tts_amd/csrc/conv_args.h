@@ -68,6 +68,9 @@ struct ConvArgs {
     float* part;
     long part_zs0, part_zs1;
     int part_ld, M2;
+    // 16-bit kernel only (round 3, the opt-in 16-bit text side): out[0] through conv_epilogue.h's epi_tile_simple (bias, alpha, none / GELU,
+    // residual, length mask) instead of the ResBlock epilogue
+    int text_epi;
 };
 
 #ifdef __cplusplus

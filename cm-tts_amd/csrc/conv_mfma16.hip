@@ -206,6 +206,19 @@ __global__ __launch_bounds__(256, (BN > 128 || MODE == 3) ? 2 : 3) void conv1d_m
         __syncthreads();
     }
 
+    // ---- the text-side FFN convs (round 3, opt-in "text16"): bias, alpha, GELU, residual, length mask — conv_epilogue.h's compile-time form
+    if (IO == 0 && MODE != 3 && a.text_epi) {      // wave-uniform
+        const ConvOut& o = a.out[0];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int mb = m0 + (wm * MT + i) * 32, n = n0 + (wn * NT + j) * 32 + l31;
+                if (o.act == ACT_GELU_ERF) epi_tile_simple<ACT_GELU_ERF>(o, acc[i][j], mb, 4 * khalf, n, a.M, a.N, z);
+                else epi_tile_simple<ACT_NONE>(o, acc[i][j], mb, 4 * khalf, n, a.M, a.N, z);
+            }
+        return;
+    }
     // ---- epilogue, specialised for the ResBlock convs (bias [+ residual] [+ accumulate], unit stride):
     // every load of a 32x32 tile is issued before its first store, and nothing fences one tile from the
     // next, so the residual / old-Y loads of tile k+1 fly while tile k is being written.
@@ -292,7 +305,11 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
     const ConvOut& o = a.out[0];
     if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || mode < 1 || mode > 3 || a.K % KC != 0) return -2;
     if ((a.x16 && a.y16) || (a.y16 && (o.res || o.accum)) || (a.x16 && (a.pre_div != 1.f))) return -2;
-    if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||
+    if (a.text_epi) {     // bias, alpha, none / GELU, residual, length mask; fp32 in and out, bf16 / fp16 operands
+        if (mode == 3 || a.x16 || a.y16 || o.bvec || o.accum || (o.act != ACT_NONE && o.act != ACT_GELU_ERF) || o.div != 1.f || o.ostride != 1 ||
+            o.ooff_base != 0 || o.ooff_mul != 0 || o.row_off != 0 || o.Tout != a.N)
+            return -2;
+    } else if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||
         o.row_off != 0 || o.Tout != a.N)
         return -2;
     // 128-frame tiles everywhere: these convs are HBM-bound, what matters is loads in flight (3 workgroups/CU)

@@ -46,6 +46,7 @@ class precision:
 
 
 _OPERAND16 = None          # None | "bf16" | "fp16": see operands16
+_TEXT16 = False            # operands16(..., text=True): the library's opt-in "text16" (16-bit in- / out-projection and FFN contractions in the FFT blocks)
 
 
 class operands16:
@@ -55,19 +56,20 @@ class operands16:
     (round-to-nearest-even from their fp32 value), products and sums stay in the working precision, and everything
     else (biases, gate, residual arithmetic, conv_pre / transposed convs / conv_post) is untouched."""
 
-    def __init__(self, mode):
+    def __init__(self, mode, text=False):
         assert mode in (None, "fp32", "bf16", "fp16", "fp16x3")
         self.mode = None if mode == "fp32" else mode
+        self.text = bool(text) and self.mode in ("bf16", "fp16")    # cmtts_model_set_option(m, "text16", 1): bf16 / fp16 models only
 
     def __enter__(self):
-        global _OPERAND16
-        self.prev = _OPERAND16
-        _OPERAND16 = self.mode
+        global _OPERAND16, _TEXT16
+        self.prev = (_OPERAND16, _TEXT16)
+        _OPERAND16, _TEXT16 = self.mode, self.text
         return self
 
     def __exit__(self, *exc):
-        global _OPERAND16
-        _OPERAND16 = self.prev
+        global _OPERAND16, _TEXT16
+        _OPERAND16, _TEXT16 = self.prev
         return False
 
 
@@ -240,7 +242,8 @@ def multihead_self_attention(x, in_w, out_w, key_pad, n_heads):
     x [B,L,C]; heads are contiguous channel slices; padded keys get -inf before softmax."""
     B, L, C = x.shape
     d = C // n_heads
-    qkv = linear(x, in_w)                                  # [B,L,3C]
+    qt = quant16 if _TEXT16 else (lambda a: a)              # "text16": in- and out-projection operands in 16 bits (scores, softmax, P V stay as they are)
+    qkv = linear(qt(x.astype(F32)), qt(in_w))              # [B,L,3C]
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     q = q * F32(1.0 / math.sqrt(d))
 
@@ -253,7 +256,7 @@ def multihead_self_attention(x, in_w, out_w, key_pad, n_heads):
     p = np.exp(s)
     p = (p / p.sum(-1, keepdims=True, dtype=F32)).astype(F32)
     o = np.matmul(p, heads(v)).transpose(0, 2, 1, 3).reshape(B, L, C)
-    return linear(o, out_w)
+    return linear(qt(o.astype(F32)), qt(out_w))
 
 
 def enc_sa_layer(sd, prefix, x, pad_mask, n_heads, kernel):
@@ -264,10 +267,11 @@ def enc_sa_layer(sd, prefix, x, pad_mask, n_heads, kernel):
                                  sd[prefix + "self_attn.out_proj.weight"], pad_mask, n_heads)
     x = (x + h) * keep
     h = layer_norm(x, sd[prefix + "layer_norm2.weight"], sd[prefix + "layer_norm2.bias"], 1e-12)
-    h = conv1d(h.transpose(0, 2, 1), sd[prefix + "ffn.ffn_1.weight"], sd[prefix + "ffn.ffn_1.bias"],
+    qt = quant16 if _TEXT16 else (lambda a: a)          # "text16": the two FFN contractions take 16-bit operands (csrc/cmtts_api.hip fft_stack)
+    h = conv1d(qt(h.transpose(0, 2, 1).astype(F32)), qt(sd[prefix + "ffn.ffn_1.weight"]), sd[prefix + "ffn.ffn_1.bias"],
                padding=kernel // 2)
     h = gelu_erf(h * F32(kernel ** -0.5)).transpose(0, 2, 1)
-    h = linear(h, sd[prefix + "ffn.ffn_2.weight"], sd[prefix + "ffn.ffn_2.bias"])
+    h = linear(qt(h.astype(F32)), qt(sd[prefix + "ffn.ffn_2.weight"]), sd[prefix + "ffn.ffn_2.bias"])
     return ((x + h) * keep).astype(F32)
 
 

@@ -182,6 +182,45 @@ def test_precision_one_residual_layer(variant):
             check_ladder(f"one residual layer {variant}", ref64, hip["fp32"], hip[dt], orc, 2, dt)
 
 
+@pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
+def test_precision_text16_encoder(golden_models, variant):
+    """The opt-in 16-bit text side (cmtts_model_set_option "text16", bf16 / fp16 models): the four weight contractions of every FFT block (in- / out-projection,
+    FFN conv, FFN linear) with 16-bit MFMA operands (conv_mfma16.hip + conv_epilogue.h's epilogue: bias, k^-0.5, GELU, residual, length mask in fp32).  Encoder output on
+    the golden texts against the float64 oracle and the float64 oracle with the same operands rounded (operands16(dt, text=True)): the scheme's
+    own error dominates, the implementation follows it; default (option off) = the fp32 text side, bit for bit, whatever the precision mode."""
+    g, cfg, sd, model = golden_models(variant)
+    tx, ln = torch.from_numpy(g["texts"]), torch.from_numpy(g["src_lens"])
+    spk = torch.from_numpy(g["spker_embeds"]) if cfg.multi_speaker else None
+    L = g["texts"].shape[1]
+    valid = (np.arange(L)[None, :] < g["src_lens"][:, None])[:, :, None]
+
+    def enc():
+        o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk)
+        return _np(o["enc_out"]) * valid
+    hip32 = enc()
+    hip = {}
+    for dt in ("bf16", "fp16"):
+        model.set_precision(dt)
+        assert np.array_equal(enc(), hip32)                 # option off: the text side does not depend on the precision mode
+        prev = model.set_option("text16", 1)
+        try:
+            hip[dt] = enc()
+        finally:
+            model.set_option("text16", prev)
+    model.set_precision("fp32")
+    assert model.set_option("text16", 1) == 0
+    assert np.array_equal(enc(), hip32)                     # fp32 models ignore the option
+    model.set_option("text16", 0)
+    src_mask = O.get_mask_from_lengths(g["src_lens"], L)
+    with O.precision("f64"):
+        ref64 = O.text_encoder(sd, cfg, g["texts"], src_mask) * valid
+        for dt in ("bf16", "fp16"):
+            with O.operands16(dt, text=True):
+                orc = O.text_encoder(sd, cfg, g["texts"], src_mask) * valid
+            check_ladder(f"text16 encoder {variant}", ref64, hip32, hip[dt], orc, 4 * cfg.enc_layers, dt, deep=True)
+            assert not np.array_equal(hip[dt], hip32)
+
+
 def test_precision_ladder_vocoder(golden):
     """HiFi-GAN on the golden mel: fp32 / fp16 / bf16 wav error relative to the float64 oracle; 16-bit ResBlock convs
     against the 16-bit-operand oracle within the derived bound (depth: 4 stages x 3 pairs x 2 convs)."""

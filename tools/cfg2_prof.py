@@ -11,6 +11,7 @@ from cmtts_amd.weights import synth_cmtts_state_dict
 cfg = get_config(os.environ.get("VAR", "VCTK"))
 m = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cfg, seed=0, dur_frames=6.0, dur_spread=0.0))
 m.set_precision(os.environ.get("LP", "bf16"))
+m.set_option("text16", int(os.environ.get("TEXT16", 0)))
 B, L, NS = int(os.environ.get("VB", 64)), int(os.environ.get("VL", 85)), int(os.environ.get("STEPS", 2))
 rs = np.random.RandomState(3)
 tx = torch.from_numpy(rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)).cuda()

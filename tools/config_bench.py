@@ -92,6 +92,10 @@ def c2(wav=True):
 m.set_precision("bf16"); voc.set_precision("bf16")
 report("configs[2] VCTK B=64, 80x512, T=2, bf16 residual blocks, text -> mel", fr, clock(lambda: c2(False), 10), "")
 report("configs[2] + universal HiFi-GAN (bf16 ResBlock convs), text -> int16 wav", fr, clock(c2, 3, 1), "")
+m.set_option("text16", 1)
+report("configs[2] with the opt-in 16-bit FFN contractions of the text encoder (set_option text16), text -> mel", fr, clock(lambda: c2(False), 10), "durations / lengths then depend on the precision mode")
+report("configs[2] text16 + universal HiFi-GAN (bf16), text -> int16 wav", fr, clock(c2, 3, 1), "")
+m.set_option("text16", 0)
 m.set_precision("fp32"); voc.set_precision("fp32")
 
 # configs[3]: LibriTTS B=256 over 8 GPUs = 32 ragged utterances per rank in the 256/512/768/1024 buckets, T=4, fp32
@@ -113,6 +117,9 @@ def c4(wav=True):
     return to_pcm(mel) if wav else mel
 m.set_precision("fp16")
 report("configs[4] LibriTTS (zero-shot speaker vectors), one rank: B=16, 80x1024, T=4, fp16 residual blocks, text -> mel", fr, clock(lambda: c4(False), 10), "")
+m.set_option("text16", 1)
+report("configs[4] with text16, text -> mel", fr, clock(lambda: c4(False), 10), "")
+m.set_option("text16", 0)
 report("configs[4] + HiFi-GAN fp32, text -> int16 wav (end-to-end wav throughput)", fr, clock(c4, 3, 1), "")
 voc.set_precision("fp16x3")
 report("configs[4] + HiFi-GAN fp16x3 (fp32-class), text -> int16 wav", fr, clock(c4, 5, 1), "")
