@@ -313,6 +313,8 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
         o.row_off != 0 || o.Tout != a.N)
         return -2;
     // 128-frame tiles everywhere: these convs are HBM-bound, what matters is loads in flight (3 workgroups/CU)
+    // the text side's short sequences (85 phonemes, 170, ...): 96-column tiles where they pad less than 128-column ones
+    if (a.text_epi && a.M > 64 && (a.N + 95) / 96 * 96 < (a.N + 127) / 128 * 128) return launch16<128, 96, 4, 1>(a, wfrag, mode, nbatch, stream);
     if (a.M > 64) {
         static const char* tile = getenv("CMTTS_C16_TILE");     // experiment switch: "22" = round-1 tiling (2 x 2 waves)
         if (tile && !strcmp(tile, "22")) return launch16<128, 128, 2, 2>(a, wfrag, mode, nbatch, stream);
