@@ -452,6 +452,7 @@ struct EncLayer {
 struct Predictor {
     std::vector<PackedConv> convs;
     std::vector<float*> convs_f;     // 256 -> 256 convs as MFMA A fragments in iteration order (conv_xl_kernel), else null
+    std::vector<void*> convs_f16[2]; // bf16 / fp16 fragment-order copies (conv_mfma16.hip; the opt-in "text16"), else null
     std::vector<float*> ln_g, ln_b;
     float *lin_w = nullptr, *lin_b = nullptr, *alpha = nullptr;
     int odim = 0;
@@ -677,6 +678,13 @@ int finalize_model(cmtts_model* m) {
                 P.convs_f.resize(n_layers, nullptr);
                 if ((cin == 256 || (cin == 128 && k == 5)) && c.pred_filter == 256 && P.convs[li].ld == 256)
                     CHK(al.upload(to_fragment_iter_order(hp, k, cin, c.pred_filter), &P.convs_f[li]));
+                for (int mode = 1; mode <= 2; ++mode) {
+                    P.convs_f16[mode - 1].resize(n_layers, nullptr);
+                    if (cin % 32 == 0 && c.pred_filter % 32 == 0 && P.convs[li].ld == c.pred_filter) {
+                        const std::vector<unsigned short> f16 = to_fragment16(hp, k, cin, c.pred_filter, mode);
+                        CHK(al.upload_bytes(f16.data(), f16.size() * 2, &P.convs_f16[mode - 1][li]));
+                    }
+                }
             }
             GET(lg, q + ".3.weight", c.pred_filter); GET(lb, q + ".3.bias", c.pred_filter);
             UP(P.ln_g[li], lg); UP(P.ln_b[li], lb);
@@ -928,8 +936,9 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 // LayerNorm over channels (eps 1e-12) [-> mask].  Result ends in bufB.
 // conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
 // block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_set_option("pred_head", 0)
+// mode16: 0, or the 16-bit operand mode (1 = bf16, 2 = fp16) of a model with the opt-in "text16": the convs on conv_mfma16.hip (bias + ReLU in fp32)
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
-              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s) {
+              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0) {
     const float* cur = in;
     int ldc = ld_in;
     auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
@@ -937,6 +946,13 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         const PackedConv& w = P.convs[li];
         int rx = -2;
         float* dst = other(cur);
+        if (mode16 && li < P.convs_f16[mode16 - 1].size() && P.convs_f16[mode16 - 1][li]) {
+            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
+            a.out[0].act = ACT_RELU;
+            a.text_epi = 1;
+            rx = cmtts_launch_conv16(&a, P.convs_f16[mode16 - 1][li], mode16, B, (void*)s);
+            if (rx == -3) return fail(CMTTS_E_HIP, "text16: predictor conv launch failed");
+        }
         if (rx != 0 && g_pred_xl && P.convs_f[li] && ldc == ld && (long)((T + 63) / 64) * B >= 192) {
             // frame-level 256 -> 256 conv: whole x tile + halo resident in LDS, weights streamed as A fragments (the HiFi-GAN
             // kernel, resblock_pair.hip; same accumulation order and epilogue expressions as the generic kernel => same bits)
@@ -1464,10 +1480,11 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     float* ec2 = ss ? w.qk + (size_t)B * H * Lp : w.c2;
     if (ss) CHK(branch_fork(ss));
     // duration predictor (masked) -> log_d
-    CHK(predictor(m->dur, w.x, Lp, B, L, Lp, src_lens, src_lens, w.c1, w.c2, log_d, 1, s));
+    const int t16mode = (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0;
+    CHK(predictor(m->dur, w.x, Lp, B, L, Lp, src_lens, src_lens, w.c1, w.c2, log_d, 1, s, t16mode));
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
-    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, nullptr, nullptr, ec1, ec2, e_pred, 1, se));
+    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, nullptr, nullptr, ec1, ec2, e_pred, 1, se, t16mode));
     if (ss) CHK(branch_join(ss));
     k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
                    w.out1, e_idx, B, H, L, Lp, s);
@@ -1515,7 +1532,7 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
         CHK(launch(a, EPI_PLAIN, B, s));
     }
     k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
-    CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s));
+    CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s, (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0));
     if (ss) CHK(branch_join(ss));
     if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
     if (m->vc.cwt_spec) {   // teacher-forced pitch: target spectrogram, statistics and uv (:379-390)

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, (BN > 128 || MODE == 3) ? 2 : 3) void conv1d_m
             for (int j = 0; j < NT; ++j) {
                 const int mb = m0 + (wm * MT + i) * 32, n = n0 + (wn * NT + j) * 32 + l31;
                 if (o.act == ACT_GELU_ERF) epi_tile_simple<ACT_GELU_ERF>(o, acc[i][j], mb, 4 * khalf, n, a.M, a.N, z);
+                else if (o.act == ACT_RELU) epi_tile_simple<ACT_RELU>(o, acc[i][j], mb, 4 * khalf, n, a.M, a.N, z);
                 else epi_tile_simple<ACT_NONE>(o, acc[i][j], mb, 4 * khalf, n, a.M, a.N, z);
             }
         return;
@@ -306,7 +307,7 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
     if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || mode < 1 || mode > 3 || a.K % KC != 0) return -2;
     if ((a.x16 && a.y16) || (a.y16 && (o.res || o.accum)) || (a.x16 && (a.pre_div != 1.f))) return -2;
     if (a.text_epi) {     // bias, alpha, none / GELU, residual, length mask; fp32 in and out, bf16 / fp16 operands
-        if (mode == 3 || a.x16 || a.y16 || o.bvec || o.accum || (o.act != ACT_NONE && o.act != ACT_GELU_ERF) || o.div != 1.f || o.ostride != 1 ||
+        if (mode == 3 || a.x16 || a.y16 || o.bvec || o.accum || (o.act != ACT_NONE && o.act != ACT_GELU_ERF && o.act != ACT_RELU) || o.div != 1.f || o.ostride != 1 ||
             o.ooff_base != 0 || o.ooff_mul != 0 || o.row_off != 0 || o.Tout != a.N)
             return -2;
     } else if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||

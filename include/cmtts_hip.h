@@ -233,7 +233,7 @@ int cmtts_set_option(const char* name, int value);
  *   cmtts_model_set_option(m, "ffn2_split", 1 (default) | 0): the FFN linear of the FFT blocks (model/blocks.py:547-551) as
  *       eight K-segment partial GEMMs added in ascending order, or as one launch — two fp32 summation orders.
  *   cmtts_model_set_option(m, "text16", 0 (default) | 1): bf16 / fp16 models only — the four weight contractions of every FFT block (encoder,
- *       decoder: in- / out-projection, FFN conv, FFN linear) with 16-bit MFMA operands too (LayerNorm, attention scores / softmax / P V, bias,
+ *       decoder: in- / out-projection, FFN conv, FFN linear) and the conv layers of the variance predictors with 16-bit MFMA operands too (LayerNorm, attention scores / softmax / P V, bias,
  *       scale, GELU, residual, mask and accumulation stay fp32).  Off by default because
  *       the text side feeds the integer stages: with it, durations / pitch buckets / lengths may differ from the fp32 model's by one unit.
  *   cmtts_vocoder_set_option(v, "ups16", 1 (default) | 0): in the 16-bit precision modes the ConvTranspose1d upsamplers take

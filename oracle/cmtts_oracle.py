@@ -46,7 +46,7 @@ class precision:
 
 
 _OPERAND16 = None          # None | "bf16" | "fp16": see operands16
-_TEXT16 = False            # operands16(..., text=True): the library's opt-in "text16" (16-bit in- / out-projection and FFN contractions in the FFT blocks)
+_TEXT16 = False            # operands16(..., text=True): the library's opt-in "text16" (16-bit in- / out-projection and FFN contractions in the FFT blocks, 16-bit variance-predictor convs)
 
 
 class operands16:
@@ -308,7 +308,8 @@ def _pred_convs(sd, prefix, xs, n_layers, kernel, mask=None):
     zero-pad, Conv1d, ReLU, LayerNorm over channels (eps 1e-12); duration also masks per layer."""
     h = xs.transpose(0, 2, 1)
     for li in range(n_layers):
-        h = conv1d(h, sd[f"{prefix}conv.{li}.1.weight"], sd[f"{prefix}conv.{li}.1.bias"],
+        qt = quant16 if _TEXT16 else (lambda a: a)          # "text16": the predictor convs' operands in 16 bits too
+        h = conv1d(qt(h.astype(F32)), qt(sd[f"{prefix}conv.{li}.1.weight"]), sd[f"{prefix}conv.{li}.1.bias"],
                    padding=(kernel - 1) // 2)
         h = np.maximum(h, 0)
         h = layer_norm(h.transpose(0, 2, 1), sd[f"{prefix}conv.{li}.3.weight"],

@@ -219,6 +219,28 @@ def test_precision_text16_encoder(golden_models, variant):
                 orc = O.text_encoder(sd, cfg, g["texts"], src_mask) * valid
             check_ladder(f"text16 encoder {variant}", ref64, hip32, hip[dt], orc, 4 * cfg.enc_layers, dt, deep=True)
             assert not np.array_equal(hip[dt], hip32)
+    # the variance predictors' convs follow the option too: log-durations (the input of the integer stages) against the oracles
+    vmask = (np.arange(L)[None, :] < g["src_lens"][:, None])
+
+    def logd():
+        return _np(model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk)["log_d_predictions"]) * vmask
+    ld32 = logd()
+    with O.precision("f64"):
+        ld64 = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], spker_embeds=g["spker_embeds"] if cfg.multi_speaker else None)["log_d"] * vmask
+    for dt in ("bf16", "fp16"):
+        model.set_precision(dt)
+        model.set_option("text16", 1)
+        try:
+            ld16 = logd()
+        finally:
+            model.set_option("text16", 0)
+            model.set_precision("fp32")
+        with O.precision("f64"), O.operands16(dt, text=True):
+            ldo = O.duration_pitch_speaker_net(sd, cfg, g["texts"], g["src_lens"], spker_embeds=g["spker_embeds"] if cfg.multi_speaker else None)["log_d"] * vmask
+        e_scheme, e_tot, e_impl = rms(ldo - ld64), rms(ld16 - ld64), rms(ld16 - ldo)
+        report(f"DTYPE_ERR text16 log-durations {variant} {dt}: fp32 vs f64 {np.abs(ld32 - ld64).max():.2e}; {dt} rms {e_tot:.2e} (scheme alone {e_scheme:.2e}); "
+               f"hip vs {dt}-operand oracle rms {e_impl:.2e}")
+        assert e_scheme > 1e-6 and e_tot <= 1.3 * e_scheme + 1e-6 and e_impl <= 1.6 * e_scheme + 1e-6
 
 
 def test_precision_ladder_vocoder(golden):

@@ -93,7 +93,7 @@ m.set_precision("bf16"); voc.set_precision("bf16")
 report("configs[2] VCTK B=64, 80x512, T=2, bf16 residual blocks, text -> mel", fr, clock(lambda: c2(False), 10), "")
 report("configs[2] + universal HiFi-GAN (bf16 ResBlock convs), text -> int16 wav", fr, clock(c2, 3, 1), "")
 m.set_option("text16", 1)
-report("configs[2] with the opt-in 16-bit FFN contractions of the text encoder (set_option text16), text -> mel", fr, clock(lambda: c2(False), 10), "durations / lengths then depend on the precision mode")
+report("configs[2] with the opt-in 16-bit text side (set_option text16: FFT-block projections / FFN and predictor convs), text -> mel", fr, clock(lambda: c2(False), 10), "durations / lengths then depend on the precision mode")
 report("configs[2] text16 + universal HiFi-GAN (bf16), text -> int16 wav", fr, clock(c2, 3, 1), "")
 m.set_option("text16", 0)
 m.set_precision("fp32"); voc.set_precision("fp32")
