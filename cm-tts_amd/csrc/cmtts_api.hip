@@ -2275,6 +2275,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
+        {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);

@@ -73,6 +73,7 @@ struct ConvArgs {
     int text_epi;
 };
 
+extern int g_conv_xt16;   // conv_xt16.hip: X-resident kernel for the text16 convs (internal switch "text_xt16")
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -81,6 +82,8 @@ extern "C" {
 int cmtts_launch_conv(const ConvArgs* a, int epi, int nbatch, void* stream);
 // 16-bit-operand variant (conv_mfma16.hip): wfrag = fragment-order weights, mode 1 = bf16, 2 = fp16.
 int cmtts_launch_conv16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
+// X-resident form for the text side's K = 256 convs (conv_xt16.hip; tried first by cmtts_launch_conv16 when a->text_epi; same bits); -2 = not covered
+int cmtts_launch_conv_xt16(const ConvArgs* a, const void* wfrag, int mode, int nbatch, void* stream);
 // X-resident variant for short sequences (conv_xres.hip): wfrag = fp32 fragment-order weights; -2 = unsupported.
 int cmtts_launch_conv_xres(const ConvArgs* a, const float* wfrag, int nbatch, void* stream);
 void cmtts_conv_set_debug(long long* dbg, int M, int K);   // generic kernel: cycle counters of the launches with this (M, K)

@@ -314,6 +314,10 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
         o.row_off != 0 || o.Tout != a.N)
         return -2;
     // 128-frame tiles everywhere: these convs are HBM-bound, what matters is loads in flight (3 workgroups/CU)
+    if (a.text_epi) {     // K = 256: the X-resident kernel (conv_xt16.hip: one staging round trip per tile, no barrier in the K loop; same bits)
+        const int rx = cmtts_launch_conv_xt16(ap, wfrag, mode, nbatch, stream_);
+        if (rx != -2) return rx;
+    }
     // the text side's short sequences (85 phonemes, 170, ...): 96-column tiles where they pad less than 128-column ones
     if (a.text_epi && a.M > 64 && (a.N + 95) / 96 * 96 < (a.N + 127) / 128 * 128) return launch16<128, 96, 4, 1>(a, wfrag, mode, nbatch, stream);
     if (a.M > 64) {

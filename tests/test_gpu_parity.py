@@ -1229,6 +1229,40 @@ def test_cond_projections_operands(variant, B, T, layers, dtype):
     model.set_precision("fp32")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 3, 85), ("VCTK", 2, 31), ("LibriTTS", 2, 170), ("LJSpeech", 1, 1)])
+def test_text16_xresident_bitwise(variant, B, L, dtype):
+    """conv_xt16.hip (the text16 convs with 256 input channels: whole x^T tile of an utterance staged once, hand-issued weight ring, no barrier
+    in the K loop) keeps conv_mfma16.hip's conversions, (chunk, tap, k-group) order and epilogue: every output of the text side — floats and
+    integers — must not change by a bit.  L = 85 / 31 / 1: one ragged 96-column tile; 170: two tiles; ragged lengths exercise the masks."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=31, dur_frames=4.0, dur_spread=0.03))
+    rs = np.random.RandomState(L)
+    ln = np.maximum((rs.uniform(0.4, 1.0, size=B) * L).astype(np.int64), 1); ln[0] = L
+    tx = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    tx[np.arange(L)[None, :] >= ln[:, None]] = 0
+    spk = torch.randn(B, cfg.external_speaker_dim, generator=torch.Generator().manual_seed(L)) if cfg.multi_speaker else None
+    model.set_precision(dtype)
+    model.set_option("text16", 1)
+    keys = ("enc_out", "log_d_predictions", "e_predictions", "cond", "d_rounded", "mel_lens", "mel2ph")
+    prev = _lib.internal_set(b"text_xt16", 0)
+    try:
+        ref = model.duration_pitch_energy_net(None, torch.from_numpy(tx), torch.from_numpy(ln), spker_embeds=spk)
+        ref = {k: ref[k].clone() for k in keys} | {"cwt": ref["p_predictions"]["cwt"].clone()}
+        _lib.internal_set(b"text_xt16", 1)
+        got = model.duration_pitch_energy_net(None, torch.from_numpy(tx), torch.from_numpy(ln), spker_embeds=spk)
+        got = {k: got[k].clone() for k in keys} | {"cwt": got["p_predictions"]["cwt"].clone()}
+        torch.cuda.synchronize()
+    finally:
+        _lib.internal_set(b"text_xt16", prev)
+        model.set_option("text16", 0)
+        model.set_precision("fp32")
+    for k in ref:
+        assert torch.isfinite(got[k].float()).all(), k
+        assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
+
+
 def test_bucketed_synthesizer_streams_match_sequential():
     """configs[3] shape: bucket groups on separate HIP streams (own workspaces) must give exactly the results of running
     the groups one after the other."""
