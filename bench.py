@@ -289,6 +289,65 @@ def multi_gpu_extras(args, cfg, model, step, timed_w, state, frames_rank, audio_
     return extras
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment starts the N ranks ITSELF (one process per GPU
+    through torch.distributed.run on 127.0.0.1) and returns their exit code; under torch.distributed.run (WORLD_SIZE set: the
+    driver's form) it checks that the launcher's world size IS --gpus and returns None.  A plain `python bench.py --gpus 8` can
+    therefore never measure one GPU and print n_gpus = 8 (VERDICT r03 missing #1).  The reference has no inference launcher
+    (synthesize.py:32,43 is single-process): this is the repo's own."""
+    import subprocess
+    n = args.gpus
+    if n < 1:
+        log(f"bench.py: --gpus {n} is not a GPU count")
+        return 2
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != n:
+            log(f"bench.py: --gpus {n} but the launcher started WORLD_SIZE={ws} ranks; refusing to report a mislabelled number "
+                f"(launch with --nproc-per-node {n}, or run `python bench.py --gpus {n}` and let it launch the ranks)")
+            return 2
+        return None
+    if n == 1:
+        return None
+    dry = os.environ.get("CMTTS_BENCH_DRYRUN") == "1"
+    if not dry:
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"bench.py: --gpus {n} but only {have} GPU(s) are visible on this node; nothing was measured")
+            return 2
+    import socket
+    with socket.socket() as sk:         # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: launching", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("OMP_PROC_BIND", None)      # set above for the single-process CPU baseline only
+    env.pop("OMP_PLACES", None)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launcher rehearsal without GPUs: every rank joins a gloo group, the ranks count themselves with one all-reduce and rank 0
+    prints the JSON line's launcher fields."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = dist.get_world_size()
+        assert int(t.item()) == seen
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": seen, "requested": args.gpus, "launcher": "self" if os.environ.get("TORCHELASTIC_RUN_ID") else "external"}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,15 +360,19 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="frames per workgroup of the fused residual block (tuning)")
     args = ap.parse_args()
 
+    rc = self_launch(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if os.environ.get("CMTTS_BENCH_DRYRUN") == "1":      # launcher rehearsal (tests/test_bench_launcher.py): rendezvous only, no GPU work
+        sys.exit(dry_run(args, rank, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=device)
+        world = torch.distributed.get_world_size()       # n_gpus in the JSON line = the ranks RCCL actually joined
 
     cfg = get_config("LJSpeech")
     sd = synth_cmtts_state_dict(cfg, seed=0, dur_frames=float(DUR), dur_spread=0.0)

@@ -892,6 +892,7 @@ class BucketedSynthesizer:
         try:
             conds = []
             done = {}
+            late_events = []
             for i in sorted(range(len(groups)), key=lambda i: i not in early):      # the early groups are queued first
                 texts, src_lens, spk, noise, bucket = groups[i]
                 st = self.streams[i % len(self.streams)]
@@ -904,6 +905,10 @@ class BucketedSynthesizer:
                         if prev_p is not None:
                             lib.cmtts_set_persistent_denoiser(prev_p)
                         done[i] = (mel, o["mel_lens"])
+                    if i not in early:      # main waits for THIS group's text side, whatever else shares its stream
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        late_events.append(ev)
                 conds.append((i, o))
             conds = [o for _, o in sorted(conds, key=lambda t: t[0])]
             if mode != "ragged":
@@ -912,9 +917,13 @@ class BucketedSynthesizer:
             lib.cmtts_set_option(b"branch_streams", prev_branch)
             if prev is not None:
                 lib.cmtts_set_persistent_denoiser(prev)
+        # every late group's text side is ordered before main by ITS OWN event: with more groups than streams a late group can
+        # share an early group's stream, whose full join only happens after the persistent launches are queued (below)
+        for ev in late_events:
+            main.wait_event(ev)
         early_streams = {id(self.streams[i % len(self.streams)]) for i in early}
         for st in self.streams:
-            if id(st) not in early_streams:      # the early groups' streams are joined after the persistent launches are queued
+            if id(st) not in early_streams:
                 main.wait_stream(st)
         if mode == "ragged":
             late = [i for i in range(len(groups)) if i not in early]

@@ -1378,6 +1378,15 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
     host.synchronize()
     for (m0, l0), (m1, l1) in zip(seq, got):
         assert torch.equal(l0, l1) and torch.equal(m0, m1), float((m0 - m1).abs().max())
+    # (d') ADVICE r03: more groups than streams, trimmed — the late (large) group shares the ONE stream with the early (set-aside)
+    # group; main must be ordered behind the late group's text side by its own event before it reads mel_lens / cond
+    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=1, tail_frames=16).run(mixed)
+    host.synchronize()
+    for (m0, l0), (m1, l1) in zip(seq, got):
+        assert torch.equal(l0, l1)
+        for b, n in enumerate(l0.tolist()):
+            keep = min(n + 16, m0.shape[1])
+            assert torch.equal(m1[b, :keep], m0[b, :keep]), (b, n)
     big = make((512, 1024), 14)                            # 14 * (8 + 16) = 336 padded tiles > 256 CUs: rounds of whole utterances
     seq = alone(big)
     got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(big)
