@@ -1683,8 +1683,9 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     // groups / longer utterances than a descriptor holds, too little work to beat the per-layer kernels) runs group after group
     bool one_launch = m->precision == 0 && g_fused_resblock && g_persist && g_persist_tail && g_inproj_fused && m->skip_f && m->outp_f &&
                       m->in_proj_f && NL <= PERSIST_MAX_LAYERS && n_groups <= PERSIST_MAX_GROUPS && padded_tiles * 2 > persist_blocks();
+    // (an utterance with more tiles than the launch can keep resident is known NOW: fall back before anything is queued — ADVICE r03)
     for (int g = 0; g < n_groups && one_launch; ++g)
-        if ((groups[g].T + 63) / 64 > 127 || groups[g].B > 1023 || (long)C * groups[g].T >= (1L << 30) ||
+        if ((groups[g].T + 63) / 64 > 127 || (groups[g].T + 63) / 64 > std::min(persist_blocks(), PERSIST_MAX_WG) || groups[g].B > 1023 || (long)C * groups[g].T >= (1L << 30) ||
             cmtts_persist_halo_bytes(groups[g].B, groups[g].T) % 16 != 0)
             one_launch = false;
     if (!one_launch) {
@@ -1736,7 +1737,12 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     }
     std::vector<DenWs> ws(n_groups);
     SideStream* ss = side_for(s);
-    if (ss) CHK(branch_fork(ss));
+    // whatever path leaves this function after a fork, the caller's stream is ordered behind the side stream again
+    struct JoinGuard {
+        SideStream* ss; bool armed;
+        ~JoinGuard() { if (armed && ss) (void)branch_join(ss); }
+    } guard{ss, false};
+    if (ss) { CHK(branch_fork(ss)); guard.armed = true; }
     bool any_aside = false;
     for (int g = 0; g < n_groups; ++g) {
         const cmtts_sample_group& G = groups[g];
@@ -1747,12 +1753,12 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         k_scale(G.noise, ws[g].xcur, (long)keep[g] * G.T * M, c.sigma_max, s);         // x_T = randn * sigma_max (karras_diffusion.py:534)
         if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)keep[g] * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
     }
-    if (ss) CHK(branch_join(ss));          // the conditioner projections; the side stream then carries the set-aside groups
+    if (ss) { guard.armed = false; CHK(branch_join(ss)); }          // the conditioner projections; the side stream then carries the set-aside groups
     if (any_aside) {
         // the small groups: the ordinary sampler (per-layer / split kernels), queued on the side stream so that its launches fill the
         // gaps of the main stream (prologues, launch boundaries) and whatever CUs the persistent grid leaves free
         hipStream_t q = ss ? ss->side : s;
-        if (ss) CHK(branch_fork(ss));
+        if (ss) { CHK(branch_fork(ss)); guard.armed = true; }
         const int prev_persist = g_persist;
         g_persist = 0;
         int rc = 0;
@@ -1842,7 +1848,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             if (prof) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
         }
     }
-    if (any_aside && ss) CHK(branch_join(ss));
+    if (any_aside && ss) { guard.armed = false; CHK(branch_join(ss)); }
     HIPCHK(hipGetLastError());
     return 0;
 }

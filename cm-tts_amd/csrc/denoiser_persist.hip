@@ -435,22 +435,26 @@ long long* g_pdbg = nullptr;
 // (the all-gather is completed on the stream before the next persistent launch), and bounded waits + NaN poisoning remain.
 int g_coop = -1;
 int g_process_group = 0;
-unsigned long long g_validated[4][5] = {};          // per variant: grids (x | y << 32) whose co-residency the runtime has confirmed
+int g_validated_wg[8] = {};          // per kernel instance: the LARGEST grid (workgroups) whose co-residency the runtime has confirmed
 
 }  // namespace
 
 extern "C" int cmtts_persist_set_cooperative(int on) { const int p = g_coop; if (on >= -1 && on <= 1) g_coop = on; return p; }
 extern "C" int cmtts_persist_note_process_group(int on) { const int p = g_process_group; if (on == 0 || on == 1) g_process_group = on; return p; }
-// Should this launch of `variant` (0 fp32, 1..3 the 16-bit modes) with grid (gx, gy) be cooperative?
+// Should this launch of `variant` (0 fp32, 1..3 the 16-bit modes, 4 the fp32 ragged instance) with grid (gx, gy) be cooperative?
+// Co-residency is a property of (kernel instance, LDS, workgroup COUNT): every grid no larger than one the runtime has accepted is
+// resident too, so only the maximum is remembered (a ring of exact shapes made most ragged launches — n_wg changes
+// with every trim — cooperative again, +24 % per step with RCCL loaded).
 extern "C" int cmtts_persist_cooperative(int variant, int gx, int gy) {
     if (g_coop >= 0) return g_coop;
     if (!g_process_group) return 0;
-    const unsigned long long key = (unsigned long long)(unsigned)gx | ((unsigned long long)(unsigned)gy << 32);
-    unsigned long long* v = g_validated[variant & 3];
-    for (int i = 0; i < 4; ++i)
-        if (v[i] == key) return 0;
-    v[v[4]++ & 3] = key;            // small ring: the shapes of a steady-state job
-    return 1;
+    const long wg = (long)gx * (gy > 0 ? gy : 1);
+    return wg > g_validated_wg[variant & 7] ? 1 : 0;
+}
+// Record a grid only AFTER hipLaunchCooperativeKernel has returned hipSuccess for it.
+extern "C" void cmtts_persist_validated(int variant, int gx, int gy) {
+    const long wg = (long)gx * (gy > 0 ? gy : 1);
+    if (wg > g_validated_wg[variant & 7]) g_validated_wg[variant & 7] = (int)wg;
 }
 
 extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
@@ -529,6 +533,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             void* params[] = {(void*)&c};
             if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>), dim3(tiles, nb),
                                            dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+            cmtts_persist_validated(0, tiles, nb);
         } else hipLaunchKernelGGL((denoiser_persist_kernel<false, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
@@ -551,10 +556,11 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
             return -3;
         attr_set = true;
     }
-    if (cmtts_persist_cooperative(0, a.n_wg, -1)) {
+    if (cmtts_persist_cooperative(4, a.n_wg, -1)) {
         void* params[] = {(void*)a_in};
         if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW),
                                        params, (unsigned)lds, stream) != hipSuccess) return -3;
+        cmtts_persist_validated(4, a.n_wg, -1);
     } else hipLaunchKernelGGL((denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

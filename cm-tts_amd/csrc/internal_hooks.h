@@ -1,6 +1,10 @@
 // NOT part of the C ABI (include/cmtts_hip.h): A/B switches between a fused kernel and the path it replaces, for the bitwise
-// cross-check tests (tests/test_gpu_parity.py) and the measurement tools (tools/).  Every pair produces identical bits; the
-// switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
+// cross-check tests (tests/test_gpu_parity.py) and the measurement tools (tools/).  Every pair produces identical bits EXCEPT:
+// attn_fused for L > 192 (the key-chunked online softmax against the two-pass softmax of the three-launch path: ~1e-7),
+// attn_fused for L <= 192 against the three-launch path (different fp32 summation order: <= 2e-5 on the encoder output),
+// cond_gemm16 (16-bit against fp32 operands of the conditioner GEMM in bf16 / fp16 / fp16x3 models: a numerics switch — since
+// round 3 the 16-bit form is the default for EVERY shape of a 16-bit model, which changed those models' default numerics against
+// round 2).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
 // (cmtts_amd/_lib.py: internal_set).
 #pragma once
 #ifdef __cplusplus

@@ -82,6 +82,7 @@ void cmtts_persist_set_debug(long long* dbg);
 // -1 (default) = automatic: once a process group / communicator exists in the process (cmtts_persist_note_process_group) the first
 // launch of every (variant, grid) is cooperative — the runtime validates co-residency — and later ones are plain (denoiser_persist.hip).
 int cmtts_persist_set_cooperative(int on);
+void cmtts_persist_validated(int variant, int gx, int gy);    // the runtime accepted a cooperative launch of this grid
 int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant 0 = fp32, 1..3 = 16-bit modes)
 int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
