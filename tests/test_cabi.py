@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import cmtts_amd
 from cmtts_amd import _lib
 
@@ -116,7 +118,16 @@ def test_cffi_declarations_from_the_header_and_address_helper():
         import cffi  # noqa: F401
     except ImportError:
         assert _lib.backend() == "ctypes"
-        return
+
+
+def test_cffi_leg_executes():
+    """north_star names "a thin C-ABI cffi layer".  cffi is NOT in this image's wheelhouse and there is no network, so this leg
+    cannot run here: it skips with that reason in the test output instead of passing silently; ctypes binds the
+    same symbols from the same header text (test above).  On a box with cffi: CMTTS_FFI=cffi python -m pytest tests/test_cabi.py."""
+    import ctypes
+    cffi = pytest.importorskip("cffi", reason="cffi is not installed in this image and cannot be (no network): the cffi ABI-mode "
+                                              "adapter (_lib._CffiLib) has never executed; ctypes binds the same symbols")
+    del cffi
     lib = _lib._CffiLib(_lib.LIB_PATH)
     assert b"gfx950" in lib.cmtts_version()
     assert lib.cmtts_create(None, None) == -1 and b"null" in lib.cmtts_last_error()
