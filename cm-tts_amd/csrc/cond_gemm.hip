@@ -64,13 +64,19 @@ __global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArg
 #pragma unroll
             for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * X_LD + j * 32];
     };
-    const int npass = a.M / (32 * MT * NW);          // 512 rows per pass
+    const int npass_all = a.M / (32 * MT * NW);      // 512 rows per pass
+    // gridDim.z workgroups share a frame tile, each walking a contiguous share of the passes (the phoneme-level factor of the
+    // conditioner projections has few tiles: the rows spread the work instead); an element's accumulation chain does not change
+    const int ppg = (npass_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int p_first = (int)blockIdx.z * ppg;
+    const int npass = min(npass_all, p_first + ppg);
+    if (p_first >= npass) return;
     f32x4 A[RING][MT];
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) load_a(A[s], w * MT, s);
+    for (int s = 0; s < RING - 1; ++s) load_a(A[s], (p_first * NW + w) * MT, s);
     __syncthreads();
 
-    for (int p = 0; p < npass; ++p) {
+    for (int p = p_first; p < npass; ++p) {
         const int mt0 = (p * NW + w) * MT;           // this wave's first m-tile in this pass
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -137,6 +143,45 @@ extern "C" int cmtts_launch_cond_gemm(const CondGemmArgs* ap, void* stream_) {
             return -3;
         attr_set = true;
     }
-    hipLaunchKernelGGL(cond_gemm_kernel, dim3((a.T + FN - 1) / FN, a.B), dim3(64 * NW), lds, (hipStream_t)stream_, a);
+    const int zsplit = a.row_split > 1 ? a.row_split : 1;
+    hipLaunchKernelGGL(cond_gemm_kernel, dim3((a.T + FN - 1) / FN, a.B, zsplit), dim3(64 * NW), lds, (hipStream_t)stream_, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+namespace {
+// cp[b][r][t] = (ph > 0 ? P1[b][r][ph - 1] : 0) + P2[r][idx],  ph = mel2ph[b][t], idx = p_idx[b][t]:
+// the conditioner projections of all layers expanded from their phoneme-level and pitch-table factors (cmtts_api.hip: cond_factored).
+// HBM-bound on the [B][M][T] write; the factors are L2 / Infinity-Cache resident (consecutive frames read the same or the
+// neighbouring phoneme and a neighbouring pitch bucket).  One thread = one frame, CEX_ROWS rows per workgroup, 8 rows in flight.
+constexpr int CEX_ROWS = 64;
+__global__ __launch_bounds__(256) void cond_expand_kernel(const float* __restrict__ p1, int ldp, int L, const float* __restrict__ p2, int ld2,
+                                                          const int64_t* __restrict__ mel2ph, const int64_t* __restrict__ pidx,
+                                                          float* __restrict__ cp, int M, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * CEX_ROWS, b = blockIdx.z;
+    if (t >= T) return;
+    const int64_t ph64 = mel2ph[(long)b * T + t];
+    const int ph = (int)(ph64 > L ? L : ph64);
+    int ix = (int)pidx[(long)b * T + t];
+    ix = ix < 0 ? 0 : (ix >= ld2 ? ld2 - 1 : ix);
+    const float* a = p1 + ((long)b * M + r0) * ldp + (ph > 0 ? ph - 1 : 0);
+    const float* q = p2 + (long)r0 * ld2 + ix;
+    float* o = cp + ((long)b * M + r0) * T + t;
+#pragma unroll 1
+    for (int r = 0; r < CEX_ROWS; r += 8) {
+        float av[8], qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { av[j] = a[(long)(r + j) * ldp]; qv[j] = q[(long)(r + j) * ld2]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[(long)(r + j) * T] = (ph > 0 ? av[j] : 0.f) + qv[j];
+    }
+}
+}  // namespace
+
+extern "C" int cmtts_launch_cond_expand(const float* p1, int ldp, int L, const float* p2, int ld2, const int64_t* mel2ph, const int64_t* pidx,
+                                        float* cp, int B, int M, int T, void* stream_) {
+    if (M % CEX_ROWS != 0 || B <= 0 || T <= 0 || L <= 0) return -2;
+    hipLaunchKernelGGL(cond_expand_kernel, dim3((T + 255) / 256, M / CEX_ROWS, B), dim3(256), 0, (hipStream_t)stream_, p1, ldp, L, p2, ld2,
+                       mel2ph, pidx, cp, M, T);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -12,12 +12,15 @@ extern "C" {
 #endif
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
-// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, text_xt16 (cmtts_api.hip: cmtts_internal_set).
+// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, text_xt16 (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 // Test hook: the stacked conditioner projections alone, with the model's current precision mode.  cond_ct [B][hidden][T] -> cp [B][NL * C][T]
 // (device pointers).  Returns a cmtts_status.
 struct cmtts_model;
 int cmtts_internal_cond_projections(struct cmtts_model* m, const float* cond_ct, int B, int T, float* cp, void* stream);
+// Test hook: the same tensor expanded from the factors cmtts_frame_forward_sub returns (cond_p1 [B][NL*C][p1_ld], mel2ph, p_idx [B][T])
+int cmtts_internal_cond_factored(struct cmtts_model* m, const float* p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx, int B, int T,
+                                 float* cp, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,8 @@ void k_embed_tokens(const int64_t* texts, const int64_t* lens, const float* E, c
 void k_layernorm_ct(const float* in, float* out, const float* gamma, const float* beta, float eps,
                     const int64_t* lens, int B, int T, int ld, hipStream_t s);          // C = 256
 void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s);
-void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s);
+void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s,
+                  const int64_t* lens = nullptr);      // lens: columns l >= lens[b] are left untouched
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
                      int tab_rows, int B, int C, int T, int ld, hipStream_t s,
                      const int64_t* lens = nullptr);      // lens: columns t >= lens[b] are written as 0

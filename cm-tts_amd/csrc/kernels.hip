@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256) void softmax_cols_kernel(float* st, const int6
 }
 
 // ---- x[b][c][l] += vec[b][c] (speaker embedding broadcast, model/modules.py:349-352)
-__global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int ld) {
+// lens (optional): columns l >= lens[b] do not exist for utterance b (a ragged text batch: its group's padded length) and stay 0
+__global__ void add_rowvec_kernel(float* x, const float* vec, int C, int L, int ld, const int64_t* lens) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
-    if (l < L) x[((long)b * C + c) * ld + l] += vec[(long)b * C + c];
+    if (l < L && !(lens && (int64_t)l >= lens[b])) x[((long)b * C + c) * ld + l] += vec[(long)b * C + c];
 }
 
 // ---- PitchPredictor/EnergyPredictor input: xs + alpha * PE[positions(xs[...,0] != 0)]
@@ -737,8 +738,8 @@ void k_layernorm_ct(const float* in, float* out, const float* gamma, const float
 void k_softmax_cols(float* st, const int64_t* lens, int nz, int H, int L, int ld, long zs, hipStream_t s) {
     hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(L, 64), nz), dim3(256), 0, s, st, lens, H, L, ld, zs);
 }
-void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld);
+void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipStream_t s, const int64_t* lens) {
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(cdiv(L, 64), C, B), dim3(64), 0, s, x, vec, C, L, ld, lens);
 }
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
                      int tab_rows, int B, int C, int T, int ld, hipStream_t s, const int64_t* lens) {

@@ -102,6 +102,21 @@ def get_mask_from_lengths(lengths, max_len=None):
     return ids >= lengths.unsqueeze(1)
 
 
+class CondFactors:
+    """The phoneme-level factor of the conditioner projections that cmtts_frame_forward_sub returns beside the conditioning
+    (include/cmtts_hip.h): with it the sampler expands cp from (p1, mel2ph, p_idx) instead of running the stacked conditioner GEMM
+    over the frames.  Bound to ONE conditioning tensor: `matches` refuses a different or since-modified cond_ct (the sampler then
+    takes the dense GEMM on whatever it was given)."""
+    __slots__ = ("p1", "p1_ld", "L", "mel2ph", "p_idx", "_ptr", "_version", "_shape")
+
+    def __init__(self, p1, p1_ld, L, mel2ph, p_idx, cond_ct):
+        self.p1, self.p1_ld, self.L, self.mel2ph, self.p_idx = p1, int(p1_ld), int(L), mel2ph, p_idx
+        self._ptr, self._version, self._shape = cond_ct.data_ptr(), cond_ct._version, tuple(cond_ct.shape)
+
+    def matches(self, cond_ct):
+        return cond_ct.data_ptr() == self._ptr and cond_ct._version == self._version and tuple(cond_ct.shape) == self._shape
+
+
 class CMTotalTTS(torch.nn.Module):
     """Drop-in for model/cm_tool/tts_net.py:40-183 (inference side).
 
@@ -121,6 +136,7 @@ class CMTotalTTS(torch.nn.Module):
         _lib.check(self.lib.cmtts_create(C.byref(cs), C.byref(self._h)))
         self._ready = False
         self._ws = _Workspace()
+        self._cond_factors = True       # the duration net returns the conditioner factors with its conditioning (fp32 models)
         self.duration_pitch_energy_net = DurationPitchSpeakerNet(self)
         self.net = CMDenoiserTTS(self)
         self.decoder = FastspeechDecoder(self)      # usable when the loaded state dict carries decoder.* (else it raises)
@@ -284,16 +300,22 @@ class DurationPitchSpeakerNet(torch.nn.Module):
                 stats = f(B, 2)
                 nf = lib.cmtts_frame_workspace_bytes(o._h, B, T)
                 fws = o._ws.get("frame", nf, dev)
-                _lib.check(lib.cmtts_frame_forward(o._h, _ptr(tws), B, L, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
-                                                   _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(fws), nf, _stream()))
+                # fp32 models: the phoneme-level factor of the conditioner projections rides along (CondFactors)
+                p1_ld = (L + 3) // 4 * 4
+                p1 = f(B, cfg.res_layers * cfg.res_channels, p1_ld) if getattr(o, "_precision_mode", 0) == 0 and o._cond_factors else None
+                _lib.check(lib.cmtts_frame_forward_sub(o._h, _ptr(tws), B, L, 0, B, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
+                                                       _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(p1), _ptr(fws), nf, _stream()))
             finally:
                 if vc is not None:
                     lib.cmtts_set_variance_controls(o._h, None)              # back to the inference defaults
                     torch.cuda.current_stream(dev).synchronize()             # targets must outlive the kernels
         mel_masks = get_mask_from_lengths(mel_len, T)
+        factors = None if p1 is None else CondFactors(p1, p1_ld, L, mel2ph, p_idx, cond_ct)
+        cond_ct._cmtts_factors = factors       # rides along with THIS tensor object: sample_with_cond(cond_ct, ...) finds it (and re-checks it)
         return {
             "cond": cond_ct.transpose(1, 2),               # [B,T,H] view of the channel-major buffer
             "cond_ct": cond_ct,
+            "cond_factors": factors,
             "p_targets": p_targets,
             "p_predictions": {"pitch_pred": None, "f0_denorm": f0, "cwt": cwt,
                               "f0_mean": stats[:, 0], "f0_std": stats[:, 1], "p_idx": p_idx},
@@ -431,9 +453,11 @@ def synchronize(device=None):
     check_async_error()
 
 
-def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
+def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise, factors=None):
     """T-step consistency sampling on precomputed conditioning (cmtts_sample).
-    noise: fp32 [n_noise,B,1,T,80] on device.  Returns mel [B,T,80]."""
+    noise: fp32 [n_noise,B,1,T,80] on device.  factors: the duration net's out["cond_factors"] for THIS cond_ct (default: the ones the
+    duration net attached to the tensor object it returned; the conditioner projections are then expanded from them,
+    cmtts_sample_factored — an unmodified, same-storage cond_ct only, else the dense GEMM).  Returns mel [B,T,80]."""
     model._require()
     lib, dev, cfg = model.lib, model.device, model.config
     B, H, T = cond_ct.shape
@@ -446,8 +470,15 @@ def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise):
         mel = torch.empty(B, T, cfg.n_mels, dtype=torch.float32, device=dev)
         nb = lib.cmtts_denoiser_workspace_bytes(model._h, B, T)
         ws = model._ws.get("den", nb, dev)
-        _lib.check(lib.cmtts_sample(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
-                                    _ptr(mel), _ptr(ws), nb, _stream()))
+        if factors is None:
+            factors = getattr(cond_ct, "_cmtts_factors", None)
+        if factors is not None and factors.matches(cond_ct):
+            _lib.check(lib.cmtts_sample_factored(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
+                                                 _ptr(mel), _ptr(ws), nb, _stream(), _ptr(factors.p1), factors.p1_ld, factors.L,
+                                                 _ptr(factors.mel2ph), _ptr(factors.p_idx)))
+        else:
+            _lib.check(lib.cmtts_sample(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
+                                        _ptr(mel), _ptr(ws), nb, _stream()))
     return mel
 
 
@@ -455,7 +486,7 @@ def sample_ragged(model: CMTotalTTS, groups, n_steps, tail_frames=0):
     """cmtts_sample_ragged: T-step consistency sampling of a RAGGED shard — every group a padded (B, T) batch with its own
     conditioning, results those of sample_with_cond on that batch — with the residual layers of ALL groups in one persistent
     launch per evaluation (buckets too small to fill the chip fill it together).
-    groups: iterable of (cond_ct [B,H,T], speaker_emb [B,H] | None, noise [n_noise,B,1,T,80], active_frames | None);
+    groups: iterable of (cond_ct [B,H,T], speaker_emb [B,H] | None, noise [n_noise,B,1,T,80], active_frames | None[, CondFactors | None]);
     active_frames = host sequence of B ints (mel_len): the utterance is then only computed as far as those frames (+ tail_frames
     + the sampler's receptive field) need — they come out bit-identical, frames beyond the computed range are zeros.
     Returns the list of mels [B,T,80]."""
@@ -469,7 +500,9 @@ def sample_ragged(model: CMTotalTTS, groups, n_steps, tail_frames=0):
     arr = (_lib.SampleGroupStruct * len(groups))()
     mels, keep = [], []
     with torch.cuda.device(dev):
-        for gi, (cond_ct, spk, noise, active) in enumerate(groups):
+        for gi, grp in enumerate(groups):
+            cond_ct, spk, noise, active = grp[:4]
+            factors = grp[4] if len(grp) > 4 else None
             B, H, T = cond_ct.shape
             assert noise.shape[0] >= n_noise and tuple(noise.shape[1:]) == (B, 1, T, cfg.n_mels)
             mel = torch.empty(B, T, cfg.n_mels, dtype=torch.float32, device=dev)
@@ -482,6 +515,10 @@ def sample_ragged(model: CMTotalTTS, groups, n_steps, tail_frames=0):
                 act = (C.c_int64 * B)(*[int(v) for v in active])
                 keep.append(act)
                 g.active_frames = C.cast(act, C.c_void_p).value
+            if factors is not None and factors.matches(cond_ct):
+                g.cond_p1, g.p1_ld, g.L = factors.p1.data_ptr(), factors.p1_ld, factors.L
+                g.mel2ph, g.p_idx = factors.mel2ph.data_ptr(), factors.p_idx.data_ptr()
+                keep.append(factors)
             mels.append(mel)
             keep += [cond_ct, spk, noise, ws]
         _lib.check(lib.cmtts_sample_ragged(model._h, arr, len(groups), n_steps, sig, std, int(tail_frames), _stream()))
@@ -546,7 +583,7 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
     for _ in range(n_steps if n_steps > 1 else 0):
         draws.append(generator.randn_like(draws[0]))
     noise = torch.stack([_f32(d, dev) for d in draws], 0)
-    return sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise)
+    return sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, noise, factors=out.get("cond_factors"))
 
 
 def out_cond(out):
@@ -836,8 +873,88 @@ class StreamPipelinedSynthesizer:
         self._keep = [out]
         if next_batch is not None:
             self.prepare(*next_batch)
-        mel = sample_with_cond(self.model, out["cond_ct"], out["speaker_emb"], self.n_steps, noise)
+        mel = sample_with_cond(self.model, out["cond_ct"], out["speaker_emb"], self.n_steps, noise, factors=out.get("cond_factors"))
         return mel, out["mel_lens"]
+
+
+ATTN_SHORT_MAX = 192        # attention.hip: all keys in registers up to here, key-chunked online softmax above (not bitwise the same)
+
+
+class CollatedShard:
+    """A ragged shard's bucket groups collated for ONE phoneme-level call per attention class (cmtts_text_forward_ragged): the
+    host-side counterpart of the reference's collate_fn padding (dataset.py), done once per shard.  `batches`: list of dicts with
+    texts [Bt,Lt], src_lens [Bt], pad_lens [Bt] (each utterance's own group's padded phoneme count), spk [Bt,D] | None and
+    `members` = [(group index, b0, n, Lg)]; `groups` keeps (noise, bucket) per group."""
+
+    def __init__(self, groups, device):
+        self.groups = [(g[3], int(g[4])) for g in groups]
+        self.n = [int(g[0].shape[0]) for g in groups]
+        classes = {}
+        for i, g in enumerate(groups):
+            classes.setdefault(int(g[0].shape[1]) > ATTN_SHORT_MAX, []).append(i)      # groups that take the same attention kernel alone and batched
+        self.batches = []
+        for _, idx in sorted(classes.items()):
+            Lt = max(int(groups[i][0].shape[1]) for i in idx)
+            Bt = sum(int(groups[i][0].shape[0]) for i in idx)
+            texts = torch.zeros(Bt, Lt, dtype=torch.int64, device=device)
+            has_spk = groups[idx[0]][2] is not None
+            src, pad, spk, members, b0 = [], [], [], [], 0
+            for i in idx:
+                tx, ln, sp = groups[i][0], groups[i][1], groups[i][2]
+                n, Lg = tx.shape
+                texts[b0:b0 + n, :Lg] = tx.to(device)
+                src.append(ln.to(device=device, dtype=torch.int64))
+                pad.append(torch.full((n,), Lg, dtype=torch.int64, device=device))
+                if has_spk:
+                    spk.append(sp.to(device=device, dtype=torch.float32))
+                members.append((i, b0, n, Lg))
+                b0 += n
+            self.batches.append({"texts": texts, "src_lens": torch.cat(src), "pad_lens": torch.cat(pad),
+                                 "spk": torch.cat(spk) if has_spk else None, "members": members})
+
+
+def collate_groups(groups, device):
+    """groups: [(texts [n,Lg], src_lens [n], spker_embeds [n,D] | None, noise, bucket)] -> CollatedShard."""
+    return CollatedShard(list(groups), _norm_device(device))
+
+
+def _text_forward_ragged(model, tb, key):
+    """One cmtts_text_forward_ragged call for a collated text batch.  Returns (text workspace, B, L, mel_len [B], speaker_emb [B,H] | None)."""
+    lib, dev, cfg = model.lib, model.device, model.config
+    texts, src, pad, spk_in = tb["texts"], tb["src_lens"], tb["pad_lens"], tb["spk"]
+    B, L = texts.shape
+    table = cfg.multi_speaker and cfg.n_speaker > 0
+    if table:
+        raise NotImplementedError("ragged text batches with a speaker-id table")
+    if cfg.multi_speaker and spk_in is None:
+        raise AssertionError("Speaker embedding should not be None")
+    with torch.cuda.device(dev):
+        mel_len = torch.empty(B, dtype=torch.int64, device=dev)
+        spk = torch.empty(B, cfg.hidden, dtype=torch.float32, device=dev) if cfg.multi_speaker else None
+        nb = lib.cmtts_text_workspace_bytes(model._h, B, L)
+        tws = model._ws.get(key, nb, dev)
+        _lib.check(lib.cmtts_text_forward_ragged(model._h, _ptr(texts), _ptr(src), _ptr(pad), _ptr(spk_in), None, B, L, 1.0,
+                                                 None, None, _ptr(mel_len), None, None, None, _ptr(spk), _ptr(tws), nb, _stream()))
+    return tws, B, L, mel_len, spk
+
+
+def _frame_forward_sub(model, tws, B_all, L_all, b0, n, T, key, want_factors=True):
+    """cmtts_frame_forward_sub for utterances [b0, b0 + n) of a text workspace -> (cond_ct, CondFactors | None)."""
+    lib, dev, cfg = model.lib, model.device, model.config
+    with torch.cuda.device(dev):
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        cond_ct = f(n, cfg.hidden, T)
+        mel2ph = torch.empty(n, T, dtype=torch.int64, device=dev)
+        p_idx = torch.empty(n, T, dtype=torch.int64, device=dev)
+        p1_ld = (L_all + 3) // 4 * 4
+        p1 = f(n, cfg.res_layers * cfg.res_channels, p1_ld) if want_factors and getattr(model, "_precision_mode", 0) == 0 and model._cond_factors else None
+        nf = lib.cmtts_frame_workspace_bytes(model._h, n, T)
+        fws = model._ws.get(key, nf, dev)
+        _lib.check(lib.cmtts_frame_forward_sub(model._h, _ptr(tws), B_all, L_all, b0, n, T, _ptr(cond_ct), _ptr(mel2ph), None, None,
+                                               _ptr(p_idx), None, _ptr(p1), _ptr(fws), nf, _stream()))
+    factors = None if p1 is None else CondFactors(p1, p1_ld, L_all, mel2ph, p_idx, cond_ct)
+    cond_ct._cmtts_factors = factors
+    return cond_ct, factors
 
 
 class BucketedSynthesizer:
@@ -849,7 +966,7 @@ class BucketedSynthesizer:
     mode "streams": every group end to end on its own stream (round 2).  Either way each group's valid frames are those of
     running the group alone."""
 
-    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None, mode="ragged", tail_frames=16, trim=True):
+    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None, mode="ragged", tail_frames=16, trim=True, batch_text=True):
         """persistent: denoiser mode while the groups run in "streams" mode (cmtts_set_persistent_denoiser; None = leave the
         process setting alone).  tail_frames: frames beyond mel_len that must be exact in the padded mel (16 covers HiFi-GAN's
         receptive field; the frames beyond the computed range are zeros instead of denoised padding).  trim=False computes
@@ -857,11 +974,94 @@ class BucketedSynthesizer:
         self.model, self.n_steps, self.persistent, self.mode = model, n_steps, persistent, mode
         self.tail_frames, self.trim = int(tail_frames), bool(trim)
         self.streams = [torch.cuda.Stream(device=model.device) for _ in range(n_streams)]
+        # round 4, mode "ragged": the phoneme-level half of ALL groups in one cmtts_text_forward_ragged call (one launch sequence for the
+        # shard instead of one per group), then each group's frame-level half on its own stream; False = one text side per group (round 3)
+        self.batch_text = bool(batch_text)
+
+    def _early_groups(self, sizes):
+        """sizes: [(n, bucket)] -> indices of the small groups that run end to end on their own stream (see run())."""
+        early = set()
+        cap = torch.cuda.get_device_properties(self.model.device).multi_processor_count
+        tiles = [n * ((bucket + 63) // 64) for n, bucket in sizes]
+        order = sorted(range(len(sizes)), key=lambda i: tiles[i])
+        rest, gone = sum(tiles), 0
+        for i in order:
+            if rest <= cap or gone + tiles[i] > 64:
+                break
+            early.add(i); rest -= tiles[i]; gone += tiles[i]
+        if not (rest * 0.92 <= cap):       # would not fit one round even after trimming: let the library decide
+            early = set()
+        return early
+
+    def _run_batched(self, coll):
+        """mode "ragged", fp32: one phoneme-level call per attention class for the whole shard, the frame-level halves per group on
+        the streams, set-aside candidates sampled end to end on theirs, ONE cmtts_sample_ragged for the rest."""
+        model, lib, dev = self.model, self.model.lib, self.model.device
+        main = torch.cuda.current_stream(dev)
+        ng = len(coll.groups)
+        early = self._early_groups([(coll.n[i], coll.groups[i][1]) for i in range(ng)]) if self.trim else set()
+        conds, lens, done, late_events = [None] * ng, [None] * ng, {}, []
+        text_done = []
+        for k, tb in enumerate(coll.batches):          # the library's branch streams stay ON here: one call, nothing to compete with
+            tws, Bt, Lt, mel_len, spk = _text_forward_ragged(model, tb, ("text_ragged", k))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            text_done.append((tb, tws, Bt, Lt, mel_len, spk, ev))
+        prev_branch = lib.cmtts_set_option(b"branch_streams", 0)       # the groups overlap across the streams from here on
+        try:
+            order = []
+            for tb, tws, Bt, Lt, mel_len, spk, ev in text_done:
+                for (i, b0, n, Lg) in tb["members"]:
+                    order.append((i not in early, i, b0, n, tws, Bt, Lt, mel_len, spk, ev))
+            for _, i, b0, n, tws, Bt, Lt, mel_len, spk, ev in sorted(order, key=lambda t: t[:2]):      # the early groups are queued first
+                noise, bucket = coll.groups[i]
+                st = self.streams[i % len(self.streams)]
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    cond_ct, factors = _frame_forward_sub(model, tws, Bt, Lt, b0, n, bucket, ("frame_ragged", i))
+                    spk_i = None if spk is None else spk[b0:b0 + n]
+                    lens[i] = mel_len[b0:b0 + n]
+                    if i in early:
+                        prev_p = lib.cmtts_set_persistent_denoiser(0)
+                        try:
+                            done[i] = (sample_with_cond(model, cond_ct, spk_i, self.n_steps, noise, factors=factors), lens[i])
+                        finally:
+                            lib.cmtts_set_persistent_denoiser(prev_p)
+                    else:
+                        e2 = torch.cuda.Event()
+                        e2.record(st)
+                        late_events.append(e2)
+                    conds[i] = (cond_ct, spk_i, factors)
+        finally:
+            lib.cmtts_set_option(b"branch_streams", prev_branch)
+        for e2 in late_events:
+            main.wait_event(e2)
+        late = [i for i in range(ng) if i not in early]
+        active = [None] * len(late)
+        if self.trim and late:      # one device -> host copy for the whole shard
+            flat = torch.cat([lens[i] for i in late]).cpu().tolist()
+            k = 0
+            for gi, i in enumerate(late):
+                active[gi] = flat[k:k + coll.n[i]]
+                k += coll.n[i]
+        mels = sample_ragged(model, [(conds[i][0], conds[i][1], coll.groups[i][0], a, conds[i][2]) for i, a in zip(late, active)],
+                             self.n_steps, self.tail_frames) if late else []
+        for i, mel in zip(late, mels):
+            done[i] = (mel, lens[i])
+        for st in self.streams:
+            main.wait_stream(st)
+        return [done[i] for i in range(ng)]
 
     def run(self, groups):
-        """groups: iterable of (texts, src_lens, spker_embeds | None, noise [n_steps+1,n,1,bucket,80], bucket).
+        """groups: iterable of (texts, src_lens, spker_embeds | None, noise [n_steps+1,n,1,bucket,80], bucket), or the CollatedShard
+        collate_groups() made of them (collation = input preparation, once per shard).
         Returns [(mel [n,bucket,80], mel_lens [n])] in the same order."""
         dev = self.model.device
+        if self.mode == "ragged" and self.batch_text and getattr(self.model, "_precision_mode", 0) == 0 and \
+                not (self.model.config.multi_speaker and self.model.config.n_speaker > 0):
+            return self._run_batched(groups if isinstance(groups, CollatedShard) else collate_groups(groups, dev))
+        if isinstance(groups, CollatedShard):
+            raise ValueError("a CollatedShard needs mode='ragged' with batch_text on an fp32 model")
         main = torch.cuda.current_stream(dev)
         out = []
         lib = self.model.lib
@@ -901,7 +1101,7 @@ class BucketedSynthesizer:
                     o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
                     if mode != "ragged" or i in early:
                         prev_p = lib.cmtts_set_persistent_denoiser(0) if i in early else None
-                        mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise)
+                        mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise, factors=o.get("cond_factors"))
                         if prev_p is not None:
                             lib.cmtts_set_persistent_denoiser(prev_p)
                         done[i] = (mel, o["mel_lens"])
@@ -1034,7 +1234,8 @@ class CMTotalTTSSynthesize:
         else:                # the duration net ran once above; the reference's in-sampler re-runs are bit-identical
             x0 = gen.randn(B, 1, T, cfg.n_mels, device=self.model.device)
             noise = torch.stack([x0] + [gen.randn_like(x0) for _ in range(draws - 1)], 0).float()
-            sample = sample_with_cond(self.model, out_dict["cond_ct"], out_dict["speaker_emb"], n_steps, noise)
+            sample = sample_with_cond(self.model, out_dict["cond_ct"], out_dict["speaker_emb"], n_steps, noise,
+                                      factors=out_dict.get("cond_factors"))
         out_put = [None] * 12
         out_put[0] = sample
         out_put[10] = kw["src_lens"]

@@ -57,9 +57,9 @@ const char* cmtts_last_error(void);
 const char* cmtts_version(void);
 /* Binary-interface revision of this header: bumped whenever a struct layout or an existing signature changes (round 2
  * inserted cmtts_config.n_speaker and the `speakers` parameter of cmtts_text_forward: revision 2; round 3 adds entry
- * points only but starts the counter: 3).  A host compares cmtts_abi_version() with the CMTTS_ABI_VERSION it was built
+ * points only but starts the counter: 3; round 4 appends the conditioner factors to cmtts_sample_group: 4).  A host compares cmtts_abi_version() with the CMTTS_ABI_VERSION it was built
  * against before it passes a struct (cmtts_amd/_lib.py does at load time). */
-#define CMTTS_ABI_VERSION 3
+#define CMTTS_ABI_VERSION 4
 int cmtts_abi_version(void);
 
 /* ---- weight import: replaces torch.load + load_state_dict (synthesize.py:79-83).
@@ -86,6 +86,18 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
                        float* log_d, float* d_rounded, int64_t* mel_len, float* e_pred, int64_t* e_idx,
                        float* enc_out_ct, float* speaker_emb,
                        void* text_ws, size_t text_ws_bytes, void* stream);
+/* The same for a RAGGED batch (round 4; BASELINE.json configs[3]): utterances of several padded groups — the bucket groups of a shard —
+ * in one call, padded to the longest group's L.  pad_lens int64 [B] (device): the padded phoneme count of each utterance's OWN group;
+ * columns l >= pad_lens[b] do not exist for utterance b.  The padded length enters the reference's arithmetic in two places: the
+ * speaker vector is added to every column of the padded batch (model/modules.py:349-352) and the energy predictor runs unmasked over
+ * them (:520-554).  Both stop at pad_lens[b]; everything else is column-local or masked by src_lens, so every utterance gets the
+ * bits of running its group alone through cmtts_text_forward.  Outputs are [B, L] with L the call's; a group's [Bg, Lg] block is the
+ * sub-array rows b0.., columns < Lg (columns >= pad_lens[b] hold unspecified values).  pad_lens NULL = cmtts_text_forward. */
+int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* pad_lens,
+                              const float* spker_embeds, const int64_t* speakers, int B, int L, float d_control,
+                              float* log_d, float* d_rounded, int64_t* mel_len, float* e_pred, int64_t* e_idx,
+                              float* enc_out_ct, float* speaker_emb,
+                              void* text_ws, size_t text_ws_bytes, void* stream);
 
 /* ---- VarianceAdaptor controls and teacher-forced targets (model/modules.py:331-343: p_control, e_control,
  * pitch_target, energy_target, duration_target; d_control is an argument of cmtts_text_forward).  The
@@ -116,6 +128,17 @@ size_t cmtts_frame_workspace_bytes(const cmtts_model* m, int B, int T);
 int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T,
                         float* cond_ct, int64_t* mel2ph, float* cwt_out, float* f0_denorm, int64_t* p_idx,
                         float* f0_stats, void* frame_ws, size_t frame_ws_bytes, void* stream);
+/* The same for the sub-batch [b0, b0 + B) of a text workspace filled for B_all utterances padded to L_all phonemes (a bucket group of a
+ * ragged shard with its own padded frame count T), and — optionally — with the phoneme-level factor of the conditioner projections:
+ *   cond_p1 fp32 [B, res_layers * res_channels, L_all rounded up to 4] (or NULL) = conditioner_projection weights of all residual
+ *   layers (model/blocks.py:663,676) applied to the phoneme-level conditioning, no bias.  Since
+ *   cond[:, t] = out1[:, mel2ph[t] - 1] + pitch_embed[p_idx[t]] (model/modules.py:373-395), the projections of the frames are
+ *   W out1 [:, mel2ph - 1] + (W pitch_embed^T + b)[:, p_idx]: cmtts_sample_factored / cmtts_sample_group expand them from cond_p1,
+ *   mel2ph and p_idx instead of running the stacked GEMM over the frames (7 instead of 43 GFLOP per 32 x 512-frame batch; fp32 rounding
+ *   differs from the dense product at the 1e-7 level). */
+int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T,
+                            float* cond_ct, int64_t* mel2ph, float* cwt_out, float* f0_denorm, int64_t* p_idx,
+                            float* f0_stats, float* cond_p1, void* frame_ws, size_t frame_ws_bytes, void* stream);
 
 /* ---- length regulator alone (LengthRegulator.forward, model/modules.py:446-448): bit-exact
  * gather x_ct [B,C,L] -> out_ct [B,C,T] given fp32 durations [B,L]; also emits mel2ph and mel_len.
@@ -144,6 +167,12 @@ int cmtts_schedule(const cmtts_model* m, int n_steps, float* sigmas_host, float*
 int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb,
                  int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
                  float* mel, void* ws, size_t ws_bytes, void* stream);
+/* cmtts_sample for conditioning that cmtts_frame_forward_sub produced together with its phoneme-level factor: cond_p1 / p1_ld / L /
+ * mel2ph / p_idx as described there.  cond_ct stays required (16-bit models and the unfused path read it); cond_p1 NULL = cmtts_sample. */
+int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb,
+                          int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
+                          float* mel, void* ws, size_t ws_bytes, void* stream,
+                          const float* cond_p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx);
 
 /* ---- the same sampler for a RAGGED shard (BASELINE.json configs[3]: variable-length utterances dealt into static frame buckets;
  * new work — the reference synthesizes one padded batch at a time, synthesize.py:195-227).  Every group is one padded (B, T) batch
@@ -170,6 +199,11 @@ typedef struct cmtts_sample_group {
     float* mel;                  /* out [B,T,80] */
     void* ws;
     size_t ws_bytes;
+    /* round 4 (ABI 4), all optional (NULL / 0 = the dense conditioner GEMM on cond_ct): the factors cmtts_frame_forward_sub returned */
+    const float* cond_p1;        /* [B, res_layers * res_channels, p1_ld] */
+    int32_t p1_ld, L;            /* row stride of cond_p1 (L_all rounded up to 4) and the phoneme count mel2ph indexes into */
+    const int64_t* mel2ph;       /* [B,T] */
+    const int64_t* p_idx;        /* [B,T] */
 } cmtts_sample_group;
 int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_groups, int n_steps,
                         const float* sigmas_host, const float* renoise_std_host, int tail_frames, void* stream);

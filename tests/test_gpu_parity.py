@@ -1229,6 +1229,119 @@ def test_cond_projections_operands(variant, B, T, layers, dtype):
     model.set_precision("fp32")
 
 
+@pytest.mark.parametrize("variant,B,L,T", [("LJSpeech", 32, 85, 512), ("VCTK", 3, 40, 200), ("LibriTTS", 2, 171, 1024), ("LJSpeech", 1, 5, 33)])
+def test_cond_factored(variant, B, L, T):
+    """Round 4: the conditioner projections expanded from their factors — cp[:, t] = (Wc out1)[:, mel2ph[t] - 1] + (Wc pitch_embed^T + b)[:, p_idx[t]]
+    (cmtts_frame_forward_sub's cond_p1, cond_expand_kernel) — against (a) the float64 product Wc cond + b of the conditioning the same call
+    returned: the same bound as the dense GEMM's (fp32 accumulation error only), and (b) the dense path on the device.  Then the sampler: mel with
+    and without the factors within 2e-5 (W (a + b) and W a + W b round differently), durations / buckets untouched (they are upstream)."""
+    import ctypes as C
+    host = _host()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=19, dur_frames=float(max(1, T // L)) - 0.2, dur_spread=0.03)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(B * 7 + L)
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    lens = np.maximum((rs.uniform(0.5, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=T)
+    f = out["cond_factors"]
+    assert f is not None and f.matches(out["cond_ct"])
+    raw = C.CDLL(_lib.LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    raw.cmtts_internal_cond_projections.argtypes = [vp, vp, ci, ci, vp, vp]
+    raw.cmtts_internal_cond_factored.argtypes = [vp, vp, ci, ci, vp, vp, ci, ci, vp, vp]
+    NL, Cc = cfg.res_layers, cfg.res_channels
+    cp_d = torch.full((B, NL * Cc, T), float("nan"), device=DEV)
+    cp_f = torch.full((B, NL * Cc, T), float("nan"), device=DEV)
+    assert raw.cmtts_internal_cond_projections(model._h, vp(out["cond_ct"].data_ptr()), B, T, vp(cp_d.data_ptr()), None) == 0
+    assert raw.cmtts_internal_cond_factored(model._h, vp(f.p1.data_ptr()), f.p1_ld, f.L, vp(f.mel2ph.data_ptr()), vp(f.p_idx.data_ptr()), B, T,
+                                            vp(cp_f.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    W = torch.cat([torch.from_numpy(np.asarray(sd[f"net.residual_layers.{l}.conditioner_projection.conv.weight"]))[:, :, 0] for l in range(NL)], 0)
+    bias = torch.cat([torch.from_numpy(np.asarray(sd[f"net.residual_layers.{l}.conditioner_projection.conv.bias"])) for l in range(NL)], 0)
+    ref = torch.einsum("mk,bkt->bmt", W.double(), out["cond_ct"].cpu().double()) + bias.double()[None, :, None]
+    scale = float(ref.abs().max())
+    e_d, e_f = float((cp_d.cpu().double() - ref).abs().max()), float((cp_f.cpu().double() - ref).abs().max())
+    assert torch.isfinite(cp_f).all()
+    assert e_d <= 2e-6 * scale and e_f <= 3e-6 * scale, (e_d, e_f, scale)
+    assert not torch.equal(cp_d, cp_f)          # another association, not another result
+    # the sampler with and without the factors
+    gen = torch.Generator().manual_seed(5)
+    nz = torch.randn(5, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
+    for n_steps in (1, 4):
+        m_f = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, nz, factors=f)
+        dense_ct = out["cond_ct"].clone()              # a copy carries no factors: the dense GEMM
+        m_d = host.sample_with_cond(model, dense_ct, out["speaker_emb"], n_steps, nz)
+        prev = _lib.internal_set("cond_factored", 0)
+        try:
+            m_off = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, nz, factors=f)
+        finally:
+            _lib.internal_set("cond_factored", prev)
+        host.synchronize()
+        assert torch.equal(m_off, m_d)                                     # the switch restores the dense GEMM
+        err = float((m_f - m_d).abs().max())
+        report(f"COND_FACTORED {variant} B={B} T={T} steps={n_steps}: cp max|d| vs f64 dense {e_d:.2e} factored {e_f:.2e} (scale {scale:.2f}); max|dmel| factored vs dense {err:.2e}")
+        assert err < 2e-5, err
+    # a modified conditioning tensor no longer matches its factors: the dense GEMM runs on what the caller passes
+    out["cond_ct"].add_(0.0)
+    assert not f.matches(out["cond_ct"])
+
+
+def test_ragged_text_batch_bitwise():
+    """Round 4 (third bullet): the phoneme-level half of all bucket groups of a shard in ONE call
+    (cmtts_text_forward_ragged, per-utterance pad_lens) + cmtts_frame_forward_sub per group: every group's conditioning, durations,
+    buckets and factors are bit-identical to running the group alone (where the padded length enters the reference's arithmetic — the
+    speaker vector added to every padded column, the unmasked energy predictor — the kernels stop at the group's own length)."""
+    host = _host()
+    lib = _lib.load()
+    import ctypes as C
+    for variant in ("LibriTTS", "LJSpeech"):
+        cfg = get_config(variant)
+        model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=12, dur_frames=4.0, dur_spread=0.03))
+        rs = np.random.RandomState(16)
+        groups = []
+        for bucket, n in ((128, 5), (512, 3), (256, 8), (1024, 2), (384, 1)):      # L = 32 / 128 / 64 / 256 (the long-attention class) / 96
+            Lmax = bucket // 4
+            ln = np.maximum((rs.uniform(0.3, 1.0, size=n) * Lmax).astype(np.int64), 1)
+            ln[0] = Lmax                                                       # one utterance fills its group: its last column has no neighbour
+            tx = rs.randint(1, cfg.n_symbols, size=(n, Lmax)).astype(np.int64)
+            tx[np.arange(Lmax)[None, :] >= ln[:, None]] = 0
+            sp = torch.from_numpy(rs.standard_normal(size=(n, cfg.external_speaker_dim)).astype(np.float32)).to(DEV) if cfg.multi_speaker else None
+            groups.append((torch.from_numpy(tx).to(DEV), torch.from_numpy(ln).to(DEV), sp, None, bucket))
+        coll = host.collate_groups(groups, DEV)
+        assert len(coll.batches) == 2                                          # L <= 192 and L > 192 stay apart (different attention kernels)
+        for k, tb in enumerate(coll.batches):
+            B, L = tb["texts"].shape
+            f32 = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float32, device=DEV)
+            log_d, d_r, e_p = f32(B, L), f32(B, L), f32(B, L)
+            e_i = torch.zeros(B, L, dtype=torch.int64, device=DEV)
+            mel_len = torch.zeros(B, dtype=torch.int64, device=DEV)
+            spk_o = f32(B, cfg.hidden) if cfg.multi_speaker else None
+            nb = lib.cmtts_text_workspace_bytes(model._h, B, L)
+            tws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            _lib.check(lib.cmtts_text_forward_ragged(model._h, p(tb["texts"]), p(tb["src_lens"]), p(tb["pad_lens"]), p(tb["spk"]), None, B, L, 1.0,
+                                                     p(log_d), p(d_r), p(mel_len), p(e_p), p(e_i), None, p(spk_o), p(tws), nb, None))
+            for (i, b0, n, Lg) in tb["members"]:
+                tx, ln, sp, _, bucket = groups[i]
+                alone = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=sp, max_mel_len=bucket)
+                cond_ct, fac = host._frame_forward_sub(model, tws, B, L, b0, n, bucket, ("frame_test", i))
+                host.synchronize()
+                sl = slice(b0, b0 + n)
+                assert torch.equal(mel_len[sl], alone["mel_lens"]), (variant, i)
+                assert torch.equal(d_r[sl, :Lg], alone["d_rounded"]) and torch.equal(log_d[sl, :Lg], alone["log_d_predictions"]), (variant, i)
+                assert torch.equal(e_p[sl, :Lg], alone["e_predictions"]) and torch.equal(e_i[sl, :Lg], alone["e_idx"]), (variant, i)
+                assert torch.equal(cond_ct, alone["cond_ct"]), (variant, i, float((cond_ct - alone["cond_ct"]).abs().max()))
+                fa = alone["cond_factors"]
+                assert torch.equal(fac.mel2ph, fa.mel2ph) and torch.equal(fac.p_idx, fa.p_idx)
+                assert torch.equal(fac.p1[:, :, :Lg], fa.p1[:, :, :Lg]), (variant, i)
+                if cfg.multi_speaker:
+                    assert torch.equal(spk_o[sl], alone["speaker_emb"])
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("variant,B,L", [("LJSpeech", 3, 85), ("VCTK", 2, 31), ("LibriTTS", 2, 170), ("LJSpeech", 1, 1)])
 def test_text16_xresident_bitwise(variant, B, L, dtype):
@@ -1338,7 +1451,7 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
             seq = []
             for tx, ln, spk, nz, bucket in groups:
                 o = model.duration_pitch_energy_net(None, tx, ln, spker_embeds=spk, max_mel_len=bucket)
-                seq.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], n_steps, nz), o["mel_lens"]))
+                seq.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], n_steps, nz, factors=o["cond_factors"]), o["mel_lens"]))
             host.synchronize()
             return seq
         finally:

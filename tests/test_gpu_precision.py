@@ -296,19 +296,27 @@ def test_text16_flip_counts_config2_size():
         report(f"TEXT16_FLIPS configs[2] size {dt}: vs fp32 path d_rounded {fl_d}/{B * L} mel_len {fl_len}/{B} e_idx {fl_e}/{B * L} "
                f"p_idx {fl_p}/{n_p} (utterances with equal durations: {int(same_len.sum())}); vs {dt}-operand oracle ({len(spot)} utterances) "
                f"d_rounded {fo_d}/{len(spot) * L} mel_len {fo_len}/{len(spot)} e_idx {fo_e}/{len(spot) * L}; the scheme vs float64: d_rounded {s_d} e_idx {s_e}")
-        # bounds: a flip needs the pre-rounding value within the scheme's error (bf16 ~3e-3, fp16 ~4e-4 on log d) of a boundary:
-        # a few per cent of the phonemes at most in bf16, a few per mille in fp16; the implementation against its own oracle
-        # differs only where the two fp32 summation orders straddle a boundary
-        lim = {"bf16": 0.06, "fp16": 0.012}[dt]
-        assert fl_d <= lim * B * L and fl_e <= lim * B * L, (fl_d, fl_e)
-        assert fo_d <= max(2, 0.01 * len(spot) * L) and fo_e <= max(2, 0.01 * len(spot) * L), (fo_d, fo_e)
-        assert (dt, fl_d, fl_len, fl_e) == KNOWN_TEXT16_FLIPS.get(dt, (dt, fl_d, fl_len, fl_e)), \
-            f"text16 flip counts changed: {(fl_d, fl_len, fl_e)} pinned {KNOWN_TEXT16_FLIPS.get(dt)}"
-        check_ladder(f"text16 encoder configs[2] size", o64["enc_out"], r32["enc"][spot], r16["enc"][spot], orc["enc_out"],
-                     4 * cfg.enc_layers, dt)
+        # bounds.  The flip RATE is a property of the scheme, not of the kernels: the float64 oracle with the same operands rounded
+        # flips s_d / s_e of the spot utterances' durations / energy buckets against plain float64 (bf16: ~2 % of the durations and
+        # ~20 % of the 256 energy buckets on this checkpoint — bucket width (e_max - e_min) / 255 against an rms error of 3e-3 on a
+        # value of rms ~1).  The HIP path against the fp32 path must flip at the scheme's rate (x 1.5 + 1 %), and against its own
+        # oracle no more than the scheme does against float64 (two realisations of the same rounding noise, as in check_ladder's
+        # deep criterion: measured hip-vs-oracle rms = 0.6-0.8 x the scheme's error on log d).
+        n_spot = len(spot) * L
+        assert fl_d / (B * L) <= 1.5 * s_d / n_spot + 0.01 and fl_e / (B * L) <= 1.5 * s_e / n_spot + 0.01, (fl_d, fl_e, s_d, s_e)
+        assert fo_d <= 1.5 * s_d + 3 and fo_e <= 1.5 * s_e + 3, (fo_d, fo_e, s_d, s_e)
+        if dt in KNOWN_TEXT16_FLIPS:
+            assert (fl_d, fl_len, fl_e, fl_p) == KNOWN_TEXT16_FLIPS[dt], f"text16 flip counts changed: {(fl_d, fl_len, fl_e, fl_p)} pinned {KNOWN_TEXT16_FLIPS[dt]}"
+        # encoder output, element-wise against the rounded-operand oracle (16 contractions deep: not a "deep" stack)
+        e_impl, e_scheme = rms(r16["enc"][spot] - orc["enc_out"]), rms(orc["enc_out"] - o64["enc_out"])
+        bound, d32 = impl_bound(o64["enc_out"], r32["enc"][spot], 4 * cfg.enc_layers, dt)
+        report(f"TEXT16_ENC configs[2] size {dt}: hip vs {dt}-operand oracle rms {e_impl:.2e} max {np.abs(r16['enc'][spot] - orc['enc_out']).max():.2e}; scheme vs f64 rms "
+               f"{e_scheme:.2e}; check_ladder's shallow bound {bound:.2e} (d32 {d32:.1e})")
+        assert e_impl <= 0.5 * e_scheme, "the implementation must sit closer to its own oracle than the scheme sits to float64"
+        assert rms(r16["enc"][spot] - o64["enc_out"]) <= 1.3 * e_scheme
 
 
-# (d_rounded, mel_len, e_idx) flips of the text16 path against the fp32 path on the checkpoint / batch of the test above, measured
+# (d_rounded, mel_len, e_idx, p_idx) flips of the text16 path against the fp32 path on the checkpoint / batch of the test above, measured
 # on MI355X (round 4): a change of these counts is a change of the text-side numerics and must be looked at
 KNOWN_TEXT16_FLIPS = {}
 
