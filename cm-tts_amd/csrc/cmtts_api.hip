@@ -1328,8 +1328,12 @@ size_t cmtts_denoiser_workspace_bytes(const cmtts_model* m, int B, int T) { retu
 
 // FFTBlocks.forward's layer loop (model/modules.py:97-99): pre-LN self-attention + Conv1D FFN blocks over channel-major
 // x = w.x [B][H][Lp], masked by `lens`.  Shared by the text encoder (L = phonemes) and the FastspeechDecoder (L = frames).
+// pad_lens (ragged text batch, else NULL): columns l >= pad_lens[b] do not exist for utterance b.  The one place of an FFT block where that
+// matters: LayerNorm2 turns a masked (zero) column into its bias vector, and the k = 9 FFN conv reads up to four such columns beyond
+// src_len — inside the padded batch they hold that bias, beyond it the conv's zero padding (model/blocks.py:612-615, 539-546): the
+// normalised tile is zeroed from pad_lens[b] on.  (LayerNorm1 feeds k = 1 projections; padded keys are masked, padded queries dropped.)
 int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs& w, const int64_t* src_lens, int B, int L,
-              hipStream_t s) {
+              hipStream_t s, const int64_t* pad_lens = nullptr) {
     const cmtts_config& c = m->cfg;
     const int H = c.hidden, Lp = round_up(L, 4), NH = c.enc_heads, dh = H / NH;
     const long hs = (long)H * Lp;
@@ -1441,7 +1445,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
         }
         if (t16) {      // LayerNorm2, FFN conv (+ k^-0.5, GELU), FFN linear (+ residual, mask): three launches instead of two
-            k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+            k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, pad_lens, B, L, Lp, s);
             ConvArgs a = conv_args(E.ffn1, w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
             a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
             a.out[0].act = ACT_GELU_ERF;
@@ -1463,11 +1467,11 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
             const bool xr = xres_cols && E.ffn1_f && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128;
             const bool ln_ffn = xr && (g_text_xres & 4);
-            if (!ln_ffn) k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
+            if (!ln_ffn) k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, pad_lens, B, L, Lp, s);
             ConvArgs a = conv_args(E.ffn1, ln_ffn ? w.x : w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
             a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
             a.out[0].act = ACT_GELU_ERF;
-            if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; }
+            if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; a.ln_lens = pad_lens; }
             int rc = -2;
             if (xr && g_ffn_fused && ffn2_seg && E.ffn2_f && E.ffn1.cout == FFN2_SEG * 128) {
                 // ... and the FFN linear's partial products in the same launch: the activated rows never leave the CU
@@ -1480,8 +1484,8 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) {
                 if (ln_ffn) {
-                    k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, nullptr, B, L, Lp, s);
-                    a.X = w.h; a.ln_g = a.ln_b = nullptr;
+                    k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, pad_lens, B, L, Lp, s);
+                    a.X = w.h; a.ln_g = a.ln_b = nullptr; a.ln_lens = nullptr;
                 }
                 CHK(launch(a, EPI_PLAIN, B, s));
             }
@@ -1517,10 +1521,11 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
 
 // The phoneme-level half for a RAGGED batch: utterances of several padded groups (bucket groups of a shard, BASELINE.json configs[3])
 // in one call, padded to the longest group's L.  pad_lens[b] = the padded phoneme count of utterance b's own group: columns
-// l >= pad_lens[b] do not exist for it.  Where the padded length enters the reference's arithmetic — the speaker vector is added to
-// every column of the padded batch (model/modules.py:349-352) and the energy predictor runs unmasked over them (:520-554), so the
-// columns src_len <= l < L of a group feed the convolutions' halos and are returned — the kernels stop at pad_lens[b]; everything else
-// on this path is column-local or masked by src_lens.  Every utterance therefore gets the bits of running its group alone
+// l >= pad_lens[b] do not exist for it.  Where the padded length enters the reference's arithmetic — LayerNorm2 of every FFT block makes
+// a masked column its bias vector, which the k = 9 FFN conv then reads (fft_stack); the speaker vector is added to every column of the
+// padded batch (model/modules.py:349-352); the energy predictor runs unmasked over them (:520-554): the columns src_len <= l < L of a
+// group feed the convolutions' halos and are returned — the kernels stop at pad_lens[b]; everything else on this path is column-local
+// or masked by src_lens.  Every utterance therefore gets the bits of running its group alone
 // (tests/test_gpu_parity.py::test_ragged_text_batch_bitwise), and ~60 latency-bound launches serve the whole shard instead of one
 // group.  pad_lens == NULL: the uniform batch (= cmtts_text_forward).
 int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* pad_lens, const float* spker_embeds,
@@ -1543,7 +1548,7 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     if (!e_idx) e_idx = w.eidx;
 
     k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
-    CHK(fft_stack(m, m->enc, w, src_lens, B, L, s));
+    CHK(fft_stack(m, m->enc, w, src_lens, B, L, s, pad_lens));
     k_layernorm_ct(w.x, w.x, m->encln_g, m->encln_b, 1e-5f, src_lens, B, L, Lp, s);
     if (enc_out_ct)
         k_copy_rows(enc_out_ct, L, w.x, Lp, L, (long)B * H, s);

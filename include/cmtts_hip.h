@@ -88,10 +88,11 @@ int cmtts_text_forward(cmtts_model* m, const int64_t* texts, const int64_t* src_
                        void* text_ws, size_t text_ws_bytes, void* stream);
 /* The same for a RAGGED batch (round 4; BASELINE.json configs[3]): utterances of several padded groups — the bucket groups of a shard —
  * in one call, padded to the longest group's L.  pad_lens int64 [B] (device): the padded phoneme count of each utterance's OWN group;
- * columns l >= pad_lens[b] do not exist for utterance b.  The padded length enters the reference's arithmetic in two places: the
- * speaker vector is added to every column of the padded batch (model/modules.py:349-352) and the energy predictor runs unmasked over
- * them (:520-554).  Both stop at pad_lens[b]; everything else is column-local or masked by src_lens, so every utterance gets the
- * bits of running its group alone through cmtts_text_forward.  Outputs are [B, L] with L the call's; a group's [Bg, Lg] block is the
+ * columns l >= pad_lens[b] do not exist for utterance b.  The padded length enters the reference's arithmetic in three places:
+ * LayerNorm2 of an FFT block turns a masked (zero) column into its bias vector, which the k = 9 FFN conv reads up to four columns beyond
+ * src_len (model/blocks.py:612-615, 539-546); the speaker vector is added to every column of the padded batch
+ * (model/modules.py:349-352); the energy predictor runs unmasked over them (:520-554).  All three stop at pad_lens[b]; everything else
+ * is column-local or masked by src_lens, so every utterance gets the bits of running its group alone through cmtts_text_forward.  Outputs are [B, L] with L the call's; a group's [Bg, Lg] block is the
  * sub-array rows b0.., columns < Lg (columns >= pad_lens[b] hold unspecified values).  pad_lens NULL = cmtts_text_forward. */
 int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_t* src_lens, const int64_t* pad_lens,
                               const float* spker_embeds, const int64_t* speakers, int B, int L, float d_control,
