@@ -319,6 +319,7 @@ int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-pro
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip; key-chunked with an online softmax above L = 192): 0 = three-launch path
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
+int g_xres_small = 1;          // round 4: conv_xres with 32-column tiles for text-side launches that cannot fill the chip (same bits); 0 = the generic kernel there
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm16 = 1;          // bf16 / fp16 / fp16x3 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
@@ -1337,9 +1338,14 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
     const cmtts_config& c = m->cfg;
     const int H = c.hidden, Lp = round_up(L, 4), NH = c.enc_heads, dh = H / NH;
     const long hs = (long)H * Lp;
-    // X-resident kernel (conv_xres.hip) for the K = 256 contractions when its 96-column tiles pad no more than 64-column ones
+    // X-resident kernel (conv_xres.hip) for the K = 256 contractions: with 96-column tiles (three n-tiles per wave) when they pad no more
+    // than 64-column ones and give every CU a workgroup; round 4: with 32-column tiles (one n-tile per wave, a third of the X tile staged
+    // per workgroup) for launches that cannot fill the chip anyway — one request, a few utterances: the LayerNorm prologue, the FFN
+    // fusion and a K loop without barriers instead of LayerNorm + generic kernel (+ FFN linear); every path has the same bits
     const int t96 = (L + 95) / 96, t64 = (L + 63) / 64;
-    const bool xres_cols = g_ffn_xres && t96 * 96 <= t64 * 64;
+    const bool cols96 = t96 * 96 <= t64 * 64;
+    const bool xres_small = g_ffn_xres && g_xres_small && (long)t96 * B * 8 < 128;        // the FFN conv's 96-column grid leaves CUs idle
+    const bool xres_cols = g_ffn_xres && (cols96 || xres_small);
     for (size_t i = 0; i < layers.size(); ++i) {
         const EncLayer& E = layers[i];
         const bool fused_attn = g_attn_fused && dh == 128;      // L <= 192: all keys in registers; longer: key-chunked online softmax (attention.hip)
@@ -1348,7 +1354,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
         // conv, FFN linear) with 16-bit MFMA operands and fp32 accumulate on conv_mfma16.hip; LayerNorm, softmax, bias, scale, GELU, residuals, masks fp32
         const int pm = m->precision;
         const bool t16 = m->text16 && (pm == 1 || pm == 2) && E.ffn1_f16[pm - 1] && E.ffn2_f16[pm - 1] && E.qkv_f16[pm - 1] && E.wo_f16[pm - 1];
-        const bool ln_qkv = !t16 && fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && (long)t96 * (3 * H / 128) * B >= 128;
+        const bool ln_qkv = !t16 && fused_attn && (g_text_xres & 1) && E.qkv_f && xres_cols && ((long)t96 * (3 * H / 128) * B >= 128 || xres_small);
         if (!ln_qkv) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
         bool attn_done = false;
         if (fused_attn) {
@@ -1439,7 +1445,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                 rc = cmtts_launch_conv16(&a, E.wo_f16[pm - 1], pm, B, (void*)s);
                 if (rc == -3) return fail(CMTTS_E_HIP, "text16: out-projection launch failed");
                 a.text_epi = 0;
-            } else if ((g_text_xres & 2) && E.wo_f && xres_cols && (long)t96 * (H / 128) * B >= 64)
+            } else if (E.wo_f && xres_cols && (((g_text_xres & 2) && (long)t96 * (H / 128) * B >= 64) || xres_small))
                 rc = cmtts_launch_conv_xres(&a, E.wo_f, B, (void*)s);
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
@@ -1465,7 +1471,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
         bool ffn_fused = false;
         {   // gelu((conv_k9(LayerNorm2(x)) + b) * k^-0.5)      (model/blocks.py:539-546, 612-615)
             // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
-            const bool xr = xres_cols && E.ffn1_f && (long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128;
+            const bool xr = xres_cols && E.ffn1_f && ((long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128 || xres_small);
             const bool ln_ffn = xr && (g_text_xres & 4);
             if (!ln_ffn) k_layernorm_ct(w.x, w.h, E.ln2_g, E.ln2_b, 1e-12f, pad_lens, B, L, Lp, s);
             ConvArgs a = conv_args(E.ffn1, ln_ffn ? w.x : w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
@@ -1623,10 +1629,13 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     SideStream* ss = side_for(s);
     hipStream_t sst = ss ? ss->side : s;
     if (ss) CHK(branch_fork(ss));
+    // the phoneme-level factor first: it fills the chip for ~40 us while the main stream runs its short, latency-bound launches
+    // (mel2ph, length regulator, the 256 -> 128 projection, positions); behind the statistics MLP it ran beside the frame-level
+    // k = 5 convs instead and both took twice as long (profiles/r04_text_side.md)
+    if (cond_p1) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
     k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
     k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
-    if (cond_p1) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
     k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
     {   // cwt_predictor[0]: Linear(H -> cwt_hidden)        (model/modules.py:204-205)
@@ -2393,6 +2402,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported

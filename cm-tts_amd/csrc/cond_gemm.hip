@@ -154,26 +154,47 @@ namespace {
 // HBM-bound on the [B][M][T] write; the factors are L2 / Infinity-Cache resident (consecutive frames read the same or the
 // neighbouring phoneme and a neighbouring pitch bucket).  One thread = one frame, CEX_ROWS rows per workgroup, 8 rows in flight.
 constexpr int CEX_ROWS = 64;
+// V = frames per thread: 4 when T % 4 == 0 (16-byte stores; the 4 gathers of a row are independent loads), else 1
+template <int V>
 __global__ __launch_bounds__(256) void cond_expand_kernel(const float* __restrict__ p1, int ldp, int L, const float* __restrict__ p2, int ld2,
                                                           const int64_t* __restrict__ mel2ph, const int64_t* __restrict__ pidx,
                                                           float* __restrict__ cp, int M, int T) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * CEX_ROWS, b = blockIdx.z;
+    // a wave = 64 threads along the frame axis (64 V consecutive frames), the four waves take a quarter of the rows each
+    const int t = (blockIdx.x * 64 + (threadIdx.x & 63)) * V;
+    const int r0 = blockIdx.y * CEX_ROWS + (threadIdx.x >> 6) * (CEX_ROWS / 4), b = blockIdx.z;
     if (t >= T) return;
-    const int64_t ph64 = mel2ph[(long)b * T + t];
-    const int ph = (int)(ph64 > L ? L : ph64);
-    int ix = (int)pidx[(long)b * T + t];
-    ix = ix < 0 ? 0 : (ix >= ld2 ? ld2 - 1 : ix);
-    const float* a = p1 + ((long)b * M + r0) * ldp + (ph > 0 ? ph - 1 : 0);
-    const float* q = p2 + (long)r0 * ld2 + ix;
+    int ph[V], ix[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int64_t p64 = mel2ph[(long)b * T + t + e];
+        ph[e] = (int)(p64 > L ? L : p64);
+        const int i = (int)pidx[(long)b * T + t + e];
+        ix[e] = i < 0 ? 0 : (i >= ld2 ? ld2 - 1 : i);
+    }
+    const float* a = p1 + ((long)b * M + r0) * ldp;
+    const float* q = p2 + (long)r0 * ld2;
     float* o = cp + ((long)b * M + r0) * T + t;
 #pragma unroll 1
-    for (int r = 0; r < CEX_ROWS; r += 8) {
-        float av[8], qv[8];
+    for (int r = 0; r < CEX_ROWS / 4; r += 4) {
+        float av[4][V], qv[4][V];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { av[j] = a[(long)(r + j) * ldp]; qv[j] = q[(long)(r + j) * ld2]; }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[(long)(r + j) * T] = (ph > 0 ? av[j] : 0.f) + qv[j];
+            for (int e = 0; e < V; ++e) {
+                av[j][e] = a[(long)(r + j) * ldp + (ph[e] > 0 ? ph[e] - 1 : 0)];
+                qv[j][e] = q[(long)(r + j) * ld2 + ix[e]];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (V == 4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (ph[e] > 0 ? av[j][e] : 0.f) + qv[j][e];
+                *reinterpret_cast<f32x4*>(o + (long)(r + j) * T) = v;
+            } else {
+                o[(long)(r + j) * T] = (ph[0] > 0 ? av[j][0] : 0.f) + qv[j][0];
+            }
+        }
     }
 }
 }  // namespace
@@ -181,7 +202,11 @@ __global__ __launch_bounds__(256) void cond_expand_kernel(const float* __restric
 extern "C" int cmtts_launch_cond_expand(const float* p1, int ldp, int L, const float* p2, int ld2, const int64_t* mel2ph, const int64_t* pidx,
                                         float* cp, int B, int M, int T, void* stream_) {
     if (M % CEX_ROWS != 0 || B <= 0 || T <= 0 || L <= 0) return -2;
-    hipLaunchKernelGGL(cond_expand_kernel, dim3((T + 255) / 256, M / CEX_ROWS, B), dim3(256), 0, (hipStream_t)stream_, p1, ldp, L, p2, ld2,
-                       mel2ph, pidx, cp, M, T);
+    if ((T & 3) == 0 && ((uintptr_t)cp & 15) == 0)
+        hipLaunchKernelGGL(cond_expand_kernel<4>, dim3((T / 4 + 63) / 64, M / CEX_ROWS, B), dim3(256), 0, (hipStream_t)stream_, p1, ldp, L, p2, ld2,
+                           mel2ph, pidx, cp, M, T);
+    else
+        hipLaunchKernelGGL(cond_expand_kernel<1>, dim3((T + 63) / 64, M / CEX_ROWS, B), dim3(256), 0, (hipStream_t)stream_, p1, ldp, L, p2, ld2,
+                           mel2ph, pidx, cp, M, T);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

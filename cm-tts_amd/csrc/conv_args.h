@@ -60,6 +60,7 @@ struct ConvArgs {
     const float* ln_g;
     const float* ln_b;
     float ln_eps;
+    int xres_nt;              // 0 = the launcher chooses 96- or 32-column tiles by how full the chip gets; 1 / 3 = forced (tests, tools)
     const int64_t* ln_lens;   // LayerNorm prologue: columns t >= ln_lens[z] become 0 (layernorm_ct_kernel's optional mask); nullptr = none
     // conv_xres.hip, FFN fusion: the k = 1 linear that follows (W2: [M2][M], M2 = 256) applied to this workgroup's 128 activated output rows while
     // they are on chip — its K-segment partial sum [M2][N] goes to part + z * part_zs0 + (m-block) * part_zs1 (row stride part_ld) instead of

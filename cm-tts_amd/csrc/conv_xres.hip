@@ -22,14 +22,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int KMAX = 256;
-constexpr int BN = 96;          // columns per workgroup (3 MFMA n-tiles)
-constexpr int NT = 3;
 constexpr int HALO = 8;         // (taps - 1) * dil <= 8
-constexpr int X_LD = BN + HALO; // 104
 constexpr int RING = 4;
 
-template <bool LN>
+// NT = MFMA n-tiles (32 columns each) per wave = per workgroup: 3 (96-column tiles: a full chip, one utterance of <= 96 phonemes per
+// tile) or 1 (round 4: 32-column tiles for launches that cannot fill the chip — a single request, a few utterances — where one
+// accumulation chain per wave and three times the workgroups finish sooner than three chains per wave; same chains, same bits)
+template <bool LN, int NT>
 __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
+    constexpr int BN = 32 * NT;          // columns per workgroup
+    constexpr int X_LD = BN + HALO;      // 104 / 40
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // cycle stamps per wave (tools/xres_phases.py; dbg == nullptr in normal operation)
@@ -53,6 +55,9 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
     const int n0 = blockIdx.x * BN;
     const int mt = by * 4 + w;             // this wave's m-tile
     const int z = bz;
+    // a ragged batch (ln_lens = each utterance's own padded length): a column tile wholly beyond it computes nothing anyone reads —
+    // the normalised input is zero there and every consumer masks those columns by select (reduce_partials, the k = 1 linear)
+    if (LN && a.ln_lens && n0 > 0 && (int64_t)n0 >= a.ln_lens[z]) return;
     const int l31 = lane & 31, khalf = lane >> 5;
     const float* Xb = a.X + z * a.x_zs0;
     const int MTn = (a.M + 31) / 32;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
     if (LN) { gs[tid] = a.ln_g[tid]; gs[256 + tid] = a.ln_b[tid]; }
     if (((n0 - a.pad) & 3) == 0 && (a.ldx & 3) == 0 && ((uintptr_t)Xb & 15) == 0) {
         // 16-byte loads: tile row = X_LD / 4 = 26 float4; a float4 that starts outside [0, ldx - 4] lies wholly outside [0, Tin)
-        constexpr int V = X_LD / 4, U = 26;
+        constexpr int V = X_LD / 4, U = NT == 3 ? 26 : 10;
         const int nvec = a.K * V;
         const int t00 = n0 - a.pad;
 #pragma unroll 1
@@ -336,22 +341,36 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
         const ConvOut& o = a.out[0];
         if (!a.part || a.M2 != 256 || a.M % 128 != 0 || a.K < 128 || o.ostride != 1 || o.ooff_base || o.ooff_mul || o.row_off || o.div != 1.0f || o.accum || o.bvec || o.act != ACT_GELU_ERF || o.res || o.lens) return -2;
     }
+    // column tiles: 96 (three n-tiles per wave) when that already gives every CU a workgroup, else 32 (one n-tile per wave: three times the
+    // workgroups, a third of the MFMAs per accumulation chain's wave); a.xres_nt forces one (tests, tools)
+    const int mblocks = ((a.M + 31) / 32 + 3) / 4;
+    const long wg96 = (long)((a.N + 95) / 96) * mblocks * nbatch;
+    const int nt = a.xres_nt == 1 || a.xres_nt == 3 ? a.xres_nt : (wg96 >= 128 ? 3 : 1);
+    const int bn = 32 * nt, x_ld = bn + HALO;
     static bool attr_set = false;
-    const size_t lds = (size_t)a.K * X_LD * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
+    const size_t lds = (size_t)a.K * x_ld * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
     if (!attr_set) {
-        const int mx = (int)((size_t)KMAX * X_LD * sizeof(float) + 2 * 256 * sizeof(float));
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+        const int mx = (int)((size_t)KMAX * (96 + HALO) * sizeof(float) + 2 * 256 * sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    dim3 grid((a.N + BN - 1) / BN, ((a.M + 31) / 32 + 3) / 4, nbatch);
+    dim3 grid((a.N + bn - 1) / bn, mblocks, nbatch);
     long long* dbg = g_xres_dbg;
     if (dbg) {    // CMTTS_XRES_DBG_M=<rows>: stamps of the launches with that many output rows only (tools/xres_phases.py)
         static const char* want = getenv("CMTTS_XRES_DBG_M");
         if (want && atoi(want) != a.M) dbg = nullptr;
     }
-    if (a.ln_g) hipLaunchKernelGGL(conv_xres_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag, dbg);
-    else hipLaunchKernelGGL(conv_xres_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream_, a, wfrag, dbg);
+    hipStream_t st = (hipStream_t)stream_;
+    if (nt == 3) {
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 3>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 3>), grid, dim3(256), lds, st, a, wfrag, dbg);
+    } else {
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

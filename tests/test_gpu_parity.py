@@ -1130,6 +1130,40 @@ def test_xres_conv_bitwise(models):
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
 
 
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 1, 25), ("VCTK", 2, 85), ("LibriTTS", 3, 130), ("LJSpeech", 8, 33), ("LJSpeech", 1, 1)])
+def test_xres_small_bitwise(variant, B, L):
+    """Round 4: launches that cannot fill the chip — a single request, a few utterances — take conv_xres.hip with 32-column tiles (one
+    n-tile per wave: LayerNorm prologue, FFN fusion, K loop without barriers) where they took LayerNorm + the generic kernel (+ the
+    FFN linear's own launch).  Same accumulation chains => the text side must not change by a bit, and a request still equals its
+    row of a full batch (which takes the 96-column tiles)."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=21, dur_frames=4.0, dur_spread=0.03))
+    rs = np.random.RandomState(B * 31 + L)
+    lens = np.maximum((rs.uniform(0.4, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=6 * L)
+    prev = _lib.internal_set(b"xres_small", 1)
+    try:
+        got = run()
+        _lib.internal_set(b"xres_small", 0)
+        ref = run()
+    finally:
+        _lib.internal_set(b"xres_small", prev)
+    host.synchronize()
+    for k in ("enc_out", "log_d_predictions", "e_predictions", "cond_ct", "mel_lens"):
+        assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
+    # the same utterances inside a batch that fills the chip (96-column tiles, or the generic kernel for L > 96)
+    rep = 40 // B + 1
+    big = model.duration_pitch_energy_net(None, torch.from_numpy(np.tile(texts, (rep, 1))), torch.from_numpy(np.tile(lens, rep)),
+                                          spker_embeds=None if spk is None else spk.repeat(rep, 1), max_mel_len=6 * L)
+    host.synchronize()
+    assert torch.equal(big["cond_ct"][:B], got["cond_ct"]) and torch.equal(big["enc_out"][:B], got["enc_out"])
+
+
 def test_ffn_fused_bitwise(models):
     """conv_xres.hip's FFN fusion (the FFN linear's K-segment partial products formed from the activated rows of the k = 9 conv
     while they are in LDS) keeps the K-segment launch's accumulation order: the text side must not change by a bit, with and
