@@ -395,6 +395,8 @@ SideStream* side_for(hipStream_t s) {
         if (x.user == s) return &x;
     if (g_sides.size() >= 16) return nullptr;          // more caller streams than that: branches run in line
     SideStream x{s, nullptr, nullptr, nullptr};
+    // (round 4: a LOW-priority branch stream was tried — the chip-filling conditioner factor GEMM stretches the latency-bound kernels of the
+    // main chain — headline 12.66 ms either way, and the ragged shard's set-aside sampler, which lives on this stream, starves: 18 -> 28 ms)
     if (hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
@@ -961,15 +963,36 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 // conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
 // block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_set_option("pred_head", 0)
 // mode16: 0, or the 16-bit operand mode (1 = bf16, 2 = fp16) of a model with the opt-in "text16": the convs on conv_mfma16.hip (bias + ReLU in fp32)
+int g_pred_xres = 1;            // round 4: phoneme-level 256 -> 256 predictor convs on conv_xres (32-column tiles), the previous block's LayerNorm as its prologue (same bits); 0 = generic kernel + LayerNorm launches
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
               const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0) {
     const float* cur = in;
     int ldc = ld_in;
     auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
+    int pend_ln = -1;            // >= 0: `cur` holds block pend_ln's conv + ReLU output, its LayerNorm not yet applied
     for (size_t li = 0; li < P.convs.size(); ++li) {
         const PackedConv& w = P.convs[li];
         int rx = -2;
         float* dst = other(cur);
+        // phoneme-level 256 -> 256 convs (round 4): X-resident, one 32-column n-tile per wave, the pending LayerNorm (eps 1e-12, length
+        // mask) applied to the staged tile.  (Round 2 tried this with 96-column tiles: 64 workgroups of ~45 us — slower; deleted in round 3.)
+        const bool small = (long)((T + 63) / 64) * B < 192;
+        if (!mode16 && g_pred_xres && small && P.convs_f[li] && w.cin == 256 && w.cout == 256 && ldc == ld) {
+            ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
+            a.out[0].act = ACT_RELU;
+            a.xres_nt = 1;
+            if (pend_ln >= 0) { a.ln_g = P.ln_g[pend_ln]; a.ln_b = P.ln_b[pend_ln]; a.ln_eps = 1e-12f; a.ln_lens = ln_lens; }
+            rx = cmtts_launch_conv_xres(&a, P.convs_f[li], B, (void*)s);
+            if (rx == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+            if (rx == 0) pend_ln = -2;       // consumed (if any)
+        }
+        if (pend_ln >= 0) {                  // the LayerNorm as its own launch
+            float* nd = other(cur);
+            k_layernorm_ct(cur, nd, P.ln_g[pend_ln], P.ln_b[pend_ln], 1e-12f, ln_lens, B, T, ld, s);
+            cur = nd;
+            dst = other(cur);
+        }
+        pend_ln = -1;
         if (mode16 && li < P.convs_f16[mode16 - 1].size() && P.convs_f16[mode16 - 1][li]) {
             ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
             a.out[0].act = ACT_RELU;
@@ -998,8 +1021,11 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
             k_ln_linear(cur, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
             return 0;
+        pend_ln = (int)li;
+    }
+    if (pend_ln >= 0) {
         float* nd = other(cur);
-        k_layernorm_ct(cur, nd, P.ln_g[li], P.ln_b[li], 1e-12f, ln_lens, B, T, ld, s);
+        k_layernorm_ct(cur, nd, P.ln_g[pend_ln], P.ln_b[pend_ln], 1e-12f, ln_lens, B, T, ld, s);
         cur = nd;
     }
     k_chan_linear(cur, P.lin_w, P.lin_b, out, out_lens, B, P.convs.back().cout, T, ld, O, s);
@@ -1066,11 +1092,19 @@ int cond_phoneme_factor(cmtts_model* m, const float* out1, int B, int Lp, float*
     memset(&g, 0, sizeof(g));
     g.X = out1; g.Wf = m->cond_all_f; g.bias = m->cond_zero_bias; g.Y = p1;
     g.B = B; g.T = Lp; g.M = c.res_layers * c.res_channels; g.K = c.hidden; g.force = 1;
-    // workgroups: frame tiles x utterances x row groups ~ two per CU
-    const long tiles = (long)((Lp + 63) / 64) * B;
+    g.flat = 1;          // 64-column tiles over all utterances' phonemes: 32 x 88 columns = 44 tiles, not 32 x 2
+    // workgroups = column tiles x row groups: as close to one per CU as the 512-row passes divide (a workgroup takes a pass in ~38 us)
+    const long tiles = ((long)B * Lp + 63) / 64;
     const int npass = g.M / 512;
-    int split = (int)((2L * persist_blocks() + tiles - 1) / tiles);
-    g.row_split = split < 1 ? 1 : (split > npass ? npass : split);
+    int best = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= npass; ++sp) {
+        const int ppg = (npass + sp - 1) / sp, groups = (npass + ppg - 1) / ppg;
+        const long wg = tiles * groups, cap = persist_blocks();
+        const double t = (double)((wg + cap - 1) / cap) * ppg;          // rounds x passes per workgroup
+        if (t < best_t - 1e-9) { best_t = t; best = sp; }
+    }
+    g.row_split = best;
     const int r = cmtts_launch_cond_gemm(&g, (void*)s);
     return r == 0 ? 0 : fail(r == -2 ? CMTTS_E_UNSUPPORTED : CMTTS_E_HIP, "cond_gemm (phoneme factor) launch failed");
 }
@@ -2402,6 +2436,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"pred_xres", &g_pred_xres, 0, 1},         // phoneme-level predictor convs on conv_xres with the LayerNorm prologue
         {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)

@@ -8,6 +8,7 @@ struct CondGemmArgs {
     float* Y;             // [B][M][T]
     int B, T, M, K;
     int force;            // take the kernel even where the generic one would finish sooner (tests)
+    int flat;             // 1: tiles run over the columns of all utterances as one axis (c = b * T + t): no per-utterance padding to 64 columns
     int row_split;        // > 1: that many workgroups per frame tile, each a contiguous share of the 512-row passes (few tiles, many rows)
 };
 

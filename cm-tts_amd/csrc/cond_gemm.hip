@@ -32,23 +32,27 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 __global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y;
     const int t0 = blockIdx.x * FN;
-    const int T = a.T;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const float* xin = a.X + (long)b * K * T;
-    float* yb = a.Y + (long)b * a.M * T;
+    // columns: frames of utterance blockIdx.y (row stride T), or — a.flat — the columns of ALL utterances in one axis (c = b * T + t:
+    // a k = 1 contraction is column-local, so a tile may span utterances; no per-utterance padding to a multiple of 64)
+    const int T = a.T;
+    const long ncol = a.flat ? (long)a.B * T : T;
+    auto col_x = [&](long c) -> long { return a.flat ? (c / T) * (long)K * T + (c % T) : (long)blockIdx.y * K * T + c; };
+    auto col_y = [&](long c) -> long { return a.flat ? (c / T) * (long)a.M * T + (c % T) : (long)blockIdx.y * a.M * T + c; };
+    const float* xin = a.X;
+    float* yb = a.Y;
 
-    {   // stage X[k][t0 .. t0+63] (zero beyond T): lane = frame, 32 rows per wave, 8 in flight
-        const int t = t0 + lane;
-        const int t_c = min(t, T - 1);
+    {   // stage X[k][t0 .. t0+63] (zero beyond the last column): lane = column, 32 rows per wave, 8 in flight
+        const long t = t0 + lane;
+        const long xo = col_x(t < ncol ? t : ncol - 1);
 #pragma unroll 1
         for (int i = 0; i < K / NW; i += 8) {
             float xv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xv[q] = xin[(unsigned)((w * (K / NW) + i + q) * T + t_c)];
+            for (int q = 0; q < 8; ++q) xv[q] = xin[xo + (long)(w * (K / NW) + i + q) * T];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xs[(w * (K / NW) + i + q) * X_LD + lane] = t < T ? xv[q] : 0.f;
+            for (int q = 0; q < 8; ++q) xs[(w * (K / NW) + i + q) * X_LD + lane] = t < ncol ? xv[q] : 0.f;
         }
     }
     const int MTn = a.M / 32;
@@ -116,10 +120,11 @@ __global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArg
             for (int r = 0; r < 16; ++r) bi[r] = ldg(a.bias, (unsigned)(m0 + acc_row(r, lane)));
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + l31;
+                const long t = t0 + j * 32 + l31;
+                const long yo = col_y(t < ncol ? t : ncol - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t < T) yb[(unsigned)((m0 + acc_row(r, lane)) * T + t)] = acc[i][j][r] + bi[r];
+                    if (t < ncol) yb[yo + (long)(m0 + acc_row(r, lane)) * T] = acc[i][j][r] + bi[r];
             }
         }
     }
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cond_gemm_kernel(const CondGemmArg
 extern "C" int cmtts_launch_cond_gemm(const CondGemmArgs* ap, void* stream_) {
     const CondGemmArgs& a = *ap;
     if (a.K != K || a.M % (32 * MT * NW) != 0 || (long)a.M * a.T >= (1L << 30) || a.B <= 0 || a.T <= 0) return -2;
+    if (a.flat && (long)a.B * a.T >= (1L << 30)) return -2;
     // a workgroup walks all M rows of its 64 frames alone (~350 us whatever the batch): below ~half a chip of frame tiles
     // the generic kernel, which spreads M over workgroups, finishes sooner (one 150-frame utterance: 347 -> ~40 us).
     // Both are bitwise equal (tests), so the choice never changes a result.
@@ -144,7 +150,8 @@ extern "C" int cmtts_launch_cond_gemm(const CondGemmArgs* ap, void* stream_) {
         attr_set = true;
     }
     const int zsplit = a.row_split > 1 ? a.row_split : 1;
-    hipLaunchKernelGGL(cond_gemm_kernel, dim3((a.T + FN - 1) / FN, a.B, zsplit), dim3(64 * NW), lds, (hipStream_t)stream_, a);
+    const dim3 grid = a.flat ? dim3((unsigned)(((long)a.B * a.T + FN - 1) / FN), 1, zsplit) : dim3((a.T + FN - 1) / FN, a.B, zsplit);
+    hipLaunchKernelGGL(cond_gemm_kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream_, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -1130,12 +1130,13 @@ def test_xres_conv_bitwise(models):
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
 
 
-@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 1, 25), ("VCTK", 2, 85), ("LibriTTS", 3, 130), ("LJSpeech", 8, 33), ("LJSpeech", 1, 1)])
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 1, 25), ("VCTK", 2, 85), ("LibriTTS", 3, 130), ("LJSpeech", 8, 33), ("LJSpeech", 1, 1), ("VCTK", 32, 85)])
 def test_xres_small_bitwise(variant, B, L):
     """Round 4: launches that cannot fill the chip — a single request, a few utterances — take conv_xres.hip with 32-column tiles (one
     n-tile per wave: LayerNorm prologue, FFN fusion, K loop without barriers) where they took LayerNorm + the generic kernel (+ the
     FFN linear's own launch).  Same accumulation chains => the text side must not change by a bit, and a request still equals its
-    row of a full batch (which takes the 96-column tiles)."""
+    row of a full batch (which takes the 96-column tiles).  The phoneme-level predictor convs likewise ("pred_xres": at every batch size —
+    M = 256 never fills the chip with 96-column tiles), the previous block's LayerNorm and length mask as the prologue."""
     host = _host()
     cfg = get_config(variant)
     model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=21, dur_frames=4.0, dur_spread=0.03))
@@ -1146,16 +1147,20 @@ def test_xres_small_bitwise(variant, B, L):
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
     run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=6 * L)
-    prev = _lib.internal_set(b"xres_small", 1)
+    prev, prev_p = _lib.internal_set(b"xres_small", 1), _lib.internal_set(b"pred_xres", 1)
     try:
         got = run()
+        _lib.internal_set(b"pred_xres", 0)          # predictor convs back on the generic kernel + LayerNorm launches
+        mid = run()
         _lib.internal_set(b"xres_small", 0)
         ref = run()
     finally:
         _lib.internal_set(b"xres_small", prev)
+        _lib.internal_set(b"pred_xres", prev_p)
     host.synchronize()
     for k in ("enc_out", "log_d_predictions", "e_predictions", "cond_ct", "mel_lens"):
         assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
+        assert torch.equal(mid[k], ref[k]), (k, float((mid[k].float() - ref[k].float()).abs().max()))
     # the same utterances inside a batch that fills the chip (96-column tiles, or the generic kernel for L > 96)
     rep = 40 // B + 1
     big = model.duration_pitch_energy_net(None, torch.from_numpy(np.tile(texts, (rep, 1))), torch.from_numpy(np.tile(lens, rep)),
