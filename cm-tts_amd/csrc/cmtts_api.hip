@@ -319,6 +319,7 @@ int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-pro
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip; key-chunked with an online softmax above L = 192): 0 = three-launch path
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
+int g_cwt_in_phoneme = 1;      // round 4: the pitch predictor's input projection applied before the length regulator (same bits); 0 = over the frames
 int g_xres_small = 1;          // round 4: conv_xres with 32-column tiles for text-side launches that cannot fill the chip (same bits); 0 = the generic kernel there
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
@@ -871,7 +872,7 @@ int finalize_model(cmtts_model* m) {
 // batch's values still do not depend on its size.
 constexpr int FFN2_SEG = 8;
 struct TextWs {
-    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *logd, *dround, *epred;
+    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *h128, *logd, *dround, *epred;
     int* cum;
     int64_t *eidx, *mlen;
     size_t bytes;
@@ -885,6 +886,7 @@ TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
     w.out1 = cv.take<float>(n);
     w.cum = cv.take<int>((size_t)B * L);
     w.spk = cv.take<float>((size_t)B * H);
+    w.h128 = cv.take<float>((size_t)B * c.cwt_hidden * Lp);      // cwt_predictor[0] applied at the phoneme level (round 4): [B][cwt_hidden][Lp]
     w.x = cv.take<float>(n);
     w.h = cv.take<float>(n);
     w.qk = cv.take<float>(3 * n);      // fused attention: [B][3H][Lp] (Q | K | V); three-launch path: Q,K [B][2H][Lp] + V^T [B][Lp][H] behind it
@@ -1615,6 +1617,13 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     if (ss) CHK(branch_join(ss));
     k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
                    w.out1, e_idx, B, H, L, Lp, s);
+    {   // cwt_predictor[0]: Linear(H -> cwt_hidden) (model/modules.py:204-205).  The reference applies it to the length-regulated frames;
+        // a k = 1 contraction commutes with the gather (frame t copies phoneme mel2ph[t] - 1, a padding frame is W 0 + b = b), so it runs
+        // over the L phonemes here and cmtts_frame_forward gathers its output: the same bits (tests/test_gpu_parity.py goldens,
+        // test_cwt_in_phoneme_level_bitwise) for a sixth of the work, off the frame-level chain
+        ConvArgs a = conv_args(m->cwt_in, w.out1, L, Lp, (long)H * Lp, w.h128, Lp, (long)c.cwt_hidden * Lp, L);
+        CHK(launch(a, EPI_PLAIN, B, s));
+    }
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
         HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
     if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
@@ -1648,6 +1657,7 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     const int L = L_all;
     TextWs tw = carve_text(c, B_all, L_all, const_cast<void*>(text_ws));
     tw.out1 += (size_t)b0 * c.hidden * round_up(L_all, 4);
+    tw.h128 += (size_t)b0 * c.cwt_hidden * round_up(L_all, 4);
     tw.cum += (size_t)b0 * L_all;
     FrameWs w = carve_frame(c, B, T, frame_ws);
     if (frame_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "frame workspace too small");
@@ -1672,7 +1682,9 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
     k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
-    {   // cwt_predictor[0]: Linear(H -> cwt_hidden)        (model/modules.py:204-205)
+    if (g_cwt_in_phoneme) {   // cwt_predictor[0] was applied at the phoneme level (cmtts_text_forward): gather it; padding frames = its bias
+        k_length_regulate(tw.h128, mel2ph, w.h128, B, CH, Lp, T, s, m->cwt_in.bias);
+    } else {   // cwt_predictor[0]: Linear(H -> cwt_hidden) over the frames       (model/modules.py:204-205)
         ConvArgs a = conv_args(m->cwt_in, w.xlr, T, T, (long)H * T, w.h128, T, (long)CH * T, T);
         CHK(launch(a, EPI_PLAIN, B, s));
     }
@@ -2436,6 +2448,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"cwt_in_phoneme", &g_cwt_in_phoneme, 0, 1},   // Linear(256 -> 128) of the pitch predictor before (1) or after (0) the length regulator
         {"pred_xres", &g_pred_xres, 0, 1},         // phoneme-level predictor convs on conv_xres with the LayerNorm prologue
         {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))

@@ -39,7 +39,7 @@ bool k_ln_linear(const float* x, const float* gamma, const float* beta, float ep
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);
 void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t s);
 void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl,
-                       int T, hipStream_t s);
+                       int T, hipStream_t s, const float* padv = nullptr);     // padv [C]: value of padding frames (default 0)
 void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* std_p, int stat_ld, float std_scale,
                    const float* uv_logit, int uv_ld, const uint8_t* uv_mask, float eps, float* r_ws, int64_t* p_idx,
                    float* f0_denorm, int B, int T, hipStream_t s);

@@ -481,12 +481,13 @@ __global__ void mel2ph_kernel(const int* cum, int64_t* mel2ph, int L, int T) {
 }
 
 // ---- length regulator gather (model/modules.py:421-448): frame t copies phoneme mel2ph-1, pad = 0
-__global__ void length_regulate_kernel(const float* out1, const int64_t* mel2ph, float* xlr, int C, int ldl, int T) {
+// padv (optional, [C]): the value of a padding frame — the bias of a k = 1 projection that was applied BEFORE the gather (W 0 + b = b)
+__global__ void length_regulate_kernel(const float* out1, const int64_t* mel2ph, float* xlr, int C, int ldl, int T, const float* padv) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
     const int64_t ph = mel2ph[(long)b * T + t];
-    xlr[((long)b * C + c) * T + t] = ph > 0 ? out1[((long)b * C + c) * ldl + (ph - 1)] : 0.f;
+    xlr[((long)b * C + c) * T + t] = ph > 0 ? out1[((long)b * C + c) * ldl + (ph - 1)] : (padv ? padv[c] : 0.f);
 }
 
 // ---- inverse CWT -> f0 -> coarse pitch bucket (model/modules.py:274-300; utils/pitch_tools.py
@@ -805,8 +806,8 @@ void k_mel2ph(const int* cum, int64_t* mel2ph, int B, int L, int T, hipStream_t 
     hipLaunchKernelGGL(mel2ph_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, s, cum, mel2ph, L, T);
 }
 void k_length_regulate(const float* out1, const int64_t* mel2ph, float* xlr, int B, int C, int ldl, int T,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(length_regulate_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, out1, mel2ph, xlr, C, ldl, T);
+                       hipStream_t s, const float* padv) {
+    hipLaunchKernelGGL(length_regulate_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, out1, mel2ph, xlr, C, ldl, T, padv);
 }
 void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* std_p, int stat_ld, float std_scale,
                    const float* uv_logit, int uv_ld, const uint8_t* uv_mask, float eps, float* r_ws, int64_t* p_idx,

@@ -1169,6 +1169,34 @@ def test_xres_small_bitwise(variant, B, L):
     assert torch.equal(big["cond_ct"][:B], got["cond_ct"]) and torch.equal(big["enc_out"][:B], got["enc_out"])
 
 
+@pytest.mark.parametrize("variant,B,L,T", [("LJSpeech", 32, 85, 512), ("VCTK", 3, 40, 150), ("LibriTTS", 2, 171, 1024)])
+def test_cwt_in_phoneme_level_bitwise(variant, B, L, T):
+    """Round 4: the pitch predictor's input projection (Linear 256 -> 128, model/modules.py:204-205) runs over the phonemes and the
+    length regulator gathers its output (padding frames = the bias) instead of running over the length-regulated frames: a k = 1
+    contraction commutes with the gather — every returned tensor must keep its bits (ragged lengths, truncated and padded frames)."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=22, dur_frames=5.0, dur_spread=0.03))
+    rs = np.random.RandomState(L)
+    lens = np.maximum((rs.uniform(0.4, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=T)
+    prev = _lib.internal_set(b"cwt_in_phoneme", 1)
+    try:
+        got = run()
+        _lib.internal_set(b"cwt_in_phoneme", 0)
+        ref = run()
+    finally:
+        _lib.internal_set(b"cwt_in_phoneme", prev)
+    host.synchronize()
+    assert torch.equal(got["cond_ct"], ref["cond_ct"]) and torch.equal(got["mel2ph"], ref["mel2ph"])
+    for k in ("cwt", "f0_denorm", "p_idx", "f0_mean", "f0_std"):
+        assert torch.equal(got["p_predictions"][k], ref["p_predictions"][k]), k
+
+
 def test_ffn_fused_bitwise(models):
     """conv_xres.hip's FFN fusion (the FFN linear's K-segment partial products formed from the activated rows of the k = 9 conv
     while they are in LDS) keeps the K-segment launch's accumulation order: the text side must not change by a bit, with and
