@@ -343,7 +343,7 @@ def dry_run(args, rank, world):
     else:
         seen = 1
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": seen, "requested": args.gpus, "launcher": "self" if os.environ.get("TORCHELASTIC_RUN_ID") else "external"}), flush=True)
+        emit_json({"dry_run": True, "n_gpus": seen, "requested": args.gpus, "launcher": "self" if os.environ.get("TORCHELASTIC_RUN_ID") else "external"})
     return 0
 
 
@@ -367,6 +367,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("CMTTS_BENCH_DRYRUN") == "1":      # launcher rehearsal (tests/test_bench_launcher.py): rendezvous only, no GPU work
         sys.exit(dry_run(args, rank, world))
+    quiet_stdout()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -700,7 +701,29 @@ def main():
     # AFTER the result at exit: drain it first so the JSON line is the last line of stdout
     C.CDLL(None).fflush(None)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit_json(result)
+
+
+_JSON_FD = None
+
+
+def quiet_stdout():
+    """stdout carries ONE JSON line (the driver's contract).  RCCL prints a version banner to fd 1 when a communicator comes up, and any
+    library may: from here on fd 1 is stderr, and emit_json() writes the line to the ORIGINAL stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_JSON_FD, line)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,7 @@ int cmtts_launch_resblock_pair16x3(const PairArgs* a, void* stream);
 // one conv of the C = 256 stage, fp16x3 operands, fp32 in / out (same file)
 int cmtts_launch_conv_xl16x3(const ConvXlArgs* a, void* stream);
 void cmtts_pair_set_debug(long long* dbg);
+int cmtts_xl_set_split(int on);      // conv_xl: m-tiles over several workgroups for launches of a few column tiles (same bits); returns the previous value
 #ifdef __cplusplus
 }
 #endif

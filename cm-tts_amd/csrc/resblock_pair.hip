@@ -330,14 +330,18 @@ int launch_pair(const PairArgs& a, hipStream_t stream) {
 // [+ y_old]; same accumulation order => bitwise equal.
 constexpr int XL_BN = 64;
 
-template <int C, int KT, int CIN = C>
-__global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
+// NWV = waves per workgroup: C / 32 (all m-tiles of a column tile in one workgroup) or — round 4, launches of a few column tiles: one
+// request through the C = 256 stage is 19 tiles — fewer, the m-tiles split over gridDim.z workgroups that each stage the tile: one
+// wave per SIMD instead of two, four times the CUs; a wave's accumulation chains are the same, so are the bits
+template <int C, int KT, int CIN = C, int NWV = C / 32>
+__global__ __launch_bounds__(64 * NWV, NWV == C / 32 ? 2 : 1) void conv_xl_kernel(const ConvXlArgs a) {
     constexpr int XW = XL_BN + (KT - 1) * 5 + 2;            // widest halo of this kernel size (dilation <= 5): k = 7 at C = 128 leaves
                                                             // 49 KB per workgroup = three per CU, k = 3 38 KB
-    constexpr int NWAVES = C / 32;                          // one m-tile per wave, both n-tiles
+    constexpr int NWAVES = NWV;                             // one m-tile per wave, both n-tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                        // [C][XW] leaky(x), column j <-> t = t0 - pad + j
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mt = (int)blockIdx.z * NWV + w;                // this wave's m-tile
     const int l31 = lane & 31;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * XL_BN;
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
     {
         const int tbase = t0 - pad;
         constexpr int ROWS_PER_WAVE = CIN / NWAVES;         // 32 (16 for the 128 -> 256 predictor conv)
+        static_assert(ROWS_PER_WAVE % 16 == 0, "staging walks 16 rows at a time");
         constexpr int XBLK = (XW + 63) / 64;                // 2
 #pragma unroll
         for (int h = 0; h < ROWS_PER_WAVE; h += 16) {       // 32 loads in flight per lane
@@ -379,17 +384,17 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
         const int t_c = min(t0 + j * 32 + l31, T - 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long off = (long)(w * 32 + acc_row(r, lane)) * a.ld + t_c;
+            const long off = (long)(mt * 32 + acc_row(r, lane)) * a.ld + t_c;
             xres[j][r] = rb ? rb[off] : 0.f;
             yo[j][r] = a.accum ? yb[off] : 0.f;
         }
     }
     __syncthreads();
     f32x16 acc[NT];
-    conv_loop<C, KT, CIN>(acc, a.wf, Xs, XW, dil, w, 0, lane);
+    conv_loop<C, KT, CIN>(acc, a.wf, Xs, XW, dil, mt, 0, lane);
     float bi[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bi[r] = a.bias[w * 32 + acc_row(r, lane)];
+    for (int r = 0; r < 16; ++r) bi[r] = a.bias[mt * 32 + acc_row(r, lane)];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int t = t0 + j * 32 + l31;
@@ -399,23 +404,35 @@ __global__ __launch_bounds__(2 * C, 2) void conv_xl_kernel(const ConvXlArgs a) {
             if (a.relu) v = v > 0.f ? v : 0.f;
             if (rb) v += xres[j][r];
             if (a.accum) v += yo[j][r];
-            if (t < T) yb[(long)(w * 32 + acc_row(r, lane)) * a.ld + t] = v;
+            if (t < T) yb[(long)(mt * 32 + acc_row(r, lane)) * a.ld + t] = v;
         }
     }
 }
 
+int g_xl_split = 1;      // internal switch "voc_xl_split": m-tiles of conv_xl over several workgroups when the launch is a few column tiles
+
 template <int C, int KT, int CIN = C>
 int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)CIN * (XL_BN + (KT - 1) * 5 + 2) * sizeof(float);
+    constexpr int NWS = 2;                      // waves per workgroup of the split form: C / 64 workgroups per column tile
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT, CIN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xl_kernel<C, KT, CIN, NWS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B);
-    hipLaunchKernelGGL((conv_xl_kernel<C, KT, CIN>), grid, dim3(2 * C), lds, stream, a);
+    const long tiles = (long)((a.T + XL_BN - 1) / XL_BN) * a.B;
+    // two waves per SIMD in C / 32-wave workgroups once every CU has one; below that the m-tiles spread over C / 64 workgroups
+    if (g_xl_split && C / 32 > 4 && tiles * (C / 64) <= 320) {      // (C = 128 has one wave per SIMD already)
+        dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B, C / (32 * NWS));
+        hipLaunchKernelGGL((conv_xl_kernel<C, KT, CIN, NWS>), grid, dim3(64 * NWS), lds, stream, a);
+    } else {
+        dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B);
+        hipLaunchKernelGGL((conv_xl_kernel<C, KT, CIN>), grid, dim3(2 * C), lds, stream, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -533,6 +550,7 @@ long long* g_pair_dbg = nullptr;
 }  // namespace
 
 extern "C" void cmtts_pair_set_debug(long long* dbg) { g_pair_dbg = dbg; }
+extern "C" int cmtts_xl_set_split(int on) { const int p = g_xl_split; if (on == 0 || on == 1) g_xl_split = on; return p; }
 
 // 0 = launched, -2 = shape not covered (the caller runs the two generic launches), -3 = HIP error
 extern "C" int cmtts_launch_resblock_pair(const PairArgs* ap, void* stream_) {

@@ -1887,6 +1887,29 @@ def test_vocoder_pair_kernel_bitwise(B, T):
         assert np.abs(_np(got) - refo).max() < 1e-4
 
 
+@pytest.mark.parametrize("B,T", [(1, 150), (2, 77), (5, 33)])
+def test_vocoder_xl_split_bitwise(B, T):
+    """Round 4: a request or two through the C = 256 stage is a few 64-column tiles; conv_xl then spreads a tile's eight m-tiles over four
+    2-wave workgroups (one wave per SIMD, four times the CUs) instead of one 8-wave workgroup.  A wave's accumulation chains and the
+    epilogue are unchanged: the wav keeps its bits, and an utterance still equals its row of a chip-filling batch."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=8))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T + B)) * 1.5 - 4).to(DEV)
+    prev = _lib.internal_set(b"voc_xl_split", 1)
+    try:
+        got = voc(mel).clone()
+        _lib.internal_set(b"voc_xl_split", 0)
+        ref = voc(mel).clone()
+    finally:
+        _lib.internal_set(b"voc_xl_split", prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.equal(got, ref), float((got - ref).abs().max())
+    big = voc(mel.repeat(24 // B + 1, 1, 1))          # > 80 tiles in the C = 256 stage: the unsplit form
+    torch.cuda.synchronize()
+    assert torch.equal(big[:B], got)
+
+
 def test_hifigan_vs_oracle_other_shape():
     host = _host()
     hcfg = HifiGanConfig()
