@@ -458,6 +458,7 @@ extern "C" void cmtts_persist_validated(int variant, int gx, int gy) {
 }
 
 extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
+extern "C" long long* cmtts_persist_get_debug(void) { return g_pdbg; }
 
 extern "C" int cmtts_persist_chunks(int B, int T, int max_blocks) {
     const int tiles = (T + FN - 1) / FN;

@@ -198,6 +198,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
     };
 
     bool gave_up = false;
+    // -DLP_STAMP (tools/lp_phases.sh; a timing-only build loaded through CMTTS_LIB, never the product library): cycle stamps of
+    // layer NL / 2 per wave, the slots of tools/persist_timing.py
+#ifdef LP_STAMP
+    const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
+#define LPSTAMP(slot) do { if (a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LPSTAMP(slot) do { } while (0)
+#endif
     for (int l = 0; l < a.NL; ++l) {
         const bool more = l + 1 < a.NL;
         constexpr int NGB = 3 * (C / 16);        // k=3 conv: group = tap * 16 + k-group
@@ -205,7 +213,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         u32x4 A[RINGM][NS][MT];
 #pragma unroll
         for (int s = 0; s < RINGM - 1; ++s) load_a(A[s], a.W3f[l], s);         // the weight stream does not depend on u
+        LPSTAMP(0);
         __syncthreads();   // (1) u^T of layer l complete
+        LPSTAMP(1);
         if (more) {        // pull the next layer's cp tile towards L2: one dword per 128-B line
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int tl = opaque(tid);
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 }
             }
         }
+        LPSTAMP(2);
 #pragma unroll
         for (int s = 0; s < RINGM - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
         {   // gate -> z^T (own buffer: no barrier between the conv and the gate)
@@ -257,7 +268,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                         put2<MODE>(zt, (j * 32 + (ln & 31)) * RS + ch, z0, z1, true, IMG);
                     }
         }
+        LPSTAMP(3);
         __syncthreads();   // (3) z^T complete, u^T of this layer dead
+        LPSTAMP(4);
 
         // =========================================================== phase C: output projection, 16 k-groups
         {
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 }
             }
         }
+        LPSTAMP(5);
         // ---- epilogue in fp32 registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
         {
             const float* bo = a.bo[l];
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         }
         if (!more) break;
         __builtin_amdgcn_sched_barrier(0);
+        LPSTAMP(6);
         const float* dpn = dp_b + (long)(l + 1) * C;
         const unsigned tag = (unsigned)l + 1;
         unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;
@@ -380,6 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 put1<MODE>(ut, (right ? FN + 1 : 0) * RS + m, uh, inside, IMG);
             }
         }
+        LPSTAMP(7);
     }
 
     if (a.tail) {
@@ -418,6 +434,9 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
     const int bc = (B + nchunks - 1) / nchunks;
     for (int b0 = 0; b0 < B; b0 += bc) {
         PersistArgs c = a;
+#ifdef LP_STAMP
+        c.dbg = cmtts_persist_get_debug();
+#endif
         const int nb = B - b0 < bc ? B - b0 : bc;
         c.x0 = a.x0 + (long)b0 * C * a.T;
         c.cp = a.cp + (long)b0 * a.cp_bstride;

@@ -77,6 +77,7 @@ int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a, void* stream);
 int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int force);   // resident workgroups of the largest launch (0 = path not taken)
 int cmtts_persist_chunks(int B, int T, int max_blocks);   // launches one call makes (0 = not supported)
 void cmtts_persist_set_debug(long long* dbg);
+long long* cmtts_persist_get_debug(void);
 // 1: launch through hipLaunchCooperativeKernel (the runtime refuses a grid that cannot be co-resident and dispatches it
 // with the cooperative-queue guarantee); 0: plain launch, grid <= CU count by construction.  Returns the previous value.
 // -1 (default) = automatic: once a process group / communicator exists in the process (cmtts_persist_note_process_group) the first

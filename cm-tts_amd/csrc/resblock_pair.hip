@@ -426,7 +426,9 @@ int launch_xl(const ConvXlArgs& a, hipStream_t stream) {
     }
     const long tiles = (long)((a.T + XL_BN - 1) / XL_BN) * a.B;
     // two waves per SIMD in C / 32-wave workgroups once every CU has one; below that the m-tiles spread over C / 64 workgroups
-    if (g_xl_split && C / 32 > 4 && tiles * (C / 64) <= 320) {      // (C = 128 has one wave per SIMD already)
+    // (C = 128 has one wave per SIMD already; above ~40 tiles the four-fold staging of the split form costs what its K loops gain: one
+    //  510-frame request, 64 tiles, 3.81 ms unsplit / 3.95 split; one 150-frame request, 19 tiles, 2.43 / 1.99)
+    if (g_xl_split && C / 32 > 4 && tiles * (C / 64) <= 160) {
         dim3 grid((a.T + XL_BN - 1) / XL_BN, a.B, C / (32 * NWS));
         hipLaunchKernelGGL((conv_xl_kernel<C, KT, CIN, NWS>), grid, dim3(64 * NWS), lds, stream, a);
     } else {
