@@ -963,7 +963,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 // conv stack of Duration/Pitch/Energy predictors (model/modules.py:477-487): Conv1d + ReLU ->
 // LayerNorm over channels (eps 1e-12) [-> mask].  Result ends in bufB.
 // conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
-// block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_set_option("pred_head", 0)
+// block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_internal_set("pred_head", 0)
 // mode16: 0, or the 16-bit operand mode (1 = bf16, 2 = fp16) of a model with the opt-in "text16": the convs on conv_mfma16.hip (bias + ReLU in fp32)
 int g_pred_xres = 1;            // round 4: phoneme-level 256 -> 256 predictor convs on conv_xres (32-column tiles), the previous block's LayerNorm as its prologue (same bits); 0 = generic kernel + LayerNorm launches
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
