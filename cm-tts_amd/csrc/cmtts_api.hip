@@ -1078,6 +1078,8 @@ struct CondFactors {
     bool usable(const cmtts_model* m) const;
 };
 int g_cond_factored = 1;        // internal switch "cond_factored": 0 = always the dense GEMM
+int g_cond_inkernel = 1;        // internal switch "cond_inkernel": the fp32 persistent kernel gathers the factors itself (FACT instances: no cp tensor, the
+                                // same bits as cond_expand_kernel + the plain instance); 0 = expand into cp first
 bool CondFactors::usable(const cmtts_model* m) const {
     return g_cond_factored && p1 && mel2ph && p_idx && m->precision == 0 && m->cond_p2 && g_fused_resblock;
 }
@@ -1201,7 +1203,8 @@ int denoiser_prologue(cmtts_model* m, const DenWs& w, const float* x_src, float 
 
 int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_scale, const float* timesteps,
                   const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
-                  SideStream* pending = nullptr, float t_host = NAN) {   // pending: a side branch (the conditioner GEMM) to join before the layers
+                  SideStream* pending = nullptr, float t_host = NAN,    // pending: a side branch (the conditioner GEMM) to join before the layers
+                  const CondFactors* cfk = nullptr, bool* cp_ready = nullptr) {   // cfk: w.cp was NOT filled — the persistent kernel gathers the factors (FACT)
     if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
         *(volatile unsigned*)g_tmo_host = 0;
         return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
@@ -1227,6 +1230,10 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         pa.B = B; pa.T = T; pa.NL = NL;
         pa.halo_zeroed = halo_zeroed;
         const int prec = m->precision;
+        if (cfk && !(cp_ready && *cp_ready)) {
+            pa.fact = 1; pa.p1 = cfk->p1; pa.p2 = m->cond_p2; pa.mel2ph = (const long long*)cfk->mel2ph; pa.pidx = (const long long*)cfk->p_idx;
+            pa.ldp = cfk->ldp; pa.Lph = cfk->L; pa.ld2 = c.pitch_bins;
+        }
         if (g_persist_tail && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
             pa.tail = 1;
             pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
@@ -1253,6 +1260,11 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             layers_done = true;
             if (pa.tail) return 0;
         }
+    }
+    if (!layers_done && cfk && !(cp_ready && *cp_ready)) {
+        // the persistent launch was expected to gather the factors and did not take this shape after all: expand them now
+        CHK(cond_factored(m, w, *cfk, B, T, s));
+        if (cp_ready) *cp_ready = true;
     }
     for (int l = 0; l < NL && !layers_done; ++l) {
         const ResLayer& R = m->res[l];
@@ -1767,9 +1779,15 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
     // once for all n_steps evaluations, on the side stream: joined before the first residual layer of the first evaluation
     SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
     if (ss) CHK(branch_fork(ss));
+    const CondFactors* cfk = nullptr;       // non-null: no cp tensor at all, the persistent launches gather the factors (denoiser_core)
+    bool cp_ready = false;
     if (g_fused_resblock) {
-        if (cf && cf->usable(m)) CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
-        else CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
+        if (cf && cf->usable(m)) {
+            const bool inkernel = g_cond_inkernel && g_persist && g_persist_tail && m->skip_f && m->outp_f && c.res_layers <= PERSIST_MAX_LAYERS &&
+                                  cmtts_persist_plan(B, T, c.res_layers, persist_blocks(), g_persist == 2) > 0;
+            if (inkernel) cfk = cf;
+            else CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
+        } else CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
     }
     k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
     const float smin = c.sigma_min, sd2 = c.sigma_data * c.sigma_data;
@@ -1788,7 +1806,7 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
         const bool renoise = renoise_std[i] >= 0.0f;
         const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * noise_stride : nullptr, c_out, c_skip,
                               renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr, t_resc));
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr, t_resc, cfk, &cp_ready));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1915,6 +1933,14 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             if (rest <= cap_all && rest > 0 && out <= 64) keep = k2;
         }
     }
+    // every group that takes part in the one launch brings usable conditioner factors: the FACT instance of the ragged kernel
+    bool fact_all = g_cond_inkernel != 0;
+    for (int g = 0; g < n_groups && fact_all; ++g) {
+        if (keep[g] == 0) continue;
+        CondFactors cf;
+        cf.p1 = groups[g].cond_p1; cf.ldp = groups[g].p1_ld; cf.L = groups[g].L; cf.mel2ph = groups[g].mel2ph; cf.p_idx = groups[g].p_idx;
+        if (!cf.usable(m)) fact_all = false;
+    }
     std::vector<DenWs> ws(n_groups);
     SideStream* ss = side_for(s);
     // whatever path leaves this function after a fork, the caller's stream is ordered behind the side stream again
@@ -1931,7 +1957,8 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         if (keep[g] == 0) continue;
         CondFactors cf;
         cf.p1 = G.cond_p1; cf.ldp = G.p1_ld; cf.L = G.L; cf.mel2ph = G.mel2ph; cf.p_idx = G.p_idx;
-        if (cf.usable(m)) CHK(cond_factored(m, ws[g], cf, keep[g], G.T, ss ? ss->side : s));
+        if (fact_all) { /* the ragged FACT instance gathers the factors itself: no cp tensor */ }
+        else if (cf.usable(m)) CHK(cond_factored(m, ws[g], cf, keep[g], G.T, ss ? ss->side : s));
         else CHK(cond_projections(m, ws[g], G.cond_ct, keep[g], G.T, ss ? ss->side : s));   // once for all evaluations, beside the first prologues
         k_scale(G.noise, ws[g].xcur, (long)keep[g] * G.T * M, c.sigma_max, s);         // x_T = randn * sigma_max (karras_diffusion.py:534)
         if (G.active_frames) HIPCHK(hipMemsetAsync(G.mel, 0, (size_t)keep[g] * G.T * M * sizeof(float), s));   // frames beyond the trimmed range: zeros
@@ -1972,6 +1999,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         pa.W3f[l] = m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
+    if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.ld2 = c.pitch_bins; }
     for (int i = 0; i < n_steps; ++i) {
         // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
         const float sg = sigmas[i];
@@ -2004,6 +2032,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.halo = w.halo;
             pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
             pg.B = Bk; pg.T = G.T; pg.tiles = tiles;
+            if (fact_all) { pg.p1 = G.cond_p1; pg.mel2ph = (const long long*)G.mel2ph; pg.pidx = (const long long*)G.p_idx; pg.ldp = G.p1_ld; pg.Lph = G.L; }
             for (int b = 0; b < Bk; ++b) {
                 const int act = (int)utt_tiles(G, b, i);
                 utts.push_back({g, b, act});
@@ -2451,6 +2480,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"cwt_in_phoneme", &g_cwt_in_phoneme, 0, 1},   // Linear(256 -> 128) of the pitch predictor before (1) or after (0) the length regulator
         {"pred_xres", &g_pred_xres, 0, 1},         // phoneme-level predictor convs on conv_xres with the LayerNorm prologue
         {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
+        {"cond_inkernel", &g_cond_inkernel, 0, 1}, // fp32 persistent denoiser gathers the conditioner factors itself (same bits as expanding them into cp first)
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported

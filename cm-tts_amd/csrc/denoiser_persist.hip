@@ -66,7 +66,8 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 // closer than NL to Tc differ from the untrimmed result; the caller keeps Tc far enough beyond the frames it uses
 // (cmtts_api.hip: sample_ragged).  The arithmetic of a computed frame is unchanged: every value is bit-identical to the uniform
 // launch of its own bucket as long as no trimmed frame lies within its receptive field.
-template <bool DBG, bool RAGGED>
+// FACT (round 4): the conditioner projections are gathered from their factors (persist_args.h) wherever cp would be read.
+template <bool DBG, bool RAGGED, bool FACT = false>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -93,13 +94,36 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     unsigned long long* halo_g = RAGGED ? a.grp[gi].halo : a.halo;
     const int B_g = RAGGED ? a.grp[gi].B : a.B, tiles_g = RAGGED ? a.grp[gi].tiles : a.tiles;
     const int mrow0 = w * 32;                          // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
-
+    // FACT: cp of (row m of layer l, frame t) from the factors; (ph, ix) = frame_idx(t)
+    const float* p1_b = nullptr;
+    const long long *m2p_b = nullptr, *pix_b = nullptr;
+    int ldp = 0, Lph = 0;
+    if (FACT) {
+        p1_b = (RAGGED ? a.grp[gi].p1 : a.p1);
+        ldp = RAGGED ? a.grp[gi].ldp : a.ldp;
+        Lph = RAGGED ? a.grp[gi].Lph : a.Lph;
+        p1_b += (long)b * a.NL * C * ldp;
+        m2p_b = (RAGGED ? a.grp[gi].mel2ph : a.mel2ph) + (long)b * T;
+        pix_b = (RAGGED ? a.grp[gi].pidx : a.pidx) + (long)b * T;
+    }
+    auto frame_idx = [&](int t_c, int& ph, int& ix) {
+        const long long p = m2p_b[t_c], q = pix_b[t_c];
+        ph = (int)(p > Lph ? Lph : p);
+        ix = q < 0 ? 0 : (q >= a.ld2 ? a.ld2 - 1 : (int)q);
+    };
+    auto cp_fact = [&](int row, int ph, int ix) -> float {      // row = l * C + m; cond_expand_kernel's expression
+        const float av = p1_b[(long)row * ldp + (ph > 0 ? ph - 1 : 0)];
+        const float qv = a.p2[(long)row * a.ld2 + ix];
+        return (ph > 0 ? av : 0.f) + qv;
+    };
 
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
     {
         const float* xin = x0_b;
         const int t = t0 + lane;
         const int t_c = min(t, T - 1);
+        int ph0 = 0, ix0 = 0;
+        if (FACT) frame_idx(t_c, ph0, ix0);
         constexpr int ROWS_PER_WAVE = C / NW;
 #pragma unroll 1
         for (int i = 0; i < ROWS_PER_WAVE; i += 8) {
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             for (int q = 0; q < 8; ++q) {
                 const int m = w * ROWS_PER_WAVE + i + q;
                 xv[q] = xin[(unsigned)(m * T + t_c)];
-                cv[q] = cp_b[(unsigned)(m * T + t_c)];
+                cv[q] = FACT ? cp_fact(m, ph0, ix0) : cp_b[(unsigned)(m * T + t_c)];
                 dq[q] = dp_b[m];
             }
 #pragma unroll
@@ -123,7 +147,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const bool right = tid >= C;
             const int th = right ? t0 + FN : t0 - 1;
             const int thc = min(max(th, 0), T - 1);
-            const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
+            float cph0;
+            if (FACT) { int ph, ix; frame_idx(thc, ph, ix); cph0 = cp_fact(m, ph, ix); }
+            else cph0 = cp_b[(unsigned)(m * T + thc)];
+            const float uh = cph0 + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
             smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < Tc) ? uh : 0.f;
         }
     }
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         stamp(l, 0);
         __syncthreads();   // (1) u of layer l complete (interior, halo columns)
         stamp(l, 1);
-        if (more && tid < 2 * C) {
+        if (!FACT && more && tid < 2 * C) {
             // pull the next layer's cp tile (256 rows x 256 B) towards this XCD's L2 now: one dword per 128-B line;
             // the x waves read it in the accumulator layout after the output projection and would otherwise pay the
             // HBM latency there
@@ -344,8 +371,16 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int t_c = min(t0 + j * 32 + c31, T - 1);
+                if (FACT) {
+                    int ph, ix;
+                    frame_idx(t_c, ph, ix);
+                    const int row0 = (l + 1) * C + mrow0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                    for (int r = 0; r < 16; ++r) cpc[j][r] = cp_fact(row0 + acc_row(r, ln), ph, ix);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -368,8 +403,15 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int ln = opaque(lane);
             float cph[C / 64];
+            if (FACT) {
+                int ph, ix;
+                frame_idx(thc, ph, ix);
 #pragma unroll
-            for (int k = 0; k < C / 64; ++k) cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)];
+                for (int k = 0; k < C / 64; ++k) cph[k] = cp_fact((l + 1) * C + ln + 64 * k, ph, ix);
+            } else {
+#pragma unroll
+                for (int k = 0; k < C / 64; ++k) cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)];
+            }
             float xv[C / 64];
 #pragma unroll
             for (int k = 0; k < C / 64; ++k) xv[k] = 0.f;
@@ -502,10 +544,15 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
+    if (a.fact && (!a.p1 || !a.p2 || !a.mel2ph || !a.pidx || a.ldp < 1 || a.ld2 < 1)) return -2;
     // every granule tag must be stale (0) when a launch starts
     if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     // utterance chunks: all workgroups of a launch must be resident (one per CU); chunks are balanced so that the last
@@ -523,19 +570,28 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
+        if (a.fact) {
+            c.p1 = a.p1 + (long)b0 * a.NL * C * a.ldp;
+            c.mel2ph = a.mel2ph + (long)b0 * a.T;
+            c.pidx = a.pidx + (long)b0 * a.T;
+        }
         if (a.tail) {
             const long off = (long)b0 * a.T * a.n_mels;
             c.xold = a.xold ? a.xold + off : nullptr;
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        if (a.dbg) hipLaunchKernelGGL((denoiser_persist_kernel<true, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-        else if (cmtts_persist_cooperative(0, tiles, nb)) {
+        const void* kfn = a.fact ? reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true>)
+                                 : reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>);
+        if (a.dbg) {
+            if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<true, false, true>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+            else hipLaunchKernelGGL((denoiser_persist_kernel<true, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        } else if (cmtts_persist_cooperative(a.fact ? 5 : 0, tiles, nb)) {
             void* params[] = {(void*)&c};
-            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>), dim3(tiles, nb),
-                                           dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
-            cmtts_persist_validated(0, tiles, nb);
-        } else hipLaunchKernelGGL((denoiser_persist_kernel<false, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+            if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+            cmtts_persist_validated(a.fact ? 5 : 0, tiles, nb);
+        } else if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<false, false, true>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+        else hipLaunchKernelGGL((denoiser_persist_kernel<false, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;
@@ -553,15 +609,25 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -3;
         attr_set = true;
     }
-    if (cmtts_persist_cooperative(4, a.n_wg, -1)) {
+    if (a.fact) {      // every group brings its factors, or none does
+        if (!a.p2 || a.ld2 < 1) return -2;
+        for (int g = 0; g < a.n_groups; ++g)
+            if (a.grp[g].B > 0 && (!a.grp[g].p1 || !a.grp[g].mel2ph || !a.grp[g].pidx || a.grp[g].ldp < 1)) return -2;
+    }
+    const void* kfn = a.fact ? reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true>)
+                             : reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>);
+    const int variant = a.fact ? 6 : 4;
+    if (cmtts_persist_cooperative(variant, a.n_wg, -1)) {
         void* params[] = {(void*)a_in};
-        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW),
-                                       params, (unsigned)lds, stream) != hipSuccess) return -3;
-        cmtts_persist_validated(4, a.n_wg, -1);
-    } else hipLaunchKernelGGL((denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
+        if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+        cmtts_persist_validated(variant, a.n_wg, -1);
+    } else if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<false, true, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
+    else hipLaunchKernelGGL((denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -19,6 +19,11 @@ struct PersistGroup {
     float* out;           // tail: [B][T][n_mels]
     long cp_bstride;
     int B, T, tiles, pad_;
+    // FACT instances (round 4): the conditioner projections gathered from their factors instead of read from cp (PersistArgs.p2 is shared)
+    const float* p1;      // [B][NL*256][ldp]
+    const long long* mel2ph;    // [B][T] int64
+    const long long* pidx;      // [B][T] int64
+    int ldp, Lph;
 };
 
 struct PersistArgs {
@@ -50,6 +55,15 @@ struct PersistArgs {
     const float* noise;   // [B][T][n_mels] or null
     float c_out, c_skip, nstd;
     float* out;           // [B][T][n_mels]
+    // FACT instances (round 4, fp32 kernel): cp[r][t] = (mel2ph[t] > 0 ? p1[r][mel2ph[t] - 1] : 0) + p2[r][pidx[t]] is formed where cp would be
+    // read — the cp tensor is neither written (cond_expand_kernel) nor read (335 MB per launch at the bench shape); the same bits as
+    // expanding first.  fact = 0: read cp.
+    int fact;
+    const float* p1;      // [B][NL*256][ldp]: conditioner weights applied to the phoneme-level conditioning, no bias
+    const float* p2;      // [NL*256][ld2]: the same weights applied to the pitch-embedding table, + bias
+    const long long* mel2ph;    // [B][T] int64: 1-based phoneme of a frame, 0 = padding
+    const long long* pidx;      // [B][T] int64: pitch bucket of a frame
+    int ldp, Lph, ld2;
     int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
     // ---- ragged launches (round 3; fp32 kernel): a 1-D grid of n_wg workgroups, workgroup i works on tile (desc >> 13 & 127) of

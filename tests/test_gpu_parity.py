@@ -1347,7 +1347,22 @@ def test_cond_factored(variant, B, L, T):
             m_off = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, nz, factors=f)
         finally:
             _lib.internal_set("cond_factored", prev)
+        # the persistent kernel gathering the factors itself (FACT instances, no cp tensor) against expanding them first: the same bits
+        # (forced persistent so that the small shapes take that kernel too)
+        lib = _lib.load()
+        prev_p = lib.cmtts_set_persistent_denoiser(2)
+        prev_k = _lib.internal_set("cond_inkernel", 1)
+        try:
+            m_ik = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, nz, factors=f)
+            _lib.internal_set("cond_inkernel", 0)
+            m_ex = host.sample_with_cond(model, out["cond_ct"], out["speaker_emb"], n_steps, nz, factors=f)
+        finally:
+            _lib.internal_set("cond_inkernel", prev_k)
+            lib.cmtts_set_persistent_denoiser(prev_p)
         host.synchronize()
+        assert torch.equal(m_ik, m_ex), float((m_ik - m_ex).abs().max())
+        assert torch.equal(m_ik, m_f) or B * ((T + 63) // 64) * 2 <= 256      # (small shapes: m_f came from the per-layer kernels — bitwise equal anyway)
+        assert torch.equal(m_ik, m_f), float((m_ik - m_f).abs().max())
         assert torch.equal(m_off, m_d)                                     # the switch restores the dense GEMM
         err = float((m_f - m_d).abs().max())
         report(f"COND_FACTORED {variant} B={B} T={T} steps={n_steps}: cp max|d| vs f64 dense {e_d:.2e} factored {e_f:.2e} (scale {scale:.2f}); max|dmel| factored vs dense {err:.2e}")
