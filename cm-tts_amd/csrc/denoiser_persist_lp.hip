@@ -232,11 +232,20 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             for (int it = 0; it < NGB; it += RINGM) {
 #pragma unroll
                 for (int s = 0; s < RINGM; ++s) {
+                    // -DLP_ABL=n (timing-only builds, wrong results): 1 = no weight loads, 2 = no LDS operand loads, 4 = no MFMAs in this loop
+#if !defined(LP_ABL) || !(LP_ABL & 1)
                     load_a(A[(s + RINGM - 1) % RINGM], a.W3f[l], min(it + s + RINGM - 1, NGB - 1));
+#endif
                     const int nx = min(it + s + 1, NGB - 1);
+#if !defined(LP_ABL) || !(LP_ABL & 2)
                     load_b(Bv[(s + 1) & 1], ut, nx & 15, nx >> 4);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
+#if !defined(LP_ABL) || !(LP_ABL & 4)
                     if (it + s < NGB) mma_group(A[s], Bv[s & 1]);
+#else
+                    if (it + s < NGB) { acc[0][0][0] += __builtin_bit_cast(float, A[s][0][0][0]) + __builtin_bit_cast(float, Bv[s & 1][0][0][0]); }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -3,7 +3,7 @@
 loaded through CMTTS_LIB): cycle-counter ticks per phase of the middle layer, per wave group."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["CMTTS_LIB"] = os.path.join(ROOT, "tools", "bin", "libcmtts_lpstamp.so")
+os.environ["CMTTS_LIB"] = os.path.join(ROOT, "tools", "bin", "libcmtts_lpstamp" + os.environ.get("LP_SUF", "") + ".so")
 import numpy as np, torch
 sys.path.insert(0, ROOT)
 import cmtts_amd
