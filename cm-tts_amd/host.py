@@ -887,6 +887,7 @@ class CollatedShard:
     `members` = [(group index, b0, n, Lg)]; `groups` keeps (noise, bucket) per group."""
 
     def __init__(self, groups, device):
+        # a group may carry a sixth element: speakers int64 [n] (models whose speaker_emb is an nn.Embedding table, model/cmtts.py:77-78)
         self.groups = [(g[3], int(g[4])) for g in groups]
         self.n = [int(g[0].shape[0]) for g in groups]
         classes = {}
@@ -898,9 +899,12 @@ class CollatedShard:
             Bt = sum(int(groups[i][0].shape[0]) for i in idx)
             texts = torch.zeros(Bt, Lt, dtype=torch.int64, device=device)
             has_spk = groups[idx[0]][2] is not None
-            src, pad, spk, members, b0 = [], [], [], [], 0
+            has_ids = len(groups[idx[0]]) > 5 and groups[idx[0]][5] is not None
+            src, pad, spk, ids, members, b0 = [], [], [], [], [], 0
             for i in idx:
                 tx, ln, sp = groups[i][0], groups[i][1], groups[i][2]
+                if has_ids:
+                    ids.append(groups[i][5].to(device=device, dtype=torch.int64))
                 n, Lg = tx.shape
                 texts[b0:b0 + n, :Lg] = tx.to(device)
                 src.append(ln.to(device=device, dtype=torch.int64))
@@ -910,7 +914,8 @@ class CollatedShard:
                 members.append((i, b0, n, Lg))
                 b0 += n
             self.batches.append({"texts": texts, "src_lens": torch.cat(src), "pad_lens": torch.cat(pad),
-                                 "spk": torch.cat(spk) if has_spk else None, "members": members})
+                                 "spk": torch.cat(spk) if has_spk else None, "speakers": torch.cat(ids) if has_ids else None,
+                                 "members": members})
 
 
 def collate_groups(groups, device):
@@ -924,16 +929,21 @@ def _text_forward_ragged(model, tb, key):
     texts, src, pad, spk_in = tb["texts"], tb["src_lens"], tb["pad_lens"], tb["spk"]
     B, L = texts.shape
     table = cfg.multi_speaker and cfg.n_speaker > 0
+    ids = tb.get("speakers") if table else None
     if table:
-        raise NotImplementedError("ragged text batches with a speaker-id table")
-    if cfg.multi_speaker and spk_in is None:
+        if ids is None:
+            raise AssertionError("speakers (ids into the speaker_emb table) should not be None")
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= cfg.n_speaker):
+            raise IndexError("index out of range in self")
+        spk_in = None
+    elif cfg.multi_speaker and spk_in is None:
         raise AssertionError("Speaker embedding should not be None")
     with torch.cuda.device(dev):
         mel_len = torch.empty(B, dtype=torch.int64, device=dev)
         spk = torch.empty(B, cfg.hidden, dtype=torch.float32, device=dev) if cfg.multi_speaker else None
         nb = lib.cmtts_text_workspace_bytes(model._h, B, L)
         tws = model._ws.get(key, nb, dev)
-        _lib.check(lib.cmtts_text_forward_ragged(model._h, _ptr(texts), _ptr(src), _ptr(pad), _ptr(spk_in), None, B, L, 1.0,
+        _lib.check(lib.cmtts_text_forward_ragged(model._h, _ptr(texts), _ptr(src), _ptr(pad), _ptr(spk_in), _ptr(ids), B, L, 1.0,
                                                  None, None, _ptr(mel_len), None, None, None, _ptr(spk), _ptr(tws), nb, _stream()))
     return tws, B, L, mel_len, spk
 
@@ -1057,8 +1067,11 @@ class BucketedSynthesizer:
         collate_groups() made of them (collation = input preparation, once per shard).
         Returns [(mel [n,bucket,80], mel_lens [n])] in the same order."""
         dev = self.model.device
-        if self.mode == "ragged" and self.batch_text and getattr(self.model, "_precision_mode", 0) == 0 and \
-                not (self.model.config.multi_speaker and self.model.config.n_speaker > 0):
+        if not isinstance(groups, CollatedShard):
+            groups = list(groups)
+        table = self.model.config.multi_speaker and self.model.config.n_speaker > 0
+        no_ids = table and not isinstance(groups, CollatedShard) and any(len(g) < 6 or g[5] is None for g in groups)
+        if self.mode == "ragged" and self.batch_text and getattr(self.model, "_precision_mode", 0) == 0 and not no_ids:
             return self._run_batched(groups if isinstance(groups, CollatedShard) else collate_groups(groups, dev))
         if isinstance(groups, CollatedShard):
             raise ValueError("a CollatedShard needs mode='ragged' with batch_text on an fp32 model")
@@ -1094,11 +1107,12 @@ class BucketedSynthesizer:
             done = {}
             late_events = []
             for i in sorted(range(len(groups)), key=lambda i: i not in early):      # the early groups are queued first
-                texts, src_lens, spk, noise, bucket = groups[i]
+                texts, src_lens, spk, noise, bucket = groups[i][:5]
+                ids = groups[i][5] if len(groups[i]) > 5 else None
                 st = self.streams[i % len(self.streams)]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    o = self.model.duration_pitch_energy_net(None, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
+                    o = self.model.duration_pitch_energy_net(ids, texts, src_lens, spker_embeds=spk, max_mel_len=bucket)
                     if mode != "ragged" or i in early:
                         prev_p = lib.cmtts_set_persistent_denoiser(0) if i in early else None
                         mel = sample_with_cond(self.model, o["cond_ct"], o["speaker_emb"], self.n_steps, noise, factors=o.get("cond_factors"))

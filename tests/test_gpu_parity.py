@@ -1130,6 +1130,43 @@ def test_xres_conv_bitwise(models):
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
 
 
+def test_collated_shard_speaker_table():
+    """A ragged shard of a model whose speaker_emb is an nn.Embedding table (speaker ids as a sixth group element): the collated one-call text
+    side through BucketedSynthesizer against every group alone, bit for bit."""
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("VCTK_table")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=14, dur_frames=4.0, dur_spread=0.0))
+    rs = np.random.RandomState(3)
+    n_steps, groups = 2, []
+    for bucket, n in ((256, 8), (512, 6), (128, 4)):
+        Lmax = bucket // 4
+        ln = np.maximum((rs.uniform(0.4, 1.0, size=n) * Lmax).astype(np.int64), 1)
+        ln[0] = Lmax
+        tx = rs.randint(1, cfg.n_symbols, size=(n, Lmax)).astype(np.int64)
+        tx[np.arange(Lmax)[None, :] >= ln[:, None]] = 0
+        gen = torch.Generator().manual_seed(bucket)
+        groups.append((torch.from_numpy(tx).to(DEV), torch.from_numpy(ln).to(DEV), None,
+                       torch.randn(n_steps + 1, n, 1, bucket, cfg.n_mels, generator=gen).to(DEV), bucket,
+                       torch.from_numpy(rs.randint(0, cfg.n_speaker, size=n).astype(np.int64)).to(DEV)))
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    try:
+        alone = []
+        for tx, ln, _, nz, bucket, ids in groups:
+            o = model.duration_pitch_energy_net(ids, tx, ln, max_mel_len=bucket)
+            alone.append((host.sample_with_cond(model, o["cond_ct"], o["speaker_emb"], n_steps, nz), o["mel_lens"]))
+        host.synchronize()
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(host.collate_groups(groups, DEV))
+    old = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False, batch_text=False).run(groups)
+    host.synchronize()
+    for (m0, l0), (m1, l1), (m2, l2) in zip(alone, got, old):
+        assert torch.equal(l0, l1) and torch.equal(l0, l2)
+        assert torch.equal(m0, m1), float((m0 - m1).abs().max())
+        assert torch.equal(m0, m2), float((m0 - m2).abs().max())
+
+
 @pytest.mark.parametrize("variant,B,L", [("LJSpeech", 1, 25), ("VCTK", 2, 85), ("LibriTTS", 3, 130), ("LJSpeech", 8, 33), ("LJSpeech", 1, 1), ("VCTK", 32, 85)])
 def test_xres_small_bitwise(variant, B, L):
     """Round 4: launches that cannot fill the chip — a single request, a few utterances — take conv_xres.hip with 32-column tiles (one
