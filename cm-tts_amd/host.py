@@ -1149,7 +1149,8 @@ class BucketedSynthesizer:
                 for gi, l in enumerate(lens):
                     active[gi] = flat[k:k + l.numel()]
                     k += l.numel()
-            mels = sample_ragged(self.model, [(conds[i]["cond_ct"], conds[i]["speaker_emb"], groups[i][3], a) for i, a in zip(late, active)],
+            mels = sample_ragged(self.model, [(conds[i]["cond_ct"], conds[i]["speaker_emb"], groups[i][3], a, conds[i].get("cond_factors"))
+                                              for i, a in zip(late, active)],
                                  self.n_steps, self.tail_frames) if late else []
             for i, mel, l in zip(late, mels, lens):
                 done[i] = (mel, l)
