@@ -976,7 +976,7 @@ class BucketedSynthesizer:
     mode "streams": every group end to end on its own stream (round 2).  Either way each group's valid frames are those of
     running the group alone."""
 
-    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None, mode="ragged", tail_frames=16, trim=True, batch_text=True):
+    def __init__(self, model: CMTotalTTS, n_steps=4, n_streams=4, persistent=None, mode="ragged", tail_frames=16, trim=True, batch_text=None):
         """persistent: denoiser mode while the groups run in "streams" mode (cmtts_set_persistent_denoiser; None = leave the
         process setting alone).  tail_frames: frames beyond mel_len that must be exact in the padded mel (16 covers HiFi-GAN's
         receptive field; the frames beyond the computed range are zeros instead of denoised padding).  trim=False computes
@@ -986,6 +986,11 @@ class BucketedSynthesizer:
         self.streams = [torch.cuda.Stream(device=model.device) for _ in range(n_streams)]
         # round 4, mode "ragged": the phoneme-level half of ALL groups in one cmtts_text_forward_ragged call (one launch sequence for the
         # shard instead of one per group), then each group's frame-level half on its own stream; False = one text side per group (round 3)
+        # None = automatic: batched once a process group exists (measured on MI355X, configs[3] shard: with RCCL loaded the one-call text side
+        # runs the shard at 860-870 k frames/s against 824-834 k for one text side per group on four streams; without RCCL 870-880 k against
+        # 877-881 k) — a CollatedShard passed to run() is always batched
+        if batch_text is None:
+            batch_text = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.batch_text = bool(batch_text)
 
     def _early_groups(self, sizes):
@@ -1071,7 +1076,7 @@ class BucketedSynthesizer:
             groups = list(groups)
         table = self.model.config.multi_speaker and self.model.config.n_speaker > 0
         no_ids = table and not isinstance(groups, CollatedShard) and any(len(g) < 6 or g[5] is None for g in groups)
-        if self.mode == "ragged" and self.batch_text and getattr(self.model, "_precision_mode", 0) == 0 and not no_ids:
+        if self.mode == "ragged" and (self.batch_text or isinstance(groups, CollatedShard)) and getattr(self.model, "_precision_mode", 0) == 0 and not no_ids:
             return self._run_batched(groups if isinstance(groups, CollatedShard) else collate_groups(groups, dev))
         if isinstance(groups, CollatedShard):
             raise ValueError("a CollatedShard needs mode='ragged' with batch_text on an fp32 model")

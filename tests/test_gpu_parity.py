@@ -1578,8 +1578,8 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
 
     groups = make((128, 256, 512, 384), 8)                 # 8 * (2 + 4 + 8 + 6) = 160 padded tiles: enough for the one-launch form
     seq = alone(groups)
-    full = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, trim=False).run(groups)
-    trim = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, tail_frames=16).run(groups)
+    full = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, trim=False, batch_text=True).run(groups)      # one-call text side
+    trim = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=3, tail_frames=16).run(groups)                  # one text side per group
     host.synchronize()
     saved = 0
     for (m0, l0), (m1, l1), (m2, l2) in zip(seq, full, trim):
@@ -1606,7 +1606,7 @@ def test_ragged_one_launch_shard_bitwise(n_steps):
     # (per-layer kernels on the side stream) while the large one takes the persistent launch
     mixed = make((1024,), 15) + make((256,), 8)
     seq = alone(mixed)
-    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(mixed)
+    got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False, batch_text=True).run(mixed)
     host.synchronize()
     for (m0, l0), (m1, l1) in zip(seq, got):
         assert torch.equal(l0, l1) and torch.equal(m0, m1), float((m0 - m1).abs().max())
