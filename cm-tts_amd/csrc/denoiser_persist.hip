@@ -396,6 +396,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         }
         if (w >= NW - 2) {
             // the last two waves also fetch the left / right halo column: x' of the neighbour's edge + dp + cp
+            // (round 4: requesting the column's cp values and a first look at the granules BEFORE this wave's own u rows, to take the two round trips
+            //  off the other waves' barrier wait, left the phase at 13.7 k cycles and cost 12 more registers — the FACT instance spilled: 12.51 -> 12.81 ms)
             const bool right = w == NW - 1;
             const int th = right ? t0 + FN : t0 - 1;
             const bool inside = th >= 0 && th < Tc;
