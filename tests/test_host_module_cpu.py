@@ -113,3 +113,36 @@ def test_get_vocoder_reads_the_reference_layout(tmp_path):
         host.get_vocoder({"vocoder": {"model": "MelGAN", "speaker": "universal"}}, "cpu", root=str(tmp_path))
     with pytest.raises(FileNotFoundError):
         host.get_vocoder({"vocoder": {"model": "HiFi-GAN", "speaker": "LJSpeech"}}, "cpu", root=str(tmp_path))
+
+
+def test_collate_groups_layout():
+    """host.collate_groups (round 4): bucket groups of a ragged shard -> one padded text batch per attention class (L <= 192 / longer), with each
+    utterance's OWN group's padded length in pad_lens and the members table that maps the batch back to the groups."""
+    from cmtts_amd import host
+    gen = torch.Generator().manual_seed(0)
+    groups = []
+    for n, L, bucket in ((3, 10, 64), (2, 200, 1024), (4, 43, 256)):
+        tx = torch.randint(1, 100, (n, L), generator=gen)
+        ln = torch.randint(1, L + 1, (n,), generator=gen)
+        groups.append((tx, ln, torch.randn(n, 512, generator=gen), None, bucket, torch.arange(n)))
+    coll = host.collate_groups(groups, "cpu")
+    assert coll.n == [3, 2, 4] and [b for _, b in coll.groups] == [64, 1024, 256]
+    short, long_ = coll.batches
+    assert tuple(short["texts"].shape) == (7, 43) and tuple(long_["texts"].shape) == (2, 200)
+    assert short["pad_lens"].tolist() == [10] * 3 + [43] * 4 and long_["pad_lens"].tolist() == [200, 200]
+    assert short["members"] == [(0, 0, 3, 10), (2, 3, 4, 43)] and long_["members"] == [(1, 0, 2, 200)]
+    assert torch.equal(short["texts"][:3, :10], groups[0][0]) and not short["texts"][:3, 10:].any()       # padded with the pad symbol 0
+    assert torch.equal(short["texts"][3:], groups[2][0])
+    assert torch.equal(short["src_lens"], torch.cat([groups[0][1], groups[2][1]]))
+    assert tuple(short["spk"].shape) == (7, 512) and short["speakers"].tolist() == [0, 1, 2, 0, 1, 2, 3]
+
+
+def test_cond_factors_bind_to_one_tensor():
+    """host.CondFactors: the conditioner factors apply to the conditioning tensor they were made with, unmodified — anything else takes the dense GEMM."""
+    from cmtts_amd import host
+    cond = torch.zeros(2, 256, 8)
+    f = host.CondFactors(torch.zeros(2, 5120, 4), 4, 3, torch.zeros(2, 8, dtype=torch.int64), torch.zeros(2, 8, dtype=torch.int64), cond)
+    assert f.matches(cond) and f.matches(cond.contiguous())
+    assert not f.matches(cond.clone()) and not f.matches(cond[:1])
+    cond.transpose(1, 2).add_(1.0)              # an in-place edit through a view bumps the shared version counter
+    assert not f.matches(cond)
