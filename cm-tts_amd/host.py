@@ -867,7 +867,8 @@ class StreamPipelinedSynthesizer:
         max_mel_len) is conditioned on the side stream.  Returns (mel, mel_lens) of the prepared batch."""
         ev, out = self.ready
         torch.cuda.current_stream(self.model.device).wait_event(ev)
-        for v in (out["cond_ct"], out["speaker_emb"]):
+        f = out.get("cond_factors")
+        for v in (out["cond_ct"], out["speaker_emb"]) + ((f.p1, f.mel2ph, f.p_idx) if f is not None else ()):
             if v is not None:
                 v.record_stream(torch.cuda.current_stream(self.model.device))
         self._keep = [out]
