@@ -2503,7 +2503,8 @@ int cmtts_internal_set(const char* name, int value) {
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
         {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };
-    if (!strcmp(name, "voc_xl_split")) return cmtts_xl_set_split(value);      // conv_xl: m-tiles over several workgroups for launches of a few column tiles
+    if (!strcmp(name, "voc_xl_split")) return cmtts_xl_set_split(value);
+    if (!strcmp(name, "xres_nt")) return cmtts_xres_set_nt(value);            // conv_xres tile width for launches that do not choose one (measurements)      // conv_xl: m-tiles over several workgroups for launches of a few column tiles
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
     if (found) return prev;

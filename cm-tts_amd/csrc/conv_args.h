@@ -88,6 +88,7 @@ int cmtts_launch_conv_xt16(const ConvArgs* a, const void* wfrag, int mode, int n
 // X-resident variant for short sequences (conv_xres.hip): wfrag = fp32 fragment-order weights; -2 = unsupported.
 int cmtts_launch_conv_xres(const ConvArgs* a, const float* wfrag, int nbatch, void* stream);
 void cmtts_conv_set_debug(long long* dbg, int M, int K);   // generic kernel: cycle counters of the launches with this (M, K)
+int cmtts_xres_set_nt(int nt);               // internal switch "xres_nt" (0 = launcher's rule, 1 / 3 = tile width of launches that do not choose); returns the previous value
 void cmtts_xres_set_debug(long long* dbg);   // cycle stamps [workgroup][wave][8] (tools/xres_phases.py); nullptr = off
 #ifdef __cplusplus
 }

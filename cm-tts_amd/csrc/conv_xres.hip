@@ -21,6 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef XRES_OCC1
+#define XRES_OCC1 2         // 32-column instances: waves per SIMD the register budget allows (41 KB of LDS per workgroup: up to three per CU)
+#endif
 constexpr int KMAX = 256;
 constexpr int HALO = 8;         // (taps - 1) * dil <= 8
 constexpr int RING = 4;
@@ -29,7 +32,7 @@ constexpr int RING = 4;
 // tile) or 1 (round 4: 32-column tiles for launches that cannot fill the chip — a single request, a few utterances — where one
 // accumulation chain per wave and three times the workgroups finish sooner than three chains per wave; same chains, same bits)
 template <bool LN, int NT>
-__global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
+__global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
     constexpr int BN = 32 * NT;          // columns per workgroup
     constexpr int X_LD = BN + HALO;      // 104 / 40
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K][X_LD]
@@ -322,10 +325,12 @@ __global__ __launch_bounds__(256, 1) void conv_xres_kernel(const ConvArgs a, con
 }
 
 long long* g_xres_dbg = nullptr;
+int g_xres_nt = 0;          // internal switch "xres_nt": 0 = the launcher's rule, 1 / 3 = every launch that does not ask for one itself (measurements)
 
 }  // namespace
 
 extern "C" void cmtts_xres_set_debug(long long* dbg) { g_xres_dbg = dbg; }
+extern "C" int cmtts_xres_set_nt(int nt) { const int p = g_xres_nt; if (nt == 0 || nt == 1 || nt == 3) g_xres_nt = nt; return p; }
 
 // Conv1d with fp32 weights as MFMA A fragments in iteration order [K/16][taps][2][ceil(M/32)][64][4]; zdiv == 1, split == INT_MAX,
 // dil > 0, K % 32 == 0, K <= 256, (taps-1)*dil <= 8, no pre-activation; a.ln_g / ln_b / ln_eps = LayerNorm prologue over the K rows.  Meant for short sequences (N of a few 96-column tiles)
@@ -345,7 +350,7 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
     // workgroups, a third of the MFMAs per accumulation chain's wave); a.xres_nt forces one (tests, tools)
     const int mblocks = ((a.M + 31) / 32 + 3) / 4;
     const long wg96 = (long)((a.N + 95) / 96) * mblocks * nbatch;
-    const int nt = a.xres_nt == 1 || a.xres_nt == 3 ? a.xres_nt : (wg96 >= 128 ? 3 : 1);
+    const int nt = a.xres_nt == 1 || a.xres_nt == 3 ? a.xres_nt : (g_xres_nt == 1 || g_xres_nt == 3 ? g_xres_nt : (wg96 >= 128 ? 3 : 1));
     const int bn = 32 * nt, x_ld = bn + HALO;
     static bool attr_set = false;
     const size_t lds = (size_t)a.K * x_ld * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
