@@ -315,7 +315,7 @@ int g_voc_upsT = 1;             // HiFi-GAN upsamplers: all phases of a ConvTran
 int g_voc_xl16 = 1;             // 16-bit HiFi-GAN convs at C >= 128 on the X-resident conv_xl16 kernel (same bits); 0 = chunked conv_mfma16 kernel
 int g_pred_xl = 1;              // frame-level 256 -> 256 predictor convs on the X-resident conv_xl kernel (bitwise equal); 0 = generic kernel
 int g_pred_head = 1;            // predictors: last LayerNorm + linear head as one launch (ln_linear_kernel); 0 = layernorm_ct + chan_linear
-int g_text_xres = 5;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel, 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
+int g_text_xres = 7;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-projection in one X-resident launch, 2 = out-projection on that kernel (round 4: its 32-column instance, default on), 4 = LayerNorm2 as the prologue of the FFN conv; 0 = separate LayerNorm launches
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip; key-chunked with an online softmax above L = 192): 0 = three-launch path
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
@@ -1493,8 +1493,13 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                 rc = cmtts_launch_conv16(&a, E.wo_f16[pm - 1], pm, B, (void*)s);
                 if (rc == -3) return fail(CMTTS_E_HIP, "text16: out-projection launch failed");
                 a.text_epi = 0;
-            } else if (E.wo_f && xres_cols && (((g_text_xres & 2) && (long)t96 * (H / 128) * B >= 64) || xres_small))
+            } else if (E.wo_f && g_ffn_xres && (g_text_xres & 2)) {
+                // round 4: M = 256 is two m-blocks — with 96-column tiles 64 workgroups at B = 32 (measured slower than the generic kernel in round 2);
+                // with 32-column tiles 192 workgroups of one short chain each, the tile staged once, no barrier in the K loop: 25 -> 13 us per block
+                a.xres_nt = 1;
                 rc = cmtts_launch_conv_xres(&a, E.wo_f, B, (void*)s);
+                a.xres_nt = 0;
+            }
             if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
         }
