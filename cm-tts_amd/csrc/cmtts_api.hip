@@ -319,6 +319,7 @@ int g_text_xres = 7;            // FFT blocks, bit mask: 1 = LayerNorm1 + in-pro
 int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE fused kernel (attention.hip; key-chunked with an online softmax above L = 192): 0 = three-launch path
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
+int g_qkv_nt = 0;              // internal switch "qkv_nt": conv_xres tile width of the in-projection (0 = launcher's rule, 1, 3) — measurements
 int g_cwt_in_phoneme = 1;      // round 4: the pitch predictor's input projection applied before the length regulator (same bits); 0 = over the frames
 int g_xres_small = 1;          // round 4: conv_xres with 32-column tiles for text-side launches that cannot fill the chip (same bits); 0 = the generic kernel there
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
@@ -489,6 +490,7 @@ struct cmtts_model {
     float *spk_wt = nullptr, *spk_b = nullptr, *spk_table = nullptr;
     Predictor dur, energy, cwt;
     PackedConv cwt_in;
+    float* cwt_in_f = nullptr;     // the same as MFMA A fragments in iteration order (conv_xres.hip)
     float *energy_bins = nullptr, *energy_emb = nullptr, *pitch_emb = nullptr;
     float *st0_wt = nullptr, *st0_b = nullptr, *st2_wt = nullptr, *st2_b = nullptr, *st4_wt = nullptr, *st4_b = nullptr;
     PackedConv in_proj, skip_proj, out_proj;
@@ -709,7 +711,12 @@ int finalize_model(cmtts_model* m) {
     {
         GET(w, va + "cwt_predictor.0.weight", c.cwt_hidden, H); GET(b, va + "cwt_predictor.0.bias", c.cwt_hidden);
         HostTensor w3 = *w; w3.shape = {c.cwt_hidden, H, 1};
-        CHK(pack_conv(al, w3, b, nullptr, &m->cwt_in));
+        {
+            std::vector<float> hp;
+            CHK(pack_conv(al, w3, b, nullptr, &m->cwt_in, &hp));
+            if (H % 32 == 0 && c.cwt_hidden % 32 == 0 && m->cwt_in.ld == c.cwt_hidden)
+                CHK(al.upload(to_fragment_iter_order(hp, 1, H, c.cwt_hidden), &m->cwt_in_f));
+        }
         GET(bins, va + "energy_bins", c.energy_bins - 1); UP(m->energy_bins, bins);
         GET(ee, va + "energy_embedding.weight", c.energy_bins, H); UP(m->energy_emb, ee);
         GET(pe, va + "pitch_embed.weight", c.pitch_bins, H); UP(m->pitch_emb, pe);
@@ -1416,7 +1423,11 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
                     k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
                     a.X = w.h; a.ln_g = a.ln_b = nullptr;
                 }
+                // more workgroups than CUs with 96-column tiles (B = 64, or two column tiles per utterance): the 32-column instance packs two
+                // per CU and overlaps their phases — 45-55 us less per text side at 64 x 85 and 32 x 171 phonemes, neutral at 32 x 85 (tools/text_xres_ab2.py)
+                a.xres_nt = g_qkv_nt ? g_qkv_nt : ((long)t96 * (3 * H / 128) * B > persist_blocks() ? 1 : 0);
                 rq = cmtts_launch_conv_xres(&a, E.qkv_f, B, (void*)s);
+                a.xres_nt = 0;
                 if (rq == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
                 if (rq != 0) k_layernorm_ct(w.x, w.h, E.ln1_g, E.ln1_b, 1e-12f, nullptr, B, L, Lp, s);
             }
@@ -1639,7 +1650,14 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
         // over the L phonemes here and cmtts_frame_forward gathers its output: the same bits (tests/test_gpu_parity.py goldens,
         // test_cwt_in_phoneme_level_bitwise) for a sixth of the work, off the frame-level chain
         ConvArgs a = conv_args(m->cwt_in, w.out1, L, Lp, (long)H * Lp, w.h128, Lp, (long)c.cwt_hidden * Lp, L);
-        CHK(launch(a, EPI_PLAIN, B, s));
+        int rc = -2;
+        if (g_ffn_xres && g_pred_xres && m->cwt_in_f) {      // 128 rows = one m-block: 32-column tiles, no barrier in the K loop (same bits)
+            a.xres_nt = 1;
+            rc = cmtts_launch_conv_xres(&a, m->cwt_in_f, B, (void*)s);
+            if (rc == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
+            a.xres_nt = 0;
+        }
+        if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
     }
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
         HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
@@ -2482,6 +2500,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
 int cmtts_internal_set(const char* name, int value) {
     if (!name) return fail(CMTTS_E_INVALID, "cmtts_internal_set: null name");
     static const Knob tab[] = {
+        {"qkv_nt", &g_qkv_nt, 0, 3},
         {"cwt_in_phoneme", &g_cwt_in_phoneme, 0, 1},   // Linear(256 -> 128) of the pitch predictor before (1) or after (0) the length regulator
         {"pred_xres", &g_pred_xres, 0, 1},         // phoneme-level predictor convs on conv_xres with the LayerNorm prologue
         {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
