@@ -1716,14 +1716,19 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
-    k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
-    if (g_cwt_in_phoneme) {   // cwt_predictor[0] was applied at the phoneme level (cmtts_text_forward): gather it; padding frames = its bias
-        k_length_regulate(tw.h128, mel2ph, w.h128, B, CH, Lp, T, s, m->cwt_in.bias);
+    // with the pitch predictor's input projection applied before the gather the length-regulated [B][H][T] tensor has ONE reader left, the pitch
+    // embedding add at the end: that kernel gathers from out1 itself (k_lr_gather_add: the same values, one launch and 2 x 17 MB less)
+    if (!g_cwt_in_phoneme) k_length_regulate(tw.out1, mel2ph, w.xlr, B, H, Lp, T, s);
+    bool hp_done = false;
+    if (g_cwt_in_phoneme) {   // cwt_predictor[0] was applied at the phoneme level (cmtts_text_forward): gather it; padding frames = its bias —
+        // inside the position-embedding add that follows (one launch, no [B][128][T] intermediate)
+        k_pos_embed_add_lr(tw.h128, Lp, mel2ph, m->cwt_in.bias, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, s);
+        hp_done = true;
     } else {   // cwt_predictor[0]: Linear(H -> cwt_hidden) over the frames       (model/modules.py:204-205)
         ConvArgs a = conv_args(m->cwt_in, w.xlr, T, T, (long)H * T, w.h128, T, (long)CH * T, T);
         CHK(launch(a, EPI_PLAIN, B, s));
     }
-    k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
+    if (!hp_done) k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
     CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s, (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0));
     if (ss) CHK(branch_join(ss));
     if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
@@ -1734,7 +1739,8 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
         k_pitch_index(cwt_out, O, f0_stats, f0_stats + 1, 2, c.cwt_std_scale, c.use_uv ? cwt_out + (O - 1) : nullptr, O, nullptr,
                       c.pitch_norm_eps, w.r, p_idx, f0_denorm, B, T, s);
     }
-    k_gather_add(w.xlr, p_idx, m->pitch_emb, cond_ct, B, H, T, s);
+    if (g_cwt_in_phoneme) k_lr_gather_add(tw.out1, mel2ph, Lp, p_idx, m->pitch_emb, cond_ct, B, H, T, s);
+    else k_gather_add(w.xlr, p_idx, m->pitch_emb, cond_ct, B, H, T, s);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -17,6 +17,9 @@ void k_add_rowvec(float* x, const float* vec, int B, int C, int L, int ld, hipSt
 void k_pos_embed_add(const float* x, float* out, const float* alpha, const float* omega, const float* tab,
                      int tab_rows, int B, int C, int T, int ld, hipStream_t s,
                      const int64_t* lens = nullptr);      // lens: columns t >= lens[b] are written as 0
+// pos_embed_add on the length-regulated input, gathered on the fly: x[c][t] = mel2ph[t] > 0 ? src[c][mel2ph[t] - 1] : padv[c]
+void k_pos_embed_add_lr(const float* src, int ldl, const int64_t* mel2ph, const float* padv, float* out, const float* alpha, const float* omega,
+                        const float* tab, int tab_rows, int B, int C, int T, hipStream_t s);
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens,
                    int B, int C, int T, int ld, int O, hipStream_t s);
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,
@@ -45,6 +48,9 @@ void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* st
                    float* f0_denorm, int B, int T, hipStream_t s);
 void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T,
                   hipStream_t s);
+// gather_add with the length regulator's gather inside: out = (mel2ph > 0 ? out1[..][mel2ph - 1] : 0) + E[idx]
+void k_lr_gather_add(const float* out1, const int64_t* mel2ph, int ldl, const int64_t* idx, const float* E, float* out, int B, int C, int T,
+                     hipStream_t s);
 void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s);
 void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
                 float nstd, float* out, int B, int T, int M, hipStream_t s);

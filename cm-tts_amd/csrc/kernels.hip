@@ -179,6 +179,33 @@ __global__ __launch_bounds__(256) void pos_embed_add_kernel(const float* x, floa
     }
 }
 
+// The same with the length regulator's gather in front (round 4): x[c][t] = mel2ph[t] > 0 ? src[c][mel2ph[t] - 1] : padv[c] is never written to a
+// buffer — src = the pitch predictor's input projection over the phonemes (row stride ldl), padv = its bias (a padding frame projects to the bias)
+__global__ __launch_bounds__(256) void pos_embed_add_lr_kernel(const float* src, int ldl, const int64_t* mel2ph, const float* padv, float* out,
+                                                               const float* alpha, const float* omega, const float* tab, int tab_rows,
+                                                               int C, int T) {
+    extern __shared__ int sh[];
+    int* counts = sh;
+    int* pos = sh + 256;
+    const int b = blockIdx.x;
+    const int64_t* mp = mel2ph + (long)b * T;
+    const float* s0 = src + (long)b * C * ldl;
+    const float pad0 = padv[0];
+    block_positions([&](int t) { const int64_t ph = mp[t]; return (ph > 0 ? s0[ph - 1] : pad0) != 0.f; }, T, pos, counts);
+    const float al = alpha[0];
+    const int c0 = blockIdx.y * POS_CG;
+    for (int cl = 0; cl < POS_CG && c0 + cl < C; ++cl) {
+        const int c = c0 + cl;
+        const float* sc = s0 + (long)c * ldl;
+        const float pc = padv[c];
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const int64_t ph = mp[t];
+            const float xv = ph > 0 ? sc[ph - 1] : pc;
+            out[((long)b * C + c) * T + t] = xv + al * pos_embed(pos[t], c, C, omega, tab, tab_rows);
+        }
+    }
+}
+
 // ---- Linear(C -> O<=16) over channel-major input, output time-major [B][T][O]
 // (duration/energy/cwt predictor heads, model/modules.py:505-506,554).  Workgroup = 64 positions x 4
 // channel slices (one wave each, 8 independent loads in flight), partial sums meet in LDS.
@@ -543,6 +570,16 @@ __global__ __launch_bounds__(256) void pitch_index_kernel(const float* cwt, int 
 }
 
 // ---- out[b][c][t] = x[b][c][t] + E[idx[b][t]][c] (pitch embedding add, model/modules.py:300,395)
+// cond[b][c][t] = LR(out1)[b][c][t] + E[idx[b][t]][c] with the length regulator's gather done here (round 4): frame t copies phoneme
+// mel2ph[t] - 1 of out1 (row stride ldl), a padding frame 0 — the value length_regulate_kernel would have written to a buffer
+__global__ void lr_gather_add_kernel(const float* out1, const int64_t* mel2ph, int ldl, const int64_t* idx, const float* E, float* out, int C, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int64_t ph = mel2ph[(long)b * T + t];
+    const float xv = ph > 0 ? out1[((long)b * C + c) * ldl + (ph - 1)] : 0.f;
+    out[((long)b * C + c) * T + t] = xv + E[idx[(long)b * T + t] * C + c];
+}
 __global__ void gather_add_kernel(const float* x, const int64_t* idx, const float* E, float* out, int C, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
@@ -747,6 +784,11 @@ void k_pos_embed_add(const float* x, float* out, const float* alpha, const float
     hipLaunchKernelGGL(pos_embed_add_kernel, dim3(B, cdiv(C, POS_CG)), dim3(256), (256 + T) * sizeof(int), s, x, out, alpha, omega, tab,
                        tab_rows, C, T, ld, lens);
 }
+void k_pos_embed_add_lr(const float* src, int ldl, const int64_t* mel2ph, const float* padv, float* out, const float* alpha, const float* omega,
+                        const float* tab, int tab_rows, int B, int C, int T, hipStream_t s) {
+    hipLaunchKernelGGL(pos_embed_add_lr_kernel, dim3(B, cdiv(C, POS_CG)), dim3(256), (256 + T) * sizeof(int), s, src, ldl, mel2ph, padv, out, alpha,
+                       omega, tab, tab_rows, C, T);
+}
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens, int B,
                    int C, int T, int ld, int O, hipStream_t s) {
     hipLaunchKernelGGL(chan_linear_kernel, dim3(cdiv(T, 64), B), dim3(256), (size_t)(O * C + 3 * 16 * 64) * sizeof(float), s,
@@ -817,6 +859,10 @@ void k_pitch_index(const float* cwt, int O, const float* mean_p, const float* st
 }
 void k_gather_add(const float* x, const int64_t* idx, const float* E, float* out, int B, int C, int T, hipStream_t s) {
     hipLaunchKernelGGL(gather_add_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, x, idx, E, out, C, T);
+}
+void k_lr_gather_add(const float* out1, const int64_t* mel2ph, int ldl, const int64_t* idx, const float* E, float* out, int B, int C, int T,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(lr_gather_add_kernel, dim3(cdiv(T, 256), C, B), dim3(256), 0, s, out1, mel2ph, ldl, idx, E, out, C, T);
 }
 void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s) {
     hipLaunchKernelGGL(mel_prep_kernel, dim3(cdiv(T, 256), M, B), dim3(256), 0, s, x, scale_b, scale, hin, T, M);
