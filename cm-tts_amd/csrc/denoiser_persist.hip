@@ -364,6 +364,22 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
             }
         }
+        // ---- halo columns of the next layer's u.  Every wave fetches the two halo entries of ITS OWN 32 rows (lanes 0-31: left halo
+        // frame t0 - 1, lanes 32-63: right halo frame t0 + FN): one cp value and one granule per lane, requested here — before the wave's
+        // own u rows — and checked after them.  (Until round 4 the last two waves fetched all 256 rows of one side each, four granules
+        // per lane, after their own rows: the phase stamps showed them 5-7 k cycles behind the other six waves at the layer barrier.)
+        const int hside = opaque(lane) >> 5, hm = mrow0 + (opaque(lane) & 31);
+        const int hth = hside ? t0 + FN : t0 - 1;
+        const bool hinside = hth >= 0 && hth < Tc;
+        // neighbour's slot: its right edge (side 1) feeds our left halo, its left edge (side 0) our right halo
+        const unsigned long long* hg = hbase + ((long)(hinside ? (hside ? tile + 1 : tile - 1) : tile) * 2 + (hside ? 0 : 1)) * C + hm;
+        float hcp;
+        {
+            const int thc = min(max(hth, 0), T - 1);
+            if (FACT) { int ph, ix; frame_idx(thc, ph, ix); hcp = cp_fact((l + 1) * C + hm, ph, ix); }
+            else hcp = (cp_b + (long)(l + 1) * C * T)[(unsigned)(hm * T + thc)];
+        }
+        unsigned long long hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- next layer's u rows of this wave: cp (L2-warm, accumulator layout) + (x' + dp)
         {
             const float* cpn = cp_b + (long)(l + 1) * C * T;
@@ -394,63 +410,24 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 }
             }
         }
-        if (w >= NW - 2) {
-            // the last two waves also fetch the left / right halo column: x' of the neighbour's edge + dp + cp
-            // (round 4: requesting the column's cp values and a first look at the granules BEFORE this wave's own u rows, to take the two round trips
-            //  off the other waves' barrier wait, left the phase at 13.7 k cycles and cost 12 more registers — the FACT instance spilled: 12.51 -> 12.81 ms)
-            const bool right = w == NW - 1;
-            const int th = right ? t0 + FN : t0 - 1;
-            const bool inside = th >= 0 && th < Tc;
-            const int thc = min(max(th, 0), T - 1);
-            const int ntile = right ? tile + 1 : tile - 1;
-            const float* cpn = cp_b + (long)(l + 1) * C * T;
-            const int ln = opaque(lane);
-            float cph[C / 64];
-            if (FACT) {
-                int ph, ix;
-                frame_idx(thc, ph, ix);
-#pragma unroll
-                for (int k = 0; k < C / 64; ++k) cph[k] = cp_fact((l + 1) * C + ln + 64 * k, ph, ix);
-            } else {
-#pragma unroll
-                for (int k = 0; k < C / 64; ++k) cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)];
-            }
-            float xv[C / 64];
-#pragma unroll
-            for (int k = 0; k < C / 64; ++k) xv[k] = 0.f;
-            if (inside && !gave_up) {   // wave-uniform
-                // neighbour's slot: its right edge (side 1) feeds our left halo, its left edge (side 0) our right halo
-                const unsigned long long* g = hbase + ((long)ntile * 2 + (right ? 0 : 1)) * C;
+        {   // the halo entries: wait for the neighbours' tags (lanes without a neighbour frame never wait)
+            if (!gave_up) {
                 unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < C / 64; ++k) {
-                        const unsigned long long v = __hip_atomic_load((gu64*)(g + ln + 64 * k), __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_AGENT);
-                        xv[k] = __uint_as_float((unsigned)v);
-                        ok &= (unsigned)(v >> 32) == tag;
-                    }
-                    if (__all(ok)) break;
+                while (!__all(!hinside || (unsigned)(hv >> 32) == tag)) {
                     if (++spins > SPIN_LIMIT) {      // wave-uniform: a neighbour never arrived
                         if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
                         gave_up = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(4);
+                    hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (gave_up) {   // poison the halo column: the utterance's mel comes out NaN (spreading one tile per layer)
-                             // instead of plausible-but-wrong, and cmtts_poll_error() reports the timeout
-#pragma unroll
-                for (int k = 0; k < C / 64; ++k) xv[k] = __builtin_nanf("");
-            }
-#pragma unroll
-            for (int k = 0; k < C / 64; ++k) {
-                const int m = ln + 64 * k;
-                const float uh = cph[k] + (xv[k] + dpn[m]);
-                u_lds[m * U_LD + (right ? FN + 1 : 0)] = inside ? uh : 0.f;
-            }
+            // after a timeout the halo column is poisoned: the utterance's mel comes out NaN (spreading one tile per layer) instead of
+            // plausible-but-wrong, and cmtts_poll_error() reports the timeout
+            const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
+            const float uh = hcp + (xh + dpn[hm]);
+            u_lds[hm * U_LD + (hside ? FN + 1 : 0)] = hinside ? uh : 0.f;
         }
         stamp(l, 7);
     }

@@ -338,6 +338,17 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
             }
         }
+        // ---- halo columns of the next layer's u^T.  Every wave fetches the two halo entries of ITS OWN 32 channels (lanes 0-31: left
+        // halo frame t0 - 1, lanes 32-63: right halo frame t0 + FN): one cp value and one granule per lane.  (Until round 4 the last two
+        // waves fetched all 256 channels of one side each, four granules per lane, after their own u^T rows: the phase stamps showed
+        // them 5 k cycles behind the other six waves at the layer barrier.)  The cp value and a first look at the granule are requested
+        // here, before the wave's own rows; the tag is checked after them.
+        const int hside = opaque(lane) >> 5, hm = mrow0 + (opaque(lane) & 31);
+        const int hth = hside ? t0 + FN : t0 - 1;
+        const bool hinside = hth >= 0 && hth < T;
+        const unsigned long long* hg = hbase + ((long)(hinside ? (hside ? tile + 1 : tile - 1) : tile) * 2 + (hside ? 0 : 1)) * C + hm;
+        const float hcp = (cp_b + (long)(l + 1) * C * T)[(unsigned)(hm * T + min(max(hth, 0), T - 1))];
+        unsigned long long hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         {   // next layer's u^T, this wave's 32 channels: cvt(cp + (x' + dp)), channel pairs packed
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int ln = opaque(lane), c31 = ln & 31;
@@ -360,49 +371,24 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 }
             }
         }
-        if (w >= NW - 2) {   // the last two waves also fetch the left / right halo frame
-            const bool right = w == NW - 1;
-            const int th = right ? t0 + FN : t0 - 1;
-            const bool inside = th >= 0 && th < T;
-            const int thc = min(max(th, 0), T - 1);
-            const int ntile = right ? tile + 1 : tile - 1;
-            const float* cpn = cp_b + (long)(l + 1) * C * T;
-            const int ln = opaque(lane);
-            float cph[C / 64], xv[C / 64];
-#pragma unroll
-            for (int k = 0; k < C / 64; ++k) { cph[k] = cpn[(unsigned)((ln + 64 * k) * T + thc)]; xv[k] = 0.f; }
-            if (inside && !gave_up) {
-                const unsigned long long* g = hbase + ((long)ntile * 2 + (right ? 0 : 1)) * C;
+        {   // the halo entries: wait for the neighbours' tags (lanes without a neighbour frame never wait)
+            if (!gave_up) {
                 unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < C / 64; ++k) {
-                        const unsigned long long v = __hip_atomic_load((gu64*)(g + ln + 64 * k), __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_AGENT);
-                        xv[k] = __uint_as_float((unsigned)v);
-                        ok &= (unsigned)(v >> 32) == tag;
-                    }
-                    if (__all(ok)) break;
+                while (!__all(!hinside || (unsigned)(hv >> 32) == tag)) {
                     if (++spins > SPIN_LIMIT) {
                         if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
                         gave_up = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_s_sleep(4);
+                    hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (gave_up) {   // poison the halo column: the utterance's mel comes out NaN (spreading one tile per layer)
-                             // instead of plausible-but-wrong, and cmtts_poll_error() reports the timeout
-#pragma unroll
-                for (int k = 0; k < C / 64; ++k) xv[k] = __builtin_nanf("");
-            }
-#pragma unroll
-            for (int k = 0; k < C / 64; ++k) {
-                const int m = ln + 64 * k;
-                const float uh = cph[k] + (xv[k] + dpn[m]);
-                put1<MODE>(ut, (right ? FN + 1 : 0) * RS + m, uh, inside, IMG);
-            }
+            // after a timeout the halo column is poisoned: the utterance's mel comes out NaN (spreading one tile per layer) instead of
+            // plausible-but-wrong, and cmtts_poll_error() reports the timeout
+            const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
+            const float uh = hcp + (xh + dpn[hm]);
+            put1<MODE>(ut, (hside ? FN + 1 : 0) * RS + hm, uh, hinside, IMG);
         }
         LPSTAMP(7);
     }
