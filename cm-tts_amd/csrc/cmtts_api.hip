@@ -150,6 +150,26 @@ std::vector<float> to_fragment_order(const std::vector<float>& p, int taps, int 
     return f;
 }
 
+// Winograd F(2,3) form of a k = 3 conv for the persistent denoiser's WINO instances (denoiser_persist.hip): k-major packed weights
+// [3][K][M] -> transformed weights G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 (formed in double, rounded once) as MFMA
+// A fragments [K/4 half-groups][M/32][2][64 lanes][4]: element q of fragment (hg, mt, ps) at lane l is transform 2 ps + (q >> 1) of
+// input channel 4 hg + 2 (q & 1) + (l >> 5), output row 32 mt + (l & 31).
+std::vector<float> to_wino_fragments(const std::vector<float>& p, int K, int M) {
+    std::vector<float> f((size_t)4 * K * M);
+    const int MTn = M / 32;
+    for (int hg = 0; hg < K / 4; ++hg)
+        for (int mt = 0; mt < MTn; ++mt)
+            for (int ps = 0; ps < 2; ++ps)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int tr = 2 * ps + (q >> 1), k = 4 * hg + 2 * (q & 1) + (lane >> 5), mrow = 32 * mt + (lane & 31);
+                        const double g0 = p[((size_t)0 * K + k) * M + mrow], g1 = p[((size_t)1 * K + k) * M + mrow], g2 = p[((size_t)2 * K + k) * M + mrow];
+                        const double v = tr == 0 ? g0 : tr == 1 ? 0.5 * (g0 + g1 + g2) : tr == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+                        f[((((size_t)hg * MTn + mt) * 2 + ps) * 64 + lane) * 4 + q] = (float)v;
+                    }
+    return f;
+}
+
 // The same fragments in the ITERATION order of the fused ResBlock pair kernels (resblock_pair.hip): the K loop walks
 // (16-channel chunk, tap, 8-channel half), so [K/16][taps][2][M/32][64 lanes][4] makes the weight stream one linear walk.
 std::vector<float> to_fragment_iter_order(const std::vector<float>& p, int taps, int K, int M) {
@@ -307,6 +327,7 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
+int g_persist_wino = 0;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
@@ -465,6 +486,7 @@ struct Predictor {
 struct ResLayer {
     PackedConv cond, conv3, outp;
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
+    float* w3w = nullptr;                   // Winograd F(2,3) transformed conv weights as A fragments (persistent denoiser, WINO instances)
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
     void *w3f16[3] = {nullptr, nullptr, nullptr}, *wof16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies
 };
@@ -767,6 +789,7 @@ int finalize_model(cmtts_model* m) {
             Allocs scratch;                                   // device copy of the k-major form is not needed
             CHK(pack_conv(scratch, *w3, b3, &perm16, &tmp, &hp));
             CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
+            if (C == 256) CHK(al.upload(to_wino_fragments(hp, C, 2 * C), &m->res[l].w3w));
             for (int mode = 1; mode <= 2; ++mode) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
                 CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].w3f16[mode - 1]));
@@ -1248,8 +1271,10 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.xold = post.xold; pa.noise = post.noise; pa.c_out = post.c_out; pa.c_skip = post.c_skip; pa.nstd = post.nstd;
             pa.out = post.out;
         }
+        pa.wino = g_persist_wino && !prec && m->res[0].w3w && w.skip && w.u;
+        pa.xst = w.u;                     // the unfused path's ping-pong buffer: free while the persistent stack runs
         for (int l = 0; l < NL; ++l) {
-            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : m->res[l].w3f;
+            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino ? m->res[l].w3w : m->res[l].w3f);
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
@@ -2024,8 +2049,11 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     pa.tail = 1;
     pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
     pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;
+    pa.wino = g_persist_wino && m->res[0].w3w;
+    for (int g = 0; g < n_groups && pa.wino; ++g)
+        if (keep[g] > 0 && (!ws[g].skip || !ws[g].u)) pa.wino = 0;
     for (int l = 0; l < NL; ++l) {
-        pa.W3f[l] = m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
+        pa.W3f[l] = pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
     if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.ld2 = c.pitch_bins; }
@@ -2058,7 +2086,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             const int tiles = (G.T + 63) / 64;
             PersistGroup& pg = pa.grp[g];
             pg.x0 = w.h; pg.cp = w.cp; pg.cp_bstride = (long)NL * C * G.T;
-            pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.halo = w.halo;
+            pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.xst = w.u; pg.halo = w.halo;
             pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
             pg.B = Bk; pg.T = G.T; pg.tiles = tiles;
             if (fact_all) { pg.p1 = G.cond_p1; pg.mel2ph = (const long long*)G.mel2ph; pg.pidx = (const long long*)G.p_idx; pg.ldp = G.p1_ld; pg.Lph = G.L; }
@@ -2515,6 +2543,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
+        {"persist_wino", &g_persist_wino, 0, 1},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
         {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
         {"ffn_fused", &g_ffn_fused, 0, 1},         // FFN linear's partial products inside the FFN conv's launch

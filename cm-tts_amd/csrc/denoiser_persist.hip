@@ -30,6 +30,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+#ifndef WINO_THREAD
+#define WINO_THREAD 1
+#endif
+#ifndef WINO_RING
+#define WINO_RING 3        // half-groups of transformed weights in flight per wave + the one in use (WINO instances)
+#endif
+
 namespace {
 
 constexpr int C = 256;
@@ -67,7 +77,16 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 // (cmtts_api.hip: sample_ragged).  The arithmetic of a computed frame is unchanged: every value is bit-identical to the uniform
 // launch of its own bucket as long as no trimmed frame lies within its receptive field.
 // FACT (round 4): the conditioner projections are gathered from their factors (persist_args.h) wherever cp would be read.
-template <bool DBG, bool RAGGED, bool FACT = false>
+// WINO (round 4): the gated k = 3 conv as a Winograd F(2,3) convolution along the frame axis — per PAIR of output frames four products
+// instead of six: m0 = (d0 - d2) g0, m1 = (d1 + d2) (g0 + g1 + g2)/2, m2 = (d2 - d1) (g0 - g1 + g2)/2, m3 = (d1 - d3) g2,
+// y(2p) = m0 + m1 + m2, y(2p+1) = m1 - m2 - m3 with d0..d3 = u(2p-1 .. 2p+2).  Each m_i is its own K = 256 contraction over the
+// channels (transformed weights W3f = [64 half-groups][16 m-tiles][2][64 lanes][4], packed by cmtts_api.hip: to_wino_fragments), so a
+// wave carries 2 m-tiles x 4 transforms = 8 accumulators over ONE 32-pair n-tile and the conv costs 2/3 of the direct form's MFMAs
+// (131 k instead of 197 k pipe cycles per layer).  u lives in LDS split by frame parity (odd frames at row offset (f + 1) / 2,
+// even frames at 33 + f / 2) so that the four d_i of a pair are unit-stride reads; the skip sum makes room in the register
+// file by living in `skip` memory between layers (read-modify-write by the lane that owns the element, L2-resident).
+// NOT bitwise equal to the direct form (fp32 Winograd: ~1e-6 relative per layer); everything else in the kernel is unchanged.
+template <bool DBG, bool RAGGED, bool FACT = false, bool WINO = false>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -118,6 +137,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         return (ph > 0 ? av : 0.f) + qv;
     };
 
+    // column of frame f (-1 .. FN) within a u row: f + 1, or (WINO) odd frames first, then even frames
+    auto uidx = [](int f) { return WINO ? ((f & 1) ? (f + 1) >> 1 : 33 + (f >> 1)) : f + 1; };
+    float *skip_b = nullptr, *xst_b = nullptr;      // WINO: the skip sum and the residual stream x between layers
+    if (WINO) {
+        skip_b = (RAGGED ? a.grp[gi].skip : a.skip) + (long)b * C * T;
+        xst_b = (RAGGED ? a.grp[gi].xst : a.xst) + (long)b * C * T;
+    }
+
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
     {
         const float* xin = x0_b;
@@ -140,7 +167,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             for (int q = 0; q < 8; ++q) {
                 const int m = w * ROWS_PER_WAVE + i + q;
                 const float uv = cv[q] + (xv[q] + dq[q]);
-                smem[m * U_LD + 1 + lane] = t < Tc ? uv : 0.f;
+                smem[m * U_LD + uidx(lane)] = t < Tc ? uv : 0.f;
             }
         }
         if (tid < 2 * C) {
@@ -152,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             if (FACT) { int ph, ix; frame_idx(thc, ph, ix); cph0 = cp_fact(m, ph, ix); }
             else cph0 = cp_b[(unsigned)(m * T + thc)];
             const float uh = cph0 + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
-            smem[m * U_LD + (right ? FN + 1 : 0)] = (th >= 0 && th < Tc) ? uh : 0.f;
+            smem[m * U_LD + uidx(right ? FN : -1)] = (th >= 0 && th < Tc) ? uh : 0.f;
         }
     }
     // resident state: st[0] = this wave's 32 rows of x, st[1] = its 32 rows of the skip sum; MFMA C layout: [j][r] = row
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 const int t_c = min(t0 + j * 32 + l31, T - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    st[i][j][r] = i == 0 ? ldg(xin, (unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)) : 0.f;
+                    st[i][j][r] = (i == 0 && !WINO) ? ldg(xin, (unsigned)((mrow0 + acc_row(r, lane)) * T + t_c)) : 0.f;
             }
     }
 
@@ -229,7 +256,21 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         };
         // the weight stream does not depend on u: its first RING-1 k-groups are requested before the barrier
         f32x4 A[RING][MT];
-        {
+        // WINO: a stage = one half-group (4 channels = 2 k-steps) of all four transforms for this wave's two m-tiles: 4 x 16 bytes per lane,
+        // element q of fragment (i, ps) = transform 2 ps + (q >> 1), k-step q & 1
+        constexpr int WR = WINO_RING, NH = C / 4;
+        f32x4 Aw[WINO ? WR : 1][MT][2];
+        auto load_aw = [&](f32x4 (&dst)[MT][2], const float* wfrag, int hg) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+                    dst[i][ps] = *reinterpret_cast<const f32x4*>(wfrag + ((((long)hg * (2 * C / 32) + w * MT + i) * 2 + ps) * 64 + lane) * 4);
+        };
+        if (WINO) {
+#pragma unroll
+            for (int s = 0; s < WR - 1; ++s) load_aw(Aw[s], a.W3f[l], s);
+        } else {
             int g8, tap;
 #pragma unroll
             for (int s = 0; s < RING - 1; ++s) {
@@ -251,7 +292,82 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         }
 
         // =========================================================== phase B: gated k=3 conv
-        {
+        f32x16 accw[WINO ? MT : 1][WINO ? 4 : 1];      // WINO: m-tile x transform, one n-tile of 32 frame PAIRS
+        if constexpr (WINO) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accw[i][tr][r] = 0.f;
+            const float* W3f = a.W3f[l];
+            // inputs of pair p = l31 for the two k-steps of a half-group (channel 4 hg + 2 kk + khalf): the raw reads of the NEXT half-group
+            // are in flight during this one's MFMAs and are transformed right in front of their own (transforming them a step ahead
+            // into a second buffer costs 8 registers this loop does not have: half of the x rows went to scratch)
+            float Vb[2][4], Dn[2][4];
+            auto load_d = [&](int hg) {
+                const float* bs = u_lds + (4 * hg + khalf) * U_LD + l31;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const float* rr = bs + 2 * kk * U_LD;
+                    Dn[kk][0] = rr[0]; Dn[kk][2] = rr[1]; Dn[kk][1] = rr[33]; Dn[kk][3] = rr[34];     // u(2p-1), u(2p+1) | u(2p), u(2p+2)
+                }
+            };
+            auto transform = [&]() {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    Vb[kk][0] = Dn[kk][0] - Dn[kk][2];
+                    Vb[kk][1] = Dn[kk][1] + Dn[kk][2];
+                    Vb[kk][2] = Dn[kk][2] - Dn[kk][1];
+                    Vb[kk][3] = Dn[kk][1] - Dn[kk][3];
+                }
+            };
+            load_d(0);
+#if WINO_ABL & 2
+            transform();
+#endif
+#pragma unroll 1
+            for (int h0 = 0; h0 < NH; h0 += WR) {
+#pragma unroll
+                for (int s = 0; s < WR; ++s) {
+                    const int hg = h0 + s;
+                    // -DWINO_ABL=n (timing-only builds, wrong results): 1 = no weight loads in the loop, 2 = no LDS reads / input transform
+#if !(WINO_ABL & 2)
+                    transform();
+#endif
+#if !(WINO_ABL & 1)
+                    load_aw(Aw[(s + WR - 1) % WR], W3f, min(hg + WR - 1, NH - 1));
+#endif
+#if !(WINO_ABL & 2)
+                    load_d(min(hg + 1, NH - 1));
+#endif
+                    if (hg < NH) {
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+                                for (int i = 0; i < MT; ++i)
+                                    accw[i][tr] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aw[s][i][tr >> 1][(tr & 1) * 2 + kk], Vb[kk][tr], accw[i][tr], 0, 0, 0);
+                    }
+#if WINO_THREAD
+                    // the step's 4 weight loads and 4 LDS reads go BETWEEN its MFMAs (a wave has ~60 idle issue cycles behind each one): in one
+                    // block in front of them, both waves of a SIMD reach their ~45 non-MFMA instructions together and the pipe idles
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
             zero_acc();
             constexpr int NG = NGB;
             const float* W3f = a.W3f[l];
@@ -274,8 +390,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             }
         }
         stamp(l, 2);
+        if (!WINO) {
 #pragma unroll
-        for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));   // output projection: same, before the gate
+            for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));   // output projection: same, before the gate
+        }
         {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
             // other waves' MFMAs); nobody reads z before barrier (3)
             const float* b3 = a.b3[l];
@@ -289,6 +407,22 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     bg[i][r] = ldg(b3, (unsigned)mg);
                     bf[i][r] = ldg(b3, (unsigned)(mg + 16));
                 }
+            if constexpr (WINO) {
+                // output transform: y(2p) = (m0 + m1) + m2, y(2p+1) = (m1 - m2) - m3; lane p writes the frame pair as one 8-byte store
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float ge = (accw[i][0][r] + accw[i][1][r]) + accw[i][2][r];
+                        const float go = (accw[i][1][r] - accw[i][2][r]) - accw[i][3][r];
+                        const float fe = (accw[i][0][r + 8] + accw[i][1][r + 8]) + accw[i][2][r + 8];
+                        const float fo = (accw[i][1][r + 8] - accw[i][2][r + 8]) - accw[i][3][r + 8];
+                        float2 zz;
+                        zz.x = cmtts_gate(ge + bg[i][r], fe + bf[i][r]);
+                        zz.y = cmtts_gate(go + bg[i][r], fo + bf[i][r]);
+                        *reinterpret_cast<float2*>(z_lds + ((w * MT + i) * 16 + acc_row(r, ln)) * U_LD + 2 * (ln & 31)) = zz;
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -298,6 +432,26 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                         const float zv = cmtts_gate(acc[i][j][r] + bg[i][r], acc[i][j][r + 8] + bf[i][r]);
                         z_lds[((w * MT + i) * 16 + acc_row(r, ln)) * U_LD + j * 32 + (ln & 31)] = zv;
                     }
+            }
+        }
+        f32x16 sk[WINO ? NT : 1];
+        if constexpr (WINO) {      // eight accumulators + the gate's operands leave no room for the projection's ring before this point
+#pragma unroll
+            for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
+            // the residual stream and the skip sum of this wave's elements (see the epilogue) are requested BEHIND the ring's first groups:
+            // loads return in order, so the projection loop never waits for them and they have landed long before its end
+            const float* xsrc = l == 0 ? x0_b : xst_b;
+            const int ln = opaque(lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t_c = min(t0 + j * 32 + (ln & 31), T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[0][j][r] = ldg(xsrc, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                if (l > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sk[j][r] = ldg(skip_b, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                }
+            }
         }
         stamp(l, 3);
         __syncthreads();   // (3) z complete, u of this layer dead
@@ -335,6 +489,22 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
                 ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
             }
+            // WINO: eight accumulators leave the conv loop no room for 64 registers of state, so the residual stream x and the skip sum
+            // wait in memory (`xst`, `skip`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
+            // the element (its own earlier stores: program order), requested ahead of the projection loop.  x' stays
+            // in registers for the publish phase below; the last layer's skip sum stays in acc[1] for the tail.
+            if constexpr (WINO) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float o = acc[0][j][r] + bor[0][r];
+                        st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
+                        const float os = acc[1][j][r] + bor[1][r];
+                        acc[1][j][r] = l > 0 ? os + sk[j][r] : os;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -344,6 +514,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     const float os = acc[1][j][r] + bor[1][r];
                     st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }
+            }
         }
         if (!more) break;
         stamp(l, 6);
@@ -406,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int r = 0; r < 16; ++r) {
                     const int m = mrow0 + acc_row(r, ln);
                     const float uv = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
-                    u_lds[m * U_LD + 1 + j * 32 + c31] = t < Tc ? uv : 0.f;
+                    u_lds[m * U_LD + uidx(j * 32 + c31)] = t < Tc ? uv : 0.f;
                 }
             }
         }
@@ -427,13 +598,29 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             // plausible-but-wrong, and cmtts_poll_error() reports the timeout
             const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
             const float uh = hcp + (xh + dpn[hm]);
-            u_lds[hm * U_LD + (hside ? FN + 1 : 0)] = hinside ? uh : 0.f;
+            u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
+        }
+        if constexpr (WINO) {      // x' and the skip sum go back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
+                                   // the acknowledgement of these 64 stores (one counter for loads and stores)
+            const int ln = opaque(lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + (ln & 31);
+                if (t < Tc) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const size_t off = (size_t)((unsigned)((mrow0 + acc_row(r, ln)) * T + t) * 4u);
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(xst_b) + off) = st[0][j][r];
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(skip_b) + off) = acc[1][j][r];
+                    }
+                }
+            }
         }
         stamp(l, 7);
     }
 
     if (a.tail) {   // skip head + post-scaling in-kernel (persist_tail.h); the u buffer is free since barrier (3), z after barrier (A) inside
-        persist_tail::run(a, smem, smem + C * U_LD, st[1], w, lane, b, t0, T, RAGGED ? a.grp[gi].xold : a.xold,
+        persist_tail::run(a, smem, smem + C * U_LD, WINO ? acc[1] : st[1], w, lane, b, t0, T, RAGGED ? a.grp[gi].xold : a.xold,
                           RAGGED ? a.grp[gi].noise : a.noise, RAGGED ? a.grp[gi].out : a.out, Tc);
     } else {   // ---- the skip sum leaves the chip once
         float* skip = (RAGGED ? a.grp[gi].skip : a.skip) + (long)b * C * T;
@@ -442,7 +629,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const int t = t0 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t < Tc) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
+                if (t < Tc) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = WINO ? acc[1][j][r] : st[1][j][r];
         }
     }
 }
@@ -518,18 +705,20 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
+    if (a.wino && (!a.skip || !a.xst)) return -2;          // the Winograd instances keep the skip sum / the residual stream in `skip` / `xst` between layers
+    // instance table: [dbg][fact][wino]
+    static const void* const kfns[2][2][2] = {
+        {{reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, true>)},
+         {reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true, true>)}},
+        {{reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, true>)},
+         {reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, true>)}}};
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
+        for (int d = 0; d < 2; ++d)
+            for (int f = 0; f < 2; ++f)
+                for (int wn = 0; wn < 2; ++wn)
+                    if (hipFuncSetAttribute(kfns[d][f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
         attr_set = true;
     }
     if (a.fact && (!a.p1 || !a.p2 || !a.mel2ph || !a.pidx || a.ldp < 1 || a.ld2 < 1)) return -2;
@@ -549,6 +738,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.dp = a.dp + (long)b0 * a.vec_stride;
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
+        if (a.xst) c.xst = a.xst + (long)b0 * C * a.T;
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
         if (a.fact) {
             c.p1 = a.p1 + (long)b0 * a.NL * C * a.ldp;
@@ -561,17 +751,13 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        const void* kfn = a.fact ? reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true>)
-                                 : reinterpret_cast<const void*>(denoiser_persist_kernel<false, false>);
-        if (a.dbg) {
-            if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<true, false, true>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-            else hipLaunchKernelGGL((denoiser_persist_kernel<true, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-        } else if (cmtts_persist_cooperative(a.fact ? 5 : 0, tiles, nb)) {
-            void* params[] = {(void*)&c};
+        const void* kfn = kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][a.wino ? 1 : 0];
+        void* params[] = {(void*)&c};
+        const int variant = (a.fact ? 5 : 0) + (a.wino ? 2 : 0);        // 0 plain, 2 wino, 5 fact, 7 fact + wino (4 / 6: the ragged instances)
+        if (!a.dbg && cmtts_persist_cooperative(variant, tiles, nb)) {
             if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
-            cmtts_persist_validated(a.fact ? 5 : 0, tiles, nb);
-        } else if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<false, false, true>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
-        else hipLaunchKernelGGL((denoiser_persist_kernel<false, false>), dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
+            cmtts_persist_validated(variant, tiles, nb);
+        } else if (hipLaunchKernel(kfn, dim3(tiles, nb), dim3(64 * NW), params, lds, stream) != hipSuccess) return -3;
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;
@@ -585,14 +771,16 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         return -2;
     for (int g = 0; g < a.n_groups; ++g)
         if ((long)C * a.grp[g].T >= (1L << 30) || a.grp[g].tiles > 127 || a.grp[g].B > 1023) return -2;
+    // instance table: [fact][wino]
+    static const void* const kfns[2][2] = {
+        {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, true>)},
+        {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, true>)}};
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -3;
+        for (int f = 0; f < 2; ++f)
+            for (int wn = 0; wn < 2; ++wn)
+                if (hipFuncSetAttribute(kfns[f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
         attr_set = true;
     }
     if (a.fact) {      // every group brings its factors, or none does
@@ -600,14 +788,16 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && (!a.grp[g].p1 || !a.grp[g].mel2ph || !a.grp[g].pidx || a.grp[g].ldp < 1)) return -2;
     }
-    const void* kfn = a.fact ? reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true>)
-                             : reinterpret_cast<const void*>(denoiser_persist_kernel<false, true>);
+    if (a.wino)        // the Winograd instances keep the skip sum / the residual stream of every group in its `skip` / `xst` buffers
+        for (int g = 0; g < a.n_groups; ++g)
+            if (a.grp[g].B > 0 && (!a.grp[g].skip || !a.grp[g].xst)) return -2;
+    const void* kfn = kfns[a.fact ? 1 : 0][a.wino ? 1 : 0];
+    // co-residency depends on the workgroup count and on (registers, LDS), which the four instances share: one record for all
     const int variant = a.fact ? 6 : 4;
+    void* params[] = {(void*)a_in};
     if (cmtts_persist_cooperative(variant, a.n_wg, -1)) {
-        void* params[] = {(void*)a_in};
         if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
         cmtts_persist_validated(variant, a.n_wg, -1);
-    } else if (a.fact) hipLaunchKernelGGL((denoiser_persist_kernel<false, true, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
-    else hipLaunchKernelGGL((denoiser_persist_kernel<false, true>), dim3(a.n_wg), dim3(64 * NW), lds, stream, a);
+    } else if (hipLaunchKernel(kfn, dim3(a.n_wg), dim3(64 * NW), params, lds, stream) != hipSuccess) return -3;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

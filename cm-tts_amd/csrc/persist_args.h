@@ -24,6 +24,7 @@ struct PersistGroup {
     const long long* mel2ph;    // [B][T] int64
     const long long* pidx;      // [B][T] int64
     int ldp, Lph;
+    float* xst;           // WINO instances: [B][256][T] residual stream between layers (kernel-private scratch)
 };
 
 struct PersistArgs {
@@ -64,6 +65,9 @@ struct PersistArgs {
     const long long* mel2ph;    // [B][T] int64: 1-based phoneme of a frame, 0 = padding
     const long long* pidx;      // [B][T] int64: pitch bucket of a frame
     int ldp, Lph, ld2;
+    int wino;             // fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
+                          // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
+    float* xst;           // WINO: [B][256][T] kernel-private storage of the residual stream x between layers (batch stride 256 T, like skip)
     int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
     // ---- ragged launches (round 3; fp32 kernel): a 1-D grid of n_wg workgroups, workgroup i works on tile (desc >> 13 & 127) of

@@ -13,6 +13,7 @@ model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cf
 B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 512)
 x = torch.randn(B, 1, T, 80, device="cuda"); cond = torch.randn(B, T, 256, device="cuda"); t = torch.full((B,), 1095.5, device="cuda")
 lib = _lib.load()
+_lib.internal_set(b"persist_wino", int(os.environ.get("WINO", 0)))      # 1: the Winograd F(2,3) instances
 for _ in range(2):
     model.net(x, t, cond, None)
 nblk = ((T + 63) // 64) * B
