@@ -327,7 +327,7 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
-int g_persist_wino = 0;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
+int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
@@ -499,6 +499,7 @@ struct cmtts_model {
     bool finalized = false;
     int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
     int text16 = 0;        // 16-bit models (precision 1 / 2): the FFN contractions of the FFT blocks with 16-bit operands too (opt-in: the text side feeds the integer stages — durations, pitch buckets, lengths — which then depend on the precision mode; cmtts_model_set_option)
+    int winograd = 1;                       // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (cmtts_model_set_option "winograd"; ~4e-6 on the mel against the direct form)
     int ffn2_split = 1;    // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (another fp32 summation order than one launch: a property of the model handle, cmtts_model_set_option)
     cmtts_variance_controls vc = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Allocs al;
@@ -1271,7 +1272,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.xold = post.xold; pa.noise = post.noise; pa.c_out = post.c_out; pa.c_skip = post.c_skip; pa.nstd = post.nstd;
             pa.out = post.out;
         }
-        pa.wino = g_persist_wino && !prec && m->res[0].w3w && w.skip && w.u;
+        pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.skip && w.u;
         pa.xst = w.u;                     // the unfused path's ping-pong buffer: free while the persistent stack runs
         for (int l = 0; l < NL; ++l) {
             pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino ? m->res[l].w3w : m->res[l].w3f);
@@ -2049,7 +2050,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     pa.tail = 1;
     pa.Wsf = m->skip_f; pa.bs = m->skip_proj.bias; pa.Wpf = m->outp_f; pa.bp = m->out_proj.bias;
     pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;
-    pa.wino = g_persist_wino && m->res[0].w3w;
+    pa.wino = g_persist_wino && m->winograd && m->res[0].w3w;
     for (int g = 0; g < n_groups && pa.wino; ++g)
         if (keep[g] > 0 && (!ws[g].skip || !ws[g].u)) pa.wino = 0;
     for (int l = 0; l < NL; ++l) {
@@ -2512,6 +2513,7 @@ int cmtts_model_set_option(cmtts_model* m, const char* name, int value) {
     const Knob tab[] = {
         {"ffn2_split", &m->ffn2_split, 0, 1},            // FFN linear of the FFT blocks as 8 K-segment partial GEMMs + one reduction (1) or one launch (0)
         {"text16", &m->text16, 0, 1},                    // bf16 / fp16 models: 16-bit operands in the FFT blocks' FFN contractions as well (default 0)
+        {"winograd", &m->winograd, 0, 1},                // fp32 persistent denoiser stack: the gated k = 3 conv as Winograd F(2,3) (default 1; 0 = the direct form, bitwise the per-layer kernels)
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);

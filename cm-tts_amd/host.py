@@ -179,7 +179,9 @@ class CMTotalTTS(torch.nn.Module):
         """Per-model numerics option (cmtts_model_set_option): "ffn2_split" 1 (default) | 0 — the FFN linear of the FFT blocks as
         eight K-segment partial GEMMs + one reduction, or as one launch (another fp32 summation order); "text16" 0 (default) | 1 — bf16 / fp16
         models: the in- / out-projections and FFN contractions of the FFT blocks and the variance predictors' convs with 16-bit operands as well (the integer stages — durations, pitch buckets, lengths —
-        then depend on the precision mode).  Returns the previous value."""
+        then depend on the precision mode); "winograd" 1 (default) | 0 — fp32 models, large batches: the gated k = 3 conv of the persistent
+        denoiser stack as a Winograd F(2,3) convolution (2/3 of the conv's MFMAs; fp32 rounding differences ~4e-6 on a mel) or in the direct
+        form (bit for bit the per-layer kernels of small batches).  Returns the previous value."""
         prev = self.lib.cmtts_model_set_option(self._h, name.encode() if isinstance(name, str) else name, int(value))
         if prev < 0:
             _lib.check(prev)

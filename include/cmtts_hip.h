@@ -271,6 +271,12 @@ int cmtts_set_option(const char* name, int value);
  *       decoder: in- / out-projection, FFN conv, FFN linear) and the conv layers of the variance predictors with 16-bit MFMA operands too (LayerNorm, attention scores / softmax / P V, bias,
  *       scale, GELU, residual, mask and accumulation stay fp32).  Off by default because
  *       the text side feeds the integer stages: with it, durations / pitch buckets / lengths may differ from the fp32 model's by one unit.
+ *   cmtts_model_set_option(m, "winograd", 1 (default) | 0): fp32 models, large batches (the persistent denoiser stack, csrc/denoiser_persist.hip):
+ *       the gated k = 3 convolution of every residual layer (model/blocks.py:672-679) as a Winograd F(2,3) convolution along the frame axis —
+ *       4 products per pair of output frames instead of 6, transformed weights formed in double and rounded once, every product and sum
+ *       in fp32 — or (0) as the direct 3-tap contraction, which is bit for bit what the per-layer kernels of small batches compute.  The
+ *       two forms differ by fp32 rounding only: <= 1e-5 on one network evaluation, ~4e-6 on a T = 4 mel, both equally far from a float64
+ *       evaluation (tests/test_gpu_precision.py); with 1 an utterance's low-order bits depend on whether its batch takes the persistent stack.
  *   cmtts_vocoder_set_option(v, "ups16", 1 (default) | 0): in the 16-bit precision modes the ConvTranspose1d upsamplers take
  *       16-bit operands as well, or stay fp32.
  * Same return convention as cmtts_set_option. */

@@ -133,6 +133,26 @@ def test_precision_ladder_denoiser(golden_models, variant):
     n_conv = 2 * cfg.res_layers * n_steps
     for dt in ("bf16", "fp16"):
         check_ladder(f"denoiser T=4 {variant}", ref64, hip["fp32"], hip[dt], orc[dt], n_conv, dt, golden32=g["mel_T4"], deep=True)
+    # the persistent stack's Winograd F(2,3) conv (the default form of the fp32 stack since round 4) against its direct form, both forced
+    # onto these small shapes: as close to float64 as the direct kernels (within 2x), i.e. the fast algorithm costs no accuracy that
+    # fp32 had
+    lib = _lib.load()
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    try:
+        wino = _np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise))
+        prev_w = _lib.internal_set("persist_wino", 0)
+        try:
+            direct = _np(host.sample_with_cond(model, cond_ct, spk, n_steps, noise))
+        finally:
+            _lib.internal_set("persist_wino", prev_w)
+    finally:
+        lib.cmtts_set_persistent_denoiser(prev)
+    assert np.array_equal(direct, hip["fp32"])                # the direct persistent stack == the per-layer kernels these shapes take
+    ew = float(np.abs(wino - ref64).max())
+    report(f"DTYPE_ERR denoiser T=4 {variant} winograd: vs f64 max|d| {ew:.2e} (direct fp32 kernels {e32:.2e}); vs the direct form {np.abs(wino - direct).max():.2e}; "
+           f"vs the reference's fp32 golden {np.abs(wino - g['mel_T4']).max():.2e}")
+    assert ew < 1e-3 and ew < max(2 * e32, 1e-5), (ew, e32)
+    assert not np.array_equal(wino, direct)
     # fp16x3 (two fp16 numbers per operand, three MFMAs per product): fp32-class — within 2x of the exact-fp32 kernels' own
     # distance from float64, far inside the north-star 1e-3; forced onto the persistent stack (its only implementation)
     lib = _lib.load()
