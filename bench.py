@@ -441,20 +441,27 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     audio_s = frames_rank * world * cfg.hop_length / cfg.sampling_rate
     C_ = cfg.res_channels
+    wino = False
     if args.unfused:   # the timed kernel is the gated k=3 conv alone
         kname = "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_) * BATCH * FRAMES_PAD
     elif persistent:   # all residual layers of one sampler step in one launch
-        kname = (f"denoiser_persist_kernel ({cfg.res_layers} residual layers: gated k=3 conv + output projection each, x / skip "
-                 "resident; skip head in the tail)")
+        # ALGORITHMIC work: the reference's convolution (3 taps x C inputs per output of the gated conv, model/blocks.py:672) — what `achieved`
+        # and `frac` are priced on, whatever algorithm the kernel runs.  Since round 4 the fp32 stack's conv is a Winograd F(2,3) convolution
+        # (4 products per pair of frames instead of 6): the MFMA work actually issued is reported next to it as `executed_*`.
+        wino = _lib.internal_set(b"persist_wino", -1) == 1 and model.set_option("winograd", -1) == 1
+        kname = (f"denoiser_persist_kernel<{'WINO' if wino else 'direct'}> ({cfg.res_layers} residual layers: gated k=3 conv"
+                 f"{' as Winograd F(2,3)' if wino else ''} + output projection each, x / skip "
+                 f"{'L2-resident between layers' if wino else 'resident in registers'}; skip head in the tail)")
         flops_launch = (2.0 * (2 * C_) * (3 * C_ + C_) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
+        flops_exec = ((2.0 * (2 * C_) * ((2 * C_ if wino else 3 * C_) + C_)) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
     else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
         kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD
     traffic, pmc_cal, pmc_commit = None, (1.0, 1.0), "?"
     try:   # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 pass of this workload
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        pmc = pj["denoiser_persist_kernel" if persistent else "resblock_fused_kernel"]
+        pmc = pj[("denoiser_persist_kernel_wino" if wino else "denoiser_persist_kernel") if persistent else "resblock_fused_kernel"]
         if not args.unfused and pmc["B"] == BATCH and pmc["T"] == FRAMES_PAD:
             traffic = pmc["bytes_per_launch"]
             pmc_cal = (pj["calibration"]["dword_4B_per_lane"]["fetch_factor"], pj["calibration"]["dword_4B_per_lane"]["write_factor"])
@@ -483,14 +490,25 @@ def main():
                      "traffic_note": "fabric-side bytes/launch = rocprofv3 FETCH_SIZE x %.1f + WRITE_SIZE x %.1f (separate --pmc passes of this "
                                      "workload at commit %s; the factors come from known-byte-count streams measured in the same session: "
                                      "FETCH_SIZE reads 1/2 on gfx950, profiles/pmc_traffic.json); Infinity-Cache hits are counted. Algorithmic "
-                                     "%.1f MB; the excess = each layer's 2.1 MB weight set once per XCD L2 (8 x 42 MB), the cp tiles touched "
-                                     "twice (L2-warming dword per line, then the read) and the polled 8-byte granules -> %.3f of the 8 TB/s HBM peak" % (
+                                     "%.1f MB; the excess = each layer's weight set once per XCD L2 (8 x 42-52 MB), the polled 8-byte granules and, for the "
+                                     "Winograd instances, the kernel-private state (x + skip sum, 2 x 16.8 MB) that every layer writes and the next re-reads "
+                                     "through the Infinity Cache because it does not fit the L2s next to the weights (19 x 67 MB; requested a projection "
+                                     "loop ahead of its use, so its latency is not on the critical path) -> %.3f of the 8 TB/s HBM peak" % (
                                          pmc_cal[0], pmc_cal[1], pmc_commit,
                                          (BATCH * FRAMES_PAD * (1024 * (cfg.res_layers + 1) + 8 * cfg.n_mels) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
                                          (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                      "flops_per_launch": flops_launch},
     }
+    if persistent and not args.unfused:
+        ex = flops_exec / (avg_ms * 1e-3) / 1e12 if n_l.value else 0.0
+        result["roofline"].update({
+            "algorithm": ("Winograd F(2,3) along the frame axis for the gated k=3 conv (fp32 transforms, weights transformed in double and rounded once; "
+                          "|d mel| ~4e-6 against the direct form, tests/test_gpu_precision.py), direct 1x1 output projection" if wino else "direct"),
+            "executed_flops_per_launch": flops_exec, "executed_tflops": round(ex, 2),
+            "executed_frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4),
+            "frac_note": "`achieved` / `frac` = the reference's (direct-form) FLOPs over the launch time, as SURVEY.md 8(d) counts them; `executed_*` = the "
+                         "MFMA FLOPs the kernel issues (2/3 of the conv's with Winograd): the matrix pipe's own duty"})
 
     if (world > 1 or gather or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:      # gather: CMTTS_FORCE_COLLECTIVE=1 on one GPU
         # every rank takes part: T = 1 / 2, configs[3] and configs[4] with their collectives (whole-job aggregates)

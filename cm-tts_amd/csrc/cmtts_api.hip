@@ -154,8 +154,9 @@ std::vector<float> to_fragment_order(const std::vector<float>& p, int taps, int 
 // [3][K][M] -> transformed weights G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 (formed in double, rounded once) as MFMA
 // A fragments [K/4 half-groups][M/32][2][64 lanes][4]: element q of fragment (hg, mt, ps) at lane l is transform 2 ps + (q >> 1) of
 // input channel 4 hg + 2 (q & 1) + (l >> 5), output row 32 mt + (l & 31).
+constexpr int WINO_PAD_HG = 4;        // half-groups of zero padding behind a layer's array: the kernel's weight ring runs a few stages past the end
 std::vector<float> to_wino_fragments(const std::vector<float>& p, int K, int M) {
-    std::vector<float> f((size_t)4 * K * M);
+    std::vector<float> f((size_t)4 * K * M + (size_t)WINO_PAD_HG * (M / 32) * 2 * 64 * 4, 0.0f);
     const int MTn = M / 32;
     for (int hg = 0; hg < K / 4; ++hg)
         for (int mt = 0; mt < MTn; ++mt)
@@ -964,6 +965,7 @@ FrameWs carve_frame(const cmtts_config& c, int B, int T, void* base) {
 
 struct DenWs {
     float *hin, *h, *u, *zb, *skip, *emb, *e1, *e2, *dproj, *sproj, *dp, *tbuf, *xcur, *cp;
+    float* pst;                 // kernel-private state of the persistent denoiser's Winograd instances
     unsigned long long* halo;   // edge-column granules of the persistent denoiser kernel
     size_t bytes;
 };
@@ -987,6 +989,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
     w.xcur = cv.take<float>((size_t)B * T * c.n_mels);
     w.cp = cv.take<float>((size_t)NL * n);       // conditioner projections of all layers [B][NL*C][T]
     w.halo = cv.take<unsigned long long>(cmtts_persist_halo_bytes(B, T) / sizeof(unsigned long long));
+    w.pst = cv.take<float>(cmtts_persist_state_floats(B, T));
     w.bytes = cv.off + 256;
     return w;
 }
@@ -1272,8 +1275,8 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.xold = post.xold; pa.noise = post.noise; pa.c_out = post.c_out; pa.c_skip = post.c_skip; pa.nstd = post.nstd;
             pa.out = post.out;
         }
-        pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.skip && w.u;
-        pa.xst = w.u;                     // the unfused path's ping-pong buffer: free while the persistent stack runs
+        pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.pst;
+        pa.xst = w.pst;
         for (int l = 0; l < NL; ++l) {
             pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino ? m->res[l].w3w : m->res[l].w3f);
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
@@ -2052,7 +2055,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     pa.skip_div = (float)sqrt((double)NL); pa.n_mels = M;
     pa.wino = g_persist_wino && m->winograd && m->res[0].w3w;
     for (int g = 0; g < n_groups && pa.wino; ++g)
-        if (keep[g] > 0 && (!ws[g].skip || !ws[g].u)) pa.wino = 0;
+        if (keep[g] > 0 && !ws[g].pst) pa.wino = 0;
     for (int l = 0; l < NL; ++l) {
         pa.W3f[l] = pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
@@ -2087,7 +2090,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             const int tiles = (G.T + 63) / 64;
             PersistGroup& pg = pa.grp[g];
             pg.x0 = w.h; pg.cp = w.cp; pg.cp_bstride = (long)NL * C * G.T;
-            pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.xst = w.u; pg.halo = w.halo;
+            pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.xst = w.pst; pg.halo = w.halo;
             pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
             pg.B = Bk; pg.T = G.T; pg.tiles = tiles;
             if (fact_all) { pg.p1 = G.cond_p1; pg.mel2ph = (const long long*)G.mel2ph; pg.pidx = (const long long*)G.p_idx; pg.ldp = G.p1_ld; pg.Lph = G.L; }

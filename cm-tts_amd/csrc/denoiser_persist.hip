@@ -33,6 +33,9 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifndef WINO_ABL
 #define WINO_ABL 0
 #endif
+#ifndef WINO_L2PF
+#define WINO_L2PF 0        // 1: touch the next layer's transformed weights into L2 during the projection (measured: no effect on the conv loop)
+#endif
 #ifndef WINO_THREAD
 #define WINO_THREAD 1
 #endif
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 
     // column of frame f (-1 .. FN) within a u row: f + 1, or (WINO) odd frames first, then even frames
     auto uidx = [](int f) { return WINO ? ((f & 1) ? (f + 1) >> 1 : 33 + (f >> 1)) : f + 1; };
-    float *skip_b = nullptr, *xst_b = nullptr;      // WINO: the skip sum and the residual stream x between layers
-    if (WINO) {
-        skip_b = (RAGGED ? a.grp[gi].skip : a.skip) + (long)b * C * T;
-        xst_b = (RAGGED ? a.grp[gi].xst : a.xst) + (long)b * C * T;
-    }
+    // WINO: the residual stream x and the skip sum of this tile between layers, in a kernel-private layout [x | skip][wave][j * 4 + q][lane][4]
+    // (element e of that float4 = accumulator register 4 q + e of n-tile j): every load / store of the state is one fully coalesced
+    // 16-byte-per-lane instruction
+    constexpr int PST_PART = NW * 8 * 64 * 4;       // floats of one part of one tile (64 KB)
+    float* pst_b = nullptr;
+    if (WINO) pst_b = (RAGGED ? a.grp[gi].xst : a.xst) + ((long)b * (RAGGED ? a.grp[gi].tiles : a.tiles) + tile) * (2 * PST_PART);
 
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
     {
@@ -260,12 +264,15 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // element q of fragment (i, ps) = transform 2 ps + (q >> 1), k-step q & 1
         constexpr int WR = WINO_RING, NH = C / 4;
         f32x4 Aw[WINO ? WR : 1][MT][2];
+        // (uniform base + 32-bit lane offset: the saddr form, no per-step VALU address arithmetic; the ring reads up to WR - 1 half-groups past
+        //  the layer's last one — the packer pads every layer's array by that much, cmtts_api.hip: to_wino_fragments)
         auto load_aw = [&](f32x4 (&dst)[MT][2], const float* wfrag, int hg) {
+            const char* base = reinterpret_cast<const char*>(wfrag) + (size_t)hg * ((2 * C / 32) * 2 * 64 * 16);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps)
-                    dst[i][ps] = *reinterpret_cast<const f32x4*>(wfrag + ((((long)hg * (2 * C / 32) + w * MT + i) * 2 + ps) * 64 + lane) * 4);
+                    dst[i][ps] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)((((w * MT + i) * 2 + ps) * 64 + lane) * 16)));
         };
         if (WINO) {
 #pragma unroll
@@ -334,12 +341,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     // -DWINO_ABL=n (timing-only builds, wrong results): 1 = no weight loads in the loop, 2 = no LDS reads / input transform
 #if !(WINO_ABL & 2)
                     transform();
+                    __builtin_amdgcn_sched_barrier(0);      // all eight values in front of the MFMAs: computed just in time (a VALU + s_nop in front of every
+                                                            // MFMA pair) the loop measured 3 % slower
 #endif
 #if !(WINO_ABL & 1)
-                    load_aw(Aw[(s + WR - 1) % WR], W3f, min(hg + WR - 1, NH - 1));
+                    load_aw(Aw[(s + WR - 1) % WR], W3f, hg + WR - 1);
 #endif
 #if !(WINO_ABL & 2)
-                    load_d(min(hg + 1, NH - 1));
+                    load_d(hg + 1);           // (the read past the last half-group lands in the z buffer: discarded)
 #endif
                     if (hg < NH) {
 #pragma unroll
@@ -435,23 +444,42 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             }
         }
         f32x16 sk[WINO ? NT : 1];
+        float l2touch = 0.f;
         if constexpr (WINO) {      // eight accumulators + the gate's operands leave no room for the projection's ring before this point
 #pragma unroll
             for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
             // the residual stream and the skip sum of this wave's elements (see the epilogue) are requested BEHIND the ring's first groups:
             // loads return in order, so the projection loop never waits for them and they have landed long before its end
-            const float* xsrc = l == 0 ? x0_b : xst_b;
             const int ln = opaque(lane);
+            if (l == 0) {      // x enters in the public [C][T] layout
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t_c = min(t0 + j * 32 + (ln & 31), T - 1);
+                for (int j = 0; j < NT; ++j) {
+                    const int t_c = min(t0 + j * 32 + (ln & 31), T - 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[0][j][r] = ldg(xsrc, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
-                if (l > 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sk[j][r] = ldg(skip_b, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                    for (int r = 0; r < 16; ++r) st[0][j][r] = ldg(x0_b, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
                 }
+            } else {
+                const f32x4* px = reinterpret_cast<const f32x4*>(pst_b) + (w * 8) * 64 + ln;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 vx = px[(j * 4 + q) * 64], vs = px[PST_PART / 4 + (j * 4 + q) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st[0][j][4 * q + e] = vx[e]; sk[j][4 * q + e] = vs[e]; }
+                    }
             }
+#if WINO_L2PF
+            if (more) {
+                // pull the NEXT layer's transformed conv weights (2 MB) towards this XCD's L2 while the projection runs: the 32 workgroups of
+                // an XCD (block id mod 8 — a placement guess that only costs speed when wrong) x 8 waves x 64 lanes touch one dword of each
+                // of its 16384 128-byte lines.  Without it every stage of the conv loop's weight ring is a first touch that all 32 CUs,
+                // in lockstep, wait out at Infinity-Cache latency (the loop ran at 82 % of its MFMA time).
+                const int bid = blockIdx.x + gridDim.x * blockIdx.y;
+                const unsigned line = (unsigned)((((bid >> 3) & 31) * NW + w) * 64 + ln);
+                l2touch = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.W3f[l + 1]) + (size_t)line * 128u);
+            }
+#endif
         }
         stamp(l, 3);
         __syncthreads();   // (3) z complete, u of this layer dead
@@ -494,6 +522,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             // the element (its own earlier stores: program order), requested ahead of the projection loop.  x' stays
             // in registers for the publish phase below; the last layer's skip sum stays in acc[1] for the tail.
             if constexpr (WINO) {
+                asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -601,20 +630,18 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
         }
         if constexpr (WINO) {      // x' and the skip sum go back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
-                                   // the acknowledgement of these 64 stores (one counter for loads and stores)
-            const int ln = opaque(lane);
+                                   // the acknowledgement of these stores (one counter for loads and stores)
+            f32x4* px = reinterpret_cast<f32x4*>(pst_b) + (w * 8) * 64 + opaque(lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + (ln & 31);
-                if (t < Tc) {
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const size_t off = (size_t)((unsigned)((mrow0 + acc_row(r, ln)) * T + t) * 4u);
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(xst_b) + off) = st[0][j][r];
-                        *reinterpret_cast<float*>(reinterpret_cast<char*>(skip_b) + off) = acc[1][j][r];
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 vx, vs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vx[e] = st[0][j][4 * q + e]; vs[e] = acc[1][j][4 * q + e]; }
+                    px[(j * 4 + q) * 64] = vx;
+                    px[PST_PART / 4 + (j * 4 + q) * 64] = vs;
                 }
-            }
         }
         stamp(l, 7);
     }
@@ -688,6 +715,11 @@ extern "C" int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int forc
     return tiles * (bc < B ? bc : B);
 }
 
+extern "C" size_t cmtts_persist_state_floats(int B, int T) {
+    const long tiles = (T + FN - 1) / FN;
+    return (size_t)B * tiles * 2 * (NW * 8 * 64 * 4);
+}
+
 extern "C" size_t cmtts_persist_halo_bytes(int B, int T) {
     const long tiles = (T + FN - 1) / FN;
     return (size_t)2 * B * tiles * 2 * C * sizeof(unsigned long long);
@@ -705,7 +737,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
-    if (a.wino && (!a.skip || !a.xst)) return -2;          // the Winograd instances keep the skip sum / the residual stream in `skip` / `xst` between layers
+    if (a.wino && !a.xst) return -2;          // the Winograd instances keep the residual stream / the skip sum in `xst` between layers
     // instance table: [dbg][fact][wino]
     static const void* const kfns[2][2][2] = {
         {{reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, true>)},
@@ -738,7 +770,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.dp = a.dp + (long)b0 * a.vec_stride;
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
-        if (a.xst) c.xst = a.xst + (long)b0 * C * a.T;
+        if (a.xst) c.xst = a.xst + (long)b0 * tiles * (2 * NW * 8 * 64 * 4);      // [B][tiles][2][16384]
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
         if (a.fact) {
             c.p1 = a.p1 + (long)b0 * a.NL * C * a.ldp;
@@ -790,7 +822,7 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
     }
     if (a.wino)        // the Winograd instances keep the skip sum / the residual stream of every group in its `skip` / `xst` buffers
         for (int g = 0; g < a.n_groups; ++g)
-            if (a.grp[g].B > 0 && (!a.grp[g].skip || !a.grp[g].xst)) return -2;
+            if (a.grp[g].B > 0 && !a.grp[g].xst) return -2;
     const void* kfn = kfns[a.fact ? 1 : 0][a.wino ? 1 : 0];
     // co-residency depends on the workgroup count and on (registers, LDS), which the four instances share: one record for all
     const int variant = a.fact ? 6 : 4;

@@ -24,7 +24,7 @@ struct PersistGroup {
     const long long* mel2ph;    // [B][T] int64
     const long long* pidx;      // [B][T] int64
     int ldp, Lph;
-    float* xst;           // WINO instances: [B][256][T] residual stream between layers (kernel-private scratch)
+    float* xst;           // WINO instances: [B][tiles][2][16384] kernel-private state (x and the skip sum of every tile between layers)
 };
 
 struct PersistArgs {
@@ -67,7 +67,8 @@ struct PersistArgs {
     int ldp, Lph, ld2;
     int wino;             // fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
-    float* xst;           // WINO: [B][256][T] kernel-private storage of the residual stream x between layers (batch stride 256 T, like skip)
+    float* xst;           // WINO: [B][tiles][2][16384] kernel-private state — the residual stream x and the skip sum of every 64-frame tile between layers
+                          // (cmtts_persist_state_floats(B, T) floats)
     int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
     // ---- ragged launches (round 3; fp32 kernel): a 1-D grid of n_wg workgroups, workgroup i works on tile (desc >> 13 & 127) of
@@ -84,6 +85,7 @@ struct PersistArgs {
 extern "C" {
 #endif
 size_t cmtts_persist_halo_bytes(int B, int T);
+size_t cmtts_persist_state_floats(int B, int T);   // PersistArgs.xst / PersistGroup.xst of a (B, T) batch
 // max_blocks = workgroups that are certainly co-resident (the CU count).  0 = launched, -2 = shape not
 // supported or (unless force) too small to pay off: the caller uses the per-layer kernels, -3 = HIP error.
 int cmtts_launch_denoiser_persist(const PersistArgs* a, int max_blocks, int force, void* stream);
