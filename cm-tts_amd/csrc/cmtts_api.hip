@@ -171,6 +171,43 @@ std::vector<float> to_wino_fragments(const std::vector<float>& p, int K, int M) 
     return f;
 }
 
+// Winograd form of a k-tap conv for conv_xlw_kernel (resblock_pair.h: WinoTab<KT>): the transformed weights of every table entry (formed in
+// double, rounded once) as A fragments in the kernel's iteration order [K/16 chunks][entries][2 halves][M/32][64 lanes][4].
+template <int KT>
+std::vector<float> to_wino_iter_fragments_k(const std::vector<float>& p, int K, int M) {
+    using TAB = WinoTab<KT>;
+    std::vector<float> f((size_t)TAB::N * K * M);
+    const int MTn = M / 32;
+    size_t o = 0;
+    for (int c = 0; c < K / 16; ++c)
+        for (int e = 0; e < TAB::N; ++e)
+            for (int h = 0; h < 2; ++h)
+                for (int mt = 0; mt < MTn; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 16 * c + 8 * h + 2 * j + (lane >> 5), mrow = 32 * mt + (lane & 31), tau = TAB::e[e].tau;
+                            auto g = [&](int tap) -> double { return tap < KT ? (double)p[((size_t)tap * K + k) * M + mrow] : 0.0; };
+                            double v = 0.0;
+                            switch (TAB::e[e].wkind) {
+                                case 0: v = g(tau); break;
+                                case 1: v = 0.5 * (g(tau) + g(tau + 1) + g(tau + 2)); break;
+                                case 2: v = 0.5 * (g(tau) - g(tau + 1) + g(tau + 2)); break;
+                                case 3: v = g(tau + 2); break;
+                                case 4: v = -g(tau); break;
+                                case 5: v = g(tau) + g(tau + 1); break;
+                                case 6: v = g(tau + 1); break;
+                            }
+                            f[o++] = (float)v;
+                        }
+    return f;
+}
+std::vector<float> to_wino_iter_fragments(const std::vector<float>& p, int taps, int K, int M) {
+    if (taps == 3) return to_wino_iter_fragments_k<3>(p, K, M);
+    if (taps == 7) return to_wino_iter_fragments_k<7>(p, K, M);
+    if (taps == 11) return to_wino_iter_fragments_k<11>(p, K, M);
+    return {};
+}
+
 // The same fragments in the ITERATION order of the fused ResBlock pair kernels (resblock_pair.hip): the K loop walks
 // (16-channel chunk, tap, 8-channel half), so [K/16][taps][2][M/32][64 lanes][4] makes the weight stream one linear walk.
 std::vector<float> to_fragment_iter_order(const std::vector<float>& p, int taps, int K, int M) {
@@ -329,6 +366,7 @@ int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partia
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
+int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
@@ -552,6 +590,8 @@ struct cmtts_vocoder {
     PackedConv c1[12][3], c2[12][3];
     void *c1f[12][3][3] = {}, *c2f[12][3][3] = {};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies of the ResBlock convs
     float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
+    float *c1w32[12][3] = {}, *c2w32[12][3] = {};    // Winograd-transformed fragments of the C >= 128 stages (conv_xlw_kernel), else null
+    int winograd = 1;                                 // fp32 generator: ResBlock convs of the C >= 128 stages in their Winograd form (cmtts_vocoder_set_option "winograd")
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
     int ups16 = 1;                                    // 16-bit modes: upsampler operands in 16 bits as well (cmtts_vocoder_set_option "ups16"; 0 = fp32 upsamplers, different numerics)
     float *post_w = nullptr, *post_b = nullptr;
@@ -2178,6 +2218,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 std::vector<float> hp;
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
+                if (co >= 128) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
@@ -2188,6 +2229,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 }
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
+                if (co >= 128) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2w32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
@@ -2369,17 +2411,21 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                 if (g_voc_xl && !v->precision && co >= 128 && v->c1f32[r][mi]) {   // wide stages: X-resident single convs
                     ConvXlArgs xa;
                     memset(&xa, 0, sizeof(xa));
-                    xa.x = xr; xa.y = bT; xa.wf = v->c1f32[r][mi]; xa.bias = v->c1[r][mi].bias;
-                    xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f;
-                    const int rc1 = cmtts_launch_conv_xl(&xa, (void*)q);
+                    // round 4: the Winograd form of both convs (conv_xlw_kernel: 4 / 10 / 15 products per output pair instead of 6 / 14 / 22)
+                    const bool xw = g_voc_wino && v->winograd && v->c1w32[r][mi] && v->c2w32[r][mi];
+                    xa.x = xr; xa.y = bT; xa.wf = xw ? v->c1w32[r][mi] : v->c1f32[r][mi]; xa.bias = v->c1[r][mi].bias;
+                    xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f; xa.wino_force = g_voc_wino == 2;
+                    int rc1 = xw ? cmtts_launch_conv_xlw(&xa, (void*)q) : -2;
+                    const bool xw1 = rc1 == 0;
+                    if (rc1 == -2) { xa.wf = v->c1f32[r][mi]; rc1 = cmtts_launch_conv_xl(&xa, (void*)q); }
                     if (rc1 == -3) return fail(CMTTS_E_HIP, "conv_xl launch failed");
                     if (rc1 == 0) {
                         if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
                         // the residual operand is read at the positions this launch writes when y == res (in place: safe,
                         // every output element reads only its own residual); the INPUT must not alias the output
-                        xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = v->c2f32[r][mi]; xa.bias = v->c2[r][mi].bias;
+                        xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = xw1 ? v->c2w32[r][mi] : v->c2f32[r][mi]; xa.bias = v->c2[r][mi].bias;
                         xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
-                        if (cmtts_launch_conv_xl(&xa, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xl launch failed");
+                        if ((xw1 ? cmtts_launch_conv_xlw(&xa, (void*)q) : cmtts_launch_conv_xl(&xa, (void*)q)) != 0) return fail(CMTTS_E_HIP, "conv_xl launch failed");
                         if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                         xr = bR;
                         continue;
@@ -2528,6 +2574,7 @@ int cmtts_vocoder_set_option(cmtts_vocoder* v, const char* name, int value) {
     if (!v || !name) return fail(CMTTS_E_INVALID, "cmtts_vocoder_set_option: null argument");
     const Knob tab[] = {
         {"ups16", &v->ups16, 0, 1},                      // 16-bit modes: 16-bit operands in the upsamplers too (1) or fp32 upsamplers (0)
+        {"winograd", &v->winograd, 0, 1},                // fp32 generator: the ResBlock convs of the C >= 128 stages in their Winograd form (default 1; 0 = the direct form)
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
@@ -2562,6 +2609,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel (two images, one workgroup per CU; only when voc_pairw = 0)
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
+        {"voc_wino", &g_voc_wino, 0, 2},           // fp32 wide-stage convs in their Winograd form (NOT bitwise: the A/B twin of the vocoder option "winograd")
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads

@@ -5,7 +5,8 @@
 // cond_gemm16 (16-bit against fp32 operands of the conditioner GEMM in bf16 / fp16 / fp16x3 models: a numerics switch — since
 // round 3 the 16-bit form is the default for EVERY shape of a 16-bit model, which changed those models' default numerics against
 // round 2), persist_wino (round 4: the fp32 persistent stack's k = 3 conv as Winograd F(2,3) — the process-wide A/B twin of the model
-// option "winograd"; 1 by default, <= 1e-5 per network evaluation against the direct form).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
+// option "winograd"; 1 by default, <= 1e-5 per network evaluation against the direct form), voc_wino (round 4: the fp32 generator's C >= 128 ResBlock
+// convs in their Winograd form — 0 never, 1 (default) launches of >= 1024 column tiles, 2 always; <= 1.2e-6 on the waveform).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
 // (cmtts_amd/_lib.py: internal_set).
 #pragma once
 #ifdef __cplusplus
@@ -13,7 +14,7 @@ extern "C" {
 #endif
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
-// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16, persist_wino (cmtts_api.hip: cmtts_internal_set).
+// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16, persist_wino, voc_wino (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 // Test hook: the stacked conditioner projections alone, with the model's current precision mode.  cond_ct [B][hidden][T] -> cp [B][NL * C][T]
 // (device pointers).  Returns a cmtts_status.

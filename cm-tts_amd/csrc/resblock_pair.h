@@ -31,12 +31,31 @@ struct ConvXlArgs {
     int relu;             // ReLU after the bias (variance-predictor convs, model/modules.py:470-499); 0 for HiFi-GAN
     int cin;              // input channels when they differ from C (0 = C); x then has its own batch stride:
     long xbstride;
+    int wino_force;       // cmtts_launch_conv_xlw: take the Winograd form whatever the launch size (tests: goldens are small)
 };
+
+// ---- Winograd form of a k-tap (dilated) Conv1d for the fp32 X-resident kernels (round 4; conv_xlw_kernel in resblock_pair.hip, weights packed by
+// cmtts_api.hip: to_wino_iter_fragments).  Outputs are computed in PAIRS (t, t + dil); with X(m) = act(x)[t + (m - (k-1)/2) dil] the k taps split
+// into groups of three consecutive taps done as F(2,3) (4 products per pair instead of 6), a leftover pair of taps as F(2,2) (3 instead of
+// 4) and a leftover single tap directly (2):  k = 3: 4 products per pair instead of 6, k = 7: 10 instead of 14, k = 11: 15 instead of 22.
+// Every product is one entry of this table: accumulator M_acc += W_kind(tau) * (X(a) + sgn X(b))   (sgn = 0: X(a) alone), and
+//   y(t) = (M0 + M1) + M2,   y(t + dil) = (M1 - M2) - M3.
+// wkind: 0 g[tau] | 1 (g[tau] + g[tau+1] + g[tau+2]) / 2 | 2 (g[tau] - g[tau+1] + g[tau+2]) / 2 | 3 g[tau+2] | 4 -g[tau] | 5 g[tau] + g[tau+1] | 6 g[tau+1]
+struct WinoEntry { signed char acc, a, b, sgn, wkind, tau; };
+#define WINO_F23(t) {0, t, (t) + 2, -1, 0, t}, {1, (t) + 1, (t) + 2, 1, 1, t}, {2, (t) + 2, (t) + 1, -1, 2, t}, {3, (t) + 1, (t) + 3, -1, 3, t}
+#define WINO_F22(t) {0, t, (t) + 1, -1, 0, t}, {1, (t) + 1, 0, 0, 5, t}, {3, (t) + 1, (t) + 2, -1, 6, t}
+#define WINO_ONE(t) {0, t, 0, 0, 0, t}, {3, (t) + 1, 0, 0, 4, t}
+template <int KT> struct WinoTab;
+template <> struct WinoTab<3> { static constexpr int N = 4; static constexpr WinoEntry e[N] = {WINO_F23(0)}; };
+template <> struct WinoTab<7> { static constexpr int N = 10; static constexpr WinoEntry e[N] = {WINO_F23(0), WINO_F23(3), WINO_ONE(6)}; };
+template <> struct WinoTab<11> { static constexpr int N = 15; static constexpr WinoEntry e[N] = {WINO_F23(0), WINO_F23(3), WINO_F23(6), WINO_F22(9)}; };
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
+// the same conv in its Winograd form (a->wf = to_wino_iter_fragments of the same weights); -2 = shape not covered (C = 128 / 256, k = 3 / 7 / 11, dilation 1 / 3 / 5)
+int cmtts_launch_conv_xlw(const ConvXlArgs* a, void* stream);
 // HiFi-GAN upsampler (ConvTranspose1d, kernel 2 s, stride s, padding s / 2), all phases in one X-resident launch (resblock_pair.hip)
 int cmtts_launch_convT(const float* x, float* y, const float* wf, const float* bias, long xbstride, long ybstride, int B, int cin,
                        int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, void* stream);

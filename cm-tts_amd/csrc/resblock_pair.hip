@@ -32,6 +32,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // -DPAIR_DBG=5 (tools/pair_phases.py): every wave stamps the cycle counter at its phase boundaries; results are unchanged
 #ifndef PAIR_DBG
@@ -409,6 +410,194 @@ __global__ __launch_bounds__(64 * NWV, NWV == C / 32 ? 2 : 1) void conv_xl_kerne
     }
 }
 
+#ifndef XLW_MT
+#define XLW_MT(DIL, KT) ((DIL) == 1 || (KT) == 3 ? 2 : 1)      // m-tiles per wave of conv_xlw_kernel: two unless the tile (dilation 3 / 5 at k >= 7) would leave one wave per SIMD
+#endif
+// ---- conv_xl in its Winograd form (resblock_pair.h: WinoTab).  A workgroup computes NP output PAIRS (t, t + DIL) per m-tile: 32 pairs = 64
+// columns at dilation 1, 30 pairs = 60 columns at dilation 3 / 5 (pair p = q DIL + r covers columns q 2 DIL + r and + DIL).  The activated x
+// tile lives in LDS split by pair parity: column j = Q 2 DIL + R of the tile goes to E[Q DIL + R] (R < DIL) or O[Q DIL + R - DIL], so that
+// X(m) of pair p — the input `m` dilated taps to the right of the pair's first output — is E[p + (m / 2) DIL] (m even) or
+// O[p + (m / 2) DIL] (m odd): unit stride across the lanes, compile-time offsets.  Every wave owns one m-tile and the four accumulators
+// M0..M3 of the tile's pairs; per table entry and k-step one ds_read2_b32 + one VALU form the transformed input, one MFMA consumes it.
+// NOT bitwise the direct form (fp32 Winograd: the same products regrouped; ~1e-6 relative per conv).
+// MT = m-tiles per wave: with two, a transformed input feeds two MFMAs (1.25 instead of 2.25 LDS / VALU / load instructions per MFMA — what
+// bounds this kernel: at MT = 1 the k = 3 instances were SLOWER than the direct form), the workgroup has C / 64 waves and smaller tiles keep
+// four (C = 128) / two (C = 256) of them on a CU; the residual operands are then read after the K loop (no registers to park them in).
+template <int C, int KT, int DIL, int MT>
+__global__ __launch_bounds__(64 * (C / (32 * MT)), 2) void conv_xlw_kernel(const ConvXlArgs a) {
+    using TAB = WinoTab<KT>;
+    constexpr int NWAVES = C / (32 * MT);
+    constexpr int NP = DIL == 1 ? 32 : 30;                  // pairs per tile
+    constexpr int BN = 2 * NP;                              // output columns per tile
+    constexpr int NEO = 32 + ((KT - 1) / 2) * DIL;          // entries of E and of O per row
+    constexpr int XWW = 2 * NEO;
+    constexpr int PAD = DIL * ((KT - 1) / 2);
+    constexpr int XIN = BN + (KT - 1) * DIL;                // staged input columns
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                        // [C][E | O]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mt0 = w * MT;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * BN;
+    const int T = a.T;
+    const float* xb = a.x + (long)b * a.bstride;
+    {
+        const int tbase = t0 - PAD;
+        constexpr int ROWS_PER_WAVE = C / NWAVES;           // 32 MT
+        constexpr int XBLK = (XIN + 63) / 64;
+        int eo[XBLK];
+#pragma unroll
+        for (int jb = 0; jb < XBLK; ++jb) {
+            const int j = jb * 64 + lane, Q = j / (2 * DIL), R = j - Q * (2 * DIL);
+            eo[jb] = R < DIL ? Q * DIL + R : NEO + Q * DIL + R - DIL;
+        }
+#pragma unroll
+        for (int h = 0; h < ROWS_PER_WAVE; h += 16) {
+            float v[XBLK][16];
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[jb][q] = xb[(long)(w * ROWS_PER_WAVE + h + q) * a.ld + t_c];
+            }
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int j = jb * 64 + lane;
+                const int t = tbase + j;
+                if (j < XIN) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        Xs[(w * ROWS_PER_WAVE + h + q) * XWW + eo[jb]] = (t >= 0 && t < T) ? leaky(v[jb][q], a.slope) : 0.f;
+                }
+            }
+        }
+    }
+    // this lane's pair: columns ca and ca + DIL of the tile
+    const int pq = l31 / DIL, pr = l31 - pq * DIL;
+    const int ta = t0 + pq * 2 * DIL + pr, tb = ta + DIL;
+    const bool pv = l31 < NP;
+    float* yb = a.y + (long)b * a.bstride;
+    const float* rb = a.res ? a.res + (long)b * a.bstride : nullptr;
+    constexpr bool PRE = MT == 1;                           // residual / old y requested before the K loop
+    float xres[PRE ? 2 : 1][16], yo[PRE ? 2 : 1][16];
+    if (PRE) {
+        const int ta_c = min(ta, T - 1), tb_c = min(tb, T - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = (long)(mt0 * 32 + acc_row(r, lane)) * a.ld;
+            xres[0][r] = rb ? rb[row + ta_c] : 0.f;
+            xres[PRE ? 1 : 0][r] = rb ? rb[row + tb_c] : 0.f;
+            yo[0][r] = a.accum ? yb[row + ta_c] : 0.f;
+            yo[PRE ? 1 : 0][r] = a.accum ? yb[row + tb_c] : 0.f;
+        }
+    }
+    __syncthreads();
+    f32x16 M[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) M[i][q][r] = 0.f;
+    {
+        // weights: iteration order [chunk][entry][half][m-tile][lane][4]; one fragment = the A operands of 4 k-steps of one entry
+        constexpr int NF = (C / 16) * TAB::N * 2;           // fragment groups of a wave
+        constexpr int RINGW = (TAB::N * 2) % 6 == 0 ? 6 : 4;      // groups in flight + the one in use; divides a chunk's count (8 / 20 / 30), so ring slots are compile-time
+        static_assert((TAB::N * 2) % RINGW == 0, "ring slots repeat per chunk");
+        const float* wl = a.wf + mt0 * 256 + lane * 4;
+        auto load_a = [&](f32x4 (&dst)[MT], int it) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) dst[i] = *reinterpret_cast<const f32x4*>(wl + (long)min(it, NF - 1) * ((C / 32) * 256) + i * 256);
+        };
+        f32x4 A[RINGW][MT];
+#pragma unroll
+        for (int s = 0; s < RINGW - 1; ++s) load_a(A[s], s);
+        const float* bl = Xs + khalf * XWW + l31;
+#pragma unroll 1
+        for (int c = 0; c < C / 16; ++c) {
+            const float* bc = bl + c * 16 * XWW;
+            int it = c * (TAB::N * 2);
+#pragma unroll
+            for (int e = 0; e < TAB::N; ++e) {
+                const int ea = TAB::e[e].a, ebb = TAB::e[e].b, sg = TAB::e[e].sgn, ac = TAB::e[e].acc;
+                const int offa = ((ea & 1) ? NEO : 0) + (ea >> 1) * DIL, offb = ((ebb & 1) ? NEO : 0) + (ebb >> 1) * DIL;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int slot = (e * 2 + h) % RINGW;
+                    load_a(A[(slot + RINGW - 1) % RINGW], it + RINGW - 1);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const float* row = bc + (8 * h + 2 * kk) * XWW;
+                        float v = row[offa];
+                        if (sg > 0) v = v + row[offb];
+                        else if (sg < 0) v = v - row[offb];
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) M[i][ac] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[slot][i][kk], v, M[i][ac], 0, 0, 0);
+                    }
+                    ++it;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float bi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bi[r] = a.bias[(mt0 + i) * 32 + acc_row(r, lane)];
+        float xr2[2][16], yo2[2][16];
+        if (!PRE) {
+            const int ta_c = min(ta, T - 1), tb_c = min(tb, T - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = (long)((mt0 + i) * 32 + acc_row(r, lane)) * a.ld;
+                xr2[0][r] = rb ? rb[row + ta_c] : 0.f;
+                xr2[1][r] = rb ? rb[row + tb_c] : 0.f;
+                yo2[0][r] = a.accum ? yb[row + ta_c] : 0.f;
+                yo2[1][r] = a.accum ? yb[row + tb_c] : 0.f;
+            }
+        }
+        if (pv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = (long)((mt0 + i) * 32 + acc_row(r, lane)) * a.ld;
+                float va = ((M[i][0][r] + M[i][1][r]) + M[i][2][r]) + bi[r];
+                float vb = ((M[i][1][r] - M[i][2][r]) - M[i][3][r]) + bi[r];
+                if (a.relu) { va = va > 0.f ? va : 0.f; vb = vb > 0.f ? vb : 0.f; }
+                if (rb) { va += PRE ? xres[0][r] : xr2[0][r]; vb += PRE ? xres[PRE ? 1 : 0][r] : xr2[1][r]; }
+                if (a.accum) { va += PRE ? yo[0][r] : yo2[0][r]; vb += PRE ? yo[PRE ? 1 : 0][r] : yo2[1][r]; }
+                if (ta < T) yb[row + ta] = va;
+                if (tb < T) yb[row + tb] = vb;
+            }
+        }
+    }
+}
+
+template <int C, int KT, int DIL>
+int launch_xlw(const ConvXlArgs& a, hipStream_t stream) {
+    constexpr int MT = XLW_MT(DIL, KT);
+    constexpr int NEO = 32 + ((KT - 1) / 2) * DIL;
+    constexpr int BN = DIL == 1 ? 64 : 60;
+    const size_t lds = (size_t)C * 2 * NEO * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xlw_kernel<C, KT, DIL, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.T + BN - 1) / BN, a.B);
+    hipLaunchKernelGGL((conv_xlw_kernel<C, KT, DIL, MT>), grid, dim3(64 * (C / (32 * MT))), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int C, int KT>
+int launch_xlw_dil(const ConvXlArgs& a, hipStream_t s) {
+    if (a.dil == 1) return launch_xlw<C, KT, 1>(a, s);
+    if (a.dil == 3) return launch_xlw<C, KT, 3>(a, s);
+    if (a.dil == 5) return launch_xlw<C, KT, 5>(a, s);
+    return -2;
+}
+
 int g_xl_split = 1;      // internal switch "voc_xl_split": m-tiles of conv_xl over several workgroups when the launch is a few column tiles
 
 template <int C, int KT, int CIN = C>
@@ -592,6 +781,29 @@ extern "C" int cmtts_launch_conv_xl(const ConvXlArgs* ap, void* stream_) {
         if (a.k == 5) return launch_xl<256, 5>(a, s);        // variance-predictor convs over frames (filter_size 256, kernel 5)
         if (a.k == 7) return launch_xl<256, 7>(a, s);
         if (a.k == 11) return launch_xl<256, 11>(a, s);
+    }
+    return -2;
+}
+
+extern "C" int cmtts_launch_conv_xlw(const ConvXlArgs* ap, void* stream_) {
+    const ConvXlArgs& a = *ap;
+    hipStream_t s = (hipStream_t)stream_;
+    if (a.B <= 0 || a.T <= 0) return 0;
+    if (a.x == a.y || (a.cin && a.cin != a.C)) return -2;
+    // launches of a few column tiles: the direct form (its split instance spreads the m-tiles over more workgroups; one 100-frame request
+    // through the Winograd form: 2.7 instead of 2.15 ms for the generator)
+    if (!a.wino_force && (long)((a.T + 63) / 64) * a.B < 1024) return -2;
+#ifdef XLW_ONLY_K            // quick experimental builds: one kernel size
+    if (a.k != XLW_ONLY_K) return -2;
+#endif
+    if (a.C == 128) {
+        if (a.k == 3) return launch_xlw_dil<128, 3>(a, s);
+        if (a.k == 7) return launch_xlw_dil<128, 7>(a, s);
+        if (a.k == 11) return launch_xlw_dil<128, 11>(a, s);
+    } else if (a.C == 256) {
+        if (a.k == 3) return launch_xlw_dil<256, 3>(a, s);
+        if (a.k == 7) return launch_xlw_dil<256, 7>(a, s);
+        if (a.k == 11) return launch_xlw_dil<256, 11>(a, s);
     }
     return -2;
 }

@@ -15,7 +15,7 @@ from cmtts_amd import _lib
 from cmtts_amd.config import get_config, HifiGanConfig
 from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
 from oracle import cmtts_oracle as O
-from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report, conv_form, same_result, WINO_TOL  # noqa: F401
+from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report, conv_form, same_result, WINO_TOL, voc_form, same_wav, same_pcm, VOC_WINO_TOL  # noqa: F401
 
 KNOWN_ORACLE_FLIPS = {"energy": 0, "pitch": 0}      # test_bucketed_ragged_shard_vs_oracle: measured on MI355X (round 2): none
 
@@ -559,6 +559,52 @@ def test_hifigan_golden(golden):
         assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
 
 
+@pytest.mark.parametrize("B,T", [(24, 350), (9, 1000), (32, 512)])
+def test_vocoder_winograd_vs_direct(B, T):
+    """conv_xlw_kernel (round 4): the ResBlock convs of the C = 256 / 128 stages as Winograd convolutions over output pairs (t, t + dilation):
+    k = 3 / 7 / 11 as F(2,3) groups + an F(2,2) / single-tap remainder, all three dilations, residual and MRF accumulation, ragged last tiles
+    (T not a multiple of the 64- / 60-column tiles).  Against the direct form on a chip-filling batch: fp32 rounding only; and the
+    reference's golden wav with the form forced onto its small shape."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=21))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(T + B)) * 1.5 - 4).to(DEV)
+    prev = _lib.internal_set(b"voc_wino", 1)
+    try:
+        got = voc(mel).clone()
+        _lib.internal_set(b"voc_wino", 0)
+        ref = voc(mel).clone()
+        _lib.internal_set(b"voc_wino", 2)
+        one = voc(mel[:1]).clone()             # forced onto one utterance: every conv of both wide stages in the Winograd form
+    finally:
+        _lib.internal_set(b"voc_wino", prev)
+    torch.cuda.synchronize()
+    d = float((got - ref).abs().max())
+    report(f"VOC_WINOGRAD B={B} T={T}: max|d wav| vs the direct form {d:.2e}; one utterance forced {float((one[0] - ref[0]).abs().max()):.2e}")
+    assert torch.isfinite(got).all() and 0 < d <= VOC_WINO_TOL
+    assert float((one[0] - ref[0]).abs().max()) <= VOC_WINO_TOL
+
+
+def test_hifigan_golden_winograd_forced(golden):
+    """The reference's own wav for the golden mel with the Winograd form forced onto its small shape (the default takes it from 1024 column
+    tiles on): the same 1e-4 bound as test_hifigan_golden, PCM within 4 LSB."""
+    host = _host()
+    g = golden("hifigan")
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=int(g["seed"])))
+    mel_ct = torch.from_numpy(np.ascontiguousarray(g["mel"].transpose(0, 2, 1)))
+    prev = _lib.internal_set(b"voc_wino", 2)
+    try:
+        wav = voc(mel_ct)
+        pcm = host.vocoder_infer(mel_ct, voc, lengths=g["mel_lens"] * 256)
+    finally:
+        _lib.internal_set(b"voc_wino", prev)
+    torch.cuda.synchronize()
+    assert np.abs(_np(wav) - g["wav"]).max() < 1e-4
+    for i, name in enumerate(["pcm0", "pcm1"]):
+        assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
+
+
 def test_fastspeech_decoder_golden_and_long(golden):
     """FastspeechDecoder over the frame axis on the encoder's FFT-block kernels: the reference module's output for
     the golden input (both mask forms), then T = 700 ragged frames against the oracle (attention over 700 keys)."""
@@ -947,7 +993,7 @@ def test_bucketed_ragged_shard_vs_oracle():
     assert np.abs(_np(mel) - ref).max() < 1e-3
 
 
-def test_end_to_end_wav_multispeaker_batch():
+def test_end_to_end_wav_multispeaker_batch(voc_form):
     """BASELINE configs[2]/[4] shape in fp32: VCTK model, T = 2, universal-vocoder architecture, int16 out.
     Every utterance of the batch must be bit-identical to synthesising it in a batch of its own padding."""
     host = _host()
@@ -980,7 +1026,7 @@ def test_end_to_end_wav_multispeaker_batch():
     sub = np.asarray([0, 5, 11])
     mel_s, _, pcm_s = run(sub)
     assert torch.equal(mel_s, mel[sub])
-    assert all(np.array_equal(a, pcm[i]) for a, i in zip(pcm_s, sub))
+    assert all(same_pcm(a, pcm[i], voc_form) for a, i in zip(pcm_s, sub))     # (Winograd form: the 16-utterance batch takes it in the C = 128 stage)
 
 
 def test_denoiser_full_size_properties(conv_form):
@@ -1959,7 +2005,7 @@ def test_vocoder_pair_kernel_bitwise(B, T):
 
 
 @pytest.mark.parametrize("B,T", [(1, 150), (2, 77), (5, 33)])
-def test_vocoder_xl_split_bitwise(B, T):
+def test_vocoder_xl_split_bitwise(B, T, voc_form):
     """Round 4: a request or two through the C = 256 stage is a few 64-column tiles; conv_xl then spreads a tile's eight m-tiles over four
     2-wave workgroups (one wave per SIMD, four times the CUs) instead of one 8-wave workgroup.  A wave's accumulation chains and the
     epilogue are unchanged: the wav keeps its bits, and an utterance still equals its row of a chip-filling batch."""
@@ -1978,7 +2024,7 @@ def test_vocoder_xl_split_bitwise(B, T):
     assert torch.isfinite(got).all() and torch.equal(got, ref), float((got - ref).abs().max())
     big = voc(mel.repeat(24 // B + 1, 1, 1))          # > 80 tiles in the C = 256 stage: the unsplit form
     torch.cuda.synchronize()
-    assert torch.equal(big[:B], got)
+    assert same_wav(big[:B], got, voc_form), float((big[:B] - got).abs().max())      # (Winograd form: the batch's C = 128 stage takes it)
 
 
 def test_hifigan_vs_oracle_other_shape():
