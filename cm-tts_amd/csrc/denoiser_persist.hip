@@ -86,8 +86,8 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 // channels (transformed weights W3f = [64 half-groups][16 m-tiles][2][64 lanes][4], packed by cmtts_api.hip: to_wino_fragments), so a
 // wave carries 2 m-tiles x 4 transforms = 8 accumulators over ONE 32-pair n-tile and the conv costs 2/3 of the direct form's MFMAs
 // (131 k instead of 197 k pipe cycles per layer).  u lives in LDS split by frame parity (odd frames at row offset (f + 1) / 2,
-// even frames at 33 + f / 2) so that the four d_i of a pair are unit-stride reads; the skip sum makes room in the register
-// file by living in `skip` memory between layers (read-modify-write by the lane that owns the element, L2-resident).
+// even frames at 33 + f / 2) so that the four d_i of a pair are unit-stride reads; the residual stream x makes room in the register
+// file by living in `xst` memory between layers (read-modify-write by the lane that owns the element, L2-resident); the skip sum stays.
 // NOT bitwise equal to the direct form (fp32 Winograd: ~1e-6 relative per layer); everything else in the kernel is unchanged.
 template <bool DBG, bool RAGGED, bool FACT = false, bool WINO = false>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
@@ -142,12 +142,11 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 
     // column of frame f (-1 .. FN) within a u row: f + 1, or (WINO) odd frames first, then even frames
     auto uidx = [](int f) { return WINO ? ((f & 1) ? (f + 1) >> 1 : 33 + (f >> 1)) : f + 1; };
-    // WINO: the residual stream x and the skip sum of this tile between layers, in a kernel-private layout [x | skip][wave][j * 4 + q][lane][4]
-    // (element e of that float4 = accumulator register 4 q + e of n-tile j): every load / store of the state is one fully coalesced
-    // 16-byte-per-lane instruction
-    constexpr int PST_PART = NW * 8 * 64 * 4;       // floats of one part of one tile (64 KB)
+    // WINO: the residual stream x of this tile between layers, in a kernel-private layout [wave][j * 4 + q][lane][4] (element e of that
+    // float4 = accumulator register 4 q + e of n-tile j): every load / store of the state is one fully coalesced 16-byte-per-lane instruction
+    constexpr int PST_TILE = NW * 8 * 64 * 4;       // floats of one tile (64 KB)
     float* pst_b = nullptr;
-    if (WINO) pst_b = (RAGGED ? a.grp[gi].xst : a.xst) + ((long)b * (RAGGED ? a.grp[gi].tiles : a.tiles) + tile) * (2 * PST_PART);
+    if (WINO) pst_b = (RAGGED ? a.grp[gi].xst : a.xst) + ((long)b * (RAGGED ? a.grp[gi].tiles : a.tiles) + tile) * PST_TILE;
 
     // ---- layer-0 staging (as resblock_fused.hip): u = cp + (x + dp), halo columns straight from x0
     {
@@ -443,13 +442,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     }
             }
         }
-        f32x16 sk[WINO ? NT : 1];
         float l2touch = 0.f;
         if constexpr (WINO) {      // eight accumulators + the gate's operands leave no room for the projection's ring before this point
 #pragma unroll
             for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
-            // the residual stream and the skip sum of this wave's elements (see the epilogue) are requested BEHIND the ring's first groups:
-            // loads return in order, so the projection loop never waits for them and they have landed long before its end
+            // the residual stream of this wave's elements (see the epilogue) is requested BEHIND the ring's first groups:
+            // loads return in order, so the projection loop never waits for it and it has landed long before the loop's end
             const int ln = opaque(lane);
             if (l == 0) {      // x enters in the public [C][T] layout
 #pragma unroll
@@ -464,9 +462,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 vx = px[(j * 4 + q) * 64], vs = px[PST_PART / 4 + (j * 4 + q) * 64];
+                        const f32x4 vx = px[(j * 4 + q) * 64];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { st[0][j][4 * q + e] = vx[e]; sk[j][4 * q + e] = vs[e]; }
+                        for (int e = 0; e < 4; ++e) st[0][j][4 * q + e] = vx[e];
                     }
             }
 #if WINO_L2PF
@@ -517,10 +515,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
                 ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
             }
-            // WINO: eight accumulators leave the conv loop no room for 64 registers of state, so the residual stream x and the skip sum
-            // wait in memory (`xst`, `skip`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
-            // the element (its own earlier stores: program order), requested ahead of the projection loop.  x' stays
-            // in registers for the publish phase below; the last layer's skip sum stays in acc[1] for the tail.
+            // WINO: eight accumulators leave the conv loop no room for all 64 registers of state: the skip sum stays resident, the residual
+            // stream x waits in memory (`xst`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
+            // the element (its own earlier stores: program order), requested ahead of the projection loop.  x' stays in registers for
+            // the publish phase below.
             if constexpr (WINO) {
                 asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
 #pragma unroll
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                         const float o = acc[0][j][r] + bor[0][r];
                         st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
                         const float os = acc[1][j][r] + bor[1][r];
-                        acc[1][j][r] = l > 0 ? os + sk[j][r] : os;
+                        st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                     }
                 }
             } else {
@@ -629,25 +627,24 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const float uh = hcp + (xh + dpn[hm]);
             u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
         }
-        if constexpr (WINO) {      // x' and the skip sum go back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
+        if constexpr (WINO) {      // x' goes back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
                                    // the acknowledgement of these stores (one counter for loads and stores)
             f32x4* px = reinterpret_cast<f32x4*>(pst_b) + (w * 8) * 64 + opaque(lane);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 vx, vs;
+                    f32x4 vx;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { vx[e] = st[0][j][4 * q + e]; vs[e] = acc[1][j][4 * q + e]; }
+                    for (int e = 0; e < 4; ++e) vx[e] = st[0][j][4 * q + e];
                     px[(j * 4 + q) * 64] = vx;
-                    px[PST_PART / 4 + (j * 4 + q) * 64] = vs;
                 }
         }
         stamp(l, 7);
     }
 
     if (a.tail) {   // skip head + post-scaling in-kernel (persist_tail.h); the u buffer is free since barrier (3), z after barrier (A) inside
-        persist_tail::run(a, smem, smem + C * U_LD, WINO ? acc[1] : st[1], w, lane, b, t0, T, RAGGED ? a.grp[gi].xold : a.xold,
+        persist_tail::run(a, smem, smem + C * U_LD, st[1], w, lane, b, t0, T, RAGGED ? a.grp[gi].xold : a.xold,
                           RAGGED ? a.grp[gi].noise : a.noise, RAGGED ? a.grp[gi].out : a.out, Tc);
     } else {   // ---- the skip sum leaves the chip once
         float* skip = (RAGGED ? a.grp[gi].skip : a.skip) + (long)b * C * T;
@@ -656,7 +653,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const int t = t0 + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t < Tc) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = WINO ? acc[1][j][r] : st[1][j][r];
+                if (t < Tc) skip[(unsigned)((mrow0 + acc_row(r, lane)) * T + t)] = st[1][j][r];
         }
     }
 }
@@ -717,7 +714,7 @@ extern "C" int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int forc
 
 extern "C" size_t cmtts_persist_state_floats(int B, int T) {
     const long tiles = (T + FN - 1) / FN;
-    return (size_t)B * tiles * 2 * (NW * 8 * 64 * 4);
+    return (size_t)B * tiles * (NW * 8 * 64 * 4);
 }
 
 extern "C" size_t cmtts_persist_halo_bytes(int B, int T) {
@@ -737,7 +734,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
-    if (a.wino && !a.xst) return -2;          // the Winograd instances keep the residual stream / the skip sum in `xst` between layers
+    if (a.wino && !a.xst) return -2;          // the Winograd instances keep the residual stream in `xst` between layers
     // instance table: [dbg][fact][wino]
     static const void* const kfns[2][2][2] = {
         {{reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, true>)},
@@ -770,7 +767,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.dp = a.dp + (long)b0 * a.vec_stride;
         c.d = a.d + (long)b0 * a.vec_stride;
         c.skip = a.skip + (long)b0 * C * a.T;
-        if (a.xst) c.xst = a.xst + (long)b0 * tiles * (2 * NW * 8 * 64 * 4);      // [B][tiles][2][16384]
+        if (a.xst) c.xst = a.xst + (long)b0 * tiles * (NW * 8 * 64 * 4);      // [B][tiles][16384]
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
         if (a.fact) {
             c.p1 = a.p1 + (long)b0 * a.NL * C * a.ldp;

@@ -24,7 +24,7 @@ struct PersistGroup {
     const long long* mel2ph;    // [B][T] int64
     const long long* pidx;      // [B][T] int64
     int ldp, Lph;
-    float* xst;           // WINO instances: [B][tiles][2][16384] kernel-private state (x and the skip sum of every tile between layers)
+    float* xst;           // WINO instances: [B][tiles][16384] kernel-private state (the residual stream x of every tile between layers)
 };
 
 struct PersistArgs {
@@ -67,7 +67,7 @@ struct PersistArgs {
     int ldp, Lph, ld2;
     int wino;             // fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
-    float* xst;           // WINO: [B][tiles][2][16384] kernel-private state — the residual stream x and the skip sum of every 64-frame tile between layers
+    float* xst;           // WINO: [B][tiles][16384] kernel-private state — the residual stream x of every 64-frame tile between layers
                           // (cmtts_persist_state_floats(B, T) floats)
     int halo_zeroed;      // the caller has already cleared `halo` on this stream (inproj.hip): the launcher skips its memset
     long long* dbg;       // optional [grid][16 waves][8] cycle stamps of layer NL/2 (phase timing, tools/persist_timing.py)
