@@ -15,14 +15,19 @@ for (B, T) in [(1, 1), (1, 2), (2, 63), (1, 64), (1, 65), (3, 129)]:
     x = torch.randn(B, 1, T, 80, generator=g); cond = torch.randn(B, T, 256, generator=g); spk = torch.randn(B, 256, generator=g)
     t = torch.full((B,), 1095.5)
     outs = []
+    _lib.internal_set(b"persist_wino", 0)          # direct conv form: persistent == per-layer bit for bit
     for mode in (0, 2):
         lib.cmtts_set_persistent_denoiser(mode)
         for prec in ("fp32", "bf16"):
             model.set_precision(prec)
             outs.append(model.net(x, t, cond, spk))
-    model.set_precision("fp32"); lib.cmtts_set_persistent_denoiser(1)
+    model.set_precision("fp32")
+    _lib.internal_set(b"persist_wino", 1)          # the default (Winograd) form of the fp32 stack: fp32 rounding only
+    wino = model.net(x, t, cond, spk)
+    lib.cmtts_set_persistent_denoiser(1)
     torch.cuda.synchronize()
-    print(B, T, "fp32 equal:", torch.equal(outs[0], outs[2]), "bf16 equal:", torch.equal(outs[1], outs[3]), "finite:", all(bool(torch.isfinite(o).all()) for o in outs))
+    print(B, T, "fp32 equal:", torch.equal(outs[0], outs[2]), "bf16 equal:", torch.equal(outs[1], outs[3]), "finite:", all(bool(torch.isfinite(o).all()) for o in outs),
+          "winograd stack max|d|: %.1e" % float((wino - outs[0]).abs().max()))
 # text side edge: one phoneme, single utterance
 out = model.duration_pitch_energy_net(None, torch.tensor([[5]]), torch.tensor([1]), spker_embeds=torch.randn(1, 512))
 print("L=1:", out["mel_lens"].tolist(), tuple(out["cond"].shape), bool(torch.isfinite(out["cond"]).all()))
