@@ -517,21 +517,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             }
             // WINO: eight accumulators leave the conv loop no room for all 64 registers of state: the skip sum stays resident, the residual
             // stream x waits in memory (`xst`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
-            // the element (its own earlier stores: program order), requested ahead of the projection loop.  x' stays in registers for
-            // the publish phase below.
-            if constexpr (WINO) {
-                asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float o = acc[0][j][r] + bor[0][r];
-                        st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
-                        const float os = acc[1][j][r] + bor[1][r];
-                        st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
-                    }
-                }
-            } else {
+            // the element (its own earlier stores: program order), requested ahead of the projection loop (st[0] holds the loaded x
+            // here).  x' stays in registers for the publish phase below.
+            if (WINO) asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -541,7 +529,6 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     const float os = acc[1][j][r] + bor[1][r];
                     st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }
-            }
         }
         if (!more) break;
         stamp(l, 6);
