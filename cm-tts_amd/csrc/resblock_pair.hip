@@ -514,27 +514,43 @@ __global__ __launch_bounds__(64 * (C / (32 * MT)), 2) void conv_xlw_kernel(const
 #pragma unroll
         for (int s = 0; s < RINGW - 1; ++s) load_a(A[s], s);
         const float* bl = Xs + khalf * XWW + l31;
+        // LDS operands of step n + 1 (one table entry x one half-chunk: 4 k-steps) are requested in front of step n's MFMAs
+        float XA[2][4], XB[2][4];
+        auto loadx = [&](float (&xa)[4], float (&xb)[4], const float* bc, int e, int h) {
+            const int ea = TAB::e[e].a, ebb = TAB::e[e].b, sg = TAB::e[e].sgn;
+            const int offa = ((ea & 1) ? NEO : 0) + (ea >> 1) * DIL, offb = ((ebb & 1) ? NEO : 0) + (ebb >> 1) * DIL;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float* row = bc + (8 * h + 2 * kk) * XWW;
+                xa[kk] = row[offa];
+                xb[kk] = sg != 0 ? row[offb] : 0.f;
+            }
+        };
+        loadx(XA[0], XB[0], bl, 0, 0);
 #pragma unroll 1
         for (int c = 0; c < C / 16; ++c) {
             const float* bc = bl + c * 16 * XWW;
             int it = c * (TAB::N * 2);
 #pragma unroll
             for (int e = 0; e < TAB::N; ++e) {
-                const int ea = TAB::e[e].a, ebb = TAB::e[e].b, sg = TAB::e[e].sgn, ac = TAB::e[e].acc;
-                const int offa = ((ea & 1) ? NEO : 0) + (ea >> 1) * DIL, offb = ((ebb & 1) ? NEO : 0) + (ebb >> 1) * DIL;
+                const int sg = TAB::e[e].sgn, ac = TAB::e[e].acc;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int slot = (e * 2 + h) % RINGW;
+                    const int n = e * 2 + h;
+                    const int slot = n % RINGW;
                     load_a(A[(slot + RINGW - 1) % RINGW], it + RINGW - 1);
+                    if (n + 1 < TAB::N * 2) loadx(XA[(n + 1) & 1], XB[(n + 1) & 1], bc, (n + 1) >> 1, (n + 1) & 1);
+                    else loadx(XA[(n + 1) & 1], XB[(n + 1) & 1], bl + min(c + 1, C / 16 - 1) * 16 * XWW, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
-                        const float* row = bc + (8 * h + 2 * kk) * XWW;
-                        float v = row[offa];
-                        if (sg > 0) v = v + row[offb];
-                        else if (sg < 0) v = v - row[offb];
+                        float v = XA[n & 1][kk];
+                        if (sg > 0) v = v + XB[n & 1][kk];
+                        else if (sg < 0) v = v - XB[n & 1][kk];
 #pragma unroll
                         for (int i = 0; i < MT; ++i) M[i][ac] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[slot][i][kk], v, M[i][ac], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                     ++it;
                 }
             }
