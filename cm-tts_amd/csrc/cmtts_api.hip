@@ -367,7 +367,8 @@ int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + in
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
-int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k = 11: two Winograd launches per pair instead of the pair kernel (measurement switch)
+int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
+int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
 int g_voc_pair128 = 1;          // 16-bit HiFi-GAN, C = 128: pair kernel (1) or two conv_xl16 launches (0); same bits
@@ -2219,7 +2220,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 std::vector<float> hp;
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
-                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 11)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
+                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
@@ -2230,7 +2231,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 }
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
-                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 11)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2w32[r][mi])); }
+                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2w32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
@@ -2382,9 +2383,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             const bool pair3 = g_voc_pair3 && v->precision == 3 && co <= 128;
             bool pair_ok = g_voc_pair && (co <= 64 || pair128 || pairw || pair3) && (v->precision != 3 || pair3) &&
                                  (v->precision ? (pair16_pays && v->c1f[r][0][v->precision - 1] != nullptr) : v->c1f32[r][0] != nullptr);
-            // fp32, C = 64, k = 11, chip-filling launches (round 4; k = 7 measured no faster than its pair kernel: 2 x 1064 against 2099 us): the pair as two Winograd launches (conv_xlw_kernel<64>: one wave per workgroup with both
-            // m-tiles, eight workgroups per CU) instead of the fused pair kernel — 15 products per output pair instead of 22 outweigh xt's trip through HBM (2 x 1321 against 3217 us)
-            const bool xw64 = g_voc_wino64 && g_voc_wino && v->winograd && !v->precision && co == 64 && rk >= 11 && v->c1w32[r][0] && v->c2w32[r][0] &&
+            // fp32, C = 64, k >= 7, chip-filling launches (round 4): the pair as two Winograd launches (conv_xlw_kernel<64>: one wave per workgroup with both
+            // m-tiles, eight workgroups per CU) instead of the fused pair kernel — 10 / 15 products per output pair instead of 14 / 22 outweigh xt's trip through HBM (k = 11: 2 x 1225 against 3217 us; k = 7: -0.3 ms per batch)
+            const bool xw64 = g_voc_wino64 && g_voc_wino && v->winograd && !v->precision && co == 64 && rk >= g_voc_wino64_k && v->c1w32[r][0] && v->c2w32[r][0] &&
                               (g_voc_wino == 2 || (long)((To + 63) / 64) * B >= 1024);
             if (xw64) pair_ok = false;
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
@@ -2615,7 +2616,8 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_pair128", &g_voc_pair128, 0, 1},     // 16-bit C = 128, k = 3 pair kernel (two images, one workgroup per CU; only when voc_pairw = 0)
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
-        {"voc_wino64", &g_voc_wino64, 0, 1},       // fp32 C = 64 stage, k = 11: two conv_xlw launches per pair (with voc_wino) instead of the pair kernel
+        {"voc_wino64_k", &g_voc_wino64_k, 3, 99},
+        {"voc_wino64", &g_voc_wino64, 0, 1},       // fp32 C = 64 stage, k >= voc_wino64_k: two conv_xlw launches per pair (with voc_wino) instead of the pair kernel
         {"voc_wino", &g_voc_wino, 0, 2},           // fp32 wide-stage convs in their Winograd form (NOT bitwise: the A/B twin of the vocoder option "winograd")
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl

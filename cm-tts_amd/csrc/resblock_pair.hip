@@ -821,7 +821,8 @@ extern "C" int cmtts_launch_conv_xlw(const ConvXlArgs* ap, void* stream_) {
         if (a.k == 7) return launch_xlw_dil<256, 7>(a, s);
         if (a.k == 11) return launch_xlw_dil<256, 11>(a, s);
     } else if (a.C == 64) {      // the C = 64 stage as two launches per pair (xt through HBM) where 2/3 of the MFMAs outweigh the two tensor passes the pair kernel saves
-        if (a.k == 11) return launch_xlw_dil<64, 11>(a, s);      // (k = 7: 2 x 1064 us against the pair kernel's 2099: not used)
+        if (a.k == 7) return launch_xlw_dil<64, 7>(a, s);
+        if (a.k == 11) return launch_xlw_dil<64, 11>(a, s);
     }
     return -2;
 }

@@ -7,6 +7,7 @@ from cmtts_amd.weights import synth_hifigan_state_dict
 voc = host.Generator(HifiGanConfig(), "cuda:0").load_state_dict(synth_hifigan_state_dict(HifiGanConfig(), seed=0))
 mel = torch.randn(32, 80, 512, device="cuda") * 1.5 - 4
 res = {}
+_lib.internal_set(b"voc_wino64_k", int(os.environ.get("K64", 11)))
 for rnd in range(3):
     for w64 in (0, 1):
         _lib.internal_set(b"voc_wino64", w64)
