@@ -61,6 +61,9 @@ def make_inputs(cfg, seed, device):
 PROFILE_STRIDE = 7
 
 
+REDUCE_DEVICE = "cuda"      # where the max-over-ranks of a timed region is reduced (the CPU rehearsal of tests/test_shard_gloo.py sets "cpu")
+
+
 def timed(fn, steps, warmup, world, before=None, flush=None):
     """`flush` completes whatever the last fn() left in flight (the async all-gather): it runs INSIDE the timed
     region, before the closing synchronize + barrier, so all K steps' work is counted."""
@@ -84,7 +87,7 @@ def timed(fn, steps, warmup, world, before=None, flush=None):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=REDUCE_DEVICE)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     return dt

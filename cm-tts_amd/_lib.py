@@ -205,6 +205,10 @@ def load():
         raise RuntimeError(f"{LIB_PATH} implements ABI revision {got}, this binding was written for {ABI_VERSION} "
                            "(include/cmtts_hip.h: CMTTS_ABI_VERSION): rebuild the library")
     _lib = lib
+    # measurement hook (tools/, A/B runs of bench.py): CMTTS_INTERNAL="persist_wino=1,voc_wino=0" flips csrc/internal_hooks.h switches at load
+    for kv in filter(None, os.environ.get("CMTTS_INTERNAL", "").split(",")):
+        k, v = kv.split("=")
+        internal_set(k.strip(), int(v))
     return lib
 
 

@@ -171,6 +171,26 @@ std::vector<float> to_wino_fragments(const std::vector<float>& p, int K, int M) 
     return f;
 }
 
+// The same transformed weights for the one-wave-per-SIMD stack (denoiser_persist4.hip): every wave reads ONE contiguous stream per layer,
+// [4 waves][2 passes][K/2 k-steps][2 m-tiles][64 lanes][4]: element tr of the fragment of (wave w, pass ps, k-step ks, i) at lane l is
+// transform tr of input channel 2 ks + (l >> 5), output row 32 ((2 w + ps) 2 + i) + (l & 31).  M = 512 only (16 m-tiles).
+constexpr int WINO4_PAD_STAGES = 8;   // ring stages of zero padding behind a layer's array (the last wave's ring runs past its stream's end)
+std::vector<float> to_wino4_fragments(const std::vector<float>& p, int K, int M) {
+    std::vector<float> f((size_t)4 * K * M + (size_t)WINO4_PAD_STAGES * 2 * 64 * 4, 0.0f);
+    const int NKS = K / 2;
+    for (int w = 0; w < 4; ++w)
+        for (int ps = 0; ps < 2; ++ps)
+            for (int ks = 0; ks < NKS; ++ks)
+                for (int i = 0; i < 2; ++i)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int mt = (2 * w + ps) * 2 + i, k = 2 * ks + (lane >> 5), mrow = 32 * mt + (lane & 31);
+                        const double g0 = p[((size_t)0 * K + k) * M + mrow], g1 = p[((size_t)1 * K + k) * M + mrow], g2 = p[((size_t)2 * K + k) * M + mrow];
+                        float* o = &f[((((((size_t)w * 2 + ps) * NKS + ks) * 2 + i) * 64) + lane) * 4];
+                        o[0] = (float)g0; o[1] = (float)(0.5 * (g0 + g1 + g2)); o[2] = (float)(0.5 * (g0 - g1 + g2)); o[3] = (float)g2;
+                    }
+    return f;
+}
+
 // Winograd form of a k-tap conv for conv_xlw_kernel (resblock_pair.h: WinoTab<KT>): the transformed weights of every table entry (formed in
 // double, rounded once) as A fragments in the kernel's iteration order [K/16 chunks][entries][2 halves][M/32][64 lanes][4].
 template <int KT>
@@ -365,7 +385,9 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
-int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form)
+int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form): 1 = the 8-wave
+                                // instances of denoiser_persist.hip (default), 2 = the one-wave-per-SIMD stack of denoiser_persist4.hip (same bits as 1;
+                                // measured 4-10 % slower: profiles/r05_persist4.md)
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
@@ -389,7 +411,18 @@ int g_split_resblock = 1;       // fp32 residual block as two launches over 4x t
 int g_cond_gemm16 = 1;          // bf16 / fp16 / fp16x3 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
-unsigned* g_tmo_host = nullptr;  // pinned, device-visible: set by the persistent kernel when a neighbour wait expires
+unsigned* g_tmo_host = nullptr;  // pinned, device-visible: 1 = a neighbour wait of the persistent kernel expired, 2 = a denoiser evaluation wrote a
+                                 // non-finite mel value (persist_tail.h, mel_post_kernel: the sampler's post-scaling sees every output element)
+// Reads and clears the device flag word: what cmtts_poll_error() reports and what every denoiser call checks before it launches.
+int check_device_flag() {
+    if (!g_tmo_host) return 0;
+    const unsigned v = *(volatile unsigned*)g_tmo_host;
+    if (!v) return 0;
+    *(volatile unsigned*)g_tmo_host = 0;
+    if (v == 1) return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out (the affected utterances' mel is NaN)");
+    return fail(CMTTS_E_HIP, "denoiser: non-finite mel values in an earlier evaluation (fp16 / fp16x3 operands overflow at 65504: "
+                             "use bf16 or fp32 for this model / input scale; fp32: non-finite weights or inputs)");
+}
 
 // Persistent launches need ALL of their workgroups resident (one per CU): two grids that together exceed the CU count
 // would split the chip and wait for each other's missing neighbours.  Launches of this process on different streams
@@ -527,7 +560,8 @@ struct Predictor {
 struct ResLayer {
     PackedConv cond, conv3, outp;
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
-    float* w3w = nullptr;                   // Winograd F(2,3) transformed conv weights as A fragments (persistent denoiser, WINO instances)
+    float* w3w = nullptr;                   // Winograd F(2,3) transformed conv weights as A fragments (persistent denoiser, 8-wave WINO instances)
+    float* w3w4 = nullptr;                  // the same as per-wave streams for the one-wave-per-SIMD stack (denoiser_persist4.hip)
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
     void *w3f16[3] = {nullptr, nullptr, nullptr}, *wof16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies
 };
@@ -834,6 +868,7 @@ int finalize_model(cmtts_model* m) {
             CHK(pack_conv(scratch, *w3, b3, &perm16, &tmp, &hp));
             CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
             if (C == 256) CHK(al.upload(to_wino_fragments(hp, C, 2 * C), &m->res[l].w3w));
+            if (C == 256) CHK(al.upload(to_wino4_fragments(hp, C, 2 * C), &m->res[l].w3w4));
             for (int mode = 1; mode <= 2; ++mode) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
                 CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].w3f16[mode - 1]));
@@ -1281,10 +1316,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
                   const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
                   SideStream* pending = nullptr, float t_host = NAN,    // pending: a side branch (the conditioner GEMM) to join before the layers
                   const CondFactors* cfk = nullptr, bool* cp_ready = nullptr) {   // cfk: w.cp was NOT filled — the persistent kernel gathers the factors (FACT)
-    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
-        *(volatile unsigned*)g_tmo_host = 0;
-        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
-    }
+    CHK(check_device_flag());
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
@@ -1318,9 +1350,10 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.out = post.out;
         }
         pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.pst;
+        if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;      // one wave per SIMD (denoiser_persist4.hip)
         pa.xst = w.pst;
         for (int l = 0; l < NL; ++l) {
-            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino ? m->res[l].w3w : m->res[l].w3f);
+            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f);
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
@@ -1404,7 +1437,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         ConvArgs b = conv_args(m->out_proj, halt, T, T, cs, w.hin, T, (long)M * T, T);
         CHK(launch(b, EPI_PLAIN, B, s));
     }
-    k_mel_post(w.hin, post.xold, post.noise, post.c_out, post.c_skip, post.nstd, post.out, B, T, M, s);
+    k_mel_post(w.hin, post.xold, post.noise, post.c_out, post.c_skip, post.nstd, post.out, B, T, M, g_tmo_host, s);
     return 0;
 }
 
@@ -1782,7 +1815,9 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     // the phoneme-level factor first: it fills the chip for ~40 us while the main stream runs its short, latency-bound launches
     // (mel2ph, length regulator, the 256 -> 128 projection, positions); behind the statistics MLP it ran beside the frame-level
     // k = 5 convs instead and both took twice as long (profiles/r04_text_side.md)
-    if (cond_p1) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
+    // (a model without the pitch-table factor — odd res_layers at C = 256, hidden != 256, a failed finalize-time GEMM — leaves cond_p1 untouched:
+    // CondFactors::usable() is false for it and the sampler takes the dense GEMM, as it did before the factors existed)
+    if (cond_p1 && m->cond_p2) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
     k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
     k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
     k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
@@ -1994,10 +2029,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         }
         return 0;
     }
-    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
-        *(volatile unsigned*)g_tmo_host = 0;
-        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out in an earlier launch (results invalid)");
-    }
+    CHK(check_device_flag());
     // ---- which utterances share the persistent launch.  Every workgroup of that launch must be resident, so a shard with more active
     // tiles than CUs needs a second ROUND of 20 layers (2.7 ms per evaluation whatever its size).  When leaving out a few SMALL
     // utterances (<= 64 active tiles together: the range where the per-layer / split kernels take < 1 ms per evaluation,
@@ -2098,8 +2130,9 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     pa.wino = g_persist_wino && m->winograd && m->res[0].w3w;
     for (int g = 0; g < n_groups && pa.wino; ++g)
         if (keep[g] > 0 && !ws[g].pst) pa.wino = 0;
+    if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;
     for (int l = 0; l < NL; ++l) {
-        pa.W3f[l] = pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
+        pa.W3f[l] = pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
     if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.ld2 = c.pitch_bins; }
@@ -2602,7 +2635,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
-        {"persist_wino", &g_persist_wino, 0, 1},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
+        {"persist_wino", &g_persist_wino, 0, 2},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
         {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
         {"ffn_fused", &g_ffn_fused, 0, 1},         // FFN linear's partial products inside the FFN conv's launch
@@ -2653,13 +2686,7 @@ int cmtts_internal_cond_factored(cmtts_model* m, const float* p1, int p1_ld, int
     return cond_factored(m, w, cf, B, T, (hipStream_t)stream);
 }
 
-int cmtts_poll_error(void) {
-    if (g_tmo_host && *(volatile unsigned*)g_tmo_host) {
-        *(volatile unsigned*)g_tmo_host = 0;
-        return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out (the affected utterances' mel is NaN)");
-    }
-    return 0;
-}
+int cmtts_poll_error(void) { return check_device_flag(); }
 
 int cmtts_set_persistent_denoiser(int mode) {
     const int prev = g_persist;

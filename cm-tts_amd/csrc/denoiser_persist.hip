@@ -655,13 +655,17 @@ long long* g_pdbg = nullptr;
 // (the all-gather is completed on the stream before the next persistent launch), and bounded waits + NaN poisoning remain.
 int g_coop = -1;
 int g_process_group = 0;
-int g_validated_wg[8] = {};          // per kernel instance: the LARGEST grid (workgroups) whose co-residency the runtime has confirmed
+// per kernel instance: the LARGEST grid (workgroups) whose co-residency the runtime has confirmed.  Instances differ in registers and
+// threads, so every one has its own record: fp32 uniform 0..5 = (direct | 8-wave Winograd | one wave per SIMD) x (cp | factors),
+// fp32 ragged 8..13 likewise, the 16-bit modes 16 + MODE (shared slots let one kernel's validation vouch for another)
+constexpr int N_VARIANTS = 24;
+int g_validated_wg[N_VARIANTS] = {};
 
 }  // namespace
 
 extern "C" int cmtts_persist_set_cooperative(int on) { const int p = g_coop; if (on >= -1 && on <= 1) g_coop = on; return p; }
 extern "C" int cmtts_persist_note_process_group(int on) { const int p = g_process_group; if (on == 0 || on == 1) g_process_group = on; return p; }
-// Should this launch of `variant` (0 fp32, 1..3 the 16-bit modes, 4 the fp32 ragged instance) with grid (gx, gy) be cooperative?
+// Should this launch of kernel instance `variant` (the table above) with grid (gx, gy) be cooperative?
 // Co-residency is a property of (kernel instance, LDS, workgroup COUNT): every grid no larger than one the runtime has accepted is
 // resident too, so only the maximum is remembered (a ring of exact shapes made most ragged launches — n_wg changes
 // with every trim — cooperative again, +24 % per step with RCCL loaded).
@@ -669,12 +673,13 @@ extern "C" int cmtts_persist_cooperative(int variant, int gx, int gy) {
     if (g_coop >= 0) return g_coop;
     if (!g_process_group) return 0;
     const long wg = (long)gx * (gy > 0 ? gy : 1);
-    return wg > g_validated_wg[variant & 7] ? 1 : 0;
+    if (variant < 0 || variant >= N_VARIANTS) return 1;
+    return wg > g_validated_wg[variant] ? 1 : 0;
 }
 // Record a grid only AFTER hipLaunchCooperativeKernel has returned hipSuccess for it.
 extern "C" void cmtts_persist_validated(int variant, int gx, int gy) {
     const long wg = (long)gx * (gy > 0 ? gy : 1);
-    if (wg > g_validated_wg[variant & 7]) g_validated_wg[variant & 7] = (int)wg;
+    if (variant >= 0 && variant < N_VARIANTS && wg > g_validated_wg[variant]) g_validated_wg[variant] = (int)wg;
 }
 
 extern "C" void cmtts_persist_set_debug(long long* dbg) { g_pdbg = dbg; }
@@ -721,7 +726,10 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
-    if (a.wino && !a.xst) return -2;          // the Winograd instances keep the residual stream in `xst` between layers
+    if (a.wino == 1 && !a.xst) return -2;     // the 8-wave Winograd instances keep the residual stream in `xst` between layers
+    const bool p4 = a.wino == 2;              // one wave per SIMD (denoiser_persist4.hip): 256 threads, state in registers
+    if (p4 && a.tail && a.n_mels > 128) return -2;
+    const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
     // instance table: [dbg][fact][wino]
     static const void* const kfns[2][2][2] = {
         {{reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, true>)},
@@ -732,9 +740,11 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
         for (int d = 0; d < 2; ++d)
-            for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < 2; ++f) {
                 for (int wn = 0; wn < 2; ++wn)
                     if (hipFuncSetAttribute(kfns[d][f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+                if (hipFuncSetAttribute(cmtts_persist4_kernel(d, 0, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+            }
         attr_set = true;
     }
     if (a.fact && (!a.p1 || !a.p2 || !a.mel2ph || !a.pidx || a.ldp < 1 || a.ld2 < 1)) return -2;
@@ -767,13 +777,13 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        const void* kfn = kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][a.wino ? 1 : 0];
+        const void* kfn = p4 ? cmtts_persist4_kernel(a.dbg ? 1 : 0, 0, a.fact ? 1 : 0) : kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][a.wino ? 1 : 0];
         void* params[] = {(void*)&c};
-        const int variant = (a.fact ? 5 : 0) + (a.wino ? 2 : 0);        // 0 plain, 2 wino, 5 fact, 7 fact + wino (4 / 6: the ragged instances)
+        const int variant = (p4 ? 2 : a.wino ? 1 : 0) * 2 + (a.fact ? 1 : 0);        // one record per kernel instance (persist_args.h)
         if (!a.dbg && cmtts_persist_cooperative(variant, tiles, nb)) {
-            if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+            if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;
             cmtts_persist_validated(variant, tiles, nb);
-        } else if (hipLaunchKernel(kfn, dim3(tiles, nb), dim3(64 * NW), params, lds, stream) != hipSuccess) return -3;
+        } else if (hipLaunchKernel(kfn, dim3(tiles, nb), dim3(threads), params, lds, stream) != hipSuccess) return -3;
         if (hipGetLastError() != hipSuccess) return -3;
     }
     return 0;
@@ -794,9 +804,11 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
     if (!attr_set) {
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f) {
             for (int wn = 0; wn < 2; ++wn)
                 if (hipFuncSetAttribute(kfns[f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+            if (hipFuncSetAttribute(cmtts_persist4_kernel(0, 1, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+        }
         attr_set = true;
     }
     if (a.fact) {      // every group brings its factors, or none does
@@ -804,16 +816,18 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && (!a.grp[g].p1 || !a.grp[g].mel2ph || !a.grp[g].pidx || a.grp[g].ldp < 1)) return -2;
     }
-    if (a.wino)        // the Winograd instances keep the skip sum / the residual stream of every group in its `skip` / `xst` buffers
+    if (a.wino == 1)   // the 8-wave Winograd instances keep the residual stream of every group in its `xst` buffer
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && !a.grp[g].xst) return -2;
-    const void* kfn = kfns[a.fact ? 1 : 0][a.wino ? 1 : 0];
-    // co-residency depends on the workgroup count and on (registers, LDS), which the four instances share: one record for all
-    const int variant = a.fact ? 6 : 4;
+    const bool p4 = a.wino == 2;
+    if (p4 && a.tail && a.n_mels > 128) return -2;
+    const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
+    const void* kfn = p4 ? cmtts_persist4_kernel(0, 1, a.fact ? 1 : 0) : kfns[a.fact ? 1 : 0][a.wino ? 1 : 0];
+    const int variant = 8 + (p4 ? 2 : a.wino ? 1 : 0) * 2 + (a.fact ? 1 : 0);      // one record per kernel instance
     void* params[] = {(void*)a_in};
     if (cmtts_persist_cooperative(variant, a.n_wg, -1)) {
-        if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
+        if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;
         cmtts_persist_validated(variant, a.n_wg, -1);
-    } else if (hipLaunchKernel(kfn, dim3(a.n_wg), dim3(64 * NW), params, lds, stream) != hipSuccess) return -3;
+    } else if (hipLaunchKernel(kfn, dim3(a.n_wg), dim3(threads), params, lds, stream) != hipSuccess) return -3;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

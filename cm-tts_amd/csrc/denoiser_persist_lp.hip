@@ -445,11 +445,11 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        if (cmtts_persist_cooperative(MODE, tiles, nb)) {
+        if (cmtts_persist_cooperative(16 + MODE, tiles, nb)) {
             void* params[] = {(void*)&c};
             if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>), dim3(tiles, nb),
                                            dim3(64 * NW), params, (unsigned)lds, stream) != hipSuccess) return -3;
-            cmtts_persist_validated(MODE, tiles, nb);
+            cmtts_persist_validated(16 + MODE, tiles, nb);
         } else hipLaunchKernelGGL(denoiser_persist_lp_kernel<MODE>, dim3(tiles, nb), dim3(64 * NW), lds, stream, c);
         if (hipGetLastError() != hipSuccess) return -3;
     }

@@ -53,7 +53,7 @@ void k_lr_gather_add(const float* out1, const int64_t* mel2ph, int ldl, const in
                      hipStream_t s);
 void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, int B, int T, int M, hipStream_t s);
 void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
-                float nstd, float* out, int B, int T, int M, hipStream_t s);
+                float nstd, float* out, int B, int T, int M, unsigned* flag, hipStream_t s);
 void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s);
 extern int g_post_v4;            // conv_post with 16-byte loads (kernels.hip; same bits; internal switch "post_v4")
 void k_conv_post(const float* x, const float* w, const float* bias, float pre_div, float slope, float* wav, int B,

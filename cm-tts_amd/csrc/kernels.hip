@@ -600,8 +600,10 @@ __global__ void mel_prep_kernel(const float* x, const float* scale_b, float scal
 
 // ---- out[b][t][m] = c_out*F[b][m][t] + c_skip*xold[b][t][m] (+ noise*nstd)
 // (karras_diffusion.py:406 and the re-noising of stochastic_iterative_sampler :852)
+// flag (pinned host word, may be null): set to 2 when a non-finite value is written — 16-bit operands that left the fp16 range, non-finite
+// weights / inputs — unless an earlier error is still pending there (cmtts_poll_error)
 __global__ void mel_post_kernel(const float* F, const float* xold, const float* noise, float c_out, float c_skip,
-                                float nstd, float* out, int T, int M) {
+                                float nstd, float* out, int T, int M, unsigned* flag) {
     const int m = threadIdx.x;
     const int t = blockIdx.x * blockDim.y + threadIdx.y;
     const int b = blockIdx.y;
@@ -611,6 +613,7 @@ __global__ void mel_post_kernel(const float* F, const float* xold, const float* 
     if (xold) v += c_skip * xold[o];
     if (noise) v += noise[o] * nstd * 0.85f;     // randn_like(x) * sqrt(next_t^2 - t_min^2) * 0.85
     out[o] = v;
+    if (flag && !(fabsf(v) <= 3.402823466e38f) && *(volatile unsigned*)flag == 0u) *(volatile unsigned*)flag = 2u;
 }
 
 // ---- DiffusionEmbedding (model/blocks.py:633-640): [sin(t*w) | cos(t*w)]
@@ -868,11 +871,11 @@ void k_mel_prep(const float* x, const float* scale_b, float scale, float* hin, i
     hipLaunchKernelGGL(mel_prep_kernel, dim3(cdiv(T, 256), M, B), dim3(256), 0, s, x, scale_b, scale, hin, T, M);
 }
 void k_mel_post(const float* F, const float* xold, const float* noise, float c_out, float c_skip, float nstd,
-                float* out, int B, int T, int M, hipStream_t s) {
+                float* out, int B, int T, int M, unsigned* flag, hipStream_t s) {
     // blockDim = (M rounded to 16 | 3 rows): 80 mels -> (80, 3) = 240 threads
     const int ty = 256 / M > 0 ? 256 / M : 1;
     hipLaunchKernelGGL(mel_post_kernel, dim3(cdiv(T, ty), B), dim3(M, ty), 0, s, F, xold, noise, c_out, c_skip, nstd,
-                       out, T, M);
+                       out, T, M, flag);
 }
 void k_diff_embed(const float* t, const float* omega, float* emb, int B, int C, hipStream_t s) {
     hipLaunchKernelGGL(diff_embed_kernel, dim3(B), dim3(C), 0, s, t, omega, emb, C);

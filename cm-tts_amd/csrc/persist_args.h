@@ -65,7 +65,8 @@ struct PersistArgs {
     const long long* mel2ph;    // [B][T] int64: 1-based phoneme of a frame, 0 = padding
     const long long* pidx;      // [B][T] int64: pitch bucket of a frame
     int ldp, Lph, ld2;
-    int wino;             // fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
+    int wino;             // 2 (round 5): the one-wave-per-SIMD stack of denoiser_persist4.hip — W3f = per-wave streams (cmtts_api.hip: to_wino4_fragments),
+                          // x and the skip sum stay in registers, `xst` unused.  1: fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
     float* xst;           // WINO: [B][tiles][16384] kernel-private state — the residual stream x of every 64-frame tile between layers
                           // (cmtts_persist_state_floats(B, T) floats)
@@ -104,7 +105,10 @@ long long* cmtts_persist_get_debug(void);
 // launch of every (variant, grid) is cooperative — the runtime validates co-residency — and later ones are plain (denoiser_persist.hip).
 int cmtts_persist_set_cooperative(int on);
 void cmtts_persist_validated(int variant, int gx, int gy);    // the runtime accepted a cooperative launch of this grid
-int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant 0 = fp32, 1..3 = 16-bit modes)
+int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant = kernel instance, denoiser_persist.hip)
+// one-wave-per-SIMD Winograd stack (denoiser_persist4.hip; PersistArgs.wino == 2): kernel instance and its workgroup size
+const void* cmtts_persist4_kernel(int dbg, int ragged, int fact);
+int cmtts_persist4_threads(void);
 int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
 }

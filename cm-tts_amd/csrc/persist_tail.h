@@ -1,9 +1,9 @@
 // Tail of the persistent denoiser kernels (denoiser_persist.hip, denoiser_persist_lp.hip): the skip head of
 // Denoiser.forward (model/modules.py:634-637: sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection) and
 // the sampler's post-scaling (karras_diffusion.py:406,852), in fp32, with the arithmetic of the generic conv epilogues
-// and of mel_post_kernel in the same order (bitwise equal to the separate launches).  Every wave passes its 32 rows x
-// 64 frames of the skip sum (MFMA accumulator layout); u_lds / z_lds are two [256][PT_LD] fp32 LDS buffers that no
-// wave reads any more.
+// and of mel_post_kernel in the same order (bitwise equal to the separate launches).  Every wave passes its TPW x 32 rows x
+// 64 frames of the skip sum (MFMA accumulator layout, rows (w * TPW + i) * 32 ..; TPW = 1 for the 8-wave kernels, 2 for the 4-wave
+// kernel of denoiser_persist4.hip); u_lds / z_lds are two [256][PT_LD] fp32 LDS buffers that no wave reads any more.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "persist_args.h"
@@ -22,11 +22,12 @@ __device__ __forceinline__ int pt_row(int r, int lane) { return (r & 3) + 8 * (r
 
 // xold / noise / out: the utterance batch's [B][T][n_mels] tensors (a.xold / a.noise / a.out, or a ragged group's); Tc: frames at and
 // beyond Tc are not stored (Tc = T unless the utterance is trimmed)
-__device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z_lds, const f32x16 (&skip)[PT_NT], int w, int lane,
+// skip = TPW x PT_NT accumulator tiles, [i * PT_NT + j]
+template <int TPW = 1>
+__device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z_lds, const f32x16* skip, int w, int lane,
                                     int b, int t0, int T, const float* xold, const float* noise, float* out, int Tc) {
     constexpr int C = PT_C, NT = PT_NT, U_LD = PT_LD, RING = PT_RING;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int mrow0 = w * 32;
     auto opaque = [](int v) { return pt_opaque(v); };
     auto acc_row = [](int r, int ln) { return pt_row(r, ln); };
     auto ldg = [](const float* p, unsigned i) { return pt_ldg(p, i); };
@@ -35,9 +36,12 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
     {
         const int ln = opaque(lane), c31 = ln & 31;
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < TPW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u_lds[(mrow0 + acc_row(r, ln)) * U_LD + j * 32 + c31] = skip[j][r] / a.skip_div;
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u_lds[((w * TPW + i) * 32 + acc_row(r, ln)) * U_LD + j * 32 + c31] = skip[i * NT + j][r] / a.skip_div;
     }
     __syncthreads();   // (A) skip tile staged; every wave has left the last output projection (z is free)
     constexpr int NGC = C / 8;
@@ -79,8 +83,10 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
             }
         }
     };
-    gemm_tile(a.Wsf, C / 32, w, u_lds);          // skip_projection rows [32w, +32)
-    {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int mrow0 = (w * TPW + i) * 32;
+        gemm_tile(a.Wsf, C / 32, w * TPW + i, u_lds);          // skip_projection rows [mrow0, +32)
         const int ln = opaque(lane), c31 = ln & 31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -96,8 +102,9 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
         }
     }
     __syncthreads();   // (B) relu(skip_projection) complete
-    const int otiles = (a.n_mels + 31) / 32;
+    const int otiles = (a.n_mels + 31) / 32;     // <= 4 (n_mels <= 128): one tile per wave of either layout
     if (w < otiles) {
+        const int mrow0 = w * 32;
         gemm_tile(a.Wpf, otiles, w, z_lds);      // output_projection rows [32w, +32) of n_mels
         const int ln = opaque(lane), c31 = ln & 31;
         const int M = a.n_mels;
@@ -115,6 +122,9 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
                     if (xold) v = __builtin_fmaf(a.c_skip, xold[o], v);
                     if (noise) v = __builtin_fmaf(noise[o] * a.nstd, 0.85f, v);
                     out[o] = v;
+                    // a non-finite mel value (16-bit operands beyond the fp16 range, non-finite weights / inputs) is reported, not just returned:
+                    // code 2 in the pinned word cmtts_poll_error() reads, unless an earlier error is still pending there
+                    if (a.tmo && !(fabsf(v) <= 3.402823466e38f) && *(volatile unsigned*)a.tmo == 0u) *(volatile unsigned*)a.tmo = 2u;
                 }
             }
         }

@@ -120,7 +120,10 @@ WINO_TOL = 3e-5
 @pytest.fixture(params=["direct", "winograd"])
 def conv_form(request):
     from cmtts_amd import _lib
-    prev = _lib.internal_set("persist_wino", 0 if request.param == "direct" else 1)
+    import os
+    # "winograd" = the default Winograd stack (1: the 8-wave instances; CMTTS_TEST_WINO=2 runs the one-wave-per-SIMD stack of
+    # denoiser_persist4.hip through every conv_form test)
+    prev = _lib.internal_set("persist_wino", 0 if request.param == "direct" else int(os.environ.get("CMTTS_TEST_WINO", "1")))
     try:
         yield request.param
     finally:

@@ -202,6 +202,113 @@ def test_precision_one_residual_layer(variant):
             check_ladder(f"one residual layer {variant}", ref64, hip["fp32"], hip[dt], orc, 2, dt)
 
 
+def _stress_case(case, cfg, seed=31):
+    """Weights / inputs far from the fan-in-scaled Gaussians every other test uses (VERDICT r04 #5b)."""
+    sd = synth_cmtts_state_dict(cfg, seed=seed)
+    rs = np.random.RandomState(seed)
+    B, T = 2, 130
+    x = rs.standard_normal(size=(B, 1, T, cfg.n_mels)).astype(np.float32)
+    cond = rs.standard_normal(size=(B, T, cfg.hidden)).astype(np.float32)
+    if case == "gain8_lognormal":       # conv / projection rows x8 and log-normal gains (sigma 1): heavy-tailed row norms, saturated gates
+        for l in range(cfg.res_layers):
+            for name, g0 in ((f"net.residual_layers.{l}.conv_layer.conv.weight", 8.0), (f"net.residual_layers.{l}.output_projection.conv.weight", 1.0)):
+                w = np.asarray(sd[name], np.float32)
+                gain = (g0 * np.exp(rs.standard_normal(size=(w.shape[0], 1, 1)))).astype(np.float32)
+                sd[name] = (w * gain).astype(np.float32)
+    elif case == "dc_offset":           # the conv input carries a DC component of 10x its variation: what F(2,3)'s neighbour differences cancel
+        cond = (cond + 10.0).astype(np.float32)
+        x = (x + 10.0).astype(np.float32)
+    elif case == "near_fp16_max":       # conv inputs up to ~5e4 (fp16 overflows at 65504)
+        cond = (cond * 1.0e4).astype(np.float32)
+    elif case == "beyond_fp16_max":
+        cond = (cond * 1.0e5).astype(np.float32)
+    return sd, x, cond, B, T
+
+
+@pytest.mark.parametrize("case", ["gain8_lognormal", "dc_offset", "near_fp16_max"])
+def test_winograd_and_fp16x3_stress_statistics(case):
+    """The Winograd stack and fp16x3 are defaults / options whose error bounds were measured on ONE weight distribution.  Here: x8 and
+    log-normal row gains, a DC offset of 10 sigma on the conv input, activations close to the fp16 range limit — one evaluation of a
+    4-layer denoiser, the direct stack, the Winograd stack and fp16x3 against the float64 oracle.  Pinned: the Winograd form stays within
+    4x of the direct form's own distance from float64 (plus 2e-6 of the output scale: its transforms add a few roundings of the INPUT,
+    which a DC offset makes larger than the variation it carries), fp16x3 within 4x of it plus its 22-bit operand model."""
+    import dataclasses
+    host = _host()
+    lib = _lib.load()
+    cfg = dataclasses.replace(get_config("VCTK"), res_layers=4)
+    sd, x, cond, B, T = _stress_case(case, cfg)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(5)
+    spk = rs.standard_normal(size=(B, cfg.hidden)).astype(np.float32)
+    t = np.full((B,), 1095.5, np.float32)
+    args = (torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(cond), torch.from_numpy(spk))
+    out = {}
+    prev = lib.cmtts_set_persistent_denoiser(2)
+    prev_w = _lib.internal_set("persist_wino", 0)
+    try:
+        out["direct"] = _np(model.net(*args))
+        for wn, name in ((1, "winograd"), (2, "winograd4")):
+            _lib.internal_set("persist_wino", wn)
+            out[name] = _np(model.net(*args))
+        model.set_precision("fp16x3")
+        out["fp16x3"] = _np(model.net(*args))
+    finally:
+        model.set_precision("fp32")
+        _lib.internal_set("persist_wino", prev_w)
+        lib.cmtts_set_persistent_denoiser(prev)
+    host.synchronize()
+    with O.precision("f64"):
+        ref = O.denoiser_forward(sd, cfg, x, t, cond, spk)
+        with O.operands16("fp16x3"):
+            o3 = O.denoiser_forward(sd, cfg, x, t, cond, spk)
+    scale = float(np.abs(ref).max())
+    e = {k: float(np.abs(v - ref).max()) for k, v in out.items()}
+    e3o = float(np.abs(o3 - ref).max())
+    report(f"DTYPE_ERR stress {case}: output scale {scale:.3g}; vs f64 max|d| direct {e['direct']:.2e}, winograd {e['winograd']:.2e}, fp16x3 {e['fp16x3']:.2e} "
+           f"(22-bit-operand oracle {e3o:.2e}); winograd vs direct {np.abs(out['winograd'] - out['direct']).max():.2e}")
+    for v in out.values():
+        assert np.isfinite(v).all()
+    assert np.array_equal(out["winograd"], out["winograd4"])
+    assert not np.array_equal(out["winograd"], out["direct"])
+    assert e["direct"] <= 1e-5 * max(scale, 1.0), (e, scale)
+    assert e["winograd"] <= 4 * e["direct"] + 2e-6 * scale, (e, scale)
+    assert e["fp16x3"] <= 4 * e["direct"] + 4 * e3o + 2e-6 * scale, (e, e3o, scale)
+
+
+def test_fp16_overflow_is_reported():
+    """Activations beyond the fp16 range (|conv input| > 65504): the fp16 and fp16x3 stacks cannot represent their operands.  The result is
+    non-finite and the library SAYS so — the sampler's post-scaling (persist_tail.h / mel_post_kernel) raises the device flag that
+    cmtts_poll_error() / the next denoiser call turn into an error — while fp32 and bf16 (8 exponent bits) take the same input."""
+    import dataclasses
+    host = _host()
+    lib = _lib.load()
+    cfg = dataclasses.replace(get_config("VCTK"), res_layers=4)
+    sd, x, cond, B, T = _stress_case("beyond_fp16_max", cfg)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    spk = torch.from_numpy(np.random.RandomState(5).standard_normal(size=(B, cfg.hidden)).astype(np.float32)).to(DEV)
+    cond_ct = torch.from_numpy(np.ascontiguousarray(cond.transpose(0, 2, 1))).to(DEV)
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=torch.Generator().manual_seed(2)).to(DEV)
+    for forced in (0, 2):                              # the per-layer kernels + mel_post, the persistent stack + its tail
+        prev = lib.cmtts_set_persistent_denoiser(forced)
+        try:
+            for dt, ok in (("fp32", True), ("bf16", True), ("fp16", False), ("fp16x3", False)):
+                if dt == "fp16x3" and forced == 0:
+                    continue                           # fp16x3 exists as the persistent stack only
+                model.set_precision(dt)
+                mel = host.sample_with_cond(model, cond_ct, spk, 1, noise)
+                if ok:
+                    host.synchronize()                 # polls: would raise
+                    assert torch.isfinite(mel).all(), dt
+                else:
+                    with pytest.raises(RuntimeError, match="non-finite mel"):
+                        host.synchronize()
+                    assert not torch.isfinite(mel).all(), dt
+        finally:
+            model.set_precision("fp32")
+            lib.cmtts_set_persistent_denoiser(prev)
+    assert lib.cmtts_poll_error() == 0                 # the flag was cleared by the report
+
+
 @pytest.mark.parametrize("variant", ["LJSpeech", "VCTK"])
 def test_precision_text16_encoder(golden_models, variant):
     """The opt-in 16-bit text side (cmtts_model_set_option "text16", bf16 / fp16 models): the four weight contractions of every FFT block (in- / out-projection,

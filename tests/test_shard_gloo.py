@@ -157,3 +157,191 @@ def test_bucketed_shard_plan_world2():
         for i, m in enumerate(mels):
             ref, n = _fake_synth(i, shard.frame_bucket(FRAMES[i]))
             assert m.shape == (n, 80) and np.array_equal(m, ref[:n].numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] at its own size: 256 ragged utterances over 8 ranks, and bench.py's N-GPU control flow
+
+
+def _cfg3_lengths(world=8, per_bucket=8, dur=6):
+    """bench.ragged_groups' recipe: per static frame bucket, per_bucket x world utterances, lengths ~ U[0.5, 1] x bucket that stay in
+    THEIR bucket, durations forced to `dur` frames per phoneme."""
+    rs = np.random.RandomState(40)
+    frames = []
+    for bi, bucket in enumerate(shard.FRAME_BUCKETS):
+        Lmax = bucket // dur
+        prev = shard.FRAME_BUCKETS[bi - 1] // dur if bi else 0
+        ln = np.maximum((rs.uniform(0.5, 1.0, size=per_bucket * world) * Lmax).astype(np.int64), prev + 1)
+        frames += [int(v) * dur for v in ln]
+    return frames
+
+
+def _mel_of(idx, n, bucket, M):
+    """Deterministic stand-in for utterance idx's mel: distinct per (utterance, frame, mel bin), zero beyond its length."""
+    mel = torch.zeros(bucket, M)
+    mel[:n] = (idx * 4099 % 9973) + torch.arange(n, dtype=torch.float32)[:, None] * 0.25 + torch.arange(M, dtype=torch.float32)[None, :] / 128
+    return mel
+
+
+def _worker_cfg3(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _cfg3_lengths(world)
+    plan = shard.plan_shards(frames, world)
+    M = 80
+    local = {}
+    for bucket, ranks in plan.items():
+        mine = ranks[rank]
+        assert len(mine) == 8 and all(i >= 0 for i in mine)          # 32 per rank in four buckets, no filler rows at this size
+        mels = torch.stack([_mel_of(i, frames[i], bucket, M) for i in mine])
+        local[bucket] = (mels, torch.tensor([frames[i] for i in mine], dtype=torch.int64))
+    assert sum(v[0].shape[0] for v in local.values()) == 32
+    got = shard.allgather_buckets(local)                                # ONE all-gather for the whole shard
+    for bucket, (mel, ln) in got.items():
+        assert mel.shape == (world * 8, bucket, M) and ln.shape == (world * 8,)
+        assert torch.equal(mel[rank * 8:(rank + 1) * 8], local[bucket][0])     # this rank's block sits at its rank offset
+    utts = shard.restore_order(got, plan, len(frames))
+    ok = all(u.shape == (frames[i], M) and torch.equal(u, _mel_of(i, frames[i], shard.frame_bucket(frames[i]), M)[:frames[i]])
+             for i, u in enumerate(utts))
+    nbytes = sum(v[0].numel() * 4 + v[1].numel() * 8 for v in local.values())
+    q.put((rank, ok, len(utts), nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_recipe_world8():
+    """256 utterances with bench.py's configs[3] length recipe -> plan_shards -> 32 per rank in four buckets of 8 (equal blocks, no
+    filler) -> allgather_buckets (one collective) -> restore_order: every rank ends with all 256 mels, trimmed, in the original
+    order, bit for bit.  10.5 MB per rank per gather at the full mel width — what DESIGN §5 prices the xGMI step on."""
+    world, port = 8, _free_port()
+    frames = _cfg3_lengths(world)
+    assert len(frames) == 256
+    plan = shard.plan_shards(frames, world)
+    assert sorted(plan) == [256, 512, 768, 1024]
+    assert all(len(ranks) == world and all(len(r) == 8 for r in ranks) for ranks in plan.values())
+    assert sorted(i for ranks in plan.values() for r in ranks for i in r) == list(range(256))
+    # dealt by length: the ranks' frame totals of a bucket differ by less than one utterance of that bucket
+    for bucket, ranks in plan.items():
+        tot = [sum(frames[i] for i in r) for r in ranks]
+        assert max(tot) - min(tot) <= bucket, (bucket, tot)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cfg3, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world)) and all(r[1] and r[2] == 256 for r in res)
+    assert all(r[3] == 8 * (256 + 512 + 768 + 1024) * 80 * 4 + 32 * 8 for r in res)          # 6.6 MB of mel per rank at this mix (10.5 MB when all 32 are 1024-frame rows)
+
+
+class _StandInHost:
+    """CPU stand-in for cmtts_amd.host with the calls bench.multi_gpu_extras makes (same shapes, dtypes and collation contract; values
+    are cheap deterministic functions of the inputs).  What the rehearsal pins is the CONTROL FLOW every rank must agree on: the order
+    of collectives and barriers, block shapes, the restored orders and the JSON fields — not kernels."""
+
+    class CMTotalTTS:
+        def __init__(self, cfg, device):
+            self.config, self.device = cfg, device
+
+        def load_state_dict(self, sd):
+            return self
+
+        def set_precision(self, mode):
+            self.mode = mode
+
+        def duration_pitch_energy_net(self, speakers, texts, lens, spker_embeds=None, max_mel_len=None):
+            B = texts.shape[0]
+            return {"cond_ct": torch.zeros(B, 4, max_mel_len), "speaker_emb": None, "mel_lens": lens * 6, "cond_factors": None}
+
+    class Generator:
+        def __init__(self, hcfg, device):
+            self.hop = 256
+
+        def load_state_dict(self, sd):
+            return self
+
+    class BucketedSynthesizer:
+        def __init__(self, model, n_steps, n_streams=4):
+            self.model = model
+
+        def run(self, coll):
+            outs = []
+            for (texts, lens, spk, noise, bucket) in coll:
+                n = texts.shape[0]
+                ln = lens * 6
+                mel = torch.zeros(n, bucket, 80)
+                for r in range(n):
+                    mel[r, :int(ln[r])] = float(texts[r, 0]) + torch.arange(int(ln[r]), dtype=torch.float32)[:, None] / 64
+                outs.append((mel, ln))
+            return outs
+
+    @staticmethod
+    def collate_groups(groups, device):
+        return list(groups)
+
+    @staticmethod
+    def sample_with_cond(model, cond_ct, spk, n_steps, nz, factors=None):
+        return nz[0, :, 0] * 0.0 + 1.0
+
+    @staticmethod
+    def vocoder_infer_device(mels, voc):
+        B, _, T = mels.shape
+        return (torch.arange(B * T * 256, dtype=torch.int64).reshape(B, T * 256) % 30011 - 15000).to(torch.int16)
+
+    @staticmethod
+    def check_async_error():
+        return None
+
+
+def _worker_extras(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import bench
+    torch.cuda.synchronize = lambda *a, **k: None           # this process has no GPU: the stand-ins compute on the host
+    bench.host = _StandInHost
+    bench.REDUCE_DEVICE = "cpu"
+    bench.synth_cmtts_state_dict = lambda *a, **k: {}
+    bench.synth_hifigan_state_dict = lambda *a, **k: {}
+    calls = []
+    state = {}
+
+    def step(n):
+        calls.append(n)
+
+    def timed_w(fn, k, warm):
+        return bench.timed(fn, k, warm, world)
+
+    args = argparse.Namespace(steps=4)
+    extras = bench.multi_gpu_extras(args, None, None, step, timed_w, state, frames_rank=100, audio_s=1.0, rank=rank, world=world,
+                                    device=torch.device("cpu"), gather=True)
+    q.put((rank, extras, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_control_flow_world2():
+    """bench.py's N-GPU extras (T = 1 / 2 rates, configs[3] through plan_shards + one all-gather of all buckets + restore_order,
+    configs[4] through the PCM all-gather) on two gloo ranks with a CPU stand-in synthesizer: the function's own assertions (restored
+    lengths = the plan's, every rank's block at its rank offset, PCM counts) hold on both ranks, both reach every barrier, and the
+    JSON fields are whole-job aggregates."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_extras, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, extras, calls in res:
+        assert set(calls) == {1, 2}
+        assert {"frames_per_s_T1", "rtf_mel_only_T1", "frames_per_s_T2", "configs3_ragged_bucketed", "configs4_end_to_end_wav"} <= set(extras)
+        c3, c4 = extras["configs3_ragged_bucketed"], extras["configs4_end_to_end_wav"]
+        assert c3["valid_frames"] == sum(_cfg3_lengths(world)) and c3["frames_per_s"] > 0
+        assert c4["frames_per_s"] > 0 and "16 utterances" in c4["workload"]
+    assert res[0][1]["configs3_ragged_bucketed"]["valid_frames"] == res[1][1]["configs3_ragged_bucketed"]["valid_frames"]

@@ -13,11 +13,13 @@ model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(synth_cmtts_state_dict(cf
 B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 512)
 x = torch.randn(B, 1, T, 80, device="cuda"); cond = torch.randn(B, T, 256, device="cuda"); t = torch.full((B,), 1095.5, device="cuda")
 lib = _lib.load()
-_lib.internal_set(b"persist_wino", int(os.environ.get("WINO", 0)))      # 1: the Winograd F(2,3) instances
+WINO = int(os.environ.get("WINO", 0))
+_lib.internal_set(b"persist_wino", WINO)      # 1: the 8-wave Winograd F(2,3) instances, 2: one wave per SIMD (denoiser_persist4.hip)
+_lib.load().cmtts_set_persistent_denoiser(2)
 for _ in range(2):
     model.net(x, t, cond, None)
 nblk = ((T + 63) // 64) * B
-NW = 8
+NW = 4 if WINO == 2 else 8
 buf = torch.zeros(nblk * NW * 8, dtype=torch.int64, device="cuda")
 lib.cmtts_set_debug_stamps(buf.data_ptr())
 model.net(x, t, cond, None)
@@ -27,7 +29,7 @@ s = buf.cpu().numpy().reshape(nblk, NW, 8).astype(np.float64)
 names = ["wait barrier(1)", "phase B loop", "gate", "wait barrier(3)", "phase C loop", "epilogue regs", "publish/u/halo"]
 d = np.diff(s, axis=2)       # [blk][wave][7]
 print(f"B={B} T={T}: cycle-counter ticks per phase of layer {cfg.res_layers // 2} (mean over workgroups)")
-for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-5", slice(4, 6)), ("waves 6-7 (also fetch the halo columns)", slice(6, 8))):
+for grp, sl in ((("waves 0-3", slice(0, 4)),) if NW == 4 else (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8)))):
     print(" ", grp)
     for i, n in enumerate(names):
         v = d[:, sl, i]
