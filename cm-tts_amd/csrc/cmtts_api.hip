@@ -412,7 +412,8 @@ int g_cond_gemm16 = 1;          // bf16 / fp16 / fp16x3 models: conditioner GEMM
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: 1 = a neighbour wait of the persistent kernel expired, 2 = a denoiser evaluation wrote a
-                                 // non-finite mel value (persist_tail.h, mel_post_kernel: the sampler's post-scaling sees every output element)
+                                 // non-finite mel value (persist_tail.h, mel_post_kernel: the sampler's post-scaling sees every output element), 3 = a conv
+                                 // input of the fp16 / fp16x3 residual blocks left the fp16 range (denoiser_persist_lp.hip, resblock_fused_lp.hip)
 // Reads and clears the device flag word: what cmtts_poll_error() reports and what every denoiser call checks before it launches.
 int check_device_flag() {
     if (!g_tmo_host) return 0;
@@ -420,6 +421,8 @@ int check_device_flag() {
     if (!v) return 0;
     *(volatile unsigned*)g_tmo_host = 0;
     if (v == 1) return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out (the affected utterances' mel is NaN)");
+    if (v == 3) return fail(CMTTS_E_HIP, "denoiser, fp16 / fp16x3 operands: a conv input left the fp16 range (|u| > 65504) in an earlier evaluation — the "
+                                         "mel is finite but wrong; use bf16 or fp32 for this model / input scale");
     return fail(CMTTS_E_HIP, "denoiser: non-finite mel values in an earlier evaluation (fp16 / fp16x3 operands overflow at 65504: "
                              "use bf16 or fp32 for this model / input scale; fp32: non-finite weights or inputs)");
 }
@@ -1387,7 +1390,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             ra.dp = dp + (long)l * C; ra.d = w.dproj + (long)l * C;
             ra.x_out = halt; ra.skip = w.skip;
             ra.W3f = R.w3f; ra.b3 = R.b3f; ra.Wof = R.wof; ra.bo = R.outp.bias;
-            ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0;
+            ra.vec_stride = (long)NL * C; ra.B = B; ra.T = T; ra.accum_skip = l > 0; ra.flag = g_tmo_host;
             if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
             int lrc;
             if (m->precision == 0 || m->precision == 3) {

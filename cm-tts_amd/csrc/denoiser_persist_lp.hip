@@ -55,6 +55,13 @@ __device__ __forceinline__ f32x16 mma16(const u32x4& a, const u32x4& b, const f3
 
 // fp32 pair -> one dword of two 16-bit values in the hi image (and, MODE 3, the fp16 remainders in the lo image IMG
 // elements further on)
+// fp16 modes: an operand beyond the fp16 range (|v| > 65504, or NaN) cannot be represented — the conversion saturates / overflows and the
+// result is finite but WRONG (measured: a mel of the right shape and the wrong values), so the u conversions record it and the kernel
+// reports it through the pinned error word (code 3, cmtts_poll_error); bf16 has fp32's exponent range and no such check.
+template <int MODE>
+__device__ __forceinline__ void note_range(bool& ovf, float v0, float v1, bool valid) {
+    if (MODE >= 2) ovf |= valid && !(fabsf(v0) <= 65504.0f && fabsf(v1) <= 65504.0f);
+}
 template <int MODE>
 __device__ __forceinline__ void put2(unsigned short* hi_img, int off, float v0, float v1, bool valid, int IMG) {
     if (MODE != 3) {
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
     const float* dp_b = a.dp + (long)b * a.vec_stride;
     const float* dv_b = a.d + (long)b * a.vec_stride;
     const int mrow0 = w * 32;                         // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
+    bool ovf = false;                                 // fp16 modes: a conv input left the fp16 range (note_range)
 
     // ---- layer-0 staging (as resblock_fused_lp.hip): u^T[j][m] = cvt(cp + (x + dp)); lane = frame, waves over channel pairs
     {
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                 const float u0 = c0[q] + (x0[q] + d0[q]);
                 const float u1 = c1[q] + (x1[q] + d1[q]);
                 put2<MODE>(ut, (1 + lane) * RS + m, u0, u1, t < T, IMG);
+                note_range<MODE>(ovf, u0, u1, t < T);
             }
         }
         {
@@ -131,6 +140,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             const int thc = min(max(th, 0), T - 1);
             const float uh = cp_b[(unsigned)(m * T + thc)] + (xin[(unsigned)(m * T + thc)] + dp_b[m]);
             put1<MODE>(ut, (right ? FN + 1 : 0) * RS + m, uh, th >= 0 && th < T, IMG);
+            note_range<MODE>(ovf, uh, 0.f, th >= 0 && th < T);
         }
     }
     f32x16 st[MT][NT];
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                     const float u0 = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
                     const float u1 = cpc[j][r + 1] + (st[0][j][r + 1] + ldg(dpn, (unsigned)(m + 1)));
                     put2<MODE>(ut, (1 + j * 32 + c31) * RS + m, u0, u1, t < T, IMG);
+                    note_range<MODE>(ovf, u0, u1, t < T);
                 }
             }
         }
@@ -389,10 +400,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
             const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
             const float uh = hcp + (xh + dpn[hm]);
             put1<MODE>(ut, (hside ? FN + 1 : 0) * RS + hm, uh, hinside, IMG);
+            note_range<MODE>(ovf, uh, 0.f, hinside);
         }
         LPSTAMP(7);
     }
 
+    if (MODE >= 2 && ovf && a.tmo && *(volatile unsigned*)a.tmo == 0u) *(volatile unsigned*)a.tmo = 3u;
     if (a.tail) {
         // skip head + post-scaling in fp32 (persist_tail.h).  Its two fp32 buffers overlay u^T / z^T: wait until every
         // wave has left the last output projection.

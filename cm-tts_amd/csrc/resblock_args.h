@@ -16,6 +16,7 @@ struct ResArgs {
     int accum_skip;       // skip += o[C:] (layers > 0) or skip = o[C:] (layer 0)
     float* z;             // split form only (resblock_split.hip): scratch [B][256][T] for the gated activations
     long long* dbg;       // optional [grid][8] cycle stamps written by wave 0 (phase timing, tools/phase_timing.py)
+    unsigned* flag;       // optional pinned error word (16-bit kernel, fp16 mode): set to 3 when a conv input leaves the fp16 range
 };
 
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const Res
     const float* dv = a.d + (long)b * a.vec_stride;
 
     // ---- stage u^T[j][m] = cvt(cp + (x + dp)), j = frame - (t0 - 1); lane = frame, waves over channel pairs
+    bool ovf = false;
     {
         const int t = t0 + lane;
         const int t_c = min(t, T - 1);
@@ -80,8 +81,11 @@ __global__ __launch_bounds__(64 * NW, 4) void resblock_fused_lp_kernel(const Res
                 const float u1 = c1[q] + (x1[q] + d1[q]);
                 const unsigned pk = t < T ? pack16<MODE>(u0, u1) : 0u;
                 *reinterpret_cast<unsigned*>(ut + (1 + lane) * RS + m) = pk;
+                // fp16: an input beyond the type's range converts to something finite and WRONG — reported (code 3, cmtts_poll_error)
+                if (MODE == 2) ovf |= t < T && !(fabsf(u0) <= 65504.0f && fabsf(u1) <= 65504.0f);
             }
         }
+        if (MODE == 2 && ovf && a.flag && *(volatile unsigned*)a.flag == 0u) *(volatile unsigned*)a.flag = 3u;
         if (tid < 2 * C) {
             const int m = tid & (C - 1);
             const bool right = tid >= C;

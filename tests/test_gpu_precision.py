@@ -257,28 +257,33 @@ def test_winograd_and_fp16x3_stress_statistics(case):
         _lib.internal_set("persist_wino", prev_w)
         lib.cmtts_set_persistent_denoiser(prev)
     host.synchronize()
+    ref32 = O.denoiser_forward(sd, cfg, x, t, cond, spk)          # the restatement in fp32: what fp32 arithmetic itself loses on THIS network
     with O.precision("f64"):
         ref = O.denoiser_forward(sd, cfg, x, t, cond, spk)
         with O.operands16("fp16x3"):
             o3 = O.denoiser_forward(sd, cfg, x, t, cond, spk)
     scale = float(np.abs(ref).max())
     e = {k: float(np.abs(v - ref).max()) for k, v in out.items()}
-    e3o = float(np.abs(o3 - ref).max())
-    report(f"DTYPE_ERR stress {case}: output scale {scale:.3g}; vs f64 max|d| direct {e['direct']:.2e}, winograd {e['winograd']:.2e}, fp16x3 {e['fp16x3']:.2e} "
-           f"(22-bit-operand oracle {e3o:.2e}); winograd vs direct {np.abs(out['winograd'] - out['direct']).max():.2e}")
+    e3o, e32 = float(np.abs(o3 - ref).max()), float(np.abs(ref32 - ref).max())
+    report(f"DTYPE_ERR stress {case}: output scale {scale:.3g}; vs f64 max|d| fp32 restatement {e32:.2e}, direct {e['direct']:.2e}, winograd {e['winograd']:.2e}, "
+           f"fp16x3 {e['fp16x3']:.2e} (22-bit-operand oracle {e3o:.2e}); winograd vs direct {np.abs(out['winograd'] - out['direct']).max():.2e}")
     for v in out.values():
         assert np.isfinite(v).all()
     assert np.array_equal(out["winograd"], out["winograd4"])
     assert not np.array_equal(out["winograd"], out["direct"])
-    assert e["direct"] <= 1e-5 * max(scale, 1.0), (e, scale)
-    assert e["winograd"] <= 4 * e["direct"] + 2e-6 * scale, (e, scale)
-    assert e["fp16x3"] <= 4 * e["direct"] + 4 * e3o + 2e-6 * scale, (e, e3o, scale)
+    # the yardstick is what fp32 itself loses on this network (saturated gates amplify every rounding: x8 log-normal rows give 1e-2 on
+    # an output of 20 in ANY fp32 evaluation order), not a fixed epsilon
+    floor = 4 * e32 + 2e-6 * scale
+    assert e["direct"] <= floor, (e, e32, scale)
+    assert e["winograd"] <= max(4 * e["direct"], floor), (e, e32, scale)
+    assert e["fp16x3"] <= max(4 * e["direct"], floor) + 4 * e3o, (e, e3o, e32, scale)
 
 
 def test_fp16_overflow_is_reported():
     """Activations beyond the fp16 range (|conv input| > 65504): the fp16 and fp16x3 stacks cannot represent their operands.  The result is
-    non-finite and the library SAYS so — the sampler's post-scaling (persist_tail.h / mel_post_kernel) raises the device flag that
-    cmtts_poll_error() / the next denoiser call turn into an error — while fp32 and bf16 (8 exponent bits) take the same input."""
+    FINITE AND WRONG (measured: |mel| <= 0.15 where fp32 gives 2.7) and the library says so — the kernels' operand conversions raise the
+    device flag that cmtts_poll_error() / the next denoiser call turn into an error — while fp32 and bf16 (8 exponent bits) take the same
+    input.  (A non-finite mel in any mode is reported the same way by the sampler's post-scaling: code 2.)"""
     import dataclasses
     host = _host()
     lib = _lib.load()
@@ -300,9 +305,8 @@ def test_fp16_overflow_is_reported():
                     host.synchronize()                 # polls: would raise
                     assert torch.isfinite(mel).all(), dt
                 else:
-                    with pytest.raises(RuntimeError, match="non-finite mel"):
+                    with pytest.raises(RuntimeError, match="left the fp16 range"):
                         host.synchronize()
-                    assert not torch.isfinite(mel).all(), dt
         finally:
             model.set_precision("fp32")
             lib.cmtts_set_persistent_denoiser(prev)
