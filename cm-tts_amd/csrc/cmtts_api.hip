@@ -1427,7 +1427,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             a.split = C;
             a.out[0].res = hcur; a.out[0].r_zs0 = cs; a.out[0].ldr = T;
             a.out[0].bvec = w.dproj + (long)l * C; a.out[0].bvec_zs = (long)NL * C;
-            a.out[0].div = (float)sqrt(2.0);
+            a.out[0].rmul = 0.70710678118654752440f;      // every form of the block scales by the fp32 reciprocal of sqrt(2) (gate.h: CMTTS_RSQRT2)
             a.out[1].Y = w.skip; a.out[1].row_off = C; a.out[1].accum = l > 0;
             CHK(launch(a, EPI_PLAIN, B, s));
         }

@@ -29,6 +29,8 @@ struct ConvOut {
     float alpha;          // v = (acc + bias) * alpha
     int act;              // ConvAct
     float div;            // v = v / div   (1 = skip)
+    float rmul;           // v = v * rmul  (0 = skip): the residual blocks' 1 / sqrt(2) as a multiplication (round 5: the IEEE division is a
+                          // ten-instruction sequence per element, and next to fp32 MFMAs every VALU instruction costs its own issue time)
     int accum;            // Y += v instead of Y = v
 };
 

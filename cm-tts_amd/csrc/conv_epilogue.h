@@ -78,6 +78,7 @@ __device__ __forceinline__ void epi_tile(const ConvOut& o, const f32x16& acc, in
             v = act_apply(v, o.act);
             if (rb || vb) v += rv[q];
             if (o.div != 1.0f) v = v / o.div;
+            if (o.rmul != 0.0f) v = v * o.rmul;
             if (o.accum) v += yv[q];
             if (!keep) v = 0.f;
             if (ok_n && m < M) yb[(unsigned)(m - o.row_off) * (unsigned)o.ldy + (unsigned)t] = v;
@@ -90,7 +91,7 @@ __device__ __forceinline__ void epi_tile(const ConvOut& o, const f32x16& acc, in
 // length mask; unit output stride, no row offset / division / accumulate / per-batch vector.  Same operations in the same
 // order as epi_tile => identical bits.
 __device__ __forceinline__ bool epi_simple(const ConvOut& o) {
-    return o.ostride == 1 && o.ooff_base == 0 && o.ooff_mul == 0 && o.row_off == 0 && o.div == 1.0f && !o.accum && !o.bvec;
+    return o.ostride == 1 && o.ooff_base == 0 && o.ooff_mul == 0 && o.row_off == 0 && o.div == 1.0f && o.rmul == 0.0f && !o.accum && !o.bvec;
 }
 template <int ACT>
 __device__ __forceinline__ void epi_tile_simple(const ConvOut& o, const f32x16& acc, int m_base, int rbase, int n, int M, int N, int zq) {

@@ -307,10 +307,10 @@ extern "C" int cmtts_launch_conv16(const ConvArgs* ap, const void* wfrag, int mo
     if (a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || mode < 1 || mode > 3 || a.K % KC != 0) return -2;
     if ((a.x16 && a.y16) || (a.y16 && (o.res || o.accum)) || (a.x16 && (a.pre_div != 1.f))) return -2;
     if (a.text_epi) {     // bias, alpha, none / GELU, residual, length mask; fp32 in and out, bf16 / fp16 operands
-        if (mode == 3 || a.x16 || a.y16 || o.bvec || o.accum || (o.act != ACT_NONE && o.act != ACT_GELU_ERF && o.act != ACT_RELU) || o.div != 1.f || o.ostride != 1 ||
+        if (mode == 3 || a.x16 || a.y16 || o.bvec || o.accum || (o.act != ACT_NONE && o.act != ACT_GELU_ERF && o.act != ACT_RELU) || o.div != 1.f || o.rmul != 0.f || o.ostride != 1 ||
             o.ooff_base != 0 || o.ooff_mul != 0 || o.row_off != 0 || o.Tout != a.N)
             return -2;
-    } else if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.ostride != 1 || o.ooff_base != 0 ||
+    } else if (!o.bias || o.bvec || o.lens || o.alpha != 1.f || o.act != ACT_NONE || o.div != 1.f || o.rmul != 0.f || o.ostride != 1 || o.ooff_base != 0 ||
         o.row_off != 0 || o.Tout != a.N)
         return -2;
     // 128-frame tiles everywhere: these convs are HBM-bound, what matters is loads in flight (3 workgroups/CU)

@@ -22,6 +22,7 @@
 // Arithmetic and accumulation order are those of resblock_fused.hip: BITWISE equal to the per-layer kernels
 // (tests/test_gpu_parity.py::test_persistent_denoiser_bitwise).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "gate.h"
 #include "persist_args.h"
 #include "persist_tail.h"
@@ -223,15 +224,21 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         for (int i = 0; i < MT; ++i)
             dst[i] = *reinterpret_cast<const f32x4*>(wfrag + ((long)group * (2 * C / 32) + i * NW + w) * 256 + lane * 4);
     };
-    auto mma_group = [&](const f32x4 (&af)[MT], const float (&bv)[4][NT]) {
+    // FIRST: the group opens the accumulators — its first k-step takes the inline constant 0 as C (`v_mfma ..., 0`: the same operation as
+    // accumulating into zeroed registers without the 64 v_mov per loop that, next to fp32 MFMAs, cost their own issue time)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mma_group = [&](auto first, const f32x4 (&af)[MT], const float (&bv)[4][NT]) {
+        constexpr bool FIRST = decltype(first)::value;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bv[kk][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bv[kk][j], FIRST && kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
     };
+    using first_t = std::integral_constant<bool, true>;
+    using later_t = std::integral_constant<bool, false>;
 
     const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
     auto stamp = [&](int l, int slot) {
@@ -376,15 +383,13 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 }
             }
         } else {
-            zero_acc();
             constexpr int NG = NGB;
             const float* W3f = a.W3f[l];
             float Bv[2][4][NT];
             int g8, tap;
             kgrp(0, g8, tap);
             load_b(Bv[0], u_lds, g8 * 8, tap);
-#pragma unroll 1
-            for (int it = 0; it < NG; it += RING) {
+            auto ring_round = [&](int it, auto first) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
                     kgrp(it + s + RING - 1, g8, tap);
@@ -392,10 +397,16 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     kgrp(it + s + 1, g8, tap);
                     load_b(Bv[(s + 1) & 1], u_lds, g8 * 8, tap);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (it + s < NG) mma_group(A[s], Bv[s & 1]);
+                    if (it + s < NG) {
+                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1]);
+                        else mma_group(later_t{}, A[s], Bv[s & 1]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            ring_round(0, first_t{});
+#pragma unroll 1
+            for (int it = RING; it < NG; it += RING) ring_round(it, later_t{});
         }
         stamp(l, 2);
         if (!WINO) {
@@ -485,22 +496,26 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 
         // =========================================================== phase C: output projection
         {
-            zero_acc();
             constexpr int NG = NGC;
             const float* Wof = a.Wof[l];
             float Bv[2][4][NT];
             load_b(Bv[0], z_lds, 0, 0);
-#pragma unroll 1
-            for (int it = 0; it < NG; it += RING) {
+            auto ring_round = [&](int it, auto first) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
                     load_ao(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
                     load_b(Bv[(s + 1) & 1], z_lds, min(it + s + 1, NG - 1) * 8, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (it + s < NG) mma_group(A[s], Bv[s & 1]);       // NG need not be a multiple of the ring depth
+                    if (it + s < NG) {       // NG need not be a multiple of the ring depth
+                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1]);
+                        else mma_group(later_t{}, A[s], Bv[s & 1]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
+            };
+            ring_round(0, first_t{});
+#pragma unroll 1
+            for (int it = RING; it < NG; it += RING) ring_round(it, later_t{});
         }
         stamp(l, 5);
         // ---- epilogue in registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float o = acc[0][j][r] + bor[0][r];
-                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
+                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) * CMTTS_RSQRT2;
                     const float os = acc[1][j][r] + bor[1][r];
                     st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }

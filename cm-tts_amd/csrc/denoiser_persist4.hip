@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
                         for (int q = 0; q < 8; ++q) {
                             const int r = 8 * h + q;
                             const float o = acc_rd(acc[i][j][r]) + box[q];
-                            xs[i][j][r] = (o + (xs[i][j][r] + ddr[q])) / 1.41421356237309504880f;
+                            xs[i][j][r] = (o + (xs[i][j][r] + ddr[q])) * CMTTS_RSQRT2;
                             const float os = acc_rd(acc[TPW + i][j][r]) + bos[q];
                             sk[i][j][r] = l > 0 ? os + sk[i][j][r] : os;
                         }

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float o = acc[0][j][r] + bor[0][r];
-                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) / 1.41421356237309504880f;
+                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) * CMTTS_RSQRT2;
                     const float os = acc[1][j][r] + bor[1][r];
                     st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }

@@ -15,3 +15,8 @@ __device__ __forceinline__ float cmtts_gate(float g, float f) {
     const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * f));   // tanh(f); saturates cleanly at +-1
     return s * th;
 }
+
+// (o + residual) / sqrt(2) of the residual block (model/blocks.py:683) as a multiplication by the fp32 reciprocal — every form of the block
+// (per-layer, split, persistent, 16-bit, the generic conv epilogue's ConvOut.rmul) uses this constant, so they stay bitwise equal to each
+// other; against the reference's true division a result differs by at most one ulp.
+#define CMTTS_RSQRT2 0.70710678118654752440f

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * NWS) void resblock_split_out_kernel(const ResA
         const int mr = mrow0 + acc_row(r, lane);
         const float o = acc[r] + bo[r];
         float v;
-        if (res_half) v = (o + (sv[r] + dd[r])) / 1.41421356237309504880f;
+        if (res_half) v = (o + (sv[r] + dd[r])) * CMTTS_RSQRT2;
         else v = a.accum_skip ? o + sv[r] : o;
         if (t < T) dst[(unsigned)(mr * T + t)] = v;
     }
