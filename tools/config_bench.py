@@ -78,7 +78,7 @@ for n in (1, 2, 4):
     report(f"configs[1] LJSpeech B=32, 80x512, T={n}, fp32, text -> mel", fr, clock(lambda: c1(n), 10), "bench.py headline" if n == 4 else "")
 report("configs[1] + HiFi-GAN fp32, T=4, text -> int16 wav", fr, clock(lambda: to_pcm(c1()), 3, 1), "")
 m.set_precision("fp16x3"); voc.set_precision("fp16x3")
-report("configs[1] with fp16x3 operands everywhere (fp32-class: hi + lo fp16 pairs, DESIGN 3.5c), T=4, text -> int16 wav", fr, clock(lambda: to_pcm(c1()), 5, 1), "")
+report("configs[1] with fp16x3 operands everywhere (fp32-class: hi + lo fp16 pairs, DESIGN 3.4), T=4, text -> int16 wav", fr, clock(lambda: to_pcm(c1()), 5, 1), "")
 m.set_precision("fp32"); voc.set_precision("fp32")
 
 # configs[2]: VCTK multi-speaker B=64, T=2, bf16 + universal vocoder (bf16 ResBlock convs), 80x512
@@ -106,7 +106,7 @@ for bucket in shard.FRAME_BUCKETS:
     groups.append((tx, ln, spk, torch.randn(5, 8, 1, bucket, cfg.n_mels, device=dev), bucket)); fr += f
 bs = host.BucketedSynthesizer(m, 4, n_streams=4)
 report("configs[3] LibriTTS, one rank's shard: 4 buckets x 8 ragged utterances, T=4, fp32, text -> mel", fr, clock(lambda: bs.run(groups), 6),
-       "all bucket groups in one persistent launch per evaluation (DESIGN 3.2a); + one RCCL all-gather per batch across ranks")
+       "all bucket groups in one persistent launch per evaluation (DESIGN 3.2, RAGGED); + one RCCL all-gather per batch across ranks")
 
 # configs[4]: zero-shot Lib->VCTK B=128 over 8 GPUs = 16 utterances per rank, 80x1024, T=4, fp16 denoiser + fp32 vocoder
 tx, ln, spk, fr = batch(cfg, 16, 170, 5)
