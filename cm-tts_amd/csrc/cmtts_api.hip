@@ -602,6 +602,7 @@ struct cmtts_model {
     // factored conditioner projections (cond_factored below): P2[r][i] = sum_k Wc[r][k] * pitch_embed[i][k] + bias[r], [NL*C][pitch_bins],
     // computed once at cmtts_finalize with cond_gemm_kernel itself; a zero bias vector for the phoneme-level factor
     float* cond_p2 = nullptr;
+    float* cond_p2t = nullptr;             // [NL][pitch_bins][C]: cond_p2 with the channels contiguous (PersistArgs.p2t)
     float* cond_zero_bias = nullptr;
     void* cond_all_f16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies (cond_gemm16.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
@@ -966,8 +967,13 @@ int finalize_model(cmtts_model* m) {
         ga.X = peT; ga.Wf = m->cond_all_f; ga.bias = m->cond_all.bias; ga.Y = (float*)p2;
         ga.B = 1; ga.T = c.pitch_bins; ga.M = NL * C; ga.K = H; ga.force = 1; ga.row_split = NL * C / 512;
         if (cmtts_launch_cond_gemm(&ga, nullptr) == 0) {
+            void* p2t = nullptr;
+            HIPCHK(hipMalloc(&p2t, (size_t)NL * C * c.pitch_bins * sizeof(float) + 256));
+            al.ptrs.push_back(p2t);
+            k_transpose((const float*)p2, (float*)p2t, NL, C, c.pitch_bins, nullptr);      // [NL][C][bins] -> [NL][bins][C]
             HIPCHK(hipStreamSynchronize(nullptr));
             m->cond_p2 = (float*)p2;
+            m->cond_p2t = (float*)p2t;
         }
     }
 #undef GET
@@ -1186,6 +1192,7 @@ int cond_projections(cmtts_model* m, const DenWs& w, const float* cond_ct, int B
 // brings its own conditioning (CMDenoiserTTS.forward, tts_net.py:29-37) has no factors and takes the dense GEMM.
 struct CondFactors {
     const float* p1 = nullptr;       // [B][NL*C][ldp]: Wc * out1, no bias
+    const float* p1t = nullptr;      // [B][NL][ldp][C]: the same with the channels contiguous (sample_core / sample_ragged transpose it into the unused cp buffer)
     int ldp = 0, L = 0;
     const int64_t* mel2ph = nullptr; // [B][T]
     const int64_t* p_idx = nullptr;  // [B][T]
@@ -1194,6 +1201,7 @@ struct CondFactors {
 int g_cond_factored = 1;        // internal switch "cond_factored": 0 = always the dense GEMM
 int g_cond_inkernel = 1;        // internal switch "cond_inkernel": the fp32 persistent kernel gathers the factors itself (FACT instances: no cp tensor, the
                                 // same bits as cond_expand_kernel + the plain instance); 0 = expand into cp first
+inline bool C_IS_256(const cmtts_config& c) { return c.res_channels == 256; }
 bool CondFactors::usable(const cmtts_model* m) const {
     return g_cond_factored && p1 && mel2ph && p_idx && m->precision == 0 && m->cond_p2 && g_fused_resblock;
 }
@@ -1344,6 +1352,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         if (cfk && !(cp_ready && *cp_ready)) {
             pa.fact = 1; pa.p1 = cfk->p1; pa.p2 = m->cond_p2; pa.mel2ph = (const long long*)cfk->mel2ph; pa.pidx = (const long long*)cfk->p_idx;
             pa.ldp = cfk->ldp; pa.Lph = cfk->L; pa.ld2 = c.pitch_bins;
+            pa.p1t = cfk->p1t; pa.p2t = m->cond_p2t;
         }
         if (g_persist_tail && m->skip_f && m->outp_f) {   // skip head + post-scaling inside the launch
             pa.tail = 1;
@@ -1918,13 +1927,21 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
     SideStream* ss = g_fused_resblock ? side_for(s) : nullptr;
     if (ss) CHK(branch_fork(ss));
     const CondFactors* cfk = nullptr;       // non-null: no cp tensor at all, the persistent launches gather the factors (denoiser_core)
+    CondFactors cf_local;
     bool cp_ready = false;
     if (g_fused_resblock) {
         if (cf && cf->usable(m)) {
             const bool inkernel = g_cond_inkernel && g_persist && g_persist_tail && m->skip_f && m->outp_f && c.res_layers <= PERSIST_MAX_LAYERS &&
                                   cmtts_persist_plan(B, T, c.res_layers, persist_blocks(), g_persist == 2) > 0;
-            if (inkernel) cfk = cf;
-            else CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
+            if (inkernel && cf->ldp <= T && m->cond_p2t && C_IS_256(c)) {
+                // the persistent launches gather the factors: w.cp (NL * C * T floats per utterance) is free and takes p1 with the channels
+                // contiguous, [B][NL][ldp][C] — one 57-MB transpose per sample call (bench shape, ~25 us) buys 16-byte gathers in every layer of
+                // every evaluation
+                k_transpose(cf->p1, w.cp, B * c.res_layers, c.res_channels, cf->ldp, s);
+                cf_local = *cf;
+                cf_local.p1t = w.cp;
+                cfk = &cf_local;
+            } else CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
         } else CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
     }
     k_scale(noise, w.xcur, nel, c.sigma_max, s);        // x_T = randn * sigma_max (karras_diffusion.py:534)
@@ -2074,7 +2091,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         if (keep[g] == 0) continue;
         CondFactors cf;
         cf.p1 = groups[g].cond_p1; cf.ldp = groups[g].p1_ld; cf.L = groups[g].L; cf.mel2ph = groups[g].mel2ph; cf.p_idx = groups[g].p_idx;
-        if (!cf.usable(m)) fact_all = false;
+        if (!cf.usable(m) || groups[g].p1_ld > groups[g].T || !m->cond_p2t) fact_all = false;
     }
     std::vector<DenWs> ws(n_groups);
     SideStream* ss = side_for(s);
@@ -2092,7 +2109,9 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         if (keep[g] == 0) continue;
         CondFactors cf;
         cf.p1 = G.cond_p1; cf.ldp = G.p1_ld; cf.L = G.L; cf.mel2ph = G.mel2ph; cf.p_idx = G.p_idx;
-        if (fact_all) { /* the ragged FACT instance gathers the factors itself: no cp tensor */ }
+        if (fact_all) {   // the ragged FACT instance gathers the factors itself: no cp tensor — the buffer takes p1 with the channels contiguous
+            k_transpose(G.cond_p1, ws[g].cp, keep[g] * NL, C, G.p1_ld, s);
+        }
         else if (cf.usable(m)) CHK(cond_factored(m, ws[g], cf, keep[g], G.T, ss ? ss->side : s));
         else CHK(cond_projections(m, ws[g], G.cond_ct, keep[g], G.T, ss ? ss->side : s));   // once for all evaluations, beside the first prologues
         k_scale(G.noise, ws[g].xcur, (long)keep[g] * G.T * M, c.sigma_max, s);         // x_T = randn * sigma_max (karras_diffusion.py:534)
@@ -2138,7 +2157,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         pa.W3f[l] = pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
-    if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.ld2 = c.pitch_bins; }
+    if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.p2t = m->cond_p2t; pa.ld2 = c.pitch_bins; }
     for (int i = 0; i < n_steps; ++i) {
         // get_scalings_for_boundary_condition in fp32 (karras_diffusion.py:87-102)
         const float sg = sigmas[i];
@@ -2171,7 +2190,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
             pg.dp = c.multi_speaker ? w.dp : w.dproj; pg.d = w.dproj; pg.skip = w.skip; pg.xst = w.pst; pg.halo = w.halo;
             pg.xold = w.xcur; pg.noise = renoise ? G.noise + (long)(1 + i) * G.B * G.T * M : nullptr; pg.out = last ? G.mel : w.xcur;
             pg.B = Bk; pg.T = G.T; pg.tiles = tiles;
-            if (fact_all) { pg.p1 = G.cond_p1; pg.mel2ph = (const long long*)G.mel2ph; pg.pidx = (const long long*)G.p_idx; pg.ldp = G.p1_ld; pg.Lph = G.L; }
+            if (fact_all) { pg.p1 = G.cond_p1; pg.p1t = w.cp; pg.mel2ph = (const long long*)G.mel2ph; pg.pidx = (const long long*)G.p_idx; pg.ldp = G.p1_ld; pg.Lph = G.L; }
             for (int b = 0; b < Bk; ++b) {
                 const int act = (int)utt_tiles(G, b, i);
                 utts.push_back({g, b, act});

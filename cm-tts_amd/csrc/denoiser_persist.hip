@@ -53,6 +53,7 @@ constexpr int RING = 6;         // register ring depth of the weight stream (k-g
 constexpr int FN = 64;
 constexpr int NT = FN / 32;
 constexpr int U_LD = FN + 4;
+constexpr int IDX_LDS_BYTES = (FN + 2) * 2 * 4;      // FACT: (phoneme, pitch bucket) of frames t0 - 1 .. t0 + FN behind the u / z buffers
 constexpr unsigned SPIN_LIMIT = 1u << 20;     // bounded wait for a neighbour (~2 s); then the timeout word is set and
                                               // this wave stops waiting for the rest of the launch (results invalid)
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     const int B_g = RAGGED ? a.grp[gi].B : a.B, tiles_g = RAGGED ? a.grp[gi].tiles : a.tiles;
     const int mrow0 = w * 32;                          // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
     // FACT: cp of (row m of layer l, frame t) from the factors; (ph, ix) = frame_idx(t)
-    const float* p1_b = nullptr;
+    const float *p1_b = nullptr, *p1t_b = nullptr;
     const long long *m2p_b = nullptr, *pix_b = nullptr;
     int ldp = 0, Lph = 0;
     if (FACT) {
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         ldp = RAGGED ? a.grp[gi].ldp : a.ldp;
         Lph = RAGGED ? a.grp[gi].Lph : a.Lph;
         p1_b += (long)b * a.NL * C * ldp;
+        p1t_b = (RAGGED ? a.grp[gi].p1t : a.p1t) + (long)b * a.NL * C * ldp;
         m2p_b = (RAGGED ? a.grp[gi].mel2ph : a.mel2ph) + (long)b * T;
         pix_b = (RAGGED ? a.grp[gi].pidx : a.pidx) + (long)b * T;
     }
@@ -186,6 +188,17 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             smem[m * U_LD + uidx(right ? FN : -1)] = (th >= 0 && th < Tc) ? uh : 0.f;
         }
     }
+    // FACT: the factor indices of the tile's frames (and of its two halo frames) are the same for every layer: one table behind the u / z
+    // buffers, filled here (visible after the first layer barrier), read by the publish phase with one ds_read_b64 per n-tile — until round 5
+    // every layer re-loaded them from HBM / L2 in front of its gathers: two of that phase's three dependent round trips (~3 k cycles each
+    // with every wave of the chip asking at once)
+    int* idx_lds = reinterpret_cast<int*>(smem + 2 * C * U_LD);
+    if (FACT && tid < FN + 2) {
+        int ph, ix;
+        frame_idx(min(max(t0 - 1 + tid, 0), T - 1), ph, ix);
+        idx_lds[2 * tid] = ph;
+        idx_lds[2 * tid + 1] = ix;
+    }
     // resident state: st[0] = this wave's 32 rows of x, st[1] = its 32 rows of the skip sum; MFMA C layout: [j][r] = row
     // acc_row(r), frame j*32 + l31
     f32x16 st[MT][NT];
@@ -203,14 +216,6 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     }
 
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
     // A fragments of one k-group (8 input channels = 4 k-steps) for this wave's MT 32-row tiles
     auto load_a = [&](f32x4 (&dst)[MT], const float* wfrag, int group) {        // k=3 conv: packed gate tiles 2w, 2w+1
 #pragma unroll
@@ -241,8 +246,21 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     using later_t = std::integral_constant<bool, false>;
 
     const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
+    // -DPUB_STAMP (timing-only builds, tools/persist_timing.py PUB=1): slots 0..5 take the publish phase's own steps instead of the layer's
+#ifdef PUB_STAMP
+    constexpr bool PUBS = true;
+#else
+    constexpr bool PUBS = false;
+#endif
     auto stamp = [&](int l, int slot) {
-        if (DBG && a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+        if (DBG && !(PUBS && slot < 6) && a.dbg && l == a.NL / 2 && lane == 0)
+            a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+    };
+    auto pstamp = [&](int l, int slot) {
+        if (DBG && PUBS && a.dbg && l == a.NL / 2 && lane == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            a.dbg[((long)bid_dbg * NW + w) * 8 + slot] = (long long)__builtin_readcyclecounter();
+        }
     };
     bool gave_up = false;
     for (int l = 0; l < a.NL; ++l) {
@@ -547,6 +565,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         }
         if (!more) break;
         stamp(l, 6);
+        pstamp(l, 0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hand the edge columns of x' to the neighbouring tiles first (their latency is what the neighbours wait for)
         const float* dpn = dp_b + (long)(l + 1) * C;
@@ -573,31 +592,83 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         const bool hinside = hth >= 0 && hth < Tc;
         // neighbour's slot: its right edge (side 1) feeds our left halo, its left edge (side 0) our right halo
         const unsigned long long* hg = hbase + ((long)(hinside ? (hside ? tile + 1 : tile - 1) : tile) * 2 + (hside ? 0 : 1)) * C + hm;
-        float hcp;
+        float hcp = 0.f;
+        int hph = 0, hix = 0;
         {
             const int thc = min(max(hth, 0), T - 1);
-            if (FACT) { int ph, ix; frame_idx(thc, ph, ix); hcp = cp_fact((l + 1) * C + hm, ph, ix); }
+            if (FACT) { hph = idx_lds[2 * (hside ? FN + 1 : 0)]; hix = idx_lds[2 * (hside ? FN + 1 : 0) + 1]; }   // (its two gathers ride with the wave's below)
             else hcp = (cp_b + (long)(l + 1) * C * T)[(unsigned)(hm * T + thc)];
         }
         unsigned long long hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pstamp(l, 1);
         // ---- next layer's u rows of this wave: cp (L2-warm, accumulator layout) + (x' + dp)
         {
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int ln = opaque(lane), c31 = ln & 31;
             f32x16 cpc[NT];
+            float dpr[16];
+            if constexpr (FACT) {
+                // Round 5: every load of this phase is ISSUED BY HAND before the first wait — the frame indices of both n-tiles and of the
+                // halo frame first (one round trip), then the wave's 64 gathers, the halo entry's two and the 16 per-row dp values (one more).
+                // Left to the compiler (at 253 of 256 registers) every element became mad_i64 / shift / add / load / s_waitcnt vmcnt(0): 32
+                // dependent L2 round trips per wave and layer, then the index loads of the second n-tile behind the first tile's gathers, then
+                // the dp loads one by one between the LDS stores — most of the publish phase's 15-20 k cycles.  The byte offset of an element
+                // is formed in 32 bits in the register the load then overwrites (saddr form: uniform layer base + lane offset); row
+                // (r & 3) + 8 (r >> 2) of the tile is a uniform multiple of the row pitch.  Same values as cp_fact: the same two loads, the
+                // same add.
+                const float* p1l = p1_b + (long)(l + 1) * C * ldp;
+                const float* p2l = a.p2 + (long)(l + 1) * C * a.ld2;
+                // the wave's own elements come from the channel-contiguous copies (persist_args.h: p1t [NL][ldp][C], p2t [NL][ld2][C]): a lane's 16 rows
+                // of a tile are four runs of four consecutive channels = four 16-byte loads per factor and n-tile (the row-major tables took 16
+                // scattered dwords each, and the phase was bound by the cache lines its gathers touch)
+                const float* p1tl = p1t_b + (long)(l + 1) * ldp * C;
+                const float* p2tl = a.p2t + (long)(l + 1) * a.ld2 * C;
+                int phj[NT], ixj[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t_c = min(t0 + j * 32 + c31, T - 1);
-                if (FACT) {
-                    int ph, ix;
-                    frame_idx(t_c, ph, ix);
-                    const int row0 = (l + 1) * C + mrow0;
+                for (int j = 0; j < NT; ++j) { phj[j] = idx_lds[2 * (1 + j * 32 + c31)]; ixj[j] = idx_lds[2 * (1 + j * 32 + c31) + 1]; }
+                f32x4 g1[NT][4], g2[NT][4];
+                unsigned h1 = (unsigned)(hm * ldp + (hph > 0 ? hph - 1 : 0)) * 4u, h2 = (unsigned)(hm * a.ld2 + hix) * 4u;
+                asm volatile("global_load_dword %0, %0, %1" : "+v"(h1) : "s"(p1l) : "memory");
+                asm volatile("global_load_dword %0, %0, %1" : "+v"(h2) : "s"(p2l) : "memory");
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cpc[j][r] = cp_fact(row0 + acc_row(r, ln), ph, ix);
-                } else {
+                for (int j = 0; j < NT; ++j) {
+                    const unsigned o1 = (unsigned)((phj[j] > 0 ? phj[j] - 1 : 0) * C + mrow0 + 4 * (ln >> 5)) * 4u;
+                    const unsigned o2 = (unsigned)(ixj[j] * C + mrow0 + 4 * (ln >> 5)) * 4u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {      // rows 8 q + 4 khalf + {0, 1, 2, 3} = accumulator registers 4 q .. 4 q + 3
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(g1[j][q]) : "v"(o1), "s"(p1tl), "n"(q * 32) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(g2[j][q]) : "v"(o2), "s"(p2tl), "n"(q * 32) : "memory");
+                    }
+                }
+                {
+                    const unsigned od = (unsigned)(mrow0 + 4 * (ln >> 5)) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=&v"(dpr[r]) : "v"(od), "s"(dpn), "n"(((r & 3) + 8 * (r >> 2)) * 4) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pstamp(l, 2);
+                asm volatile("" : "+v"(h1), "+v"(h2));
+                hcp = (hph > 0 ? __uint_as_float(h1) : 0.f) + __uint_as_float(h2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(dpr[r]));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(g1[j][q]), "+v"(g2[j][q]));      // not before the wait
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cpc[j][4 * q + e] = (phj[j] > 0 ? g1[j][q][e] : 0.f) + g2[j][q][e];
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int t_c = min(t0 + j * 32 + c31, T - 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpr[r] = ldg(dpn, (unsigned)(mrow0 + acc_row(r, ln)));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -605,11 +676,12 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mrow0 + acc_row(r, ln);
-                    const float uv = cpc[j][r] + (st[0][j][r] + ldg(dpn, (unsigned)m));
+                    const float uv = cpc[j][r] + (st[0][j][r] + dpr[r]);
                     u_lds[m * U_LD + uidx(j * 32 + c31)] = t < Tc ? uv : 0.f;
                 }
             }
         }
+        pstamp(l, 3);
         {   // the halo entries: wait for the neighbours' tags (lanes without a neighbour frame never wait)
             if (!gave_up) {
                 unsigned spins = 0;
@@ -629,6 +701,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const float uh = hcp + (xh + dpn[hm]);
             u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
         }
+        pstamp(l, 4);
         if constexpr (WINO) {      // x' goes back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
                                    // the acknowledgement of these stores (one counter for loads and stores)
             f32x4* px = reinterpret_cast<f32x4*>(pst_b) + (w * 8) * 64 + opaque(lane);
@@ -642,6 +715,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     px[(j * 4 + q) * 64] = vx;
                 }
         }
+        pstamp(l, 5);
         stamp(l, 7);
     }
 
@@ -752,7 +826,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         {{reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, true>)},
          {reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, true>)}}};
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
+    const size_t lds = (size_t)2 * C * U_LD * sizeof(float) + IDX_LDS_BYTES;
     if (!attr_set) {
         for (int d = 0; d < 2; ++d)
             for (int f = 0; f < 2; ++f) {
@@ -763,6 +837,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         attr_set = true;
     }
     if (a.fact && (!a.p1 || !a.p2 || !a.mel2ph || !a.pidx || a.ldp < 1 || a.ld2 < 1)) return -2;
+    if (a.fact && !p4 && (!a.p1t || !a.p2t)) return -2;      // the 8-wave FACT instances gather the channel-contiguous tables in their publish phase
     // every granule tag must be stale (0) when a launch starts
     if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     // utterance chunks: all workgroups of a launch must be resident (one per CU); chunks are balanced so that the last
@@ -783,6 +858,7 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
         c.halo = a.halo + (long)b0 * tiles * 2 * C;      // [parity][B][tiles][2][C]: the parity stride keeps a.B
         if (a.fact) {
             c.p1 = a.p1 + (long)b0 * a.NL * C * a.ldp;
+            if (a.p1t) c.p1t = a.p1t + (long)b0 * a.NL * C * a.ldp;
             c.mel2ph = a.mel2ph + (long)b0 * a.T;
             c.pidx = a.pidx + (long)b0 * a.T;
         }
@@ -817,7 +893,7 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, true>)},
         {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, true>)}};
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * C * U_LD * sizeof(float);
+    const size_t lds = (size_t)2 * C * U_LD * sizeof(float) + IDX_LDS_BYTES;
     if (!attr_set) {
         for (int f = 0; f < 2; ++f) {
             for (int wn = 0; wn < 2; ++wn)
@@ -830,6 +906,11 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         if (!a.p2 || a.ld2 < 1) return -2;
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && (!a.grp[g].p1 || !a.grp[g].mel2ph || !a.grp[g].pidx || a.grp[g].ldp < 1)) return -2;
+        if (a.wino != 2) {
+            if (!a.p2t) return -2;
+            for (int g = 0; g < a.n_groups; ++g)
+                if (a.grp[g].B > 0 && !a.grp[g].p1t) return -2;
+        }
     }
     if (a.wino == 1)   // the 8-wave Winograd instances keep the residual stream of every group in its `xst` buffer
         for (int g = 0; g < a.n_groups; ++g)

@@ -24,6 +24,7 @@ struct PersistGroup {
     const long long* mel2ph;    // [B][T] int64
     const long long* pidx;      // [B][T] int64
     int ldp, Lph;
+    const float* p1t;     // [B][NL][ldp][256]: p1 with the channels contiguous (round 5: the publish phase's 16-byte gathers; PersistArgs.p2t)
     float* xst;           // WINO instances: [B][tiles][16384] kernel-private state (the residual stream x of every tile between layers)
 };
 
@@ -65,6 +66,12 @@ struct PersistArgs {
     const long long* mel2ph;    // [B][T] int64: 1-based phoneme of a frame, 0 = padding
     const long long* pidx;      // [B][T] int64: pitch bucket of a frame
     int ldp, Lph, ld2;
+    // Round 5: the same factors with the CHANNELS contiguous — p1t [B][NL][ldp][256], p2t [NL][ld2][256] — for the 8-wave FACT instances'
+    // publish phase: an element's 16 rows are four runs of four consecutive channels, i.e. four 16-byte loads per factor and n-tile where
+    // the row-major tables needed 16 scattered dwords each (the phase was bound by the cache lines its gathers touch).  Layer-0 staging and the
+    // halo entries (one element per lane) keep reading p1 / p2.
+    const float* p1t;
+    const float* p2t;
     int wino;             // 2 (round 5): the one-wave-per-SIMD stack of denoiser_persist4.hip — W3f = per-wave streams (cmtts_api.hip: to_wino4_fragments),
                           // x and the skip sum stay in registers, `xst` unused.  1: fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form

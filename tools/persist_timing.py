@@ -16,17 +16,30 @@ lib = _lib.load()
 WINO = int(os.environ.get("WINO", 0))
 _lib.internal_set(b"persist_wino", WINO)      # 1: the 8-wave Winograd F(2,3) instances, 2: one wave per SIMD (denoiser_persist4.hip)
 _lib.load().cmtts_set_persistent_denoiser(2)
+FACT = os.environ.get("FACT") == "1"      # the production path: conditioner factors gathered in-kernel (FACT instances) through the sampler
+if FACT:
+    from cmtts_amd.weights import synth_cmtts_state_dict as _sd
+    model = host.CMTotalTTS(cfg, "cuda:0").load_state_dict(_sd(cfg, seed=0, dur_frames=6.0, dur_spread=0.0))
+    L = T // 6
+    texts = torch.randint(1, cfg.n_symbols, (B, L), device="cuda"); lens = torch.full((B,), L, dtype=torch.int64, device="cuda")
+    out = model.duration_pitch_energy_net(None, texts, lens, max_mel_len=T)
+    nz = torch.randn(1, B, 1, T, 80, device="cuda")
+    run = lambda: host.sample_with_cond(model, out["cond_ct"], None, 1, nz, factors=out.get("cond_factors"))
+else:
+    run = lambda: model.net(x, t, cond, None)
 for _ in range(2):
-    model.net(x, t, cond, None)
+    run()
 nblk = ((T + 63) // 64) * B
 NW = 4 if WINO == 2 else 8
 buf = torch.zeros(nblk * NW * 8, dtype=torch.int64, device="cuda")
 lib.cmtts_set_debug_stamps(buf.data_ptr())
-model.net(x, t, cond, None)
+run()
 torch.cuda.synchronize()
 lib.cmtts_set_debug_stamps(None)
 s = buf.cpu().numpy().reshape(nblk, NW, 8).astype(np.float64)
 names = ["wait barrier(1)", "phase B loop", "gate", "wait barrier(3)", "phase C loop", "epilogue regs", "publish/u/halo"]
+if os.environ.get("PUB") == "1":      # a -DPUB_STAMP build (CMTTS_LIB): the publish phase's own steps in slots 0..5
+    names = ["granule stores + index loads issued", "indices + all gathers landed", "u rows formed and written to LDS", "halo wait + halo column", "x' stored to xst", "(slot 5 -> 6: next layer)", "(slot 6 -> 7)"]
 d = np.diff(s, axis=2)       # [blk][wave][7]
 print(f"B={B} T={T}: cycle-counter ticks per phase of layer {cfg.res_layers // 2} (mean over workgroups)")
 for grp, sl in ((("waves 0-3", slice(0, 4)),) if NW == 4 else (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8)))):
