@@ -108,26 +108,43 @@ __device__ __forceinline__ void run(const PersistArgs& a, float* u_lds, float* z
         gemm_tile(a.Wpf, otiles, w, z_lds);      // output_projection rows [32w, +32) of n_mels
         const int ln = opaque(lane), c31 = ln & 31;
         const int M = a.n_mels;
+        // Round 5: every load of this epilogue is an UNCONDITIONAL load from a clamped address, all of an n-tile in flight before the first
+        // use, and only the stores are predicated.  Written with the loads under the per-lane `m < M && t < Tc` branch (and the non-finite
+        // check's flag read behind another) the compiler emitted, per element, bias load / wait / xold load / wait / noise load / wait /
+        // store / wait: ~128 dependent round trips on the three waves that own the mel rows — 2-3 % of a launch.  Same expressions per
+        // element, same bits.
+        float bi[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + acc_row(r, ln);
-            const float bi = m < M ? ldg(a.bp, (unsigned)m) : 0.f;
+        for (int r = 0; r < 16; ++r) bi[r] = ldg(a.bp, (unsigned)min(mrow0 + acc_row(r, ln), M - 1));
+        bool bad = false;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + c31;
-                if (m < M && t < Tc) {
-                    const long o = ((long)b * T + t) * M + m;
-                    const float F = h[j][r] + bi;
-                    float v = a.c_out * F;
-                    if (xold) v = __builtin_fmaf(a.c_skip, xold[o], v);
-                    if (noise) v = __builtin_fmaf(noise[o] * a.nstd, 0.85f, v);
-                    out[o] = v;
-                    // a non-finite mel value (16-bit operands beyond the fp16 range, non-finite weights / inputs) is reported, not just returned:
-                    // code 2 in the pinned word cmtts_poll_error() reads, unless an earlier error is still pending there
-                    if (a.tmo && !(fabsf(v) <= 3.402823466e38f) && *(volatile unsigned*)a.tmo == 0u) *(volatile unsigned*)a.tmo = 2u;
-                }
+        for (int j = 0; j < NT; ++j) {
+            const int t = t0 + j * 32 + c31;
+            const long ob = ((long)b * T + min(t, T - 1)) * M;
+            float xo[16], nz[16];
+            if (xold) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xo[r] = xold[ob + min(mrow0 + acc_row(r, ln), M - 1)];
+            }
+            if (noise) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nz[r] = noise[ob + min(mrow0 + acc_row(r, ln), M - 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + acc_row(r, ln);
+                const bool ok = m < M && t < Tc;
+                const float F = h[j][r] + (m < M ? bi[r] : 0.f);
+                float v = a.c_out * F;
+                if (xold) v = __builtin_fmaf(a.c_skip, xo[r], v);
+                if (noise) v = __builtin_fmaf(nz[r] * a.nstd, 0.85f, v);
+                if (ok) out[ob + m] = v;
+                // a non-finite mel value (16-bit operands beyond the fp16 range, non-finite weights / inputs) is reported, not just returned
+                bad |= ok && !(fabsf(v) <= 3.402823466e38f);
             }
         }
+        // code 2 in the pinned word cmtts_poll_error() reads, unless an earlier error is still pending there
+        if (bad && a.tmo && *(volatile unsigned*)a.tmo == 0u) *(volatile unsigned*)a.tmo = 2u;
     }
 }
 
