@@ -1103,7 +1103,7 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
             ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
             a.out[0].act = ACT_RELU;
             a.xres_nt = 1;
-            if (pend_ln >= 0) { a.ln_g = P.ln_g[pend_ln]; a.ln_b = P.ln_b[pend_ln]; a.ln_eps = 1e-12f; a.ln_lens = ln_lens; }
+            if (pend_ln >= 0) { a.ln_g = P.ln_g[pend_ln]; a.ln_b = P.ln_b[pend_ln]; a.ln_eps = 1e-12f; a.ln_lens = ln_lens; a.ln_skip_tiles = 1; }      // (the next block's LayerNorm / ln_linear masks the same columns)
             rx = cmtts_launch_conv_xres(&a, P.convs_f[li], B, (void*)s);
             if (rx == -3) return fail(CMTTS_E_HIP, "conv_xres launch failed");
             if (rx == 0) pend_ln = -2;       // consumed (if any)
@@ -1657,7 +1657,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             ConvArgs a = conv_args(E.ffn1, ln_ffn ? w.x : w.h, L, Lp, hs, w.f, Lp, 4 * hs, L);
             a.out[0].alpha = (float)pow((double)c.ffn_kernel, -0.5);
             a.out[0].act = ACT_GELU_ERF;
-            if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; a.ln_lens = pad_lens; }
+            if (ln_ffn) { a.ln_g = E.ln2_g; a.ln_b = E.ln2_b; a.ln_eps = 1e-12f; a.ln_lens = pad_lens; a.ln_skip_tiles = pad_lens != nullptr; }      // (reduce_partials and the k = 1 linear mask by select)
             int rc = -2;
             if (xr && g_ffn_fused && ffn2_seg && E.ffn2_f && E.ffn1.cout == FFN2_SEG * 128) {
                 // ... and the FFN linear's partial products in the same launch: the activated rows never leave the CU

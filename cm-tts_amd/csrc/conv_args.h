@@ -64,6 +64,9 @@ struct ConvArgs {
     float ln_eps;
     int xres_nt;              // 0 = the launcher chooses 96- or 32-column tiles by how full the chip gets; 1 / 3 = forced (tests, tools)
     const int64_t* ln_lens;   // LayerNorm prologue: columns t >= ln_lens[z] become 0 (layernorm_ct_kernel's optional mask); nullptr = none
+    int ln_skip_tiles;        // conv_xres only, with ln_lens: a column tile WHOLLY beyond ln_lens[z] is not computed and its outputs are NOT WRITTEN
+                              // (stale workspace contents stay).  Set only by callers whose every consumer of those columns masks them by select with
+                              // the same lengths: the ragged FFT blocks (pad_lens) and the predictor convs (the next LayerNorm's mask)
     // conv_xres.hip, FFN fusion: the k = 1 linear that follows (W2: [M2][M], M2 = 256) applied to this workgroup's 128 activated output rows while
     // they are on chip — its K-segment partial sum [M2][N] goes to part + z * part_zs0 + (m-block) * part_zs1 (row stride part_ld) instead of
     // the activated rows going to out[0].Y; w2frag = W2 as A fragments in iteration order [M/16][2][M2/32][64][4] (to_fragment_iter_order)

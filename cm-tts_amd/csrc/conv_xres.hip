@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
     const int z = bz;
     // a ragged batch (ln_lens = each utterance's own padded length): a column tile wholly beyond it computes nothing anyone reads —
     // the normalised input is zero there and every consumer masks those columns by select (reduce_partials, the k = 1 linear)
-    if (LN && a.ln_lens && n0 > 0 && (int64_t)n0 >= a.ln_lens[z]) return;
+    if (LN && a.ln_skip_tiles && a.ln_lens && n0 > 0 && (int64_t)n0 >= a.ln_lens[z]) return;
     const int l31 = lane & 31, khalf = lane >> 5;
     const float* Xb = a.X + z * a.x_zs0;
     const int MTn = (a.M + 31) / 32;

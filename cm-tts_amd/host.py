@@ -107,14 +107,19 @@ class CondFactors:
     (include/cmtts_hip.h): with it the sampler expands cp from (p1, mel2ph, p_idx) instead of running the stacked conditioner GEMM
     over the frames.  Bound to ONE conditioning tensor: `matches` refuses a different or since-modified cond_ct (the sampler then
     takes the dense GEMM on whatever it was given)."""
-    __slots__ = ("p1", "p1_ld", "L", "mel2ph", "p_idx", "_ptr", "_version", "_shape")
+    __slots__ = ("p1", "p1_ld", "L", "mel2ph", "p_idx", "_ptr", "_version", "_shape", "_aux")
 
     def __init__(self, p1, p1_ld, L, mel2ph, p_idx, cond_ct):
         self.p1, self.p1_ld, self.L, self.mel2ph, self.p_idx = p1, int(p1_ld), int(L), mel2ph, p_idx
         self._ptr, self._version, self._shape = cond_ct.data_ptr(), cond_ct._version, tuple(cond_ct.shape)
+        # mel2ph and p_idx are the very tensors the caller received (out["mel2ph"], out["p_predictions"]["p_idx"]) and p1 is reachable too:
+        # an in-place edit of any of them after the duration net would change the mel on the factored path only (ADVICE r04) — their
+        # version counters are part of the match
+        self._aux = (p1._version, mel2ph._version, p_idx._version)
 
     def matches(self, cond_ct):
-        return cond_ct.data_ptr() == self._ptr and cond_ct._version == self._version and tuple(cond_ct.shape) == self._shape
+        return (cond_ct.data_ptr() == self._ptr and cond_ct._version == self._version and tuple(cond_ct.shape) == self._shape and
+                (self.p1._version, self.mel2ph._version, self.p_idx._version) == self._aux)
 
 
 class CMTotalTTS(torch.nn.Module):
@@ -539,7 +544,7 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
     if generator is None:
         generator = DummyGenerator()
     B, one, T, M = shape
-    ode = sampler in ("heun", "dpm", "euler", "ancestral", "our_multistep")
+    ode = sampler in ("heun", "dpm", "euler", "ancestral", "our_multistep", "progdist")
     distilled = getattr(diffusion, "distillation", False)
     # cmtts_schedule / cmtts_sample take sigma_min, sigma_max, sigma_data and rho from the model's config; a caller
     # whose arguments or diffusion object say otherwise gets the reference's host-side loop, which honours them
@@ -561,18 +566,19 @@ def karras_sample_tts(diffusion, model, shape, steps=2, clip_denoised=False, pro
         n_steps = len(ts) - 1 if fused else 0
         ode = not fused                # any other `ts` schedule: the reference's loop, host-side
     elif not ode:
-        raise NotImplementedError(f"sampler {sampler!r}: progdist is a training-time schedule (SURVEY.md §2)")
+        raise KeyError(sampler)          # the reference's dispatch table has no other entry (karras_diffusion.py:536-545)
     dev = model.device
     kw = dict(model_kwargs or {})
     out = model.duration_pitch_energy_net(kw.get("speakers"), kw["texts"], kw["src_lens"],
                                           spker_embeds=kw.get("spker_embeds"), max_mel_len=T)
     if ode:
         # the reference's other loops (karras_diffusion.py:538-577), host-side around the denoiser kernels
-        sigmas = get_sigmas_karras(steps, sigma_min, sigma_max, rho)
+        sigmas = get_sigmas_karras(steps + 1 if sampler == "progdist" else steps, sigma_min, sigma_max, rho)     # karras_diffusion.py:529-532
         x_T = _f32(generator.randn(*shape, device=dev), dev) * sigma_max
         dist = make_distiller(diffusion, model, out_cond(out), out["speaker_emb"])
         fn = {"heun": sample_heun, "dpm": sample_dpm, "euler": sample_euler, "ancestral": sample_euler_ancestral,
-              "our_multistep": our_multistep, "onestep": sample_onestep, "multistep": stochastic_iterative_sampler}[sampler]
+              "our_multistep": our_multistep, "onestep": sample_onestep, "multistep": stochastic_iterative_sampler,
+              "progdist": sample_progdist}[sampler]
         args = {}
         if sampler in ("heun", "dpm"):
             args = {k: unused[k] for k in ("s_churn", "s_tmin", "s_tmax", "s_noise") if k in unused}
@@ -640,6 +646,17 @@ def _churn(x, sigmas, i, generator, s_churn, s_tmin, s_tmax, s_noise):
     if gamma > 0:
         x = x + eps * float((sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5)
     return x, sigma_hat
+
+
+def sample_progdist(denoiser, x, sigmas, generator=None, **kw):
+    """karras_diffusion.py:856-888: Euler steps over the schedule WITHOUT its trailing zero (the progressive-distillation teacher's
+    sampler; `steps + 1` sigmas are requested for it, :529-530)."""
+    s_in = x.new_ones([x.shape[0]])
+    sigmas = sigmas[:-1]
+    for i in range(len(sigmas) - 1):
+        d = to_d(x, sigmas[i], denoiser(x, float(sigmas[i]) * s_in))
+        x = x + d * float(sigmas[i + 1] - sigmas[i])
+    return x
 
 
 def sample_heun(denoiser, x, sigmas, generator, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, **kw):

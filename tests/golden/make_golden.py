@@ -244,7 +244,7 @@ def golden_hifigan():
 
 def golden_samplers():
     """The reference's other sampler loops (karras_diffusion.py: sample_euler :743, sample_heun :693,
-    sample_dpm :775, sample_euler_ancestral :605) run through karras_sample_tts on the LJSpeech golden
+    sample_dpm :775, sample_euler_ancestral :605, sample_progdist :856) run through karras_sample_tts on the LJSpeech golden
     model and inputs (same seed, weights and noise draws as cmtts_LJSpeech.npz)."""
     from model.cm_tool.karras_diffusion import karras_sample_tts
     variant = "LJSpeech"
@@ -261,7 +261,7 @@ def golden_samplers():
     kwargs = dict(speakers=speakers, texts=t_texts, src_lens=t_lens, spker_embeds=None)
     out = {"seed": np.int64(seed)}
     with torch.no_grad():
-        for sampler, steps in (("euler", 3), ("heun", 3), ("dpm", 2), ("ancestral", 3)):
+        for sampler, steps in (("euler", 3), ("heun", 3), ("dpm", 2), ("ancestral", 3), ("progdist", 3)):
             gen = FixedNoise([torch.from_numpy(n) for n in noise])
             mel = karras_sample_tts(diffusion=diffusion, model=model, shape=(B, 1, T, cfg.n_mels), steps=steps,
                                     model_kwargs=kwargs, device="cpu", sigma_max=cfg.sigma_max,

@@ -416,9 +416,9 @@ def test_host_side_samplers_match_fused(models):
     assert torch.isfinite(twice).all() and tuple(twice.shape) == (B, 1, T, cfg.n_mels)
 
 
-@pytest.mark.parametrize("sampler", ["euler", "heun", "dpm", "ancestral"])
+@pytest.mark.parametrize("sampler", ["euler", "heun", "dpm", "ancestral", "progdist"])
 def test_ode_samplers_golden(models, golden, sampler):
-    """§8(f) item 3: karras_sample_tts(sampler=euler|heun|dpm|ancestral) — the reference's other loops run
+    """§8(f) item 3: karras_sample_tts(sampler=euler|heun|dpm|ancestral|progdist) — the reference's other loops run
     host-side around the HIP denoiser — against the reference's own output for the same noise draws."""
     host = _host()
     g, cfg, sd, model = models("LJSpeech")

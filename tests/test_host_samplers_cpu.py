@@ -62,6 +62,20 @@ def test_sampler_loops_match_oracle(sampler, kw):
     assert gen.i == {"euler": 0, "heun": steps, "dpm": steps, "ancestral": steps}[sampler]
 
 
+def test_progdist_is_euler_without_the_trailing_zero():
+    """karras_diffusion.py:856-888 (sampler "progdist", steps + 1 sigmas requested for it :529-530): Euler steps that stop at the last
+    non-zero sigma, no noise draws."""
+    shape = (2, 1, 7, 5)
+    x0 = (_noise(1, shape, seed=11)[0] * SIGMA_MAX).astype(np.float32)
+    steps = 4
+    sig_np = O.get_sigmas_karras(steps + 1, SIGMA_MIN, SIGMA_MAX, RHO)
+    ref = O.ode_samplers(_denoiser_np, x0, sig_np[:-1], [], "euler")
+    gen = _Gen([])
+    got = host.sample_progdist(_denoiser_t, torch.from_numpy(x0), host.get_sigmas_karras(steps + 1, SIGMA_MIN, SIGMA_MAX, RHO), gen)
+    np.testing.assert_allclose(got.numpy(), ref, rtol=2e-4, atol=2e-4)
+    assert gen.i == 0
+
+
 def test_stochastic_iterative_sampler_schedule():
     """karras_diffusion.py:830-854 with a general ts: evaluation sigmas and re-noising follow the oracle's schedule."""
     shape = (1, 1, 4, 3)
