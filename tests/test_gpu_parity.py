@@ -559,6 +559,29 @@ def test_hifigan_golden(golden):
         assert np.abs(pcm[i].astype(np.int32) - g[name].astype(np.int32)).max() <= 4
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 7), (3, 65), (5, 129), (1, 700), (33, 513)])
+def test_vocoder_winograd_odd_shapes(B, T):
+    """VERDICT r04 #5a for the generator: the Winograd form of the wide-stage convs works on output PAIRS one dilation apart (30- / 32-pair
+    tiles) — a one-frame mel, lengths that leave a lone column / a lone pair in the last tile at every dilation, an odd batch.  Forced onto
+    every shape (voc_wino = 2), against the direct form: fp32 rounding only."""
+    host = _host()
+    hcfg = HifiGanConfig()
+    voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=22))
+    mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(7 * T + B)) * 1.5 - 4).to(DEV)
+    prev = _lib.internal_set(b"voc_wino", 2)
+    try:
+        got = voc(mel).clone()
+        _lib.internal_set(b"voc_wino", 0)
+        ref = voc(mel).clone()
+    finally:
+        _lib.internal_set(b"voc_wino", prev)
+    torch.cuda.synchronize()
+    d = float((got - ref).abs().max())
+    report(f"VOC_WINOGRAD_ODD B={B} T={T}: max|d wav| vs the direct form {d:.2e}")
+    assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all()
+    assert 0 < d <= VOC_WINO_TOL, d
+
+
 @pytest.mark.parametrize("B,T", [(24, 350), (9, 1000), (32, 512)])
 def test_vocoder_winograd_vs_direct(B, T):
     """conv_xlw_kernel (round 4): the ResBlock convs of the C = 256 / 128 stages as Winograd convolutions over output pairs (t, t + dilation):
@@ -1116,6 +1139,42 @@ def test_persistent_denoiser_bitwise(variant, B, T, conv_form):
         assert not torch.equal(one, ref)          # the Winograd instance did run (it is not bitwise the direct form)
         report(f"WINOGRAD {variant} B={B} T={T}: max|d| vs the per-layer kernels: one evaluation {float((one - ref).abs().max()):.2e}, "
                f"T=2 mel {float((mel_p - mel_r).abs().max()):.2e}")
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (2, 63), (1, 64), (1, 65), (3, 129)])
+def test_denoiser_edge_shapes_every_mode(B, T):
+    """tools/edge_check.py in the tracked suite (VERDICT r04 #5a): T = 1, 2, 63, 64, 65, 129 through every execution mode of the denoiser —
+    per-layer vs forced persistent, fp32 (direct form) and bf16: bit for bit; the Winograd stack within WINO_TOL; and a one-phoneme text."""
+    from conftest import WINO_TOL
+    host = _host()
+    lib = _lib.load()
+    cfg = get_config("VCTK")
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=1, dur_frames=3.0, dur_spread=0.0))
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, 1, T, 80, generator=g); cond = torch.randn(B, T, 256, generator=g); spk = torch.randn(B, 256, generator=g)
+    t = torch.full((B,), 1095.5)
+    outs = {}
+    prev = lib.cmtts_set_persistent_denoiser(0)
+    prev_w = _lib.internal_set("persist_wino", 0)
+    try:
+        for mode in (0, 2):
+            lib.cmtts_set_persistent_denoiser(mode)
+            for prec in ("fp32", "bf16"):
+                model.set_precision(prec)
+                outs[(mode, prec)] = model.net(x, t, cond, spk).clone()
+        model.set_precision("fp32")
+        _lib.internal_set("persist_wino", 1)
+        wino = model.net(x, t, cond, spk).clone()
+    finally:
+        model.set_precision("fp32")
+        _lib.internal_set("persist_wino", prev_w)
+        lib.cmtts_set_persistent_denoiser(prev)
+    host.synchronize()
+    assert all(bool(torch.isfinite(o).all()) for o in outs.values())
+    assert torch.equal(outs[(0, "fp32")], outs[(2, "fp32")]) and torch.equal(outs[(0, "bf16")], outs[(2, "bf16")])
+    assert float((wino - outs[(0, "fp32")]).abs().max()) <= WINO_TOL
+    out = model.duration_pitch_energy_net(None, torch.tensor([[5]]), torch.tensor([1]), spker_embeds=torch.randn(1, 512))
+    assert out["mel_lens"].tolist() == [3] and bool(torch.isfinite(out["cond"]).all())
 
 
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 1, 150), ("VCTK", 3, 33), ("VCTK", 2, 257), ("LJSpeech", 5, 64)])
