@@ -689,8 +689,9 @@ def main():
                           "|d mel| ~4e-6 against the direct form, tests/test_gpu_precision.py), direct 1x1 output projection" if wino else "direct"),
             "executed_flops_per_launch": flops_exec, "executed_tflops": round(ex, 2),
             "executed_frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4),
-            "frac_note": "`achieved` / `frac` = the reference's (direct-form) FLOPs over the launch time, as SURVEY.md 8(d) counts them; `executed_*` = the "
-                         "MFMA FLOPs the kernel issues (2/3 of the conv's with Winograd): the matrix pipe's own duty"})
+            "frac_note": "`achieved` / `frac` = the reference's (direct-form) FLOPs over the launch time, as SURVEY.md 8(d) counts them — with the Winograd "
+                         "form the kernel issues only 2/3 of the conv's multiplies, so this figure can EXCEED 1.0 without the hardware exceeding its peak; "
+                         "`executed_*` = the MFMA FLOPs actually issued, i.e. the matrix pipe's own duty, and `mfma_busy*` the counters' view of the same"})
 
     if (world > 1 or gather or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:      # gather: CMTTS_FORCE_COLLECTIVE=1 on one GPU
         # every rank takes part: T = 1 / 2, configs[3] and configs[4] with their collectives (whole-job aggregates)
