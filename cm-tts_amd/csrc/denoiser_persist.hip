@@ -53,7 +53,8 @@ constexpr int RING = 6;         // register ring depth of the weight stream (k-g
 constexpr int FN = 64;
 constexpr int NT = FN / 32;
 constexpr int U_LD = FN + 4;
-constexpr int IDX_LDS_BYTES = (FN + 2) * 2 * 4;      // FACT: (phoneme, pitch bucket) of frames t0 - 1 .. t0 + FN behind the u / z buffers
+constexpr int IDX_LDS_BYTES = (FN + 2) * 2 * 4 + NW * 64 * 4;      // behind the u / z buffers: FACT's (phoneme, pitch bucket) table of frames t0 - 1 .. t0 + FN, and
+                                                                   // 64 floats per wave to turn its two edge columns into ONE 64-lane granule store
 constexpr unsigned SPIN_LIMIT = 1u << 20;     // bounded wait for a neighbour (~2 s); then the timeout word is set and
                                               // this wave stops waiting for the rest of the launch (results invalid)
 
@@ -573,15 +574,20 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         unsigned long long* hbase = halo_g + ((((long)(l & 1) * B_g + b) * tiles_g) * 2) * C;    // [parity][b][tile][side][C]
         {
             const int ln = opaque(lane), c31 = ln & 31;
-            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1)
+            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1).  The two columns sit in four lanes (16 registers
+            // each): stored from there they were 32 store instructions of two active lanes — ~100 cycles of issue apiece, 3-5 k per wave and
+            // layer at the head of the phase the neighbours wait for (round 5, -DPUB_STAMP).  Through 64 floats of LDS (a wave's own LDS
+            // operations execute in order: no barrier) every lane owns one granule and the wave stores them with ONE coalesced instruction.
+            float* edge = reinterpret_cast<float*>(smem + 2 * C * U_LD) + (FN + 2) * 2 + w * 64;
             if (c31 == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + acc_row(r, ln), tag, st[0][0][r]);
+                for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = st[0][0][r];
             }
             if (c31 == 31) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
+                for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = st[0][NT - 1][r];
             }
+            store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + (ln & 31), tag, edge[ln]);
         }
         // ---- halo columns of the next layer's u.  Every wave fetches the two halo entries of ITS OWN 32 rows (lanes 0-31: left halo
         // frame t0 - 1, lanes 32-63: right halo frame t0 + FN): one cp value and one granule per lane, requested here — before the wave's

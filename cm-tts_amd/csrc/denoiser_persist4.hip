@@ -456,21 +456,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         unsigned long long* hbase = halo_g + ((((long)(l & 1) * B_g + b) * tiles_g) * 2) * C;    // [parity][b][tile][side][C]
         {
             const int ln = opaque(lane), c31 = ln & 31;
-            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1)
-            if (c31 == 0) {
+            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1); through the wave's LDS scratch (behind the
+            // u / z buffers and the 8-wave kernel's index table) so that every lane stores one granule per row tile (denoiser_persist.hip)
+            float* edge = smem + 2 * C * U_LD + (FN + 2) * 2 + w * (64 * TPW);
 #pragma unroll
-                for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW; ++i) {
+                if (c31 == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + 32 * i + acc_row(r, ln), tag, xs[i][0][r]);
+                    for (int r = 0; r < 16; ++r) edge[64 * i + acc_row(r, ln)] = xs[i][0][r];
+                }
+                if (c31 == 31) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) edge[64 * i + 32 + acc_row(r, ln)] = xs[i][NT - 1][r];
+                }
             }
-            if (c31 == 31) {
 #pragma unroll
-                for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + 32 * i + acc_row(r, ln), tag, xs[i][NT - 1][r]);
-            }
+            for (int i = 0; i < TPW; ++i)
+                store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + 32 * i + (ln & 31), tag, edge[64 * i + ln]);
         }
         // ---- halo columns of the next layer's u: every wave fetches the two halo entries of ITS OWN 64 rows (lanes 0-31: left halo frame
         // t0 - 1, lanes 32-63: right halo frame t0 + FN; two rows per lane), requested here — before the wave's own u rows — and checked after

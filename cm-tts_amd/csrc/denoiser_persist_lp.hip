@@ -339,14 +339,18 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
         unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;
         {   // edge columns of x' (fp32) to the neighbouring tiles
             const int ln = opaque(lane), c31 = ln & 31;
+            // through 64 floats of the wave's own LDS scratch (behind the images): one coalesced 64-lane granule store instead of 32
+            // two-lane ones (denoiser_persist.hip, round 5)
+            float* edge = reinterpret_cast<float*>(lds16 + (MODE == 3 ? 2 : 1) * IMG) + w * 64;
             if (c31 == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 0) * C + mrow0 + acc_row(r, ln), tag, st[0][0][r]);
+                for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = st[0][0][r];
             }
             if (c31 == 31) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_granule(hbase + ((long)tile * 2 + 1) * C + mrow0 + acc_row(r, ln), tag, st[0][NT - 1][r]);
+                for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = st[0][NT - 1][r];
             }
+            store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + (ln & 31), tag, edge[ln]);
         }
         // ---- halo columns of the next layer's u^T.  Every wave fetches the two halo entries of ITS OWN 32 channels (lanes 0-31: left
         // halo frame t0 - 1, lanes 32-63: right halo frame t0 + FN): one cp value and one granule per lane.  (Until round 4 the last two
@@ -428,7 +432,8 @@ template <int MODE>
 int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t stream) {
     static bool attr_set = false;
     // the fp32 tail overlays two [256][68] float buffers on the 16-bit u^T / z^T images
-    const size_t lds16b = (size_t)(MODE == 3 ? 2 : 1) * (2 * FN + 2) * RS * sizeof(unsigned short), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
+    // (+ 64 floats per wave behind the images: the edge-column scratch of the granule store)
+    const size_t lds16b = (size_t)(MODE == 3 ? 2 : 1) * (2 * FN + 2) * RS * sizeof(unsigned short) + NW * 64 * sizeof(float), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
     const size_t lds = a.tail && ldstail > lds16b ? ldstail : lds16b;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>),
