@@ -615,7 +615,7 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     audio_s = frames_rank * world * cfg.hop_length / cfg.sampling_rate
     C_ = cfg.res_channels
-    wino = False
+    wino, pw, wform = False, 0, ""
     if args.unfused:   # the timed kernel is the gated k=3 conv alone
         kname = "conv1d_mfma_kernel<128,128,2,2,GATED> (denoiser k=3 gated conv)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_) * BATCH * FRAMES_PAD
@@ -623,19 +623,26 @@ def main():
         # ALGORITHMIC work: the reference's convolution (3 taps x C inputs per output of the gated conv, model/blocks.py:672) — what `achieved`
         # and `frac` are priced on, whatever algorithm the kernel runs.  Since round 4 the fp32 stack's conv is a Winograd F(2,3) convolution
         # (4 products per pair of frames instead of 6): the MFMA work actually issued is reported next to it as `executed_*`.
-        wino = _lib.internal_set(b"persist_wino", -1) == 1 and model.set_option("winograd", -1) == 1
-        kname = (f"denoiser_persist_kernel<{'WINO' if wino else 'direct'}> ({cfg.res_layers} residual layers: gated k=3 conv"
-                 f"{' as Winograd F(2,3)' if wino else ''} + output projection each, x / skip "
+        # Round 5: F(4,3) — 6 products per quad of frames instead of 12 (persist_wino = 3, the default; 1 / 2 = F(2,3)).
+        mw = model.set_option("winograd", -1)      # model option: 1 = F(4,3) (default), 2 = F(2,3), 0 = direct
+        pw = _lib.internal_set(b"persist_wino", -1) if mw else 0
+        if pw == 3 and mw == 2:
+            pw = 1
+        wino = pw in (1, 2, 3)
+        wform = {0: "", 1: "F(2,3)", 2: "F(2,3)", 3: "F(4,3)"}[pw]
+        taps_issued = {0: 3.0, 1: 2.0, 2: 2.0, 3: 1.5}[pw]      # MFMA products issued per output of the k = 3 conv, in units of C inputs
+        kname = (f"denoiser_persist_kernel<{'WINO ' + wform if wino else 'direct'}> ({cfg.res_layers} residual layers: gated k=3 conv"
+                 f"{' as Winograd ' + wform if wino else ''} + output projection each, x / skip "
                  f"{'L2-resident between layers' if wino else 'resident in registers'}; skip head in the tail)")
         flops_launch = (2.0 * (2 * C_) * (3 * C_ + C_) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
-        flops_exec = ((2.0 * (2 * C_) * ((2 * C_ if wino else 3 * C_) + C_)) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
+        flops_exec = ((2.0 * (2 * C_) * (taps_issued * C_ + C_)) * cfg.res_layers + 2.0 * C_ * (C_ + cfg.n_mels)) * BATCH * FRAMES_PAD
     else:              # fused residual block: gated k=3 conv + output projection (cp is precomputed)
         kname = "resblock_fused_kernel (gated k=3 conv + output projection of one residual layer)"
         flops_launch = 2.0 * (2 * C_) * (3 * C_ + C_) * BATCH * FRAMES_PAD
     traffic, pmc_cal, pmc_commit, pmc = None, (1.0, 1.0), "?", {}
     try:   # PMC counters cannot be sampled from inside the process: use the committed rocprofv3 pass of this workload
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        pmc = pj[("denoiser_persist_kernel_wino" if wino else "denoiser_persist_kernel") if persistent else "resblock_fused_kernel"]
+        pmc = pj[(("denoiser_persist_kernel_wino43" if pw == 3 else "denoiser_persist_kernel_wino") if wino else "denoiser_persist_kernel") if persistent else "resblock_fused_kernel"]
         if not args.unfused and pmc["B"] == BATCH and pmc["T"] == FRAMES_PAD:
             traffic = pmc["bytes_per_launch"]
             pmc_cal = (pj["calibration"]["dword_4B_per_lane"]["fetch_factor"], pj["calibration"]["dword_4B_per_lane"]["write_factor"])
@@ -685,12 +692,12 @@ def main():
     if persistent and not args.unfused:
         ex = flops_exec / (avg_ms * 1e-3) / 1e12 if n_l.value else 0.0
         result["roofline"].update({
-            "algorithm": ("Winograd F(2,3) along the frame axis for the gated k=3 conv (fp32 transforms, weights transformed in double and rounded once; "
-                          "|d mel| ~4e-6 against the direct form, tests/test_gpu_precision.py), direct 1x1 output projection" if wino else "direct"),
+            "algorithm": (f"Winograd {wform} along the frame axis for the gated k=3 conv (fp32 transforms, weights transformed in double and rounded once; "
+                          f"|d mel| ~{'8e-6' if pw == 3 else '4e-6'} against the direct form, tests/test_gpu_precision.py), direct 1x1 output projection" if wino else "direct"),
             "executed_flops_per_launch": flops_exec, "executed_tflops": round(ex, 2),
             "executed_frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4),
             "frac_note": "`achieved` / `frac` = the reference's (direct-form) FLOPs over the launch time, as SURVEY.md 8(d) counts them — with the Winograd "
-                         "form the kernel issues only 2/3 of the conv's multiplies, so this figure can EXCEED 1.0 without the hardware exceeding its peak; "
+                         "form the kernel issues only 1/2 (F(4,3)) or 2/3 (F(2,3)) of the conv's multiplies, so this figure can EXCEED 1.0 without the hardware exceeding its peak; "
                          "`executed_*` = the MFMA FLOPs actually issued, i.e. the matrix pipe's own duty, and `mfma_busy*` the counters' view of the same"})
 
     if (world > 1 or gather or os.environ.get("CMTTS_MULTI_EXTRAS") == "1") and not args.no_extras:      # gather: CMTTS_FORCE_COLLECTIVE=1 on one GPU

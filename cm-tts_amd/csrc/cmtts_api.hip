@@ -191,6 +191,35 @@ std::vector<float> to_wino4_fragments(const std::vector<float>& p, int K, int M)
     return f;
 }
 
+// Winograd F(4,3) form of the same conv for the persistent denoiser's WINO == 2 instances (points 0, +-1, +-2, inf): transformed weights
+// U0 = g0 / 4, U1 = -(g0 + g1 + g2) / 6, U2 = -(g0 - g1 + g2) / 6, U3 = g0 / 24 + g1 / 12 + g2 / 6, U4 = g0 / 24 - g1 / 12 + g2 / 6, U5 = g2
+// (formed in double, rounded once) as A fragments of v_mfma_f32_16x16x4_f32 in the kernel's iteration order
+// [K/4 k-steps][M/64 waves][6 transforms][64 lanes][4]: element e at lane l is input channel 4 ks + (l >> 4), output row 64 w + 16 e + (l & 15).
+constexpr int WINO43_PAD_KS = 4;      // k-steps of zero padding behind a layer's array (the weight ring runs a few stages past the end)
+std::vector<float> to_wino43_fragments(const std::vector<float>& p, int K, int M) {
+    const int NWV = M / 64;
+    std::vector<float> f((size_t)(K / 4 + WINO43_PAD_KS) * NWV * 6 * 64 * 4, 0.0f);
+    for (int ks = 0; ks < K / 4; ++ks)
+        for (int w = 0; w < NWV; ++w)
+            for (int tr = 0; tr < 6; ++tr)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * ks + (lane >> 4), mrow = 64 * w + 16 * e + (lane & 15);
+                        const double g0 = p[((size_t)0 * K + k) * M + mrow], g1 = p[((size_t)1 * K + k) * M + mrow], g2 = p[((size_t)2 * K + k) * M + mrow];
+                        double v;
+                        switch (tr) {
+                            case 0: v = g0 / 4.0; break;
+                            case 1: v = -(g0 + g1 + g2) / 6.0; break;
+                            case 2: v = -(g0 - g1 + g2) / 6.0; break;
+                            case 3: v = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+                            case 4: v = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                            default: v = g2; break;
+                        }
+                        f[((((size_t)ks * NWV + w) * 6 + tr) * 64 + lane) * 4 + e] = (float)v;
+                    }
+    return f;
+}
+
 // Winograd form of a k-tap conv for conv_xlw_kernel (resblock_pair.h: WinoTab<KT>): the transformed weights of every table entry (formed in
 // double, rounded once) as A fragments in the kernel's iteration order [K/16 chunks][entries][2 halves][M/32][64 lanes][4].
 template <int KT>
@@ -385,9 +414,9 @@ int g_persist_tail = 1;      // skip head + post-scaling inside the persistent d
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
-int g_persist_wino = 1;         // fp32 persistent denoiser: the k = 3 conv as Winograd F(2,3) (2/3 of the MFMAs; NOT bitwise the direct form): 1 = the 8-wave
-                                // instances of denoiser_persist.hip (default), 2 = the one-wave-per-SIMD stack of denoiser_persist4.hip (same bits as 1;
-                                // measured 4-10 % slower: profiles/r05_persist4.md)
+int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a Winograd form (NOT bitwise the direct form): 3 = F(4,3), the 8-wave WINO == 2 instances
+                                // of denoiser_persist.hip (default since round 5: half of the conv's MFMAs), 1 = F(2,3), the 8-wave WINO == 1 instances (2/3), 2 = the
+                                // one-wave-per-SIMD F(2,3) stack of denoiser_persist4.hip (same bits as 1; measured 4-10 % slower), 0 = direct
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
@@ -564,6 +593,7 @@ struct ResLayer {
     PackedConv cond, conv3, outp;
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
     float* w3w = nullptr;                   // Winograd F(2,3) transformed conv weights as A fragments (persistent denoiser, 8-wave WINO instances)
+    float* w3w43 = nullptr;                 // Winograd F(4,3) transformed conv weights (8-wave WINO == 2 instances: to_wino43_fragments)
     float* w3w4 = nullptr;                  // the same as per-wave streams for the one-wave-per-SIMD stack (denoiser_persist4.hip)
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
     void *w3f16[3] = {nullptr, nullptr, nullptr}, *wof16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies
@@ -577,7 +607,8 @@ struct cmtts_model {
     bool finalized = false;
     int precision = 0;     // operand precision of the residual-block contractions: 0 fp32, 1 bf16, 2 fp16
     int text16 = 0;        // 16-bit models (precision 1 / 2): the FFN contractions of the FFT blocks with 16-bit operands too (opt-in: the text side feeds the integer stages — durations, pitch buckets, lengths — which then depend on the precision mode; cmtts_model_set_option)
-    int winograd = 1;                       // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (cmtts_model_set_option "winograd"; ~4e-6 on the mel against the direct form)
+    int winograd = 1;                       // fp32 persistent denoiser: Winograd k = 3 conv (cmtts_model_set_option "winograd"): 1 = F(4,3) (~8e-6 on the mel against the direct form),
+                                            // 2 = F(2,3) (~4e-6), 0 = direct
     int ffn2_split = 1;    // FFT blocks: the FFN linear as 8 partial GEMMs over K segments + one reduction (another fp32 summation order than one launch: a property of the model handle, cmtts_model_set_option)
     cmtts_variance_controls vc = {1.f, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Allocs al;
@@ -873,6 +904,7 @@ int finalize_model(cmtts_model* m) {
             CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
             if (C == 256) CHK(al.upload(to_wino_fragments(hp, C, 2 * C), &m->res[l].w3w));
             if (C == 256) CHK(al.upload(to_wino4_fragments(hp, C, 2 * C), &m->res[l].w3w4));
+            if (C == 256) CHK(al.upload(to_wino43_fragments(hp, C, 2 * C), &m->res[l].w3w43));
             for (int mode = 1; mode <= 2; ++mode) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
                 CHK(al.upload_bytes(f16.data(), f16.size() * 2, &m->res[l].w3f16[mode - 1]));
@@ -1363,9 +1395,10 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         }
         pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.pst;
         if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;      // one wave per SIMD (denoiser_persist4.hip)
+        if (pa.wino && g_persist_wino == 3 && m->winograd == 1 && m->res[0].w3w43) pa.wino = 3;     // F(4,3) (model option "winograd" = 2 keeps F(2,3))
         pa.xst = w.pst;
         for (int l = 0; l < NL; ++l) {
-            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f);
+            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino == 3 ? m->res[l].w3w43 : pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f);
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
@@ -2153,8 +2186,9 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     for (int g = 0; g < n_groups && pa.wino; ++g)
         if (keep[g] > 0 && !ws[g].pst) pa.wino = 0;
     if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;
+    if (pa.wino && g_persist_wino == 3 && m->winograd == 1 && m->res[0].w3w43) pa.wino = 3;
     for (int l = 0; l < NL; ++l) {
-        pa.W3f[l] = pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
+        pa.W3f[l] = pa.wino == 3 ? m->res[l].w3w43 : pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
     if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.p2t = m->cond_p2t; pa.ld2 = c.pitch_bins; }
@@ -2624,7 +2658,7 @@ int cmtts_model_set_option(cmtts_model* m, const char* name, int value) {
     const Knob tab[] = {
         {"ffn2_split", &m->ffn2_split, 0, 1},            // FFN linear of the FFT blocks as 8 K-segment partial GEMMs + one reduction (1) or one launch (0)
         {"text16", &m->text16, 0, 1},                    // bf16 / fp16 models: 16-bit operands in the FFT blocks' FFN contractions as well (default 0)
-        {"winograd", &m->winograd, 0, 1},                // fp32 persistent denoiser stack: the gated k = 3 conv as Winograd F(2,3) (default 1; 0 = the direct form, bitwise the per-layer kernels)
+        {"winograd", &m->winograd, 0, 2},                // fp32 persistent denoiser stack: the gated k = 3 conv as Winograd F(4,3) (default 1), F(2,3) (2) or in the direct form (0: bitwise the per-layer kernels)
     };
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);
@@ -2657,7 +2691,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
-        {"persist_wino", &g_persist_wino, 0, 2},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
+        {"persist_wino", &g_persist_wino, 0, 3},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
         {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
         {"ffn_fused", &g_ffn_fused, 0, 1},         // FFN linear's partial products inside the FFN conv's launch

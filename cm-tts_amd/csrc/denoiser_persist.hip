@@ -40,6 +40,12 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifndef WINO_THREAD
 #define WINO_THREAD 1
 #endif
+#ifndef W43_ABL
+#define W43_ABL 0
+#endif
+#ifndef WINO43_RING
+#define WINO43_RING 3      // k-steps of F(4,3) transformed weights in flight per wave + the one in use (24 registers each)
+#endif
 #ifndef WINO_RING
 #define WINO_RING 3        // half-groups of transformed weights in flight per wave + the one in use (WINO instances)
 #endif
@@ -92,7 +98,7 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 // even frames at 33 + f / 2) so that the four d_i of a pair are unit-stride reads; the residual stream x makes room in the register
 // file by living in `xst` memory between layers (read-modify-write by the lane that owns the element, L2-resident); the skip sum stays.
 // NOT bitwise equal to the direct form (fp32 Winograd: ~1e-6 relative per layer); everything else in the kernel is unchanged.
-template <bool DBG, bool RAGGED, bool FACT = false, bool WINO = false>
+template <bool DBG, bool RAGGED, bool FACT = false, int WINO = 0>
 __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     };
 
     // column of frame f (-1 .. FN) within a u row: f + 1, or (WINO) odd frames first, then even frames
-    auto uidx = [](int f) { return WINO ? ((f & 1) ? (f + 1) >> 1 : 33 + (f >> 1)) : f + 1; };
+    auto uidx = [](int f) { return WINO == 1 ? ((f & 1) ? (f + 1) >> 1 : 33 + (f >> 1)) : f + 1; };
     // WINO: the residual stream x of this tile between layers, in a kernel-private layout [wave][j * 4 + q][lane][4] (element e of that
     // float4 = accumulator register 4 q + e of n-tile j): every load / store of the state is one fully coalesced 16-byte-per-lane instruction
     constexpr int PST_TILE = NW * 8 * 64 * 4;       // floats of one tile (64 KB)
@@ -288,7 +294,17 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // WINO: a stage = one half-group (4 channels = 2 k-steps) of all four transforms for this wave's two m-tiles: 4 x 16 bytes per lane,
         // element q of fragment (i, ps) = transform 2 ps + (q >> 1), k-step q & 1
         constexpr int WR = WINO_RING, NH = C / 4;
-        f32x4 Aw[WINO ? WR : 1][MT][2];
+        f32x4 Aw[WINO == 1 ? WR : 1][MT][2];
+        // WINO == 2, F(4,3): a stage = one k-step of FOUR channels of all six transforms for this wave's four 16-row m-tiles: 6 x 16 bytes per lane,
+        // element e of fragment p = transform p, m-tile e (cmtts_api.hip: to_wino43_fragments)
+        constexpr int WR4 = WINO43_RING, NS4 = C / 4;
+        f32x4 A4[WINO == 2 ? WR4 : 1][6];
+        // (one per-lane pointer at the wave's FOURTH fragment: the six loads of a k-step are immediate offsets -3072 .. +2048 from it)
+        auto load_a4 = [&](f32x4 (&dst)[6], const float* wfrag, int ks) {
+            const char* base = reinterpret_cast<const char*>(wfrag) + ((w * 6 + 3) * 64 + lane) * 16 + (size_t)ks * (NW * 6 * 64 * 16);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) dst[p] = *reinterpret_cast<const f32x4*>(base + (p - 3) * 1024);
+        };
         // (uniform base + 32-bit lane offset: the saddr form, no per-step VALU address arithmetic; the ring reads up to WR - 1 half-groups past
         //  the layer's last one — the packer pads every layer's array by that much, cmtts_api.hip: to_wino_fragments)
         auto load_aw = [&](f32x4 (&dst)[MT][2], const float* wfrag, int hg) {
@@ -299,7 +315,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 for (int ps = 0; ps < 2; ++ps)
                     dst[i][ps] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)((((w * MT + i) * 2 + ps) * 64 + lane) * 16)));
         };
-        if (WINO) {
+        if (WINO == 2) {
+#pragma unroll
+            for (int s = 0; s < WR4 - 1; ++s) load_a4(A4[s], a.W3f[l], s);
+        } else if (WINO == 1) {
 #pragma unroll
             for (int s = 0; s < WR - 1; ++s) load_aw(Aw[s], a.W3f[l], s);
         } else {
@@ -324,8 +343,81 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         }
 
         // =========================================================== phase B: gated k=3 conv
-        f32x16 accw[WINO ? MT : 1][WINO ? 4 : 1];      // WINO: m-tile x transform, one n-tile of 32 frame PAIRS
-        if constexpr (WINO) {
+        f32x16 accw[WINO == 1 ? MT : 1][WINO == 1 ? 4 : 1];      // WINO: m-tile x transform, one n-tile of 32 frame PAIRS
+        f32x4 acc4[WINO == 2 ? 4 : 1][WINO == 2 ? 6 : 1];        // F(4,3): 16-row m-tile x transform, one n-tile of the 16 frame QUADS
+        if constexpr (WINO == 2) {
+            // F(4,3) along the frame axis (header comment): per quad of output frames six products instead of twelve.  One n-tile of
+            // v_mfma_f32_16x16x4_f32 is one transform of the tile's 16 quads, so lane (q = l & 15, k = l >> 4) reads the six inputs
+            // u(4q-1 .. 4q+4) of its quad in channel 4 ks + k (one 16-byte + one 8-byte LDS read, natural frame order), forms the six
+            // transformed inputs (12 VALU) and feeds 6 transforms x 4 m-tiles = 24 MFMAs of 32 cycles.
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc4[i][p][r] = 0.f;
+            const float* W3f = a.W3f[l];
+            float V4[6];
+            f32x4 Da;
+            float2 Db;
+            auto load_d4 = [&](int ks) {      // (the read past the last k-step lands in the z buffer: discarded)
+                const float* rr = u_lds + (4 * ks + (lane >> 4)) * U_LD + 4 * (lane & 15);
+                Da = *reinterpret_cast<const f32x4*>(rr);
+                Db = *reinterpret_cast<const float2*>(rr + 4);
+            };
+            auto transform4 = [&]() {
+                const float d0 = Da[0], d1 = Da[1], d2 = Da[2], d3 = Da[3], d4 = Db.x, d5 = Db.y;
+                const float t0 = __builtin_fmaf(-4.f, d2, d4), t1 = __builtin_fmaf(-4.f, d1, d3);
+                const float t2 = d4 - d2, t3 = d3 - d1;
+                V4[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+                V4[1] = t0 + t1;
+                V4[2] = t0 - t1;
+                V4[3] = __builtin_fmaf(2.f, t3, t2);
+                V4[4] = __builtin_fmaf(-2.f, t3, t2);
+                V4[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            };
+            load_d4(0);
+#if W43_ABL & 2
+            transform4();
+#endif
+#pragma unroll 1
+            for (int s0 = 0; s0 < NS4; s0 += WR4) {
+#pragma unroll
+                for (int s = 0; s < WR4; ++s) {
+                    const int ks = s0 + s;
+                    // -DW43_ABL=n (timing-only builds, wrong results): 1 = no weight loads in the loop, 2 = no LDS reads / input transform
+#if !(W43_ABL & 2)
+                    transform4();
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+#if !(W43_ABL & 1)
+                    load_a4(A4[(s + WR4 - 1) % WR4], W3f, ks + WR4 - 1);
+#endif
+#if !(W43_ABL & 2)
+                    load_d4(ks + 1);
+#endif
+                    if (ks < NS4) {
+#pragma unroll
+                        for (int p = 0; p < 6; ++p)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc4[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[s][p][i], V4[p], acc4[i][p], 0, 0, 0);
+                    }
+                    // the stage's 6 weight loads and 2 LDS reads between its MFMAs (as the F(2,3) loop)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (WINO == 1) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -432,7 +524,41 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
             for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));   // output projection: same, before the gate
         }
-        {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
+        if constexpr (WINO == 2) {
+            // output transform + gate: y0 = m0 + (m1 + m2) + (m3 + m4), y1 = (m1 - m2) + 2 (m3 - m4), y2 = (m1 + m2) + 4 (m3 + m4),
+            // y3 = (m1 - m2) + 8 (m3 - m4) + m5 — all six transforms of a quad sit in the same lane and register; m-tiles 2 cb / 2 cb + 1 are
+            // the sigmoid / tanh rows of the same 16 channels, and the lane writes its quad of z as one 16-byte store
+            const float* b3 = a.b3[l];
+            const int ln = opaque(lane), q4 = ln & 15, rb = ln >> 4;
+            float bg[2][4], bf[2][4];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bg[cb][r] = ldg(b3, (unsigned)(64 * w + 32 * cb + 4 * rb + r));
+                    bf[cb][r] = ldg(b3, (unsigned)(64 * w + 32 * cb + 16 + 4 * rb + r));
+                }
+            auto out4 = [&](int i, int r, float bias, float (&y)[4]) {
+                const float m0 = acc4[i][0][r], m1 = acc4[i][1][r], m2 = acc4[i][2][r], m3 = acc4[i][3][r], m4 = acc4[i][4][r], m5 = acc4[i][5][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                y[0] = ((m0 + s12) + s34) + bias;
+                y[1] = __builtin_fmaf(2.f, d34, d12) + bias;
+                y[2] = __builtin_fmaf(4.f, s34, s12) + bias;
+                y[3] = (__builtin_fmaf(8.f, d34, d12) + m5) + bias;
+            };
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yg[4], yf[4];
+                    out4(2 * cb, r, bg[cb][r], yg);
+                    out4(2 * cb + 1, r, bf[cb][r], yf);
+                    f32x4 zz;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zz[e] = cmtts_gate(yg[e], yf[e]);
+                    *reinterpret_cast<f32x4*>(z_lds + (32 * w + 16 * cb + 4 * rb + r) * U_LD + 4 * q4) = zz;
+                }
+        } else {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
             // other waves' MFMAs); nobody reads z before barrier (3)
             const float* b3 = a.b3[l];
             const int ln = opaque(lane);
@@ -445,7 +571,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     bg[i][r] = ldg(b3, (unsigned)mg);
                     bf[i][r] = ldg(b3, (unsigned)(mg + 16));
                 }
-            if constexpr (WINO) {
+            if constexpr (WINO == 1) {
                 // output transform: y(2p) = (m0 + m1) + m2, y(2p+1) = (m1 - m2) - m3; lane p writes the frame pair as one 8-byte store
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -751,8 +877,8 @@ long long* g_pdbg = nullptr;
 int g_coop = -1;
 int g_process_group = 0;
 // per kernel instance: the LARGEST grid (workgroups) whose co-residency the runtime has confirmed.  Instances differ in registers and
-// threads, so every one has its own record: fp32 uniform 0..5 = (direct | 8-wave Winograd | one wave per SIMD) x (cp | factors),
-// fp32 ragged 8..13 likewise, the 16-bit modes 16 + MODE (shared slots let one kernel's validation vouch for another)
+// threads, so every one has its own record: fp32 uniform 0..7 = (direct | 8-wave F(2,3) | 8-wave F(4,3) | one wave per SIMD) x (cp | factors),
+// fp32 ragged 8..15 likewise, the 16-bit modes 16 + MODE (shared slots let one kernel's validation vouch for another)
 constexpr int N_VARIANTS = 24;
 int g_validated_wg[N_VARIANTS] = {};
 
@@ -821,22 +947,22 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     if (!force && (long)tiles * a.B * 2 <= (long)max_blocks) return -2;
     a.tiles = tiles;
     a.dbg = g_pdbg;
-    if (a.wino == 1 && !a.xst) return -2;     // the 8-wave Winograd instances keep the residual stream in `xst` between layers
+    if ((a.wino == 1 || a.wino == 3) && !a.xst) return -2;     // the 8-wave Winograd instances keep the residual stream in `xst` between layers
+    const int wsel = a.wino == 3 ? 2 : a.wino ? 1 : 0;         // instance: direct | F(2,3) | F(4,3)
     const bool p4 = a.wino == 2;              // one wave per SIMD (denoiser_persist4.hip): 256 threads, state in registers
     if (p4 && a.tail && a.n_mels > 128) return -2;
     const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
     // instance table: [dbg][fact][wino]
-    static const void* const kfns[2][2][2] = {
-        {{reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, false, true>)},
-         {reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, false, true, true>)}},
-        {{reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, false, true>)},
-         {reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<true, false, true, true>)}}};
+#define KFN(D, R, F, W) reinterpret_cast<const void*>(denoiser_persist_kernel<D, R, F, W>)
+    static const void* const kfns[2][2][3] = {
+        {{KFN(false, false, false, 0), KFN(false, false, false, 1), KFN(false, false, false, 2)}, {KFN(false, false, true, 0), KFN(false, false, true, 1), KFN(false, false, true, 2)}},
+        {{KFN(true, false, false, 0), KFN(true, false, false, 1), KFN(true, false, false, 2)}, {KFN(true, false, true, 0), KFN(true, false, true, 1), KFN(true, false, true, 2)}}};
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float) + IDX_LDS_BYTES;
     if (!attr_set) {
         for (int d = 0; d < 2; ++d)
             for (int f = 0; f < 2; ++f) {
-                for (int wn = 0; wn < 2; ++wn)
+                for (int wn = 0; wn < 3; ++wn)
                     if (hipFuncSetAttribute(kfns[d][f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
                 if (hipFuncSetAttribute(cmtts_persist4_kernel(d, 0, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
             }
@@ -874,9 +1000,9 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        const void* kfn = p4 ? cmtts_persist4_kernel(a.dbg ? 1 : 0, 0, a.fact ? 1 : 0) : kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][a.wino ? 1 : 0];
+        const void* kfn = p4 ? cmtts_persist4_kernel(a.dbg ? 1 : 0, 0, a.fact ? 1 : 0) : kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][wsel];
         void* params[] = {(void*)&c};
-        const int variant = (p4 ? 2 : a.wino ? 1 : 0) * 2 + (a.fact ? 1 : 0);        // one record per kernel instance (persist_args.h)
+        const int variant = (p4 ? 3 : wsel) * 2 + (a.fact ? 1 : 0);        // one record per kernel instance (persist_args.h)
         if (!a.dbg && cmtts_persist_cooperative(variant, tiles, nb)) {
             if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;
             cmtts_persist_validated(variant, tiles, nb);
@@ -895,14 +1021,13 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
     for (int g = 0; g < a.n_groups; ++g)
         if ((long)C * a.grp[g].T >= (1L << 30) || a.grp[g].tiles > 127 || a.grp[g].B > 1023) return -2;
     // instance table: [fact][wino]
-    static const void* const kfns[2][2] = {
-        {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, false, true>)},
-        {reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, false>), reinterpret_cast<const void*>(denoiser_persist_kernel<false, true, true, true>)}};
+    static const void* const kfns[2][3] = {{KFN(false, true, false, 0), KFN(false, true, false, 1), KFN(false, true, false, 2)},
+                                           {KFN(false, true, true, 0), KFN(false, true, true, 1), KFN(false, true, true, 2)}};
     static bool attr_set = false;
     const size_t lds = (size_t)2 * C * U_LD * sizeof(float) + IDX_LDS_BYTES;
     if (!attr_set) {
         for (int f = 0; f < 2; ++f) {
-            for (int wn = 0; wn < 2; ++wn)
+            for (int wn = 0; wn < 3; ++wn)
                 if (hipFuncSetAttribute(kfns[f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
             if (hipFuncSetAttribute(cmtts_persist4_kernel(0, 1, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
         }
@@ -918,14 +1043,15 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
                 if (a.grp[g].B > 0 && !a.grp[g].p1t) return -2;
         }
     }
-    if (a.wino == 1)   // the 8-wave Winograd instances keep the residual stream of every group in its `xst` buffer
+    if (a.wino == 1 || a.wino == 3)   // the 8-wave Winograd instances keep the residual stream of every group in its `xst` buffer
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && !a.grp[g].xst) return -2;
     const bool p4 = a.wino == 2;
     if (p4 && a.tail && a.n_mels > 128) return -2;
     const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
-    const void* kfn = p4 ? cmtts_persist4_kernel(0, 1, a.fact ? 1 : 0) : kfns[a.fact ? 1 : 0][a.wino ? 1 : 0];
-    const int variant = 8 + (p4 ? 2 : a.wino ? 1 : 0) * 2 + (a.fact ? 1 : 0);      // one record per kernel instance
+    const int wsel = a.wino == 3 ? 2 : a.wino ? 1 : 0;
+    const void* kfn = p4 ? cmtts_persist4_kernel(0, 1, a.fact ? 1 : 0) : kfns[a.fact ? 1 : 0][wsel];
+    const int variant = 8 + (p4 ? 3 : wsel) * 2 + (a.fact ? 1 : 0);      // one record per kernel instance
     void* params[] = {(void*)a_in};
     if (cmtts_persist_cooperative(variant, a.n_wg, -1)) {
         if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;

@@ -3,6 +3,8 @@ algebra the HIP kernels rely on is checked on the CPU against the plain convolut
 
   * denoiser_persist.hip, WINO instances (cm-tts_amd/csrc/cmtts_api.hip: to_wino_fragments): the gated k = 3, dilation-1 conv of
     ResidualBlock.forward (reference model/blocks.py:672) as F(2,3) over frame pairs;
+  * denoiser_persist.hip, WINO == 2 instances (round 5; cmtts_api.hip: to_wino43_fragments): the same conv as F(4,3) over frame quads
+    (conv1d_f43 below: the kernel's transforms in the kernel's operation order);
   * resblock_pair.hip: conv_xlw_kernel (cm-tts_amd/csrc/resblock_pair.h: WinoTab<k>, cmtts_api.hip: to_wino_iter_fragments): the k = 3 / 7 / 11 dilated convs of
     hifigan ResBlock1 (reference hifigan/models.py:96-103) over output pairs one dilation apart — groups of three taps as F(2,3), a remainder of two taps
     as F(2,2), a single remaining tap directly.
@@ -64,4 +66,36 @@ def conv1d_winograd(x, w, dil=1):
     y = np.zeros((cout, Tp + dil), x.dtype)
     y[:, t_first] = (M[0] + M[1]) + M[2]
     y[:, t_first + dil] = (M[1] - M[2]) - M[3]
+    return y[:, :T]
+
+
+def f43_weights(w):
+    """w [Cout][Cin][3] -> the six transformed weights U_p [Cout][Cin] (points 0, +-1, +-2, inf; cmtts_api.hip: to_wino43_fragments forms them in
+    double and rounds once)."""
+    g0, g1, g2 = (w[..., i].astype(np.float64) for i in range(3))
+    return [g0 / 4.0, -(g0 + g1 + g2) / 6.0, -(g0 - g1 + g2) / 6.0, g0 / 24.0 + g1 / 12.0 + g2 / 6.0, g0 / 24.0 - g1 / 12.0 + g2 / 6.0, g2]
+
+
+def conv1d_f43(x, w):
+    """The k = 3, dilation-1, padding-1 conv through F(4,3): outputs in quads 4q .. 4q + 3 from inputs d0 .. d5 = x(4q - 1 .. 4q + 4)
+    (denoiser_persist.hip, WINO == 2: transform4 / out4, same expressions)."""
+    cout, cin, k = w.shape
+    assert k == 3
+    T = x.shape[1]
+    Tq = -(-T // 4) * 4
+    xp = np.pad(x, ((0, 0), (1, Tq - T + 4)))
+    q0 = np.arange(0, Tq, 4)
+    d = [xp[:, q0 + i] for i in range(6)]                      # [Cin][quads] each
+    dt = x.dtype.type
+    t0, t1 = d[4] - dt(4) * d[2], d[3] - dt(4) * d[1]
+    t2, t3 = d[4] - d[2], d[3] - d[1]
+    V = [dt(4) * d[0] + (d[4] - dt(5) * d[2]), t0 + t1, t0 - t1, t2 + dt(2) * t3, t2 - dt(2) * t3, dt(4) * d[1] + (d[5] - dt(5) * d[3])]
+    U = [u.astype(x.dtype) for u in f43_weights(w)]
+    m = [U[p] @ V[p] for p in range(6)]
+    s12, d12, s34, d34 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+    y = np.zeros((cout, Tq), x.dtype)
+    y[:, q0] = (m[0] + s12) + s34
+    y[:, q0 + 1] = d12 + dt(2) * d34
+    y[:, q0 + 2] = s12 + dt(4) * s34
+    y[:, q0 + 3] = (d12 + dt(8) * d34) + m[5]
     return y[:, :T]

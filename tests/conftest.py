@@ -109,9 +109,9 @@ def golden():
     return get
 
 
-# The fp32 persistent denoiser stack runs its gated k = 3 conv as a Winograd F(2,3) convolution by default (round 4; model option
-# "winograd", process-wide A/B switch "persist_wino"): 2/3 of the conv's MFMAs, NOT bitwise the direct form of the per-layer kernels
-# (measured: <= 1e-5 on one network evaluation, ~4e-6 on a T = 4 mel).  Tests that compare the persistent stack with the per-layer kernels
+# The fp32 persistent denoiser stack runs its gated k = 3 conv as a Winograd convolution by default (F(2,3) in round 4, F(4,3) since
+# round 5; model option "winograd", process-wide A/B switch "persist_wino"): 2/3 resp. 1/2 of the conv's MFMAs, NOT bitwise the direct form
+# of the per-layer kernels (measured: F(2,3) <= 9e-6 / F(4,3) <= 1.6e-5 on one network evaluation, 4e-6 / 8e-6 on a T = 2 mel).  Tests that compare the persistent stack with the per-layer kernels
 # run in both forms: "direct" keeps every assertion bitwise, "winograd" keeps the persistent-vs-persistent assertions bitwise and
 # bounds the persistent-vs-per-layer ones by WINO_TOL.
 WINO_TOL = 3e-5
@@ -121,13 +121,32 @@ WINO_TOL = 3e-5
 def conv_form(request):
     from cmtts_amd import _lib
     import os
-    # "winograd" = the default Winograd stack (1: the 8-wave instances; CMTTS_TEST_WINO=2 runs the one-wave-per-SIMD stack of
-    # denoiser_persist4.hip through every conv_form test)
-    prev = _lib.internal_set("persist_wino", 0 if request.param == "direct" else int(os.environ.get("CMTTS_TEST_WINO", "1")))
+    # "winograd" = the default Winograd stack (3: the 8-wave F(4,3) instances; CMTTS_TEST_WINO=1 runs the F(2,3) instances and
+    # CMTTS_TEST_WINO=2 the one-wave-per-SIMD stack of denoiser_persist4.hip through every conv_form test)
+    prev = _lib.internal_set("persist_wino", 0 if request.param == "direct" else int(os.environ.get("CMTTS_TEST_WINO", "3")))
     try:
         yield request.param
     finally:
         _lib.internal_set("persist_wino", prev)
+
+
+# F(4,3) forms every output of a frame QUAD from all six inputs of the quad: the inputs outside an output's own three taps cancel
+# exactly in real arithmetic but not in its rounding, so a frame near the end of a TRIMMED utterance (cmtts_sample_ragged: frames beyond
+# the computed range are zeros instead of denoised padding) can differ from the untrimmed run in the last bit although no trimmed frame
+# is inside its receptive field (measured 1.1e-6 after one evaluation, a few 1e-6 after four).  Direct and F(2,3) (each output from its own taps only) stay bit for bit.
+WINO_TRIM_TOL = 1.5e-5
+
+
+def trim_exact(form):
+    import os
+    return form == "direct" or os.environ.get("CMTTS_TEST_WINO", "3") in ("1", "2")
+
+
+def same_trimmed(a, b, form):
+    import torch
+    if trim_exact(form):
+        return torch.equal(a, b)
+    return a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= WINO_TRIM_TOL
 
 
 def same_result(a, b, form, strict=False):

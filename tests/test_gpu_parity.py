@@ -15,7 +15,7 @@ from cmtts_amd import _lib
 from cmtts_amd.config import get_config, HifiGanConfig
 from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
 from oracle import cmtts_oracle as O
-from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report, conv_form, same_result, WINO_TOL, voc_form, same_wav, same_pcm, VOC_WINO_TOL  # noqa: F401
+from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report, conv_form, same_result, WINO_TOL, voc_form, same_wav, same_pcm, VOC_WINO_TOL, same_trimmed, trim_exact  # noqa: F401
 
 KNOWN_ORACLE_FLIPS = {"energy": 0, "pitch": 0}      # test_bucketed_ragged_shard_vs_oracle: measured on MI355X (round 2): none
 
@@ -1163,8 +1163,10 @@ def test_denoiser_edge_shapes_every_mode(B, T):
                 model.set_precision(prec)
                 outs[(mode, prec)] = model.net(x, t, cond, spk).clone()
         model.set_precision("fp32")
-        _lib.internal_set("persist_wino", 1)
-        wino = model.net(x, t, cond, spk).clone()
+        wino = {}
+        for wn in (1, 3):
+            _lib.internal_set("persist_wino", wn)
+            wino[wn] = model.net(x, t, cond, spk).clone()
     finally:
         model.set_precision("fp32")
         _lib.internal_set("persist_wino", prev_w)
@@ -1172,7 +1174,8 @@ def test_denoiser_edge_shapes_every_mode(B, T):
     host.synchronize()
     assert all(bool(torch.isfinite(o).all()) for o in outs.values())
     assert torch.equal(outs[(0, "fp32")], outs[(2, "fp32")]) and torch.equal(outs[(0, "bf16")], outs[(2, "bf16")])
-    assert float((wino - outs[(0, "fp32")]).abs().max()) <= WINO_TOL
+    for wn in (1, 3):
+        assert float((wino[wn] - outs[(0, "fp32")]).abs().max()) <= WINO_TOL
     out = model.duration_pitch_energy_net(None, torch.tensor([[5]]), torch.tensor([1]), spker_embeds=torch.randn(1, 512))
     assert out["mel_lens"].tolist() == [3] and bool(torch.isfinite(out["cond"]).all())
 
@@ -1473,11 +1476,12 @@ def test_model_without_pitch_table_factor_takes_the_dense_gemm():
 @pytest.mark.parametrize("variant,B,T", [("VCTK", 33, 513), ("LJSpeech", 5, 65), ("VCTK", 1, 5000), ("LJSpeech", 70, 300), ("VCTK", 7, 1),
                                          ("LJSpeech", 3, 63), ("VCTK", 32, 512)])
 def test_winograd_stack_odd_shapes(variant, B, T):
-    """VERDICT r04 #5a: the Winograd forms of the fp32 persistent stack work on frame PAIRS — odd T, a one-frame utterance, a lone tail
-    tile, utterance chunking (70 x 5 tiles > 256 CUs) and 79-tile utterances are where a pair-wise transform breaks.  Three stacks on the
-    same inputs: direct (bitwise the per-layer kernels, proven elsewhere), the 8-wave Winograd instances (the default) and the
-    one-wave-per-SIMD stack (denoiser_persist4.hip, opt-in): the two Winograd stacks bit for bit (same arithmetic per element, different
-    ownership of rows / registers / LDS), both within WINO_TOL of the direct form — one network evaluation and a T = 2 sample."""
+    """VERDICT r04 #5a: the Winograd forms of the fp32 persistent stack work on frame PAIRS (F(2,3)) or QUADS (F(4,3), the default since
+    round 5) — odd T, a one-frame utterance, a lone tail tile, utterance chunking (70 x 5 tiles > 256 CUs) and 79-tile utterances are
+    where a tile-wise transform breaks.  Four stacks on the same inputs: direct (bitwise the per-layer kernels, proven elsewhere), the
+    8-wave F(2,3) instances, the one-wave-per-SIMD F(2,3) stack (denoiser_persist4.hip, opt-in) and the 8-wave F(4,3) instances: the two
+    F(2,3) stacks bit for bit (same arithmetic per element, different ownership of rows / registers / LDS), every Winograd stack
+    within WINO_TOL of the direct form — one network evaluation and a T = 2 sample."""
     from conftest import WINO_TOL
     host = _host()
     lib = _lib.load()
@@ -1494,19 +1498,32 @@ def test_winograd_stack_odd_shapes(variant, B, T):
     prev = lib.cmtts_set_persistent_denoiser(2)
     prev_w = _lib.internal_set("persist_wino", 0)
     try:
-        for wn in (0, 1, 2):
+        for wn in (0, 1, 2, 3):
             _lib.internal_set("persist_wino", wn)
             outs[wn] = model.net(x, t, cond, spk).clone()
             mels[wn] = host.sample_with_cond(model, cond_ct, spk, 2, noise).clone()
+        # the per-model option on top of the process default (3): 2 = F(2,3), 0 = direct
+        try:
+            model.set_option("winograd", 2)
+            opt2 = model.net(x, t, cond, spk).clone()
+            model.set_option("winograd", 0)
+            opt0 = model.net(x, t, cond, spk).clone()
+        finally:
+            model.set_option("winograd", 1)
     finally:
         _lib.internal_set("persist_wino", prev_w)
         lib.cmtts_set_persistent_denoiser(prev)
     host.synchronize()
-    assert torch.isfinite(outs[1]).all() and torch.isfinite(mels[1]).all()
+    for wn in (1, 3):
+        assert torch.isfinite(outs[wn]).all() and torch.isfinite(mels[wn]).all()
     assert torch.equal(outs[1], outs[2]) and torch.equal(mels[1], mels[2]), float((outs[1] - outs[2]).abs().max())
+    assert torch.equal(opt2, outs[1]) and torch.equal(opt0, outs[0])
     d1, dm = float((outs[1] - outs[0]).abs().max()), float((mels[1] - mels[0]).abs().max())
-    report(f"WINOGRAD_ODD {variant} B={B} T={T}: max|d| vs the direct stack: one evaluation {d1:.2e}, T=2 mel {dm:.2e}; 8-wave == one-wave-per-SIMD bitwise")
+    d3, dm3 = float((outs[3] - outs[0]).abs().max()), float((mels[3] - mels[0]).abs().max())
+    report(f"WINOGRAD_ODD {variant} B={B} T={T}: max|d| vs the direct stack: one evaluation F(2,3) {d1:.2e} F(4,3) {d3:.2e}, T=2 mel {dm:.2e} / {dm3:.2e}; "
+           "8-wave == one-wave-per-SIMD bitwise")
     assert 0 < d1 <= WINO_TOL and dm <= WINO_TOL, (d1, dm)
+    assert 0 < d3 <= WINO_TOL and dm3 <= WINO_TOL, (d3, dm3)
 
 
 @pytest.mark.parametrize("variant,B,L,T", [("LJSpeech", 32, 85, 512), ("VCTK", 3, 40, 200), ("LibriTTS", 2, 171, 1024), ("LJSpeech", 1, 5, 33)])
@@ -1719,8 +1736,8 @@ def test_ragged_one_launch_shard_bitwise(n_steps, conv_form):
     """VERDICT r02 next #2, BASELINE.json configs[3]: all bucket groups of a ragged shard through ONE persistent launch per
     evaluation (cmtts_sample_ragged, tile-descriptor list).  (a) untrimmed: every frame of every padded group is bit-identical
     to running the group alone (parity is defined per padded bucket, model/modules.py:429-430); (b) trimmed to mel_len + 16
-    frames (+ the sampler's receptive field): every frame below mel_len + 16 is still bit-identical, frames beyond the computed
-    range are zeros; (c) a shard with more active tiles than CUs runs in rounds and stays bit-identical."""
+    frames (+ the sampler's receptive field): every frame below mel_len + 16 is still bit-identical (direct, F(2,3); within
+    WINO_TRIM_TOL in the F(4,3) form: conftest.py), frames beyond the computed range are zeros; (c) a shard with more active tiles than CUs runs in rounds and stays bit-identical."""
     host = _host()
     lib = _lib.load()
     cfg = get_config("LibriTTS")
@@ -1764,7 +1781,7 @@ def test_ragged_one_launch_shard_bitwise(n_steps, conv_form):
         assert torch.equal(m0, m1), float((m0 - m1).abs().max())
         for b, n in enumerate(l0.tolist()):
             keep = min(n + 16, m0.shape[1])
-            assert torch.equal(m2[b, :keep], m0[b, :keep]), (b, n, float((m2[b, :keep] - m0[b, :keep]).abs().max()))
+            assert same_trimmed(m2[b, :keep], m0[b, :keep], conv_form), (b, n, float((m2[b, :keep] - m0[b, :keep]).abs().max()))
             cut = min(m0.shape[1], (n + 16 + cfg.res_layers + 63) // 64 * 64)      # the last evaluation's computed range
             assert not m2[b, cut:].any()
             saved += m0.shape[1] - cut
@@ -1778,7 +1795,10 @@ def test_ragged_one_launch_shard_bitwise(n_steps, conv_form):
             lens_w = (l0 * cfg.hop_length).tolist()
             w_full = host.vocoder_infer(m0.transpose(1, 2).contiguous(), voc, lengths=lens_w)
             w_trim = host.vocoder_infer(m2.transpose(1, 2).contiguous(), voc, lengths=lens_w)
-            assert all(np.array_equal(a, b) for a, b in zip(w_full, w_trim))
+            if trim_exact(conv_form):
+                assert all(np.array_equal(a, b) for a, b in zip(w_full, w_trim))
+            else:      # F(4,3): mels within WINO_TRIM_TOL -> samples within one int16 step
+                assert all(a.shape == b.shape and int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max()) <= 1 for a, b in zip(w_full, w_trim))
     # (d) 15 x 16 + 8 x 4 = 272 padded tiles: leaving the small group out fits one round — it is set aside for the ordinary sampler
     # (per-layer kernels on the side stream) while the large one takes the persistent launch
     # (the set-aside group: within WINO_TOL of `alone` in the Winograd form, the persistent group bit for bit in either form)
@@ -1796,7 +1816,8 @@ def test_ragged_one_launch_shard_bitwise(n_steps, conv_form):
         assert torch.equal(l0, l1)
         for b, n in enumerate(l0.tolist()):
             keep = min(n + 16, m0.shape[1])
-            assert same_result(m1[b, :keep], m0[b, :keep], conv_form, strict=gi == 0), (gi, b, n)
+            assert (same_trimmed(m1[b, :keep], m0[b, :keep], conv_form) if gi == 0 else same_result(m1[b, :keep], m0[b, :keep], conv_form)), \
+                (gi, b, n, float((m1[b, :keep] - m0[b, :keep]).abs().max()))
     big = make((512, 1024), 14)                            # 14 * (8 + 16) = 336 padded tiles > 256 CUs: rounds of whole utterances
     seq = alone(big)
     got = host.BucketedSynthesizer(model, n_steps=n_steps, n_streams=2, trim=False).run(big)

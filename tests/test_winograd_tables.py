@@ -34,3 +34,29 @@ def test_winograd_fp32_error_is_rounding_level():
         e_dir = np.abs(W.conv1d_direct(x, w, dil) - ref64).max()
         e_win = np.abs(W.conv1d_winograd(x, w, dil) - ref64).max()
         assert e_win < 4 * e_dir + 1e-6, (k, dil, e_win, e_dir)
+
+
+@pytest.mark.parametrize("T", [1, 3, 4, 63, 64, 65, 130])
+def test_f43_equals_direct_conv(T):
+    """Round 5: the F(4,3) form of the denoiser's gated conv (denoiser_persist.hip, WINO == 2) is the k = 3 conv — exactly, in float64, at
+    lengths that are not multiples of the quad."""
+    rs = np.random.RandomState(T)
+    x = rs.standard_normal((16, T))
+    w = rs.standard_normal((8, 16, 3))
+    assert np.abs(W.conv1d_f43(x, w) - W.conv1d_direct(x, w, 1)).max() < 1e-12
+
+
+def test_f43_fp32_error_and_its_growth_with_the_input_scale():
+    """fp32: within an order of magnitude of the direct form on one conv (the kernels measure 1.5e-5 against 8e-6 for F(2,3) on one network evaluation);
+    the error is RELATIVE to the inputs' magnitude in every form, F(4,3) with the largest constant (transform coefficients up to 5 and 8) —
+    what test_winograd_and_fp16x3_stress_statistics[near_fp16_max] sees on the GPU."""
+    rs = np.random.RandomState(11)
+    w = (rs.standard_normal((64, 256, 3)) / np.sqrt(3 * 256)).astype(np.float32)
+    for scale in (1.0, 3e4):
+        x = (rs.standard_normal((256, 256)) * scale).astype(np.float32)
+        ref64 = W.conv1d_direct(x.astype(np.float64), w.astype(np.float64), 1)
+        e_dir = np.abs(W.conv1d_direct(x, w, 1) - ref64).max()
+        e_23 = np.abs(W.conv1d_winograd(x, w, 1) - ref64).max()
+        e_43 = np.abs(W.conv1d_f43(x, w) - ref64).max()
+        assert e_23 < 4 * e_dir and e_43 < 16 * e_dir, (scale, e_dir, e_23, e_43)      # measured: 1.5x and 8x on the MAXIMUM of one conv (rms: 2x)
+        assert e_43 < 3e-5 * scale
