@@ -40,9 +40,6 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifndef WINO_THREAD
 #define WINO_THREAD 1
 #endif
-#ifndef W43_ABL
-#define W43_ABL 0
-#endif
 #ifndef WINO43_RING
 #define WINO43_RING 3      // k-steps of F(4,3) transformed weights in flight per wave + the one in use (24 registers each)
 #endif
@@ -239,12 +236,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     // FIRST: the group opens the accumulators — its first k-step takes the inline constant 0 as C (`v_mfma ..., 0`: the same operation as
     // accumulating into zeroed registers without the 64 v_mov per loop that, next to fp32 MFMAs, cost their own issue time)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto mma_group = [&](auto first, const f32x4 (&af)[MT], const float (&bv)[4][NT]) {
+    // I0: the first m-tile this group computes (1 in the LAST layer's output projection: nobody reads that layer's x')
+    auto mma_group = [&](auto first, const f32x4 (&af)[MT], const float (&bv)[4][NT], auto i0) {
         constexpr bool FIRST = decltype(first)::value;
+        constexpr int I0 = decltype(i0)::value;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = I0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bv[kk][j], FIRST && kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
@@ -377,25 +376,15 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 V4[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
             };
             load_d4(0);
-#if W43_ABL & 2
-            transform4();
-#endif
 #pragma unroll 1
             for (int s0 = 0; s0 < NS4; s0 += WR4) {
 #pragma unroll
                 for (int s = 0; s < WR4; ++s) {
                     const int ks = s0 + s;
-                    // -DW43_ABL=n (timing-only builds, wrong results): 1 = no weight loads in the loop, 2 = no LDS reads / input transform
-#if !(W43_ABL & 2)
                     transform4();
-#endif
                     __builtin_amdgcn_sched_barrier(0);
-#if !(W43_ABL & 1)
                     load_a4(A4[(s + WR4 - 1) % WR4], W3f, ks + WR4 - 1);
-#endif
-#if !(W43_ABL & 2)
                     load_d4(ks + 1);
-#endif
                     if (ks < NS4) {
 #pragma unroll
                         for (int p = 0; p < 6; ++p)
@@ -403,17 +392,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                             for (int i = 0; i < 4; ++i)
                                 acc4[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(A4[s][p][i], V4[p], acc4[i][p], 0, 0, 0);
                     }
-                    // the stage's 6 weight loads and 2 LDS reads between its MFMAs (as the F(2,3) loop)
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
+                    // (the stage's loads are placed by the compiler — it clusters them behind the stage's MFMAs: 7.97 ms per T = 4 sample; threaded
+                    // between the MFMAs with sched_group_barrier as in the F(2,3) loop 8.16, all in front 8.06, in the first half 8.20.  Timing-only
+                    // ablations of this loop mislead: with the weight ring or the inputs left constant the chip clocks differently, and removing
+                    // work made the launch SLOWER.  Doubling the transform's 12 VALU operations costs 3 %: one VALU operation per stage = 0.25 %.)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -509,8 +491,8 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     load_b(Bv[(s + 1) & 1], u_lds, g8 * 8, tap);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) {
-                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1]);
-                        else mma_group(later_t{}, A[s], Bv[s & 1]);
+                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
+                        else mma_group(later_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -645,22 +627,30 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const float* Wof = a.Wof[l];
             float Bv[2][4][NT];
             load_b(Bv[0], z_lds, 0, 0);
-            auto ring_round = [&](int it, auto first) {
+            auto ring_round = [&](int it, auto first, auto i0) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
                     load_ao(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
                     load_b(Bv[(s + 1) & 1], z_lds, min(it + s + 1, NG - 1) * 8, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) {       // NG need not be a multiple of the ring depth
-                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1]);
-                        else mma_group(later_t{}, A[s], Bv[s & 1]);
+                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], i0);
+                        else mma_group(later_t{}, A[s], Bv[s & 1], i0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            ring_round(0, first_t{});
+            if (more) {
+                ring_round(0, first_t{}, std::integral_constant<int, 0>{});
 #pragma unroll 1
-            for (int it = RING; it < NG; it += RING) ring_round(it, later_t{});
+                for (int it = RING; it < NG; it += RING) ring_round(it, later_t{}, std::integral_constant<int, 0>{});
+            } else {      // the last layer: only the skip half of the projection (its x' has no reader): half of this loop's MFMAs, 0.6 % of a launch
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[0][j] = zero16;
+                ring_round(0, first_t{}, std::integral_constant<int, 1>{});
+#pragma unroll 1
+                for (int it = RING; it < NG; it += RING) ring_round(it, later_t{}, std::integral_constant<int, 1>{});
+            }
         }
         stamp(l, 5);
         // ---- epilogue in registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
