@@ -29,6 +29,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 #ifndef WINO_ABL
@@ -298,11 +299,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // element e of fragment p = transform p, m-tile e (cmtts_api.hip: to_wino43_fragments)
         constexpr int WR4 = WINO43_RING, NS4 = C / 4;
         f32x4 A4[WINO == 2 ? WR4 : 1][6];
-        // (one per-lane pointer at the wave's FOURTH fragment: the six loads of a k-step are immediate offsets -3072 .. +2048 from it)
+        // (buffer loads: the layer's array as a descriptor, the lane's fragment offset in a VGPR that never changes, the k-step's offset
+        //  in an SGPR — no per-load VALU address arithmetic next to the MFMAs; flat loads took two 64-bit VALU adds per k-step)
         auto load_a4 = [&](f32x4 (&dst)[6], const float* wfrag, int ks) {
-            const char* base = reinterpret_cast<const char*>(wfrag) + ((w * 6 + 3) * 64 + lane) * 16 + (size_t)ks * (NW * 6 * 64 * 16);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, (NS4 + 4) * (NW * 6 * 64 * 16), 0x00020000);
+            const int voff = (w * 6 * 64 + lane) * 16;
 #pragma unroll
-            for (int p = 0; p < 6; ++p) dst[p] = *reinterpret_cast<const f32x4*>(base + (p - 3) * 1024);
+            for (int p = 0; p < 6; ++p)
+                dst[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + p * 1024, ks * (NW * 6 * 64 * 16), 0));
         };
         // (uniform base + 32-bit lane offset: the saddr form, no per-step VALU address arithmetic; the ring reads up to WR - 1 half-groups past
         //  the layer's last one — the packer pads every layer's array by that much, cmtts_api.hip: to_wino_fragments)
@@ -364,16 +368,18 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 Da = *reinterpret_cast<const f32x4*>(rr);
                 Db = *reinterpret_cast<const float2*>(rr + 4);
             };
+            // (written on float pairs: the compiler then issues v_pk_fma_f32 / v_pk_add_f32 — 8 VALU operations per k-step instead of 12 + moves;
+            //  the same fused operations on the same values)
             auto transform4 = [&]() {
-                const float d0 = Da[0], d1 = Da[1], d2 = Da[2], d3 = Da[3], d4 = Db.x, d5 = Db.y;
-                const float t0 = __builtin_fmaf(-4.f, d2, d4), t1 = __builtin_fmaf(-4.f, d1, d3);
-                const float t2 = d4 - d2, t3 = d3 - d1;
-                V4[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-                V4[1] = t0 + t1;
-                V4[2] = t0 - t1;
-                V4[3] = __builtin_fmaf(2.f, t3, t2);
-                V4[4] = __builtin_fmaf(-2.f, t3, t2);
-                V4[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+                const f32x2 P01 = {Da[0], Da[1]}, P23 = {Da[2], Da[3]}, P45 = {Db.x, Db.y};
+                const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, c2 = {2.f, -2.f};
+                const f32x2 V05 = __builtin_elementwise_fma(c4, P01, __builtin_elementwise_fma(cm5, P23, P45));
+                const float t0 = __builtin_fmaf(-4.f, Da[2], Db.x), t1 = __builtin_fmaf(-4.f, Da[1], Da[3]);
+                const float t2 = Db.x - Da[2], t3 = Da[3] - Da[1];
+                const f32x2 a0 = {t0, t0}, a1 = {t1, -t1}, b0 = {t2, t2}, b1 = {t3, t3};
+                const f32x2 V12 = a0 + a1;
+                const f32x2 V34 = __builtin_elementwise_fma(c2, b1, b0);
+                V4[0] = V05.x; V4[1] = V12.x; V4[2] = V12.y; V4[3] = V34.x; V4[4] = V34.y; V4[5] = V05.y;
             };
             load_d4(0);
 #pragma unroll 1
