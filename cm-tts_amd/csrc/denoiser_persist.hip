@@ -630,14 +630,31 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         // =========================================================== phase C: output projection
         {
             constexpr int NG = NGC;
-            const float* Wof = a.Wof[l];
+            // Round 5: no VALU address arithmetic in this loop either — the weights through a buffer descriptor (lane offset constant, k-group
+            // offset scalar; groups past the end are out of range and read as zeros: no clamps), z through one LDS pointer per ring round
+            // with immediate offsets (the reads past the last group land behind z, inside the allocation, and are not used)
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wof[l]), 0, NG * (2 * C / 32) * 256 * 4, 0x00020000);
+            const int wvo = (w * 64 + lane) * 16;
+            auto load_aob = [&](f32x4 (&dst)[MT], int group) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo + i * (NW * 1024), group * ((2 * C / 32) * 1024), 0));
+            };
             float Bv[2][4][NT];
-            load_b(Bv[0], z_lds, 0, 0);
+            const float* zb0 = z_lds + khalf * U_LD + l31;
+            auto load_bz = [&](float (&dst)[4][NT], const float* zb, int goff) {      // goff: groups beyond zb's
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) dst[kk][j] = zb[(goff * 8 + 2 * kk) * U_LD + j * 32];
+            };
+            load_bz(Bv[0], zb0, 0);
             auto ring_round = [&](int it, auto first, auto i0) {
+                const float* zb = zb0 + it * 8 * U_LD;
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
-                    load_ao(A[(s + RING - 1) % RING], Wof, min(it + s + RING - 1, NG - 1));
-                    load_b(Bv[(s + 1) & 1], z_lds, min(it + s + 1, NG - 1) * 8, 0);
+                    load_aob(A[(s + RING - 1) % RING], it + s + RING - 1);
+                    load_bz(Bv[(s + 1) & 1], zb, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) {       // NG need not be a multiple of the ring depth
                         if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], i0);
