@@ -57,7 +57,7 @@ constexpr int RING = 6;         // register ring depth of the weight stream (k-g
 constexpr int FN = 64;
 constexpr int NT = FN / 32;
 constexpr int U_LD = FN + 4;
-constexpr int IDX_LDS_BYTES = (FN + 2) * 2 * 4 + NW * 64 * 4;      // behind the u / z buffers: FACT's (phoneme, pitch bucket) table of frames t0 - 1 .. t0 + FN, and
+constexpr int IDX_LDS_BYTES = (FN + 2) * 2 * 4 + NW * 64 * 4 + NW * 4;      // behind the u / z buffers: FACT's (phoneme, pitch bucket) table of frames t0 - 1 .. t0 + FN, and
                                                                    // 64 floats per wave to turn its two edge columns into ONE 64-lane granule store
 constexpr unsigned SPIN_LIMIT = 1u << 20;     // bounded wait for a neighbour (~2 s); then the timeout word is set and
                                               // this wave stops waiting for the rest of the launch (results invalid)
@@ -198,6 +198,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     // every layer re-loaded them from HBM / L2 in front of its gathers: two of that phase's three dependent round trips (~3 k cycles each
     // with every wave of the chip asking at once)
     int* idx_lds = reinterpret_cast<int*>(smem + 2 * C * U_LD);
+    // one word per wave behind the edge scratch: the last layer whose gate output (z rows 32 w ..) this wave has written — what the output
+    // projection waits for, k-block by k-block, instead of a workgroup barrier (phase C)
+    int* zflag = idx_lds + (FN + 2) * 2 + NW * 64;
+    if (tid < NW) zflag[tid] = 0;
     if (FACT && tid < FN + 2) {
         int ph, ix;
         frame_idx(min(max(t0 - 1 + tid, 0), T - 1), ph, ix);
@@ -624,7 +628,29 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #endif
         }
         stamp(l, 3);
-        __syncthreads();   // (3) z complete, u of this layer dead
+        // (3) no barrier here since round 5.  The two waves of a SIMD do not finish the conv together (the older one is served first: 87 k
+        // against 116 k cycles, -DDBG stamps), and behind a barrier the early wave idled ~27 k cycles per layer while the late one ran the
+        // pipe alone at half its rate.  Now every wave announces its z rows (release store of the layer number) and the projection's
+        // K loop — ordered by source wave — only waits for the block it is about to read: the early waves start the projection on the
+        // early waves' rows under the late waves' conv tail.  Everything the barrier also ordered still holds: a wave writes the next u
+        // (publish) only after it has consumed all eight blocks, i.e. after every wave has left the conv; z is rewritten behind barrier (1).
+        if (lane == 0) __hip_atomic_store(zflag + w, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned zready = 0;      // bit v: wave v's z rows of this layer are written (wave-uniform)
+        auto need_z = [&](int v) {
+            if (v >= NW || ((zready >> v) & 1u)) return;
+            unsigned spins = 0;
+            for (;;) {
+                const int f = __hip_atomic_load(zflag + (lane & (NW - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                zready = (unsigned)__ballot(f > l) & ((1u << NW) - 1u);
+                if ((zready >> v) & 1u) break;
+                if (++spins > SPIN_LIMIT) {      // cannot happen (every wave of the workgroup runs this code); bounded like every wait of this kernel
+                    if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                    zready = (1u << NW) - 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
         stamp(l, 4);
 
         // =========================================================== phase C: output projection
@@ -648,12 +674,14 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
 #pragma unroll
                     for (int j = 0; j < NT; ++j) dst[kk][j] = zb[(goff * 8 + 2 * kk) * U_LD + j * 32];
             };
+            need_z(0);
             load_bz(Bv[0], zb0, 0);
             auto ring_round = [&](int it, auto first, auto i0) {
                 const float* zb = zb0 + it * 8 * U_LD;
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
                     load_aob(A[(s + RING - 1) % RING], it + s + RING - 1);
+                    if (((it + s + 1) & 3) == 0) need_z((it + s + 1) >> 2);      // k-group it + s + 1 opens the z rows of the next wave
                     load_bz(Bv[(s + 1) & 1], zb, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) {       // NG need not be a multiple of the ring depth
