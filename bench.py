@@ -674,12 +674,14 @@ def main():
                      "traffic_note": "fabric-side bytes/launch = rocprofv3 FETCH_SIZE x %.1f + WRITE_SIZE x %.1f (separate --pmc passes of this "
                                      "workload at commit %s; the factors come from known-byte-count streams measured in the same session: "
                                      "FETCH_SIZE reads 1/2 on gfx950, profiles/pmc_traffic.json); Infinity-Cache hits are counted. Algorithmic "
-                                     "%.1f MB; the excess = each layer's weight set once per XCD L2 (8 x 42-52 MB), the polled 8-byte granules and, for the "
+                                     "%.1f MB; the excess = each layer's weight set once per XCD L2 (8 x %.0f MB), the polled 8-byte granules and, for the "
                                      "Winograd instances, the kernel-private residual stream x (16.8 MB) that every layer writes and the next re-reads "
                                      "through the Infinity Cache because it does not fit the L2s next to the weights (19 x 34 MB; requested a projection "
                                      "loop ahead of its use, so its latency is not on the critical path) -> %.3f of the 8 TB/s HBM peak" % (
                                          pmc_cal[0], pmc_cal[1], pmc_commit,
                                          (BATCH * FRAMES_PAD * (1024 * (cfg.res_layers + 1) + 8 * cfg.n_mels) if persistent else BATCH * FRAMES_PAD * 5120) / 1e6,
+                                         # transformed conv weights (6 / 4 / 3 sets of [2C][C]) + the output projection, fp32, all layers
+                                         ({3: 6, 1: 4, 2: 4}.get(pw, 3) + 1) * 2 * C_ * C_ * 4 * cfg.res_layers / 1e6,
                                          (traffic or 0) / max(avg_ms, 1e-9) / 1e-3 / (HBM_PEAK_GBS * 1e9)),
                      "launches": n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                      "flops_per_launch": flops_launch,

@@ -87,7 +87,16 @@ __device__ __forceinline__ void store_granule(unsigned long long* g, unsigned ta
 // (cmtts_api.hip: sample_ragged).  The arithmetic of a computed frame is unchanged: every value is bit-identical to the uniform
 // launch of its own bucket as long as no trimmed frame lies within its receptive field.
 // FACT (round 4): the conditioner projections are gathered from their factors (persist_args.h) wherever cp would be read.
-// WINO (round 4): the gated k = 3 conv as a Winograd F(2,3) convolution along the frame axis — per PAIR of output frames four products
+// WINO == 2 (round 5, the default): the same conv as Winograd F(4,3) over QUADS of output frames with the points 0, +-1, +-2, inf — six
+// products per quad instead of twelve (98 k pipe cycles per layer).  With d0..d5 = u(4q-1 .. 4q+4): V0 = 4 d0 - 5 d2 + d4,
+// V1 = (d4 - 4 d2) + (d3 - 4 d1), V2 = (d4 - 4 d2) - (d3 - 4 d1), V3 = (d4 - d2) + 2 (d3 - d1), V4 = (d4 - d2) - 2 (d3 - d1),
+// V5 = 4 d1 - 5 d3 + d5; m_p = U_p V_p with U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6, U3 = g0/24 + g1/12 + g2/6,
+// U4 = g0/24 - g1/12 + g2/6, U5 = g2 (cmtts_api.hip: to_wino43_fragments); y0 = m0 + (m1+m2) + (m3+m4), y1 = (m1-m2) + 2 (m3-m4),
+// y2 = (m1+m2) + 4 (m3+m4), y3 = (m1-m2) + 8 (m3-m4) + m5.  One n-tile of v_mfma_f32_16x16x4_f32 = one transform of the tile's 16 quads
+// (all six transforms of a quad in the same lane), a wave carries 4 sixteen-row m-tiles x 6 transforms = 24 accumulators of 4 registers;
+// u in natural frame order.  State, barriers, halo protocol, FACT, RAGGED, tail: as WINO == 1.  Restated in oracle/winograd_ref.py
+// (conv1d_f43) and checked against the plain conv on the CPU (tests/test_winograd_tables.py).
+// WINO == 1 (round 4): the gated k = 3 conv as a Winograd F(2,3) convolution along the frame axis — per PAIR of output frames four products
 // instead of six: m0 = (d0 - d2) g0, m1 = (d1 + d2) (g0 + g1 + g2)/2, m2 = (d2 - d1) (g0 - g1 + g2)/2, m3 = (d1 - d3) g2,
 // y(2p) = m0 + m1 + m2, y(2p+1) = m1 - m2 - m3 with d0..d3 = u(2p-1 .. 2p+2).  Each m_i is its own K = 256 contraction over the
 // channels (transformed weights W3f = [64 half-groups][16 m-tiles][2][64 lanes][4], packed by cmtts_api.hip: to_wino_fragments), so a

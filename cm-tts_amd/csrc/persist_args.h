@@ -72,7 +72,9 @@ struct PersistArgs {
     // halo entries (one element per lane) keep reading p1 / p2.
     const float* p1t;
     const float* p2t;
-    int wino;             // 2 (round 5): the one-wave-per-SIMD stack of denoiser_persist4.hip — W3f = per-wave streams (cmtts_api.hip: to_wino4_fragments),
+    int wino;             // 3 (round 5, the default): the 8-wave F(4,3) instances (denoiser_persist.hip, WINO == 2) — W3f = six transformed weight sets as
+                          // v_mfma_f32_16x16x4_f32 fragments (cmtts_api.hip: to_wino43_fragments), state as for 1.
+                          // 2 (round 5): the one-wave-per-SIMD stack of denoiser_persist4.hip — W3f = per-wave streams (cmtts_api.hip: to_wino4_fragments),
                           // x and the skip sum stay in registers, `xst` unused.  1: fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
     float* xst;           // WINO: [B][tiles][16384] kernel-private state — the residual stream x of every 64-frame tile between layers

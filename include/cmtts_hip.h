@@ -185,7 +185,8 @@ int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_
  *   will use (its mel_len).  With it the utterance is only computed on its first
  *   ceil((active_frames + tail_frames + res_layers * (n_steps - i)) / 64) 64-frame tiles in evaluation i — an output frame
  *   depends on res_layers frames of input to either side, so every frame below active_frames + tail_frames comes out
- *   BIT-IDENTICAL to the untrimmed result; frames beyond the computed range are unspecified padding — zeros in the one-launch
+ *   BIT-IDENTICAL to the untrimmed result in the direct and F(2,3) forms of the stack, and within fp32 rounding of it (<= 1.5e-5) in the
+ *   default F(4,3) form (model option "winograd" below: a quad of frames is rounded from all six inputs of the quad); frames beyond the computed range are unspecified padding — zeros in the one-launch
  *   form, the untrimmed values when the call falls back to cmtts_sample per group (the reference fills them with denoised
  *   padding that every caller slices off: utils/tools.py:575-576, utils/model.py:199-203).
  *   tail_frames: frames beyond active_frames that must still be exact (the receptive field of whatever consumes the padded
@@ -271,12 +272,14 @@ int cmtts_set_option(const char* name, int value);
  *       decoder: in- / out-projection, FFN conv, FFN linear) and the conv layers of the variance predictors with 16-bit MFMA operands too (LayerNorm, attention scores / softmax / P V, bias,
  *       scale, GELU, residual, mask and accumulation stay fp32).  Off by default because
  *       the text side feeds the integer stages: with it, durations / pitch buckets / lengths may differ from the fp32 model's by one unit.
- *   cmtts_model_set_option(m, "winograd", 1 (default) | 0): fp32 models, large batches (the persistent denoiser stack, csrc/denoiser_persist.hip):
- *       the gated k = 3 convolution of every residual layer (model/blocks.py:672-679) as a Winograd F(2,3) convolution along the frame axis —
- *       4 products per pair of output frames instead of 6, transformed weights formed in double and rounded once, every product and sum
- *       in fp32 — or (0) as the direct 3-tap contraction, which is bit for bit what the per-layer kernels of small batches compute.  The
- *       two forms differ by fp32 rounding only: <= 1e-5 on one network evaluation, ~4e-6 on a T = 4 mel, both equally far from a float64
- *       evaluation (tests/test_gpu_precision.py); with 1 an utterance's low-order bits depend on whether its batch takes the persistent stack.
+ *   cmtts_model_set_option(m, "winograd", 1 (default) | 2 | 0): fp32 models, large batches (the persistent denoiser stack, csrc/denoiser_persist.hip):
+ *       the gated k = 3 convolution of every residual layer (model/blocks.py:672-679) as a Winograd convolution along the frame axis —
+ *       1: F(4,3), 6 products per quad of output frames instead of 12 (round 5); 2: F(2,3), 4 per pair instead of 6 (round 4); transformed
+ *       weights formed in double and rounded once, every product and sum in fp32 — or (0) as the direct 3-tap contraction, which is bit for
+ *       bit what the per-layer kernels of small batches compute.  The forms differ by fp32 rounding only: F(4,3) <= 1.8e-5 / F(2,3) <= 1e-5 on
+ *       one network evaluation, ~8e-6 / ~4e-6 on a T = 4 mel, all equally far from a float64 evaluation at ordinary activation scales
+ *       (tests/test_gpu_precision.py; F(4,3) loses a decimal digit on conv inputs of ~6e4); with 1 or 2 an utterance's low-order bits depend on
+ *       whether its batch takes the persistent stack.
  *   cmtts_vocoder_set_option(v, "winograd", 1 (default) | 0): fp32 generator, launches of >= 1024 column tiles (large batches): the k = 3 / 7 / 11
  *       ResBlock convs of the C = 256 and C = 128 stages and the k = 7 / 11 ResBlock convs of the C = 64 stage (hifigan/models.py:96-103) as Winograd convolutions over pairs of outputs one dilation
  *       apart — groups of three taps as F(2,3), a remainder of two taps as F(2,2): 4 / 10 / 15 fp32 products per pair instead of 6 / 14 / 22 — or (0)
