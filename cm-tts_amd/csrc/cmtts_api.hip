@@ -257,6 +257,42 @@ std::vector<float> to_wino_iter_fragments(const std::vector<float>& p, int taps,
     return {};
 }
 
+// F(4,3) form of a k-tap, dilation-1 conv for conv_xlq_kernel (conv_xlq.hip: QTab<KT>): per k-step of four input channels the transformed weights of
+// every group of three taps (U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6, U3 = g0/24 + g1/12 + g2/6, U4 = g0/24 - g1/12 + g2/6, U5 = g2; a tap beyond the
+// kernel is zero) and, for k = 7, of the seventh tap on its own (g, g/2, g/2, g) — formed in double, rounded once — as A fragments of v_mfma_f32_16x16x4_f32 in
+// the kernel's iteration order [K/4 k-steps][M/64 waves][points][64 lanes][4]: element i at lane l = input channel 4 ks + (l >> 4), output row 64 w + 16 i + (l & 15).
+std::vector<float> to_wino43_iter_fragments(const std::vector<float>& p, int taps, int K, int M) {
+    if ((taps != 3 && taps != 7 && taps != 11) || K % 4 || M % 64) return {};
+    const int ngrp = taps == 3 ? 1 : taps == 7 ? 2 : 4, npt = ngrp * 6 + (taps == 7 ? 4 : 0), NWV = M / 64;
+    std::vector<float> f((size_t)(K / 4) * NWV * npt * 256);
+    for (int ks = 0; ks < K / 4; ++ks)
+        for (int w = 0; w < NWV; ++w)
+            for (int pt = 0; pt < npt; ++pt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = 4 * ks + (lane >> 4), mrow = 64 * w + 16 * i + (lane & 15);
+                        auto g = [&](int tap) -> double { return tap < taps ? (double)p[((size_t)tap * K + k) * M + mrow] : 0.0; };
+                        double v;
+                        if (pt < ngrp * 6) {
+                            const int tau = 3 * (pt / 6);
+                            const double g0 = g(tau), g1 = g(tau + 1), g2 = g(tau + 2);
+                            switch (pt % 6) {
+                                case 0: v = g0 / 4.0; break;
+                                case 1: v = -(g0 + g1 + g2) / 6.0; break;
+                                case 2: v = -(g0 - g1 + g2) / 6.0; break;
+                                case 3: v = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+                                case 4: v = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+                                default: v = g2; break;
+                            }
+                        } else {
+                            const int q = pt - ngrp * 6;
+                            v = (q == 1 || q == 2) ? 0.5 * g(6) : g(6);
+                        }
+                        f[((((size_t)ks * NWV + w) * npt + pt) * 64 + lane) * 4 + i] = (float)v;
+                    }
+    return f;
+}
+
 // The same fragments in the ITERATION order of the fused ResBlock pair kernels (resblock_pair.hip): the K loop walks
 // (16-channel chunk, tap, 8-channel half), so [K/16][taps][2][M/32][64 lanes][4] makes the weight stream one linear walk.
 std::vector<float> to_fragment_iter_order(const std::vector<float>& p, int taps, int K, int M) {
@@ -419,6 +455,7 @@ int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a
                                 // one-wave-per-SIMD F(2,3) stack of denoiser_persist4.hip (same bits as 1; measured 4-10 % slower), 0 = direct
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
+int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the dilation-1 convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
@@ -661,6 +698,7 @@ struct cmtts_vocoder {
     PackedConv c1[12][3], c2[12][3];
     void *c1f[12][3][3] = {}, *c2f[12][3][3] = {};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies of the ResBlock convs
     float *c1f32[12][3] = {}, *c2f32[12][3] = {};    // fp32 fragments in iteration order (resblock_pair.hip: pair kernels at C <= 64, conv_xl above)
+    float *c1q32[12][3] = {}, *c2q32[12][3] = {};    // F(4,3) fragments of the dilation-1 convs (conv_xlq_kernel; c1q32 only for the first pair of a ResBlock), else null
     float *c1w32[12][3] = {}, *c2w32[12][3] = {};    // Winograd-transformed fragments of the C >= 128 stages (conv_xlw_kernel), else null
     int winograd = 1;                                 // fp32 generator: ResBlock convs of the C >= 128 stages in their Winograd form (cmtts_vocoder_set_option "winograd")
     int precision = 0;                                // 0 fp32, 1 bf16, 2 fp16 operands in the ResBlock convs
@@ -2310,6 +2348,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
                 if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
+                if ((co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) && v->rb_dil[mi] == 1) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1q32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
@@ -2321,6 +2360,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
                 if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2w32[r][mi])); }
+                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2q32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
@@ -2511,7 +2551,11 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                     const bool xw = g_voc_wino && v->winograd && v->c1w32[r][mi] && v->c2w32[r][mi];
                     xa.x = xr; xa.y = bT; xa.wf = xw ? v->c1w32[r][mi] : v->c1f32[r][mi]; xa.bias = v->c1[r][mi].bias;
                     xa.bstride = cs; xa.B = B; xa.C = co; xa.T = To; xa.ld = ld; xa.k = rk; xa.dil = dil; xa.slope = 0.1f; xa.wino_force = g_voc_wino == 2;
-                    int rc1 = xw ? cmtts_launch_conv_xlw(&xa, (void*)q) : -2;
+                    // round 5: dilation-1 convs (every conv2, conv1 of the first pair) in the F(4,3) form (conv_xlq_kernel: 6 / 16 / 24 products per quad of outputs where
+                    // the F(2,3) tap groups take 8 / 20 / 30); -2 = launch too small or shape not covered: the F(2,3) form, then the direct one
+                    int rc1 = -2;
+                    if (xw && g_voc_wino43 && dil == 1 && v->c1q32[r][mi]) { xa.wf = v->c1q32[r][mi]; rc1 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc1 == -2) xa.wf = v->c1w32[r][mi]; }
+                    if (rc1 == -2 && xw) rc1 = cmtts_launch_conv_xlw(&xa, (void*)q);
                     const bool xw1 = rc1 == 0;
                     if (rc1 == -2) { xa.wf = v->c1f32[r][mi]; rc1 = cmtts_launch_conv_xl(&xa, (void*)q); }
                     if (rc1 == -3) return fail(CMTTS_E_HIP, "conv_xl launch failed");
@@ -2521,7 +2565,10 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                         // every output element reads only its own residual); the INPUT must not alias the output
                         xa.x = bT; xa.y = lastm ? bufS : bR; xa.wf = xw1 ? v->c2w32[r][mi] : v->c2f32[r][mi]; xa.bias = v->c2[r][mi].bias;
                         xa.res = xr; xa.dil = 1; xa.accum = lastm && j > 0;
-                        if ((xw1 ? cmtts_launch_conv_xlw(&xa, (void*)q) : cmtts_launch_conv_xl(&xa, (void*)q)) != 0) return fail(CMTTS_E_HIP, "conv_xl launch failed");
+                        int rc2 = -2;
+                        if (xw1 && g_voc_wino43 && v->c2q32[r][mi]) { xa.wf = v->c2q32[r][mi]; rc2 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc2 == -2) xa.wf = v->c2w32[r][mi]; }
+                        if (rc2 == -2) rc2 = xw1 ? cmtts_launch_conv_xlw(&xa, (void*)q) : cmtts_launch_conv_xl(&xa, (void*)q);
+                        if (rc2 != 0) return fail(CMTTS_E_HIP, "conv_xl launch failed");
                         if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
                         xr = bR;
                         continue;
@@ -2706,6 +2753,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
         {"voc_wino64_k", &g_voc_wino64_k, 3, 99},
+        {"voc_wino43", &g_voc_wino43, 0, 1},       // fp32 dilation-1 convs of the Winograd path as F(4,3) (conv_xlq_kernel; NOT bitwise F(2,3) or direct)
         {"voc_wino64", &g_voc_wino64, 0, 1},       // fp32 C = 64 stage, k >= voc_wino64_k: two conv_xlw launches per pair (with voc_wino) instead of the pair kernel
         {"voc_wino", &g_voc_wino, 0, 2},           // fp32 wide-stage convs in their Winograd form (NOT bitwise: the A/B twin of the vocoder option "winograd")
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16

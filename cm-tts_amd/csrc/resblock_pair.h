@@ -56,6 +56,9 @@ extern "C" {
 int cmtts_launch_conv_xl(const ConvXlArgs* a, void* stream);
 // the same conv in its Winograd form (a->wf = to_wino_iter_fragments of the same weights); -2 = shape not covered (C = 128 / 256, k = 3 / 7 / 11, dilation 1 / 3 / 5)
 int cmtts_launch_conv_xlw(const ConvXlArgs* a, void* stream);
+// the dilation-1 conv in its F(4,3) form (conv_xlq.hip; a->wf = to_wino43_iter_fragments of the same weights); -2 = shape not covered (C = 64 / 128 / 256, k = 3 / 7 / 11)
+// or a launch of fewer than 1024 column tiles without a->wino_force
+int cmtts_launch_conv_xlq(const ConvXlArgs* a, void* stream);
 // HiFi-GAN upsampler (ConvTranspose1d, kernel 2 s, stride s, padding s / 2), all phases in one X-resident launch (resblock_pair.hip)
 int cmtts_launch_convT(const float* x, float* y, const float* wf, const float* bias, long xbstride, long ybstride, int B, int cin,
                        int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, void* stream);

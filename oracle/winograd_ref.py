@@ -3,6 +3,8 @@ algebra the HIP kernels rely on is checked on the CPU against the plain convolut
 
   * denoiser_persist.hip, WINO instances (cm-tts_amd/csrc/cmtts_api.hip: to_wino_fragments): the gated k = 3, dilation-1 conv of
     ResidualBlock.forward (reference model/blocks.py:672) as F(2,3) over frame pairs;
+  * conv_xlq.hip: conv_xlq_kernel (round 5): the dilation-1 ResBlock convs of HiFi-GAN as F(4,3) tap groups over output quads
+    (conv1d_f43_taps below);
   * denoiser_persist.hip, WINO == 2 instances (round 5; cmtts_api.hip: to_wino43_fragments): the same conv as F(4,3) over frame quads
     (conv1d_f43 below: the kernel's transforms in the kernel's operation order);
   * resblock_pair.hip: conv_xlw_kernel (cm-tts_amd/csrc/resblock_pair.h: WinoTab<k>, cmtts_api.hip: to_wino_iter_fragments): the k = 3 / 7 / 11 dilated convs of
@@ -98,4 +100,43 @@ def conv1d_f43(x, w):
     y[:, q0 + 1] = d12 + dt(2) * d34
     y[:, q0 + 2] = s12 + dt(4) * s34
     y[:, q0 + 3] = (d12 + dt(8) * d34) + m[5]
+    return y[:, :T]
+
+
+# conv_xlq.hip: QTab<k> — per k the entries (kind, tap offset): F(4,3) groups of three taps (a tap beyond the kernel is zero), k = 7's seventh tap alone
+F43_TAPS = {3: [("f43", 0)], 7: [("f43", 0), ("f43", 3), ("one", 6)], 11: [("f43", 0), ("f43", 3), ("f43", 6), ("f43", 9)]}
+
+
+def conv1d_f43_taps(x, w):
+    """The k = 3 / 7 / 11, dilation-1, padding-(k-1)/2 conv through conv_xlq_kernel's products (cm-tts_amd/csrc/conv_xlq.hip; weights as
+    cmtts_api.hip: to_wino43_iter_fragments forms them): all tap groups into six transform-domain accumulators, one output transform."""
+    cout, cin, k = w.shape
+    T = x.shape[1]
+    Tq = -(-T // 4) * 4
+    pad = (k - 1) // 2
+    xp = np.pad(x, ((0, 0), (pad, Tq - T + pad + 2)))
+    q0 = np.arange(0, Tq, 4)
+    dt = x.dtype.type
+    M = [np.zeros((cout, q0.size), x.dtype) for _ in range(6)]
+    wz = np.concatenate([w, np.zeros((cout, cin, 2), w.dtype)], axis=2)
+    for kind, o in F43_TAPS[k]:
+        if kind == "f43":
+            d = [xp[:, q0 + o + i] for i in range(6)]
+            t0, t1 = d[4] - dt(4) * d[2], d[3] - dt(4) * d[1]
+            t2, t3 = d[4] - d[2], d[3] - d[1]
+            V = [dt(4) * d[0] + (d[4] - dt(5) * d[2]), t0 + t1, t0 - t1, t2 + dt(2) * t3, t2 - dt(2) * t3, dt(4) * d[1] + (d[5] - dt(5) * d[3])]
+            U = [u.astype(x.dtype) for u in f43_weights(wz[:, :, o:o + 3])]
+            for p in range(6):
+                M[p] = M[p] + U[p] @ V[p]
+        else:
+            xs = [xp[:, q0 + o + i] for i in range(4)]
+            g = wz[:, :, o].astype(np.float64)
+            for p, (u, v) in zip((0, 1, 2, 5), ((g, xs[0] - xs[2]), (0.5 * g, xs[1] + xs[2]), (0.5 * g, xs[2] - xs[1]), (g, xs[3] - xs[1]))):
+                M[p] = M[p] + u.astype(x.dtype) @ v
+    s12, d12, s34, d34 = M[1] + M[2], M[1] - M[2], M[3] + M[4], M[3] - M[4]
+    y = np.zeros((cout, Tq), x.dtype)
+    y[:, q0] = (M[0] + s12) + s34
+    y[:, q0 + 1] = d12 + dt(2) * d34
+    y[:, q0 + 2] = s12 + dt(4) * s34
+    y[:, q0 + 3] = (d12 + dt(8) * d34) + M[5]
     return y[:, :T]

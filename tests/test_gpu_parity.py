@@ -561,33 +561,40 @@ def test_hifigan_golden(golden):
 
 @pytest.mark.parametrize("B,T", [(1, 1), (2, 7), (3, 65), (5, 129), (1, 700), (33, 513)])
 def test_vocoder_winograd_odd_shapes(B, T):
-    """VERDICT r04 #5a for the generator: the Winograd form of the wide-stage convs works on output PAIRS one dilation apart (30- / 32-pair
-    tiles) — a one-frame mel, lengths that leave a lone column / a lone pair in the last tile at every dilation, an odd batch.  Forced onto
-    every shape (voc_wino = 2), against the direct form: fp32 rounding only."""
+    """VERDICT r04 #5a for the generator: the Winograd forms of the wide-stage convs work on output PAIRS one dilation apart (conv_xlw_kernel:
+    30- / 32-pair tiles) or, for dilation 1 since round 5, on QUADS of outputs (conv_xlq_kernel: 16-quad tiles, F(4,3) tap groups) — a
+    one-frame mel, lengths that leave a lone column / pair / quad in the last tile at every dilation, an odd batch.  Both forced onto every
+    shape (voc_wino = 2; voc_wino43 = 1 | 0), against the direct form: fp32 rounding only."""
     host = _host()
     hcfg = HifiGanConfig()
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=22))
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(7 * T + B)) * 1.5 - 4).to(DEV)
     prev = _lib.internal_set(b"voc_wino", 2)
+    prev43 = _lib.internal_set(b"voc_wino43", 1)
     try:
         got = voc(mel).clone()
+        _lib.internal_set(b"voc_wino43", 0)
+        got23 = voc(mel).clone()
         _lib.internal_set(b"voc_wino", 0)
         ref = voc(mel).clone()
     finally:
         _lib.internal_set(b"voc_wino", prev)
+        _lib.internal_set(b"voc_wino43", prev43)
     torch.cuda.synchronize()
-    d = float((got - ref).abs().max())
-    report(f"VOC_WINOGRAD_ODD B={B} T={T}: max|d wav| vs the direct form {d:.2e}")
-    assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all()
-    assert 0 < d <= VOC_WINO_TOL, d
+    d, d23 = float((got - ref).abs().max()), float((got23 - ref).abs().max())
+    report(f"VOC_WINOGRAD_ODD B={B} T={T}: max|d wav| vs the direct form: F(4,3) for dilation 1 {d:.2e}, F(2,3) tap groups everywhere {d23:.2e}")
+    assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all() and torch.isfinite(got23).all()
+    assert 0 < d <= VOC_WINO_TOL and 0 < d23 <= VOC_WINO_TOL, (d, d23)
+    assert not torch.equal(got, got23)
 
 
 @pytest.mark.parametrize("B,T", [(24, 350), (9, 1000), (32, 512)])
 def test_vocoder_winograd_vs_direct(B, T):
     """conv_xlw_kernel (round 4): the ResBlock convs of the C = 256 / 128 stages as Winograd convolutions over output pairs (t, t + dilation):
     k = 3 / 7 / 11 as F(2,3) groups + an F(2,2) / single-tap remainder, all three dilations, residual and MRF accumulation, ragged last tiles
-    (T not a multiple of the 64- / 60-column tiles).  Against the direct form on a chip-filling batch: fp32 rounding only; and the
-    reference's golden wav with the form forced onto its small shape."""
+    (T not a multiple of the 64- / 60-column tiles); conv_xlq_kernel (round 5, the default for dilation 1): F(4,3) groups over output quads.
+    Against the direct form on a chip-filling batch: fp32 rounding only; and the reference's golden wav with the form forced onto its
+    small shape."""
     host = _host()
     hcfg = HifiGanConfig()
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=21))

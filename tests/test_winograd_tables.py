@@ -60,3 +60,20 @@ def test_f43_fp32_error_and_its_growth_with_the_input_scale():
         e_43 = np.abs(W.conv1d_f43(x, w) - ref64).max()
         assert e_23 < 4 * e_dir and e_43 < 16 * e_dir, (scale, e_dir, e_23, e_43)      # measured: 1.5x and 8x on the MAXIMUM of one conv (rms: 2x)
         assert e_43 < 3e-5 * scale
+
+
+@pytest.mark.parametrize("k", [3, 7, 11])
+def test_f43_tap_groups_equal_direct_conv(k):
+    """conv_xlq_kernel's products (HiFi-GAN dilation-1 convs, round 5): F(4,3) groups of three taps + k = 7's single tap + k = 11's zero twelfth
+    tap, all into six accumulators, reproduce the k-tap conv — exactly in float64 at ragged lengths, to fp32 rounding in float32."""
+    rs = np.random.RandomState(k)
+    for T in (1, 2, 5, 63, 64, 66, 131):
+        x = rs.standard_normal((16, T))
+        w = rs.standard_normal((8, 16, k))
+        assert np.abs(W.conv1d_f43_taps(x, w) - W.conv1d_direct(x, w, 1)).max() < 1e-11, (k, T)
+    x = rs.standard_normal((128, 300)).astype(np.float32)
+    w = (rs.standard_normal((64, 128, k)) / np.sqrt(128 * k)).astype(np.float32)
+    ref64 = W.conv1d_direct(x.astype(np.float64), w.astype(np.float64), 1)
+    e_dir = np.abs(W.conv1d_direct(x, w, 1) - ref64).max()
+    e_q = np.abs(W.conv1d_f43_taps(x, w) - ref64).max()
+    assert e_q < 16 * e_dir + 1e-6, (k, e_q, e_dir)
