@@ -455,7 +455,7 @@ int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a
                                 // one-wave-per-SIMD F(2,3) stack of denoiser_persist4.hip (same bits as 1; measured 4-10 % slower), 0 = direct
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
-int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the dilation-1 convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch)
+int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch; 1 = dilation 1 everywhere + dilation 3 / 5 at C = 256 (default), 2 = only dilation 1, 3 = every dilation)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
@@ -2348,7 +2348,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
                 if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
-                if ((co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) && v->rb_dil[mi] == 1) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1q32[r][mi])); }
+                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1q32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
@@ -2554,7 +2554,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                     // round 5: dilation-1 convs (every conv2, conv1 of the first pair) in the F(4,3) form (conv_xlq_kernel: 6 / 16 / 24 products per quad of outputs where
                     // the F(2,3) tap groups take 8 / 20 / 30); -2 = launch too small or shape not covered: the F(2,3) form, then the direct one
                     int rc1 = -2;
-                    if (xw && g_voc_wino43 && dil == 1 && v->c1q32[r][mi]) { xa.wf = v->c1q32[r][mi]; rc1 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc1 == -2) xa.wf = v->c1w32[r][mi]; }
+                    // (dilation 3 / 5 in that form only at C = 256, where it measures -20 %: at C = 128 / 64 the 15-quad class tiles with their strided stores are slower
+                    //  than the F(2,3) pair tiles — +11 % at C = 128, k = 7; voc_wino43 = 3 forces them for tests)
+                    if (xw && g_voc_wino43 && (dil == 1 || (g_voc_wino43 == 1 && co == 256) || g_voc_wino43 == 3) && v->c1q32[r][mi]) { xa.wf = v->c1q32[r][mi]; rc1 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc1 == -2) xa.wf = v->c1w32[r][mi]; }
                     if (rc1 == -2 && xw) rc1 = cmtts_launch_conv_xlw(&xa, (void*)q);
                     const bool xw1 = rc1 == 0;
                     if (rc1 == -2) { xa.wf = v->c1f32[r][mi]; rc1 = cmtts_launch_conv_xl(&xa, (void*)q); }
@@ -2753,7 +2755,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_rb16", &g_voc_rb16, 0, 2},           // 16-bit whole-ResBlock kernel: 0 never, 1 where it pays, 2 always
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
         {"voc_wino64_k", &g_voc_wino64_k, 3, 99},
-        {"voc_wino43", &g_voc_wino43, 0, 1},       // fp32 dilation-1 convs of the Winograd path as F(4,3) (conv_xlq_kernel; NOT bitwise F(2,3) or direct)
+        {"voc_wino43", &g_voc_wino43, 0, 3},       // fp32 dilation-1 convs of the Winograd path as F(4,3) (conv_xlq_kernel; NOT bitwise F(2,3) or direct)
         {"voc_wino64", &g_voc_wino64, 0, 1},       // fp32 C = 64 stage, k >= voc_wino64_k: two conv_xlw launches per pair (with voc_wino) instead of the pair kernel
         {"voc_wino", &g_voc_wino, 0, 2},           // fp32 wide-stage convs in their Winograd form (NOT bitwise: the A/B twin of the vocoder option "winograd")
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16

@@ -1,4 +1,4 @@
-// HiFi-GAN ResBlock convs of dilation 1, fp32, in a Winograd F(4,3) form (round 5) — the X-resident single-conv kernel of resblock_pair.hip
+// HiFi-GAN ResBlock convs (dilation 1; 3 / 5 by residue classes, below), fp32, in a Winograd F(4,3) form (round 5) — the X-resident single-conv kernel of resblock_pair.hip
 // (conv_xl_kernel / conv_xlw_kernel; hifigan/models.py:96-103: xt = c1(leaky_relu(x)); x = c2(leaky_relu(xt)) + x) with the products of
 // denoiser_persist.hip's WINO == 2 instances: outputs in QUADS (4q .. 4q + 3), every group of three consecutive taps as F(4,3) over the
 // points 0, +-1, +-2, inf — six products per quad and group instead of twelve (conv_xlw_kernel's F(2,3) groups: eight) — all groups of a conv
@@ -37,20 +37,27 @@ template <> struct QTab<3> { static constexpr int NE = 1, NPT = 6; static conste
 template <> struct QTab<7> { static constexpr int NE = 3, NPT = 16; static constexpr int kind[3] = {0, 0, 1}, off[3] = {0, 3, 6}, pt0[3] = {0, 6, 12}; };
 template <> struct QTab<11> { static constexpr int NE = 4, NPT = 24; static constexpr int kind[4] = {0, 0, 0, 0}, off[4] = {0, 3, 6, 9}, pt0[4] = {0, 6, 12, 18}; };
 
-template <int C, int KT>
+// Dilation DIL = 3 / 5 (conv1 of a ResBlock's second / third pair): the outputs of a residue class t = r (mod DIL) form an UNDILATED conv on that
+// class's subsequence, so the tile is 60 columns = DIL classes x (5 | 3) quads (15 of the 16 quad lanes), the activated tile lives in LDS class by
+// class ([C][DIL][CP], CP = the class's entries rounded up to 4) and lane (class r, quad m) reads, transforms and accumulates exactly as at dilation 1
+// from base r CP + 4 m; only the staging scatter and the strided stores differ.
+template <int C, int KT, int DIL>
 __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXlArgs a) {
     using TAB = QTab<KT>;
     constexpr int NWV = C / 64;
     constexpr int NE = TAB::NE, NPT = TAB::NPT;
-    constexpr int PAD = (KT - 1) / 2;
-    constexpr int XIN = 64 + (KT == 11 ? KT : KT - 1);      // staged columns (k = 11: one more, under the zero twelfth tap)
-    constexpr int XW = (XIN + 3) / 4 * 4;                   // row pitch: 68 / 72 / 76 floats (16-byte aligned quads)
+    constexpr int PAD = DIL * ((KT - 1) / 2);
+    constexpr int BN = DIL == 1 ? 64 : 60;                  // output columns per tile
+    constexpr int QPC = BN / (4 * DIL);                     // quads per residue class: 16 / 5 / 3
+    constexpr int XIN = BN + DIL * (KT == 11 ? KT : KT - 1);   // staged columns (k = 11: one more per class, under the zero twelfth tap)
+    constexpr int CP = (XIN / DIL + 3) / 4 * 4;             // entries per class, 16-byte aligned quads: 68 / 72 / 76 at dilation 1
+    constexpr int XW = DIL * CP;                            // row pitch
     constexpr int NKS = C / 4;                              // k-steps of four channels
-    extern __shared__ __attribute__((aligned(16))) float Xs[];      // [C][XW]
+    extern __shared__ __attribute__((aligned(16))) float Xs[];      // [C][DIL][CP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * 64;
+    const int t0 = blockIdx.x * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
     {   // stage the activated tile: wave w its 64 rows, lanes along the frame axis (coalesced), zeros outside [0, T)
@@ -68,9 +75,10 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
 #pragma unroll
             for (int jb = 0; jb < XBLK; ++jb) {
                 const int j = jb * 64 + lane, t = tbase + j;
+                const int jc = DIL == 1 ? j : (j % DIL) * CP + j / DIL;      // class-major position
                 if (j < XIN) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Xs[(w * 64 + h + r) * XW + j] = (t >= 0 && t < T) ? leaky(v[jb][r], a.slope) : 0.f;
+                    for (int r = 0; r < 16; ++r) Xs[(w * 64 + h + r) * XW + jc] = (t >= 0 && t < T) ? leaky(v[jb][r], a.slope) : 0.f;
                 }
             }
         }
@@ -98,7 +106,8 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
                 if (p < (TAB::kind[e] ? 4 : 6)) dst[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + p * 1024, soff, 0));
         };
         // raw inputs of an entry: two aligned LDS reads (three at tap offset 3); lane's quad at column 4 q of row 4 ks + (lane >> 4)
-        const float* xl = Xs + (lane >> 4) * XW + 4 * (lane & 15);
+        const int lq = min(lane & 15, DIL * QPC - 1);      // (dilation 3 / 5: the sixteenth quad lane repeats the fifteenth; it stores nothing)
+        const float* xl = Xs + (lane >> 4) * XW + (lq / QPC) * CP + 4 * (lq % QPC);
         float D[2][6];
         auto load_d = [&](float (&d)[6], int ks0, int n) {
             const int e = n % NE, ks = ks0 + n / NE;
@@ -170,8 +179,10 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
     float* yb = a.y + (long)b * a.bstride;
     const float* rb = a.res ? a.res + (long)b * a.bstride : nullptr;
     const int q4 = lane & 15, rq = lane >> 4;
-    const int tq = t0 + 4 * q4;
-    const bool vec = ((a.ld & 3) == 0) && ((reinterpret_cast<size_t>(yb) & 15) == 0) && (!rb || (reinterpret_cast<size_t>(rb) & 15) == 0) && tq + 3 < T;
+    // this lane's quad: columns tq, tq + DIL, tq + 2 DIL, tq + 3 DIL
+    const int tq = t0 + (DIL == 1 ? 4 * q4 : (q4 / QPC) + 4 * DIL * (q4 % QPC));
+    const bool qv = q4 < DIL * QPC;
+    const bool vec = DIL == 1 && ((a.ld & 3) == 0) && ((reinterpret_cast<size_t>(yb) & 15) == 0) && (!rb || (reinterpret_cast<size_t>(rb) & 15) == 0) && tq + 3 < T;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float bi[4];
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const long oc = (long)row * a.ld + min(tq + c, T - 1);
+                    const long oc = (long)row * a.ld + min(tq + c * DIL, T - 1);
                     xr[r][c] = rb ? rb[oc] : 0.f;
                     yo[r][c] = a.accum ? yb[oc] : 0.f;
                 }
@@ -213,44 +224,53 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
             }
             const long o = (long)row * a.ld + tq;
             if (vec) *reinterpret_cast<f32x4*>(yb + o) = y;
-            else {
+            else if (qv) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (tq + c < T) yb[o + c] = y[c];
+                    if (tq + c * DIL < T) yb[o + c * DIL] = y[c];
             }
         }
     }
 }
 
-template <int C, int KT>
+template <int C, int KT, int DIL>
 int launch_xlq(const ConvXlArgs& a, hipStream_t stream) {
-    constexpr int XIN = 64 + (KT == 11 ? KT : KT - 1), XW = (XIN + 3) / 4 * 4;
-    const size_t lds = (size_t)C * XW * sizeof(float);
+    constexpr int BN = DIL == 1 ? 64 : 60;
+    constexpr int XIN = BN + DIL * (KT == 11 ? KT : KT - 1), CP = (XIN / DIL + 3) / 4 * 4;
+    const size_t lds = (size_t)C * DIL * CP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xlq_kernel<C, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xlq_kernel<C, KT, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
         attr_set = true;
     }
-    dim3 grid((a.T + 63) / 64, a.B);
-    hipLaunchKernelGGL((conv_xlq_kernel<C, KT>), grid, dim3(64 * (C / 64)), lds, stream, a);
+    dim3 grid((a.T + BN - 1) / BN, a.B);
+    hipLaunchKernelGGL((conv_xlq_kernel<C, KT, DIL>), grid, dim3(64 * (C / 64)), lds, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int C, int KT>
+int launch_xlq_d(const ConvXlArgs& a, hipStream_t s) {
+    if (a.dil == 1) return launch_xlq<C, KT, 1>(a, s);
+    if (a.dil == 3) return launch_xlq<C, KT, 3>(a, s);
+    if (a.dil == 5) return launch_xlq<C, KT, 5>(a, s);
+    return -2;
 }
 
 template <int C>
 int launch_xlq_k(const ConvXlArgs& a, hipStream_t s) {
-    if (a.k == 3) return launch_xlq<C, 3>(a, s);
-    if (a.k == 7) return launch_xlq<C, 7>(a, s);
-    if (a.k == 11) return launch_xlq<C, 11>(a, s);
+    if (a.k == 3) return launch_xlq_d<C, 3>(a, s);
+    if (a.k == 7) return launch_xlq_d<C, 7>(a, s);
+    if (a.k == 11) return launch_xlq_d<C, 11>(a, s);
     return -2;
 }
 
 }  // namespace
 
-// The dilation-1 conv in its F(4,3) form (a->wf = to_wino43_iter_fragments of the same weights).  Returns 0, -2 (shape not covered: C = 64 / 128 / 256,
-// k = 3 / 7 / 11, dilation 1, C_in = C; or a launch too small to pay for the transforms unless a->wino_force) or -3 (HIP error).
+// The conv in its F(4,3) form (a->wf = to_wino43_iter_fragments of the same weights).  Returns 0, -2 (shape not covered: C = 64 / 128 / 256,
+// k = 3 / 7 / 11, dilation 1 / 3 / 5, C_in = C; or a launch too small to pay for the transforms unless a->wino_force) or -3 (HIP error).
 extern "C" int cmtts_launch_conv_xlq(const ConvXlArgs* a, void* stream_) {
     hipStream_t s = (hipStream_t)stream_;
-    if (a->dil != 1 || (a->cin && a->cin != a->C) || a->T < 1 || a->B < 1) return -2;
+    if ((a->cin && a->cin != a->C) || a->T < 1 || a->B < 1) return -2;
     if (!a->wino_force && (long)((a->T + 63) / 64) * a->B < 1024) return -2;
     if (a->C == 64) return launch_xlq_k<64>(*a, s);
     if (a->C == 128) return launch_xlq_k<128>(*a, s);

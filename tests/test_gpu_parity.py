@@ -570,9 +570,11 @@ def test_vocoder_winograd_odd_shapes(B, T):
     voc = host.Generator(hcfg, DEV).load_state_dict(synth_hifigan_state_dict(hcfg, seed=22))
     mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(7 * T + B)) * 1.5 - 4).to(DEV)
     prev = _lib.internal_set(b"voc_wino", 2)
-    prev43 = _lib.internal_set(b"voc_wino43", 1)
+    prev43 = _lib.internal_set(b"voc_wino43", 3)      # F(4,3) at every dilation and width (the default takes dilation 3 / 5 in that form only at C = 256)
     try:
         got = voc(mel).clone()
+        _lib.internal_set(b"voc_wino43", 1)
+        got_default = voc(mel).clone()
         _lib.internal_set(b"voc_wino43", 0)
         got23 = voc(mel).clone()
         _lib.internal_set(b"voc_wino", 0)
@@ -581,10 +583,10 @@ def test_vocoder_winograd_odd_shapes(B, T):
         _lib.internal_set(b"voc_wino", prev)
         _lib.internal_set(b"voc_wino43", prev43)
     torch.cuda.synchronize()
-    d, d23 = float((got - ref).abs().max()), float((got23 - ref).abs().max())
-    report(f"VOC_WINOGRAD_ODD B={B} T={T}: max|d wav| vs the direct form: F(4,3) for dilation 1 {d:.2e}, F(2,3) tap groups everywhere {d23:.2e}")
-    assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all() and torch.isfinite(got23).all()
-    assert 0 < d <= VOC_WINO_TOL and 0 < d23 <= VOC_WINO_TOL, (d, d23)
+    d, d23, dd = float((got - ref).abs().max()), float((got23 - ref).abs().max()), float((got_default - ref).abs().max())
+    report(f"VOC_WINOGRAD_ODD B={B} T={T}: max|d wav| vs the direct form: F(4,3) everywhere {d:.2e}, the default mix {dd:.2e}, F(2,3) tap groups everywhere {d23:.2e}")
+    assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all() and torch.isfinite(got23).all() and torch.isfinite(got_default).all()
+    assert 0 < d <= VOC_WINO_TOL and 0 < d23 <= VOC_WINO_TOL and 0 < dd <= VOC_WINO_TOL, (d, d23, dd)
     assert not torch.equal(got, got23)
 
 

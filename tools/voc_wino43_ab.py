@@ -15,7 +15,7 @@ ok = True
 for B, T in [(1, 1), (2, 7), (3, 65), (1, 700), (33, 129)]:
     mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
     out = {}
-    for name, wn, w43 in (("direct", 0, 0), ("f23", 2, 0), ("f43", 2, 1)):
+    for name, wn, w43 in (("direct", 0, 0), ("f23", 2, 0), ("f43", 2, 3)):
         _lib.internal_set(b"voc_wino", wn); _lib.internal_set(b"voc_wino43", w43)
         out[name] = voc(mel).double()
     torch.cuda.synchronize()
@@ -27,9 +27,9 @@ print("ALL OK" if ok else "FAILED", flush=True)
 B, T = int(os.environ.get("VB", 32)), int(os.environ.get("VT", 512))
 mel = torch.randn(B, 80, T, device="cuda") * 1.5 - 4
 _lib.internal_set(b"voc_wino", 1)
-out, times = {}, {0: [], 1: []}
+out, times = {}, {0: [], 1: [], 2: []}
 for rnd in range(int(os.environ.get("ROUNDS", 3))):
-    for w43 in (0, 1):
+    for w43 in (0, 2, 1):
         _lib.internal_set(b"voc_wino43", w43)
         for _ in range(2 if rnd == 0 else 1):
             w = voc(mel)
@@ -41,5 +41,5 @@ for rnd in range(int(os.environ.get("ROUNDS", 3))):
 _lib.internal_set(b"voc_wino43", 1)
 d = (out[1] - out[0]).double()
 fl = B * T * 614.105088e6
-print(f"B={B} T={T}: F(2,3) tap groups {min(times[0])*1e3:.2f} ms ({fl/min(times[0])/1e12:.1f} TFLOP/s), F(4,3) for dilation 1 {min(times[1])*1e3:.2f} ms ({fl/min(times[1])/1e12:.1f} TFLOP/s of the direct form's FLOPs)")
+print(f"B={B} T={T}: F(2,3) tap groups {min(times[0])*1e3:.2f} ms ({fl/min(times[0])/1e12:.1f} TFLOP/s), F(4,3) for dilation 1 only {min(times[2])*1e3:.2f} ms, the default (+ dilation 3 / 5 at C = 256) {min(times[1])*1e3:.2f} ms ({fl/min(times[1])/1e12:.1f} TFLOP/s of the direct form's FLOPs)")
 print(f"  wav: max|d| {float(d.abs().max()):.3e} rms {float(d.pow(2).mean().sqrt()):.3e}, finite {bool(torch.isfinite(out[1]).all())}")
