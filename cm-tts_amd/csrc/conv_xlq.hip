@@ -60,7 +60,34 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
     const int t0 = blockIdx.x * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
-    {   // stage the activated tile: wave w its 64 rows, lanes along the frame axis (coalesced), zeros outside [0, T)
+    if constexpr (DIL == 1) {
+        // stage the activated tile: wave w its 64 rows as 16-byte loads (NV per row, item = (row, quad of columns) on consecutive lanes), ALL of them in
+        // flight before the first LDS write — one round trip per tile where the dword form took four of 32 loads each (the tile's overhead, not its
+        // K loop, is what the C = 128 / 64 instances lose to the ideal); zeros outside [0, T)
+        const int tbase = t0 - PAD;
+        constexpr int NV = (XIN + 3) / 4;
+        f32x4 v[NV];
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = it * 64 + lane, r = idx / NV, q = idx - r * NV;
+            const int t = tbase + 4 * q;
+            const float* src = xb + (long)(w * 64 + r) * a.ld;
+            if (t >= 0 && t + 3 < T) v[it] = *reinterpret_cast<const f32x4*>(src + t);      // (4-byte aligned: global_load_dwordx4 takes it)
+            else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[it][c] = src[min(max(t + c, 0), T - 1)];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int idx = it * 64 + lane, r = idx / NV, q = idx - r * NV;
+            const int t = tbase + 4 * q;
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (t + c >= 0 && t + c < T) ? leaky(v[it][c], a.slope) : 0.f;
+            *reinterpret_cast<f32x4*>(Xs + (w * 64 + r) * XW + 4 * q) = o;
+        }
+    } else {   // dilation 3 / 5: lanes along the frame axis, scattered class-major
         const int tbase = t0 - PAD;
         constexpr int XBLK = (XIN + 63) / 64;
 #pragma unroll
@@ -75,7 +102,7 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
 #pragma unroll
             for (int jb = 0; jb < XBLK; ++jb) {
                 const int j = jb * 64 + lane, t = tbase + j;
-                const int jc = DIL == 1 ? j : (j % DIL) * CP + j / DIL;      // class-major position
+                const int jc = (j % DIL) * CP + j / DIL;      // class-major position
                 if (j < XIN) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Xs[(w * 64 + h + r) * XW + jc] = (t >= 0 && t < T) ? leaky(v[jb][r], a.slope) : 0.f;
@@ -183,53 +210,59 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
     const int tq = t0 + (DIL == 1 ? 4 * q4 : (q4 / QPC) + 4 * DIL * (q4 % QPC));
     const bool qv = q4 < DIL * QPC;
     const bool vec = DIL == 1 && ((a.ld & 3) == 0) && ((reinterpret_cast<size_t>(yb) & 15) == 0) && (!rb || (reinterpret_cast<size_t>(rb) & 15) == 0) && tq + 3 < T;
+    // (two m-tiles per round trip: all residual / old-y loads of a pair of m-tiles in flight before the first use)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float bi[4];
-        f32x4 xr[4], yo[4];
+    for (int i0 = 0; i0 < 4; i0 += 2) {
+        float bi[2][4];
+        f32x4 xr[2][4], yo[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = w * 64 + 16 * i + 4 * rq + r;
-            bi[r] = a.bias[row];
-            const long o = (long)row * a.ld + tq;
-            if (vec) {
-                xr[r] = rb ? *reinterpret_cast<const f32x4*>(rb + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-                yo[r] = a.accum ? *reinterpret_cast<const f32x4*>(yb + o) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const long oc = (long)row * a.ld + min(tq + c * DIL, T - 1);
-                    xr[r][c] = rb ? rb[oc] : 0.f;
-                    yo[r][c] = a.accum ? yb[oc] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const int row = w * 64 + 16 * (i0 + ii) + 4 * rq + r;
+                bi[ii][r] = a.bias[row];
+                const long o = (long)row * a.ld + tq;
+                if (vec) {
+                    xr[ii][r] = rb ? *reinterpret_cast<const f32x4*>(rb + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    yo[ii][r] = a.accum ? *reinterpret_cast<const f32x4*>(yb + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const long oc = (long)row * a.ld + min(tq + c * DIL, T - 1);
+                        xr[ii][r][c] = rb ? rb[oc] : 0.f;
+                        yo[ii][r][c] = a.accum ? yb[oc] : 0.f;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = w * 64 + 16 * i + 4 * rq + r;
-            const float m0 = M[i][0][r], m1 = M[i][1][r], m2 = M[i][2][r], m3 = M[i][3][r], m4 = M[i][4][r], m5 = M[i][5][r];
-            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-            f32x4 y;
-            y[0] = ((m0 + s12) + s34) + bi[r];
-            y[1] = __builtin_fmaf(2.f, d34, d12) + bi[r];
-            y[2] = __builtin_fmaf(4.f, s34, s12) + bi[r];
-            y[3] = (__builtin_fmaf(8.f, d34, d12) + m5) + bi[r];
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = y[c];
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                if (rb) v += xr[r][c];
-                if (a.accum) v += yo[r][c];
-                y[c] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + ii;
+                const int row = w * 64 + 16 * i + 4 * rq + r;
+                const float m0 = M[i][0][r], m1 = M[i][1][r], m2 = M[i][2][r], m3 = M[i][3][r], m4 = M[i][4][r], m5 = M[i][5][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                f32x4 y;
+                y[0] = ((m0 + s12) + s34) + bi[ii][r];
+                y[1] = __builtin_fmaf(2.f, d34, d12) + bi[ii][r];
+                y[2] = __builtin_fmaf(4.f, s34, s12) + bi[ii][r];
+                y[3] = (__builtin_fmaf(8.f, d34, d12) + m5) + bi[ii][r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = y[c];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    if (rb) v += xr[ii][r][c];
+                    if (a.accum) v += yo[ii][r][c];
+                    y[c] = v;
+                }
+                const long o = (long)row * a.ld + tq;
+                if (vec) *reinterpret_cast<f32x4*>(yb + o) = y;
+                else if (qv) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (tq + c * DIL < T) yb[o + c * DIL] = y[c];
+                }
             }
-            const long o = (long)row * a.ld + tq;
-            if (vec) *reinterpret_cast<f32x4*>(yb + o) = y;
-            else if (qv) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (tq + c * DIL < T) yb[o + c * DIL] = y[c];
-            }
-        }
     }
 }
 
