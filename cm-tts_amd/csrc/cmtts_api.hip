@@ -455,7 +455,7 @@ int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a
                                 // one-wave-per-SIMD F(2,3) stack of denoiser_persist4.hip (same bits as 1; measured 4-10 % slower), 0 = direct
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
-int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch; 1 = dilation 1 everywhere + dilation 3 / 5 at C = 256 (default), 2 = only dilation 1, 3 = every dilation)
+int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch; 1 = dilation 1 and 3 everywhere + dilation 5 at C = 256 or k = 3 (default), 2 = only dilation 1, 3 = every dilation)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
@@ -2554,9 +2554,9 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
                     // round 5: dilation-1 convs (every conv2, conv1 of the first pair) in the F(4,3) form (conv_xlq_kernel: 6 / 16 / 24 products per quad of outputs where
                     // the F(2,3) tap groups take 8 / 20 / 30); -2 = launch too small or shape not covered: the F(2,3) form, then the direct one
                     int rc1 = -2;
-                    // (dilation 3 / 5 in that form only at C = 256, where it measures -20 %: at C = 128 / 64 the 15-quad class tiles with their strided stores are slower
-                    //  than the F(2,3) pair tiles — +11 % at C = 128, k = 7; voc_wino43 = 3 forces them for tests)
-                    if (xw && g_voc_wino43 && (dil == 1 || (g_voc_wino43 == 1 && co == 256) || g_voc_wino43 == 3) && v->c1q32[r][mi]) { xa.wf = v->c1q32[r][mi]; rc1 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc1 == -2) xa.wf = v->c1w32[r][mi]; }
+                    // (dilation 3 in that form everywhere, dilation 5 only at C = 256 or k = 3: the five-class tiles of C = 128 / 64 (one workgroup fewer per CU, 15 of
+                    //  16 quad lanes, strided stores) are slower than the F(2,3) pair tiles at k = 7 / 11 — 3.63 vs 2.44 ms at C = 128, k = 11; voc_wino43 = 3 forces them for tests)
+                    if (xw && g_voc_wino43 && (dil == 1 || (g_voc_wino43 == 1 && (co == 256 || dil == 3 || rk == 3)) || g_voc_wino43 == 3) && v->c1q32[r][mi]) { xa.wf = v->c1q32[r][mi]; rc1 = cmtts_launch_conv_xlq(&xa, (void*)q); if (rc1 == -2) xa.wf = v->c1w32[r][mi]; }
                     if (rc1 == -2 && xw) rc1 = cmtts_launch_conv_xlw(&xa, (void*)q);
                     const bool xw1 = rc1 == 0;
                     if (rc1 == -2) { xa.wf = v->c1f32[r][mi]; rc1 = cmtts_launch_conv_xl(&xa, (void*)q); }

@@ -60,10 +60,34 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
     const int t0 = blockIdx.x * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
-    if constexpr (DIL == 1) {
+    if constexpr (DIL > 1 && C == 256) {      // (measured: at C = 256 the dword form, lanes along the frame axis, beats the 16-byte form's four scattered LDS writes per item by 4 %)
+        const int tbase = t0 - PAD;
+        constexpr int XBLK = (XIN + 63) / 64;
+#pragma unroll
+        for (int h = 0; h < 64; h += 16) {
+            float v[XBLK][16];
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[jb][r] = xb[(long)(w * 64 + h + r) * a.ld + t_c];
+            }
+#pragma unroll
+            for (int jb = 0; jb < XBLK; ++jb) {
+                const int j = jb * 64 + lane, t = tbase + j;
+                const int jc = (j % DIL) * CP + j / DIL;      // class-major position
+                if (j < XIN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Xs[(w * 64 + h + r) * XW + jc] = (t >= 0 && t < T) ? leaky(v[jb][r], a.slope) : 0.f;
+                }
+            }
+        }
+    } else {
         // stage the activated tile: wave w its 64 rows as 16-byte loads (NV per row, item = (row, quad of columns) on consecutive lanes), ALL of them in
         // flight before the first LDS write — one round trip per tile where the dword form took four of 32 loads each (the tile's overhead, not its
-        // K loop, is what the C = 128 / 64 instances lose to the ideal); zeros outside [0, T)
+        // K loop, is what the C = 128 / 64 instances lose to the ideal); zeros outside [0, T).  Dilation 3 / 5: the four columns of an item go to
+        // their class-major positions one by one.  (Requesting the weight ring's first stages and the first residual operands in front of this
+        // staging changed nothing: 64.3 vs 64.2 ms per batch — the other workgroups of the CU already cover those round trips.)
         const int tbase = t0 - PAD;
         constexpr int NV = (XIN + 3) / 4;
         f32x4 v[NV];
@@ -85,27 +109,12 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (t + c >= 0 && t + c < T) ? leaky(v[it][c], a.slope) : 0.f;
-            *reinterpret_cast<f32x4*>(Xs + (w * 64 + r) * XW + 4 * q) = o;
-        }
-    } else {   // dilation 3 / 5: lanes along the frame axis, scattered class-major
-        const int tbase = t0 - PAD;
-        constexpr int XBLK = (XIN + 63) / 64;
+            if constexpr (DIL == 1) *reinterpret_cast<f32x4*>(Xs + (w * 64 + r) * XW + 4 * q) = o;
+            else {
 #pragma unroll
-        for (int h = 0; h < 64; h += 16) {
-            float v[XBLK][16];
-#pragma unroll
-            for (int jb = 0; jb < XBLK; ++jb) {
-                const int t_c = min(max(tbase + jb * 64 + lane, 0), T - 1);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[jb][r] = xb[(long)(w * 64 + h + r) * a.ld + t_c];
-            }
-#pragma unroll
-            for (int jb = 0; jb < XBLK; ++jb) {
-                const int j = jb * 64 + lane, t = tbase + j;
-                const int jc = (j % DIL) * CP + j / DIL;      // class-major position
-                if (j < XIN) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Xs[(w * 64 + h + r) * XW + jc] = (t >= 0 && t < T) ? leaky(v[jb][r], a.slope) : 0.f;
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 4 * q + c;
+                    if (j < XIN) Xs[(w * 64 + r) * XW + (j % DIL) * CP + j / DIL] = o[c];
                 }
             }
         }

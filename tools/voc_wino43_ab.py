@@ -41,5 +41,5 @@ for rnd in range(int(os.environ.get("ROUNDS", 3))):
 _lib.internal_set(b"voc_wino43", 1)
 d = (out[1] - out[0]).double()
 fl = B * T * 614.105088e6
-print(f"B={B} T={T}: F(2,3) tap groups {min(times[0])*1e3:.2f} ms ({fl/min(times[0])/1e12:.1f} TFLOP/s), F(4,3) for dilation 1 only {min(times[2])*1e3:.2f} ms, the default (+ dilation 3 / 5 at C = 256) {min(times[1])*1e3:.2f} ms ({fl/min(times[1])/1e12:.1f} TFLOP/s of the direct form's FLOPs)")
+print(f"B={B} T={T}: F(2,3) tap groups {min(times[0])*1e3:.2f} ms ({fl/min(times[0])/1e12:.1f} TFLOP/s), F(4,3) for dilation 1 only {min(times[2])*1e3:.2f} ms, the default (+ dilation 3, + dilation 5 at C = 256 or k = 3) {min(times[1])*1e3:.2f} ms ({fl/min(times[1])/1e12:.1f} TFLOP/s of the direct form's FLOPs)")
 print(f"  wav: max|d| {float(d.abs().max()):.3e} rms {float(d.pow(2).mean().sqrt()):.3e}, finite {bool(torch.isfinite(out[1]).all())}")
