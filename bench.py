@@ -841,8 +841,8 @@ def main():
         extras["vocoder_fp32"] = {"ms_per_batch": round(d_v * 1e3, 2), "achieved_tflops": round(vflops / d_v / 1e12, 1),
                                   "frac_of_fp32_mfma_peak": round(vflops / d_v / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                   "bound": "mfma", "flops_per_batch": vflops,
-                                  "algorithm": ("ResBlock convs of the C >= 128 stages (and k >= 7 at C = 64) in a Winograd form: dilation 1 (and 3 / 5 at C = 256) as F(4,3) tap groups — "
-                                                "6 / 16 / 24 products per quad of outputs instead of 12 / 28 / 44 — the other dilated convs as F(2,3) tap groups (4 / 10 / 15 per "
+                                  "algorithm": ("ResBlock convs of the C >= 128 stages (and k >= 7 at C = 64) in a Winograd form: dilation 1 and 3 (and 5 at C = 256 or k = 3) as F(4,3) tap groups — "
+                                                "6 / 16 / 24 products per quad of outputs instead of 12 / 28 / 44 — the other dilation-5 convs as F(2,3) tap groups (4 / 10 / 15 per "
                                                 "pair instead of 6 / 14 / 22); |d wav| <= 1.4e-6 against the direct form; `achieved_tflops` / the fraction count the "
                                                 "reference's direct-form FLOPs" if _lib.internal_set(b"voc_wino", -1) >= 1 and voc.set_option("winograd", -1) == 1 else "direct")}
         # BASELINE.json configs[2] shape: bf16 residual blocks + bf16 HiFi-GAN ResBlock convs (fp32 accumulate)
