@@ -2209,3 +2209,72 @@ def test_errors_are_loud():
     model.load_state_dict(sd)
     with pytest.raises(AssertionError):      # model/cmtts.py:80
         model.duration_pitch_energy_net(None, torch.ones(1, 4, dtype=torch.long), torch.tensor([4]))
+
+
+def _pack_wino43(w):
+    """w [Cout][Cin][k] (torch layout) -> conv_xlq_kernel's weight stream (cmtts_api.hip: to_wino43_iter_fragments; conv_xlq.hip: QTab<k>):
+    [Cin/4 k-steps][Cout/64 waves][points][64 lanes][4], element i at lane l = input channel 4 ks + (l >> 4), output row 64 w + 16 i + (l & 15)."""
+    from oracle import winograd_ref as W
+    cout, cin, k = w.shape
+    wz = np.concatenate([w.astype(np.float64), np.zeros((cout, cin, 2))], axis=2)
+    pts = []                                                      # every point's [Cout][Cin] transformed weights, in stream order
+    for kind, o in W.F43_TAPS[k]:
+        if kind == "f43":
+            pts += W.f43_weights(wz[:, :, o:o + 3])
+        else:
+            g = wz[:, :, o]
+            pts += [g, 0.5 * g, 0.5 * g, g]
+    P = np.stack(pts).astype(np.float32)                          # [npt][Cout][Cin]
+    lane = np.arange(64)
+    out = np.empty((cin // 4, cout // 64, len(pts), 64, 4), np.float32)
+    for ks in range(cin // 4):
+        for wv in range(cout // 64):
+            for i in range(4):
+                out[ks, wv, :, :, i] = P[:, 64 * wv + 16 * i + (lane & 15), 4 * ks + (lane >> 4)]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("Cc,k,dil,T,ld", [(64, 7, 1, 131, 131), (64, 11, 3, 200, 203), (128, 3, 1, 66, 68), (128, 7, 1, 257, 260), (128, 11, 5, 130, 130),
+                                            (128, 3, 5, 59, 64), (256, 11, 1, 64, 64), (256, 7, 3, 121, 124), (256, 3, 1, 5, 8)])
+def test_conv_xlq_kernel_vs_oracle(Cc, k, dil, T, ld):
+    """conv_xlq_kernel (round 5: HiFi-GAN's ResBlock convs as F(4,3) tap groups over output quads) called alone against the oracle — the plain
+    conv in float64 (oracle/winograd_ref.py: conv1d_direct) and the restatement of the kernel's own products in fp32 (conv1d_f43_taps at dilation
+    1): LeakyReLU on the input, bias, residual and y += (the MRF sum) in the epilogue, lengths that leave a ragged quad and a ragged tile at every
+    dilation, row strides that are not a multiple of 16 bytes (the generator itself only ever presents whole quads and aligned rows, so this is
+    the only place the scalar epilogue runs at dilation 1)."""
+    import ctypes as C
+    from oracle import winograd_ref as W
+    lib = C.CDLL(_lib.LIB_PATH)
+
+    class XlArgs(C.Structure):
+        _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                    ("bstride", C.c_long), ("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("ld", C.c_int), ("k", C.c_int),
+                    ("dil", C.c_int), ("accum", C.c_int), ("slope", C.c_float), ("relu", C.c_int), ("cin", C.c_int), ("xbstride", C.c_long),
+                    ("wino_force", C.c_int)]
+    lib.cmtts_launch_conv_xlq.restype = C.c_int
+    rs = np.random.RandomState(Cc + 10 * k + dil)
+    B = 2
+    x = rs.standard_normal((B, Cc, ld)).astype(np.float32)
+    res = rs.standard_normal((B, Cc, ld)).astype(np.float32)
+    y0 = rs.standard_normal((B, Cc, ld)).astype(np.float32)
+    w = (rs.standard_normal((Cc, Cc, k)) / np.sqrt(Cc * k)).astype(np.float32)
+    bias = rs.standard_normal(Cc).astype(np.float32)
+    xd, rd, bd = (torch.from_numpy(v).to(DEV) for v in (x, res, bias))
+    wf = torch.from_numpy(_pack_wino43(w)).to(DEV)
+    act = np.where(x > 0, x, x * np.float32(0.1))[:, :, :T]
+    for accum in (0, 1):
+        yd = torch.from_numpy(y0).to(DEV)
+        a = XlArgs(xd.data_ptr(), yd.data_ptr(), wf.data_ptr(), bd.data_ptr(), rd.data_ptr(), Cc * ld, B, Cc, T, ld, k, dil, accum, 0.1, 0, 0, 0, 1)
+        assert lib.cmtts_launch_conv_xlq(C.byref(a), None) == 0
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        assert np.array_equal(got[:, :, T:], y0[:, :, T:])                  # nothing written beyond T
+        for b in range(B):
+            ref = W.conv1d_direct(act[b].astype(np.float64), w.astype(np.float64), dil) + bias[:, None] + res[b, :, :T]
+            if accum:
+                ref = ref + y0[b, :, :T]
+            err = np.abs(got[b, :, :T] - ref).max()
+            assert err < 2e-5, (accum, b, err)
+            if dil == 1 and not accum:      # the restatement of the kernel's own products, fp32: same sums up to the MFMA's accumulation order
+                own = W.conv1d_f43_taps(act[b], w) + bias[:, None] + res[b, :, :T]
+                assert np.abs(got[b, :, :T] - own).max() < 3e-5      # (measured 1.3e-5 at C = 256: numpy's and the MFMA's K = 256 sums round differently)
