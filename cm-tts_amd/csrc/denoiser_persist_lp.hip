@@ -105,6 +105,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
     const float* dv_b = a.d + (long)b * a.vec_stride;
     const int mrow0 = w * 32;                         // this wave's 32 rows of x (state tile 0) and of the skip sum (tile 1)
     bool ovf = false;                                 // fp16 modes: a conv input left the fp16 range (note_range)
+    // one word per wave behind the edge scratch: the last layer whose gate output (z^T channels 32 w ..) this wave has written — what the output
+    // projection waits for, k-block by k-block, instead of barrier (3) (denoiser_persist.hip, round 5: same protocol, same argument)
+    int* zflag = reinterpret_cast<int*>(lds16 + (MODE == 3 ? 2 : 1) * IMG) + NW * 64;
+    if (tid < NW) zflag[tid] = 0;
 
     // ---- layer-0 staging (as resblock_fused_lp.hip): u^T[j][m] = cvt(cp + (x + dp)); lane = frame, waves over channel pairs
     {
@@ -288,19 +292,39 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_lp_kernel(const P
                     }
         }
         LPSTAMP(3);
-        __syncthreads();   // (3) z^T complete, u^T of this layer dead
+        // (3) per-wave flags instead of a barrier: the projection's K loop (ordered by source wave: two 16-channel k-groups per wave) acquires
+        // the flag of the block it is about to read; a wave writes the next u^T only after it has consumed all eight blocks
+        if (lane == 0) __hip_atomic_store(zflag + w, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned zready = 0;
+        auto need_z = [&](int v) {
+            if (v >= NW || ((zready >> v) & 1u)) return;
+            unsigned spins = 0;
+            for (;;) {
+                const int f = __hip_atomic_load(zflag + (lane & (NW - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                zready = (unsigned)__ballot(f > l) & ((1u << NW) - 1u);
+                if ((zready >> v) & 1u) break;
+                if (++spins > SPIN_LIMIT) {      // cannot happen; bounded like every wait of this kernel
+                    if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                    zready = (1u << NW) - 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
         LPSTAMP(4);
 
         // =========================================================== phase C: output projection, 16 k-groups
         {
             zero_acc();
             u32x4 Bv[2][NS][NT];
+            need_z(0);
             load_b(Bv[0], zt, 0, 0);
 #pragma unroll 1
             for (int it = 0; it < NGC; it += RINGM) {
 #pragma unroll
                 for (int s = 0; s < RINGM; ++s) {
                     load_ao(A[(s + RINGM - 1) % RINGM], a.Wof[l], min(it + s + RINGM - 1, NGC - 1));
+                    if (((it + s + 1) & 1) == 0) need_z((it + s + 1) >> 1);      // k-group it + s + 1 opens the next wave's channels
                     load_b(Bv[(s + 1) & 1], zt, min(it + s + 1, NGC - 1), 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NGC) mma_group(A[s], Bv[s & 1]);
@@ -433,7 +457,7 @@ int launch_mode(const PersistArgs& a, int tiles, int max_blocks, hipStream_t str
     static bool attr_set = false;
     // the fp32 tail overlays two [256][68] float buffers on the 16-bit u^T / z^T images
     // (+ 64 floats per wave behind the images: the edge-column scratch of the granule store)
-    const size_t lds16b = (size_t)(MODE == 3 ? 2 : 1) * (2 * FN + 2) * RS * sizeof(unsigned short) + NW * 64 * sizeof(float), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
+    const size_t lds16b = (size_t)(MODE == 3 ? 2 : 1) * (2 * FN + 2) * RS * sizeof(unsigned short) + NW * 64 * sizeof(float) + NW * sizeof(int), ldstail = (size_t)2 * C * persist_tail::PT_LD * sizeof(float);
     const size_t lds = a.tail && ldstail > lds16b ? ldstail : lds16b;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(denoiser_persist_lp_kernel<MODE>),
