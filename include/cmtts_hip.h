@@ -281,9 +281,10 @@ int cmtts_set_option(const char* name, int value);
  *       (tests/test_gpu_precision.py; F(4,3) loses a decimal digit on conv inputs of ~6e4); with 1 or 2 an utterance's low-order bits depend on
  *       whether its batch takes the persistent stack.
  *   cmtts_vocoder_set_option(v, "winograd", 1 (default) | 0): fp32 generator, launches of >= 1024 column tiles (large batches): the k = 3 / 7 / 11
- *       ResBlock convs of the C = 256 and C = 128 stages and the k = 7 / 11 ResBlock convs of the C = 64 stage (hifigan/models.py:96-103) as Winograd convolutions over pairs of outputs one dilation
- *       apart — groups of three taps as F(2,3), a remainder of two taps as F(2,2): 4 / 10 / 15 fp32 products per pair instead of 6 / 14 / 22 — or (0)
- *       in the direct form, which small batches always take.  fp32 rounding differences only: <= 1.2e-6 on the waveform, both forms
+ *       ResBlock convs of the C = 256 and C = 128 stages and the k = 7 / 11 ResBlock convs of the C = 64 stage (hifigan/models.py:96-103) as Winograd convolutions — since round 5
+ *       over QUADS of outputs one dilation apart, groups of three taps as F(4,3): 6 / 16 / 24 fp32 products per quad instead of 12 / 28 / 44 (csrc/conv_xlq.hip; dilation 1 and 3, dilation 5 at
+ *       C = 256 or k = 3); the remaining dilation-5 convs over PAIRS of outputs, groups of three taps as F(2,3), a remainder of two taps as F(2,2): 4 / 10 / 15 products per pair instead of
+ *       6 / 14 / 22 (round 4) — or (0) in the direct form, which small batches always take.  fp32 rounding differences only: <= 1.4e-6 on the waveform, both forms
  *       1.0e-6 from a float64 evaluation (tests/test_gpu_precision.py); with 1 an utterance's int16 samples may differ by one LSB between a
  *       large and a small batch.
  *   cmtts_vocoder_set_option(v, "ups16", 1 (default) | 0): in the 16-bit precision modes the ConvTranspose1d upsamplers take
