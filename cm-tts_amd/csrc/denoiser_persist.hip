@@ -539,25 +539,48 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     bg[cb][r] = ldg(b3, (unsigned)(64 * w + 32 * cb + 4 * rb + r));
                     bf[cb][r] = ldg(b3, (unsigned)(64 * w + 32 * cb + 16 + 4 * rb + r));
                 }
-            auto out4 = [&](int i, int r, float bias, float (&y)[4]) {
-                const float m0 = acc4[i][0][r], m1 = acc4[i][1][r], m2 = acc4[i][2][r], m3 = acc4[i][3][r], m4 = acc4[i][4][r], m5 = acc4[i][5][r];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            // (on ROW PAIRS: registers r, r + 1 of an accumulator are adjacent, so the output transform's adds and the gate's multiplies / adds run as
+            //  v_pk_*_f32 on two rows at once — the same operations on the same values, half the VALU instructions next to the other waves' MFMAs)
+            auto out4 = [&](int i, int h, f32x2 bias, f32x2 (&y)[4]) {
+                auto P = [&](int p) { return f32x2{acc4[i][p][2 * h], acc4[i][p][2 * h + 1]}; };
+                const f32x2 m0 = P(0), m1 = P(1), m2 = P(2), m3 = P(3), m4 = P(4), m5 = P(5);
+                const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
                 y[0] = ((m0 + s12) + s34) + bias;
-                y[1] = __builtin_fmaf(2.f, d34, d12) + bias;
-                y[2] = __builtin_fmaf(4.f, s34, s12) + bias;
-                y[3] = (__builtin_fmaf(8.f, d34, d12) + m5) + bias;
+                y[1] = __builtin_elementwise_fma(c2, d34, d12) + bias;
+                y[2] = __builtin_elementwise_fma(c4, s34, s12) + bias;
+                y[3] = (__builtin_elementwise_fma(c8, d34, d12) + m5) + bias;
+            };
+            auto gate2 = [&](f32x2 g, f32x2 f) -> f32x2 {      // cmtts_gate (gate.h) on two elements: the same multiplies, v_exp / v_rcp, adds and fma per element
+                const f32x2 nl2e = {-1.44269504088896340736f, -1.44269504088896340736f}, l2e = {1.44269504088896340736f, 1.44269504088896340736f};
+                const f32x2 one = {1.f, 1.f}, m2c = {-2.f, -2.f};
+                const f32x2 ag = g * nl2e;
+                const f32x2 eg = {__builtin_amdgcn_exp2f(ag.x), __builtin_amdgcn_exp2f(ag.y)};
+                const f32x2 dg = one + eg;
+                const f32x2 sg = {__builtin_amdgcn_rcpf(dg.x), __builtin_amdgcn_rcpf(dg.y)};
+                const f32x2 af = (f + f) * l2e;
+                const f32x2 ef = {__builtin_amdgcn_exp2f(af.x), __builtin_amdgcn_exp2f(af.y)};
+                const f32x2 df = one + ef;
+                const f32x2 rf = {__builtin_amdgcn_rcpf(df.x), __builtin_amdgcn_rcpf(df.y)};
+                const f32x2 th = __builtin_elementwise_fma(m2c, rf, one);
+                return sg * th;
             };
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float yg[4], yf[4];
-                    out4(2 * cb, r, bg[cb][r], yg);
-                    out4(2 * cb + 1, r, bf[cb][r], yf);
-                    f32x4 zz;
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 yg[4], yf[4];
+                    out4(2 * cb, h, f32x2{bg[cb][2 * h], bg[cb][2 * h + 1]}, yg);
+                    out4(2 * cb + 1, h, f32x2{bf[cb][2 * h], bf[cb][2 * h + 1]}, yf);
+                    f32x4 z0, z1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) zz[e] = cmtts_gate(yg[e], yf[e]);
-                    *reinterpret_cast<f32x4*>(z_lds + (32 * w + 16 * cb + 4 * rb + r) * U_LD + 4 * q4) = zz;
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 zz = gate2(yg[e], yf[e]);
+                        z0[e] = zz.x; z1[e] = zz.y;
+                    }
+                    float* zr = z_lds + (32 * w + 16 * cb + 4 * rb + 2 * h) * U_LD + 4 * q4;
+                    *reinterpret_cast<f32x4*>(zr) = z0;
+                    *reinterpret_cast<f32x4*>(zr + U_LD) = z1;
                 }
         } else {   // gate: z goes to its own buffer, so a wave gates as soon as ITS k=3 conv is done (VALU under the
             // other waves' MFMAs); nobody reads z before barrier (3)
