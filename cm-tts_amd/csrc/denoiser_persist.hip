@@ -287,13 +287,6 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         float* u_lds = smem;                  // u of the current layer, then assembled in place for the next one
         float* z_lds = smem + C * U_LD;       // gate output
         const bool more = l + 1 < a.NL;
-        auto load_b = [&](float (&dst)[4][NT], const float* src, int krow0, int col) {
-            const float* bs = src + (krow0 + khalf) * U_LD + l31 + col;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) dst[kk][j] = bs[2 * kk * U_LD + j * 32];
-        };
         constexpr int NGB = (C / 8) * 3;         // k-groups of the k=3 conv: (16-channel chunk, tap, 8-half)
         constexpr int NGC = C / 8;               // k-groups of the output projection
         auto kgrp = [&](int it, int& g8, int& tap) {
@@ -495,30 +488,46 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 }
             }
         } else {
-            constexpr int NG = NGB;
-            const float* W3f = a.W3f[l];
+            // Round 5: one ring round = one 16-channel chunk (tap-major, two 8-channel halves: six k-groups = the ring depth), so every offset inside
+            // a round is a compile-time constant — the weights through a buffer descriptor (lane offset constant, group offset scalar), u through
+            // one LDS pointer per round with immediate offsets: no VALU address arithmetic and no clamps next to the MFMAs (the projection loop's
+            // form; same loads of the same values in the same order, same bits)
+            static_assert(RING == 6, "a ring round is one chunk of six k-groups");
+            const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W3f[l]), 0, 3 * (C / 8) * (2 * C / 32) * 1024, 0x00020000);
+            const int wvo3 = (w * MT * 64 + lane) * 16;
+            // stage n of the round that starts at chunk q: chunk q + n / 6, tap (n % 6) >> 1, half n & 1
+            auto load_a3 = [&](f32x4 (&dst)[MT], int q, int n) {
+                const int qq = q + n / 6, ss = n % 6;
+                const int group = (ss >> 1) * (C / 8) + 2 * qq + (ss & 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w3rs, wvo3 + i * 1024, group * ((2 * C / 32) * 1024), 0));
+            };
             float Bv[2][4][NT];
-            int g8, tap;
-            kgrp(0, g8, tap);
-            load_b(Bv[0], u_lds, g8 * 8, tap);
-            auto ring_round = [&](int it, auto first) {
+            const float* ub0 = u_lds + khalf * U_LD + l31;
+            auto load_b3 = [&](float (&dst)[4][NT], const float* ub, int n) {
+                const int ro = (n / 6) * 16 + (n & 1) * 8, col = (n % 6) >> 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) dst[kk][j] = ub[(ro + 2 * kk) * U_LD + col + j * 32];
+            };
+            load_b3(Bv[0], ub0, 0);
+            auto ring_round = [&](int q, auto first) {
+                const float* ub = ub0 + q * 16 * U_LD;
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
-                    kgrp(it + s + RING - 1, g8, tap);
-                    load_a(A[(s + RING - 1) % RING], W3f, tap * (C / 8) + g8);
-                    kgrp(it + s + 1, g8, tap);
-                    load_b(Bv[(s + 1) & 1], u_lds, g8 * 8, tap);
+                    load_a3(A[(s + RING - 1) % RING], q, s + RING - 1);
+                    load_b3(Bv[(s + 1) & 1], ub, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (it + s < NG) {
-                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
-                        else mma_group(later_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
-                    }
+                    if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
+                    else mma_group(later_t{}, A[s], Bv[s & 1], std::integral_constant<int, 0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             ring_round(0, first_t{});
 #pragma unroll 1
-            for (int it = RING; it < NG; it += RING) ring_round(it, later_t{});
+            for (int q = 1; q < C / 16; ++q) ring_round(q, later_t{});
         }
         stamp(l, 2);
         if (!WINO) {
