@@ -2278,3 +2278,46 @@ def test_conv_xlq_kernel_vs_oracle(Cc, k, dil, T, ld):
             if dil == 1 and not accum:      # the restatement of the kernel's own products, fp32: same sums up to the MFMA's accumulation order
                 own = W.conv1d_f43_taps(act[b], w) + bias[:, None] + res[b, :, :T]
                 assert np.abs(got[b, :, :T] - own).max() < 3e-5      # (measured 1.3e-5 at C = 256: numpy's and the MFMA's K = 256 sums round differently)
+
+
+@pytest.mark.parametrize("layers", [1, 2, 3])
+def test_persistent_stack_few_layers(layers):
+    """The persistent stacks with one, two and three residual layers — the first layer is then (also) the last one: no publish phase, only the
+    skip half of the output projection (round 5), the in-kernel tail straight behind it.  Forced onto a small batch: the direct form bit for bit
+    the per-layer kernels (fp32 and bf16), both Winograd forms within WINO_TOL, one evaluation and a T = 2 sample."""
+    import dataclasses
+    host = _host()
+    lib = _lib.load()
+    cfg = dataclasses.replace(get_config("VCTK"), res_layers=layers)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=layers))
+    B, T = 3, 130
+    g = torch.Generator().manual_seed(layers)
+    x = torch.randn(B, 1, T, 80, generator=g).to(DEV); cond = torch.randn(B, T, 256, generator=g).to(DEV); spk = torch.randn(B, 256, generator=g).to(DEV)
+    t = torch.full((B,), 1095.5, device=DEV)
+    noise = torch.randn(3, B, 1, T, 80, generator=g).to(DEV)
+    cond_ct = cond.transpose(1, 2).contiguous()
+    outs, mels = {}, {}
+    prev = lib.cmtts_set_persistent_denoiser(0)
+    prev_w = _lib.internal_set("persist_wino", 0)
+    try:
+        for prec in ("fp32", "bf16"):
+            model.set_precision(prec)
+            lib.cmtts_set_persistent_denoiser(0)
+            outs[("layers", prec)] = model.net(x, t, cond, spk).clone()
+            mels[("layers", prec)] = host.sample_with_cond(model, cond_ct, spk, 2, noise).clone()
+            lib.cmtts_set_persistent_denoiser(2)
+            for wn in ((0, 1, 3) if prec == "fp32" else (0,)):
+                _lib.internal_set("persist_wino", wn)
+                outs[(wn, prec)] = model.net(x, t, cond, spk).clone()
+                mels[(wn, prec)] = host.sample_with_cond(model, cond_ct, spk, 2, noise).clone()
+            _lib.internal_set("persist_wino", 0)
+    finally:
+        model.set_precision("fp32")
+        _lib.internal_set("persist_wino", prev_w)
+        lib.cmtts_set_persistent_denoiser(prev)
+    host.synchronize()
+    for prec in ("fp32", "bf16"):
+        assert torch.equal(outs[(0, prec)], outs[("layers", prec)]) and torch.equal(mels[(0, prec)], mels[("layers", prec)]), prec
+    for wn in (1, 3):
+        d, dm = float((outs[(wn, "fp32")] - outs[(0, "fp32")]).abs().max()), float((mels[(wn, "fp32")] - mels[(0, "fp32")]).abs().max())
+        assert torch.isfinite(outs[(wn, "fp32")]).all() and 0 < d <= WINO_TOL and dm <= WINO_TOL, (wn, d, dm)
