@@ -18,6 +18,7 @@
 #include "conv_epilogue.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -31,7 +32,13 @@ constexpr int RING = 4;
 // NT = MFMA n-tiles (32 columns each) per wave = per workgroup: 3 (96-column tiles: a full chip, one utterance of <= 96 phonemes per
 // tile) or 1 (round 4: 32-column tiles for launches that cannot fill the chip — a single request, a few utterances — where one
 // accumulation chain per wave and three times the workgroups finish sooner than three chains per wave; same chains, same bits)
-template <bool LN, int NT>
+// WQ (round 5): the k = 9 FFN conv of the fused launch as three F(4,3) tap groups over output QUADS (points 0, +-1, +-2, inf: 18 products per quad instead of 36) —
+// denoiser_persist.hip's WINO == 2 products on v_mfma_f32_16x16x4_f32: lane (q = l & 15, k = l >> 4) owns quad q of an n-tile of 16 quads in channel 4 ks + k; a wave's
+// 32 rows = two 16-row m-tiles x six transforms x NTQ n-tiles (96-column tiles: 24 quads in two n-tiles, the last eight quad lanes idle; 32-column tiles: eight quads in
+// one).  wfrag = cmtts_api.hip: to_wino43_xres_fragments ([K/4][M/32][9][64 lanes][4]: element (pt & 1) * 2 + i of vector pt / 2 = transform pt, m-tile i).  Every
+// output element sees the same products in the same order whatever the tile width, so the 96- and 32-column instances agree bit for bit; against the direct form the
+// difference is fp32 rounding (tests/test_gpu_parity.py).  Everything around the K loop — staging, LayerNorm prologue, GELU, the FFN linear's partial product — is unchanged.
+template <bool LN, int NT, bool WQ = false>
 __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
     constexpr int BN = 32 * NT;          // columns per workgroup
     constexpr int X_LD = BN + HALO;      // 104 / 40
@@ -74,8 +81,10 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
         dst = *reinterpret_cast<const f32x4*>(wl + (long)min(it, total - 1) * MTn * 256);
     };
     f32x4 A[RING];
+    if constexpr (!WQ) {
 #pragma unroll
-    for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+        for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
+    }
 
     const int xw = BN + (a.taps - 1) * a.dil;
     float* gs = xs + a.K * X_LD;                   // LayerNorm weight / bias [2][256] behind the tile
@@ -200,46 +209,127 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
     }
     stamp(2);
 
+    constexpr int NTQ = NT == 3 ? 2 : 1;
+    f32x4 Mq[WQ ? 2 : 1][WQ ? NTQ : 1][6];
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // scalar walk over (chunk, tap, half): boff = float offset of the group's first row / tap column in the X tile
     const float* bl = xs + khalf * X_LD + l31;
-    int boff = 0, tap = 0, half = 0;
-    const int boff_max = (a.K - 8) * X_LD + (a.taps - 1) * a.dil;
-    auto advance = [&]() {
-        if (half == 0) { half = 1; boff += 8 * X_LD; }
-        else {
-            half = 0; boff -= 8 * X_LD; ++tap; boff += a.dil;
-            if (tap == a.taps) { tap = 0; boff += 16 * X_LD - a.taps * a.dil; }
-        }
-    };
-    float Bv[2][4][NT];
+    if constexpr (WQ) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Bv[0][kk][j] = bl[2 * kk * X_LD + j * 32];
-    // loads are threaded between the MFMAs (one k-step's three ds_reads + the A load of a later group per k-step): a wave
-    // issues in order, so loads bunched between two groups of MFMAs leave the matrix pipe idle while they issue
+            for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) Mq[i][nt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int R = 3, U = 2;      // ring of three entries (tap groups); two k-steps = six entries per unrolled round (ring slots and input buffers compile-time)
+        const int NKS = a.K / 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, NKS * MTn * 9 * 1024, 0x00020000);
+        const int voff = lane * 16;
+        const int mtu = __builtin_amdgcn_readfirstlane(mtc);
+        f32x4 Aq[R][3];
+        auto load_aq = [&](f32x4 (&dst)[3], int ks0, int n) {      // entry n of the round starting at k-step ks0: k-step ks0 + n / 3, tap group n % 3 (past the end: out of range, zeros)
+            const int soff = (((ks0 + n / 3) * MTn + mtu) * 9 + 3 * (n % 3)) * 1024;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + j * 1024, soff, 0));
+        };
+        // raw inputs: quad Q = q + 16 nt reads columns 4 Q + 3 g .. + 5 of row 4 ks + (lane >> 4) (column c of the tile <-> t = n0 - pad + c, pad = 4)
+        const float* xl = xs + (lane >> 4) * X_LD + 4 * (lane & 15);
+        float D[2][NTQ][6];
+        auto load_dq = [&](float (&d)[NTQ][6], int ks0, int n) {
+            const int g = n % 3;
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) {
+                const float* r = xl + (ks0 + n / 3) * (4 * X_LD) + nt * 64;
+                if (g == 0) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(r);
+                    const f32x2 q = *reinterpret_cast<const f32x2*>(r + 4);
+                    d[nt][0] = p[0]; d[nt][1] = p[1]; d[nt][2] = p[2]; d[nt][3] = p[3]; d[nt][4] = q.x; d[nt][5] = q.y;
+                } else if (g == 1) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(r + 4);
+                    d[nt][0] = r[3]; d[nt][1] = p[0]; d[nt][2] = p[1]; d[nt][3] = p[2]; d[nt][4] = p[3]; d[nt][5] = r[8];
+                } else {
+                    const f32x2 q = *reinterpret_cast<const f32x2*>(r + 6);
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(r + 8);
+                    d[nt][0] = q.x; d[nt][1] = q.y; d[nt][2] = p[0]; d[nt][3] = p[1]; d[nt][4] = p[2]; d[nt][5] = p[3];
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) load_aq(Aq[s], 0, s);
+        load_dq(D[0], 0, 0);
 #pragma unroll 1
-    for (int it = 0; it < total; it += RING) {
+        for (int ks0 = 0; ks0 < NKS; ks0 += U) {
 #pragma unroll
-        for (int s = 0; s < RING; ++s) {
-            advance();
-            const float* bs = bl + min(boff, boff_max);
-            load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+            for (int n = 0; n < U * 3; ++n) {
+                const int slot = n % R;
+                float V[NTQ][6];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+                for (int nt = 0; nt < NTQ; ++nt) {
+                    const float (&d)[6] = D[n & 1][nt];
+                    const f32x2 P01 = {d[0], d[1]}, P23 = {d[2], d[3]}, P45 = {d[4], d[5]};
+                    const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, c2 = {2.f, -2.f};
+                    const f32x2 V05 = __builtin_elementwise_fma(c4, P01, __builtin_elementwise_fma(cm5, P23, P45));
+                    const float u0 = __builtin_fmaf(-4.f, d[2], d[4]), u1 = __builtin_fmaf(-4.f, d[1], d[3]);
+                    const float u2 = d[4] - d[2], u3 = d[3] - d[1];
+                    const f32x2 a0 = {u0, u0}, a1 = {u1, -u1}, b0 = {u2, u2}, b1 = {u3, u3};
+                    const f32x2 V12 = a0 + a1;
+                    const f32x2 V34 = __builtin_elementwise_fma(c2, b1, b0);
+                    V[nt][0] = V05.x; V[nt][1] = V12.x; V[nt][2] = V12.y; V[nt][3] = V34.x; V[nt][4] = V34.y; V[nt][5] = V05.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_aq(Aq[(slot + R - 1) % R], ks0, n + R - 1);
+                load_dq(D[(n + 1) & 1], ks0, n + 1);
+                if (ks0 + n / 3 < NKS) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * X_LD + j * 32];
+                    for (int p = 0; p < 6; ++p)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-                if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int nt = 0; nt < NTQ; ++nt)
+                                Mq[i][nt][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aq[slot][p >> 1][(p & 1) * 2 + i], V[nt][p], Mq[i][nt][p], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // scalar walk over (chunk, tap, half): boff = float offset of the group's first row / tap column in the X tile
+        int boff = 0, tap = 0, half = 0;
+        const int boff_max = (a.K - 8) * X_LD + (a.taps - 1) * a.dil;
+        auto advance = [&]() {
+            if (half == 0) { half = 1; boff += 8 * X_LD; }
+            else {
+                half = 0; boff -= 8 * X_LD; ++tap; boff += a.dil;
+                if (tap == a.taps) { tap = 0; boff += 16 * X_LD - a.taps * a.dil; }
+            }
+        };
+        float Bv[2][4][NT];
+    #pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) Bv[0][kk][j] = bl[2 * kk * X_LD + j * 32];
+        // loads are threaded between the MFMAs (one k-step's three ds_reads + the A load of a later group per k-step): a wave
+        // issues in order, so loads bunched between two groups of MFMAs leave the matrix pipe idle while they issue
+    #pragma unroll 1
+        for (int it = 0; it < total; it += RING) {
+    #pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                advance();
+                const float* bs = bl + min(boff, boff_max);
+                load_a(A[(s + RING - 1) % RING], it + s + RING - 1);
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+    #pragma unroll
+                    for (int j = 0; j < NT; ++j) Bv[(s + 1) & 1][kk][j] = bs[2 * kk * X_LD + j * 32];
+    #pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][kk], Bv[s & 1][kk][j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                    if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                }
             }
         }
     }
@@ -261,6 +351,37 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) bi[r] = o.bias ? o.bias[(unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf)] : 0.f;
         __syncthreads();                                 // every wave is done with the X tile
+        if constexpr (WQ) {
+            // output transform (y0 = m0 + (m1 + m2) + (m3 + m4), y1 = (m1 - m2) + 2 (m3 - m4), y2 = (m1 + m2) + 4 (m3 + m4), y3 = (m1 - m2) + 8 (m3 - m4) + m5), then the
+            // direct form's epilogue per element; the lane's quad of a row as one 16-byte LDS store
+            const int q4 = lane & 15, rq = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowl = w * 32 + 16 * i + 4 * rq + r;
+                    const float bq = o.bias ? o.bias[(unsigned)(mt * 32 + 16 * i + 4 * rq + r)] : 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NTQ; ++nt) {
+                        const float m0 = Mq[i][nt][0][r], m1 = Mq[i][nt][1][r], m2 = Mq[i][nt][2][r], m3 = Mq[i][nt][3][r], m4 = Mq[i][nt][4][r], m5 = Mq[i][nt][5][r];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        f32x4 y;
+                        y[0] = (m0 + s12) + s34;
+                        y[1] = __builtin_fmaf(2.f, d34, d12);
+                        y[2] = __builtin_fmaf(4.f, s34, s12);
+                        y[3] = __builtin_fmaf(8.f, d34, d12) + m5;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = y[c];
+                            if (o.bias) v += bq;
+                            v *= o.alpha;
+                            y[c] = act_apply(v, ACT_GELU_ERF);
+                        }
+                        const int col = 4 * (q4 + 16 * nt);
+                        if (col < BN) *reinterpret_cast<f32x4*>(xs + rowl * X_LD + col) = y;
+                    }
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -271,6 +392,7 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
                 v = act_apply(v, ACT_GELU_ERF);
                 xs[(w * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * X_LD + j * 32 + l31] = v;
             }
+        }
         __syncthreads();
         f32x16 acc2[2][NT];
 #pragma unroll
@@ -376,6 +498,54 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
     } else {
         if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
         else hipLaunchKernelGGL((conv_xres_kernel<false, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// The fused FFN launch (a.w2frag set: k = 9 conv + GELU + the FFN linear's K-segment partial product) with the conv as three F(4,3) tap groups (template parameter WQ);
+// wfrag = to_wino43_xres_fragments of the same weights.  Returns 0, -2 (not that launch: use cmtts_launch_conv_xres) or -3.
+extern "C" int cmtts_launch_conv_xresq(const ConvArgs* ap, const float* wfrag, int nbatch, void* stream_) {
+    const ConvArgs& a = *ap;
+    if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
+    if (!wfrag || a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || a.K % 32 != 0 || a.K > KMAX || (a.taps - 1) * a.dil > HALO ||
+        a.pre_div != 1.0f || a.pre_slope != 1.0f)
+        return -2;
+    if (a.ln_g && (!a.ln_b || a.K != 256)) return -2;
+    if (!a.w2frag || a.taps != 9 || a.dil != 1 || a.pad != 4 || a.K != 256) return -2;      // the fused FFN launch of an FFT block only
+    if (a.w2frag) {      // FFN fusion: 128-row m-blocks = K segments of a 256-row linear, plain GELU epilogue, an LDS tile of at least 128 rows
+        const ConvOut& o = a.out[0];
+        if (!a.part || a.M2 != 256 || a.M % 128 != 0 || a.K < 128 || o.ostride != 1 || o.ooff_base || o.ooff_mul || o.row_off || o.div != 1.0f || o.accum || o.bvec || o.act != ACT_GELU_ERF || o.res || o.lens) return -2;
+    }
+    // column tiles: 96 (three n-tiles per wave) when that already gives every CU a workgroup, else 32 (one n-tile per wave: three times the
+    // workgroups, a third of the MFMAs per accumulation chain's wave); a.xres_nt forces one (tests, tools)
+    const int mblocks = ((a.M + 31) / 32 + 3) / 4;
+    const long wg96 = (long)((a.N + 95) / 96) * mblocks * nbatch;
+    const int nt = a.xres_nt == 1 || a.xres_nt == 3 ? a.xres_nt : (g_xres_nt == 1 || g_xres_nt == 3 ? g_xres_nt : (wg96 >= 128 ? 3 : 1));
+    const int bn = 32 * nt, x_ld = bn + HALO;
+    static bool attr_set = false;
+    const size_t lds = (size_t)a.K * x_ld * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
+    if (!attr_set) {
+        const int mx = (int)((size_t)KMAX * (96 + HALO) * sizeof(float) + 2 * 256 * sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+            return -3;
+        attr_set = true;
+    }
+    dim3 grid((a.N + bn - 1) / bn, mblocks, nbatch);
+    long long* dbg = g_xres_dbg;
+    if (dbg) {    // CMTTS_XRES_DBG_M=<rows>: stamps of the launches with that many output rows only (tools/xres_phases.py)
+        static const char* want = getenv("CMTTS_XRES_DBG_M");
+        if (want && atoi(want) != a.M) dbg = nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    if (nt == 3) {
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 3, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 3, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
+    } else {
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 1, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

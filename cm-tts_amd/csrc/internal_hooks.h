@@ -16,7 +16,7 @@ extern "C" {
 #endif
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
-// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16, persist_wino, voc_wino, voc_wino43, voc_wino64, voc_wino64_k (cmtts_api.hip: cmtts_internal_set).
+// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16, persist_wino, ffn_wino (round 5: the FFT blocks' k = 9 FFN conv as F(4,3) tap groups in the fused launch, fp32; 4e-6 on the encoder output against the direct form), voc_wino, voc_wino43, voc_wino64, voc_wino64_k (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 // Test hook: the stacked conditioner projections alone, with the model's current precision mode.  cond_ct [B][hidden][T] -> cp [B][NL * C][T]
 // (device pointers).  Returns a cmtts_status.

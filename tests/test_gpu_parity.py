@@ -1235,6 +1235,7 @@ def test_xres_conv_bitwise(models):
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     prev = _lib.internal_set(b"ffn_xres", 1)
     prev_t = _lib.internal_set(b"text_xres", 0)
+    prev_w = _lib.internal_set(b"ffn_wino", 0)        # the direct form of the FFN conv: what these switches keep bit for bit (the F(4,3) default: test_ffn_winograd)
     try:
         run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
         one = run()                                   # X-resident k=9 conv, separate LayerNorm launches
@@ -1247,6 +1248,7 @@ def test_xres_conv_bitwise(models):
     finally:
         _lib.internal_set(b"ffn_xres", prev)
         _lib.internal_set(b"text_xres", prev_t)
+        _lib.internal_set(b"ffn_wino", prev_w)
     torch.cuda.synchronize()
     for k in ("enc_out", "log_d_predictions", "cond"):
         for name, got in [("xres", one)] + outs:
@@ -1374,6 +1376,7 @@ def test_ffn_fused_bitwise(models):
     texts[np.arange(L)[None, :] >= lens[:, None]] = 0
     prev = _lib.internal_set(b"ffn_fused", 1)
     prev_t = _lib.internal_set(b"text_xres", 5)
+    prev_w = _lib.internal_set(b"ffn_wino", 0)        # the direct form (see test_xres_conv_bitwise)
     try:
         run = lambda: model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), max_mel_len=512)
         outs = [("fused", run())]
@@ -1385,11 +1388,45 @@ def test_ffn_fused_bitwise(models):
     finally:
         _lib.internal_set(b"ffn_fused", prev)
         _lib.internal_set(b"text_xres", prev_t)
+        _lib.internal_set(b"ffn_wino", prev_w)
     torch.cuda.synchronize()
     for k in ("enc_out", "log_d_predictions", "cond"):
         for name, got in outs:
             assert torch.equal(got[k], ref[k]), (name, k, float((got[k] - ref[k]).abs().max()))
     assert torch.equal(one["enc_out"][0], outs[0][1]["enc_out"][0])
+
+
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 16, 100), ("LJSpeech", 5, 128), ("LibriTTS", 3, 300)])
+def test_ffn_winograd(variant, B, L):
+    """Round 5: the FFT blocks' k = 9 FFN conv as three F(4,3) tap groups inside the fused launch (conv_xres.hip, WQ instances; the default for fp32 models) against
+    the direct form: encoder output by fp32 rounding only, durations and mel lengths equal.  And the property the direct form had by construction: ONE form at every
+    shape — the 96-column tiles of a chip-filling batch, the 32-column tiles of a single request, lengths at which the direct form takes the generic kernel — so an
+    utterance's encoder output does not depend on the batch it is in (bit for bit)."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=9, dur_frames=4.0, dur_spread=0.0))
+    rs = np.random.RandomState(B * 7 + L)
+    lens = rs.randint(max(L // 2, 1), L + 1, size=B).astype(np.int64)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal((B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    tx, ln = torch.from_numpy(texts), torch.from_numpy(lens)
+    run = lambda nb: model.duration_pitch_energy_net(None, tx[:nb], ln[:nb], spker_embeds=None if spk is None else spk[:nb])
+    prev = _lib.internal_set(b"ffn_wino", 1)
+    try:
+        got, one = run(B), run(1)
+        _lib.internal_set(b"ffn_wino", 0)
+        ref = run(B)
+    finally:
+        _lib.internal_set(b"ffn_wino", prev)
+    torch.cuda.synchronize()
+    d = float((got["enc_out"] - ref["enc_out"]).abs().max())
+    report(f"FFN_WINOGRAD {variant} B={B} L={L}: max|d enc_out| vs the direct form {d:.2e} (scale {float(ref['enc_out'].abs().max()):.2f}); "
+           f"log-durations {float((got['log_d_predictions'] - ref['log_d_predictions']).abs().max()):.2e}")
+    assert torch.isfinite(got["enc_out"]).all() and 0 < d <= 2e-5
+    assert torch.equal(got["mel_lens"], ref["mel_lens"]) and torch.equal(got["mel2ph"], ref["mel2ph"])
+    assert torch.equal(one["enc_out"][0], got["enc_out"][0]) and torch.equal(one["log_d_predictions"][0], got["log_d_predictions"][0])
 
 
 @pytest.mark.parametrize("variant,B,T", [("LJSpeech", 3, 200), ("VCTK", 2, 77), ("LJSpeech", 32, 512)])
