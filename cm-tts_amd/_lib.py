@@ -7,6 +7,7 @@ fails loudly.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMTTS_LIB") or os.path.join(_HERE, "libcmtts_hip.so")     # CMTTS_LIB: an experimental build of the same ABI (tools/)
@@ -95,7 +96,7 @@ SIGNATURES = {
     "cmtts_conv1d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
-ABI_VERSION = 4          # include/cmtts_hip.h: CMTTS_ABI_VERSION
+ABI_VERSION = 5          # include/cmtts_hip.h: CMTTS_ABI_VERSION
 _lib = None
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cmtts_hip.h")
 
@@ -205,10 +206,25 @@ def load():
         raise RuntimeError(f"{LIB_PATH} implements ABI revision {got}, this binding was written for {ABI_VERSION} "
                            "(include/cmtts_hip.h: CMTTS_ABI_VERSION): rebuild the library")
     _lib = lib
-    # measurement hook (tools/, A/B runs of bench.py): CMTTS_INTERNAL="persist_wino=1,voc_wino=0" flips csrc/internal_hooks.h switches at load
-    for kv in filter(None, os.environ.get("CMTTS_INTERNAL", "").split(",")):
-        k, v = kv.split("=")
-        internal_set(k.strip(), int(v))
+    # measurement hook (tools/, A/B runs of bench.py): CMTTS_INTERNAL="persist_wino=1,voc_wino=0" flips csrc/internal_hooks.h switches at load.
+    # These switches change numerics, so a stray variable must not reach a production process: it is honoured only together with
+    # CMTTS_INTERNAL_ENABLE=1, every entry is validated, an unknown name is an error, and what was applied is logged.
+    spec = os.environ.get("CMTTS_INTERNAL", "")
+    if spec:
+        if os.environ.get("CMTTS_INTERNAL_ENABLE") != "1":
+            print(f"cmtts_amd: ignoring CMTTS_INTERNAL={spec!r} (measurement hook: set CMTTS_INTERNAL_ENABLE=1 to apply it)", file=sys.stderr)
+        else:
+            for kv in filter(None, (e.strip() for e in spec.split(","))):
+                k, sep, v = kv.partition("=")
+                try:
+                    val = int(v)
+                except ValueError:
+                    val = None
+                if not sep or not k.strip() or val is None:
+                    raise RuntimeError(f"CMTTS_INTERNAL: malformed entry {kv!r} (expected name=integer[,name=integer...])")
+                if internal_set(k.strip(), val) < 0:
+                    raise RuntimeError(f"CMTTS_INTERNAL: unknown switch {k.strip()!r} (csrc/internal_hooks.h)")
+                print(f"cmtts_amd: CMTTS_INTERNAL applied {k.strip()}={val}", file=sys.stderr)
     return lib
 
 

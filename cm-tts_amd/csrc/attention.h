@@ -16,6 +16,7 @@ extern "C" {
 #endif
 // 0 = launched, -2 = shape not covered (L > 192, dh != 128), -3 = HIP error
 int cmtts_launch_attention(const AttnArgs* a, void* stream);
+int cmtts_attention_set_qb(int on);         // internal switch "attn_qb": 1 (default) = L <= 128 with the queries split over workgroups (attention_qb_kernel; same bits); returns the previous value
 #ifdef __cplusplus
 }
 #endif

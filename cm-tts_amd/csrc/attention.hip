@@ -181,6 +181,148 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same attention with the QUERIES split over workgroups too (L <= 128).  attention_kernel above runs one (utterance, head)
+// per workgroup: 64 workgroups at B = 32 — a quarter of the chip — each wave walking all key tiles twice behind four staging round
+// trips (27 us per FFT block for 10 us of MFMAs per wave).  Here a workgroup is one (utterance, head, block of 32 queries), four waves:
+//   * K_h and V_h are staged WHOLE (<= 128 keys: one round trip for K, V requested behind it and written while the scores form);
+//   * wave j forms the score tile of keys 32 j .. 32 j + 31 (one 64-step chain instead of NMT), the column maxima meet in LDS;
+//   * the un-normalised probabilities of all tiles go through LDS in the accumulator layout, every wave adds them up in
+//     attention_kernel's order (tile by tile, register by register, then the other lane half) and divides — so all four hold the
+//     same P, bit for bit what attention_kernel holds;
+//   * wave w forms output channels 32 w .. 32 w + 31 over all keys (one 16 NMT-step chain instead of four).
+// Every chain has attention_kernel's operands in attention_kernel's order: BITWISE equal to it (tests/test_gpu_parity.py::
+// test_attention_qb_bitwise); 3 x the workgroups, a third of the serial MFMA work per wave, two staging round trips instead of four.
+template <int NMT>               // 32-key tiles (= query blocks of the launch): L in (32 (NMT-1), 32 NMT], NMT <= 4
+__global__ __launch_bounds__(256) void attention_qb_kernel(const AttnArgs a) {
+    constexpr int NK = 32 * NMT;         // staged keys
+    constexpr int VL = NK + 1;           // row stride of the V tile [DH][VL]: lanes walk down the channels
+    extern __shared__ __attribute__((aligned(16))) float qsm[];
+    float* Ks = qsm;                     // [DH][NK]
+    float* Vs = Ks + DH * NK;            // [DH][VL]
+    float* Es = Vs + ((DH * VL + 3) & ~3);      // [NMT][16][64]: exp(s - max) in the accumulator layout of the wave that formed it
+    float* Mx = Es + NMT * 16 * 64;      // [4][32] column maxima per wave
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int z = blockIdx.x, b = z / a.H, h = z - b * a.H, qb = blockIdx.y;
+    const int L = a.L, ld = a.ld;
+    const int len = min((int)a.lens[b], L);
+    const float* qp = a.qkv + (long)b * a.bstride + (long)(h * DH) * ld;
+    const float* kp = a.qkv + (long)b * a.bstride + (long)(a.H * DH + h * DH) * ld;
+    const float* vp = a.qkv + (long)b * a.bstride + (long)(2 * a.H * DH + h * DH) * ld;
+
+    constexpr int NV = DH * (NK / 4);
+    constexpr int PER = NV / 256;        // 8 NMT float4 per thread
+    f32x4 kv[PER], vv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = tid + u * 256;
+        const int d = idx / (NK / 4), c4 = idx - d * (NK / 4);
+        kv[u] = *reinterpret_cast<const f32x4*>(kp + (long)d * ld + min(4 * c4, ld - 4));
+    }
+    // this block's queries as B operands (wave j < NMT multiplies them with key tile j): lane (i = l31, khalf) holds Q[2 kk + khalf][32 qb + i]
+    float Qr[DH / 2];
+    {
+        const int i_c = min(32 * qb + l31, L - 1);
+#pragma unroll
+        for (int kk = 0; kk < DH / 2; ++kk) Qr[kk] = qp[(long)(2 * kk + khalf) * ld + i_c];
+    }
+    auto put = [&](const f32x4 (&v)[PER], float* dst, int dst_ld) {      // keys beyond L zero-filled (a float4 that starts beyond ld - 4 lies wholly beyond L)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + u * 256;
+            const int d = idx / (NK / 4), c4 = idx - d * (NK / 4);
+            const int j = 4 * c4;
+            const bool in = j <= ld - 4;
+            float* p = dst + d * dst_ld + j;
+            p[0] = in && j + 0 < L ? v[u][0] : 0.f;
+            p[1] = in && j + 1 < L ? v[u][1] : 0.f;
+            p[2] = in && j + 2 < L ? v[u][2] : 0.f;
+            p[3] = in && j + 3 < L ? v[u][3] : 0.f;
+        }
+    };
+    put(kv, Ks, NK);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = tid + u * 256;
+        const int d = idx / (NK / 4), c4 = idx - d * (NK / 4);
+        vv[u] = *reinterpret_cast<const f32x4*>(vp + (long)d * ld + min(4 * c4, ld - 4));
+    }
+    __syncthreads();
+
+    // ---- S^T tile w: keys 32 w .. 32 w + 31 against the block's 32 queries
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    if (w < NMT) {
+        const float* ks = Ks + khalf * NK + w * 32 + l31;
+        float av = ks[0];
+#pragma unroll
+        for (int kk = 0; kk < DH / 2; ++kk) {
+            const float nav = kk + 1 < DH / 2 ? ks[(kk + 1) * 2 * NK] : 0.f;
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Qr[kk], S, 0, 0, 0);
+            av = nav;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * w + acc_row(r, lane);
+            const float v = S[r] * a.scale;
+            S[r] = v;
+            if (key < len) mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (khalf == 0) Mx[w * 32 + l31] = mx;
+    }
+    put(vv, Vs, VL);
+    __syncthreads();
+    if (w < NMT) {
+        float mx = Mx[l31];
+#pragma unroll
+        for (int j = 1; j < NMT; ++j) mx = fmaxf(mx, Mx[j * 32 + l31]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * w + acc_row(r, lane);
+            Es[(w * 16 + r) * 64 + lane] = key < len ? expf(S[r] - mx) : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- every wave: the probabilities of all key tiles, summed in attention_kernel's order
+    float P[NMT][16];
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                P[m][r] = Es[(m * 16 + r) * 64 + lane];
+                sum += P[m][r];
+            }
+        sum += __shfl_xor(sum, 32);
+        const float den = sum > 0.f ? sum : 1.f;     // len == 0: all probabilities 0
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[m][r] = P[m][r] / den;
+    }
+    // ---- O rows 32 w .. 32 w + 31 = sum_key V[d][key] P[key][query]
+    f32x16 O;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = 0.f;
+    const float* vs = Vs + (w * 32 + l31) * VL + 4 * khalf;
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            O = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[m * 32 + (r & 3) + 8 * (r >> 2)], P[m][r], O, 0, 0, 0);
+    float* ob = a.out + (long)b * a.obstride + (long)(h * DH) * ld;
+    const int i = 32 * qb + l31;
+    if (i < L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[(long)(w * 32 + acc_row(r, lane)) * ld + i] = O[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Long sequences (L > 192: the FastspeechDecoder over the frame axis, texts up to max_seq_len = 1000 — config/LJSpeech/model.yaml:55;
 // round 3, VERDICT r02 missing #5): the same attention with the keys walked in 64-key chunks and an ONLINE softmax, so that neither
 // the scores nor the probabilities of a query ever exist in full.  Workgroup = (utterance, head, block of NWQ x 32 queries): the grid
@@ -319,7 +461,11 @@ __global__ __launch_bounds__(64 * NWQ) void attention_long_kernel(const AttnArgs
     }
 }
 
+int g_attn_qb = 1;          // internal switch "attn_qb": L <= 128 on attention_qb_kernel (1) or attention_kernel (0); same bits
+
 }  // namespace
+
+extern "C" int cmtts_attention_set_qb(int on) { const int p = g_attn_qb; if (on == 0 || on == 1) g_attn_qb = on; return p; }
 
 // 0 = launched, -2 = shape not covered (head_dim != 128, unaligned rows: the caller runs the three-launch path), -3 = HIP error
 extern "C" int cmtts_launch_attention(const AttnArgs* ap, void* stream_) {
@@ -342,6 +488,27 @@ extern "C" int cmtts_launch_attention(const AttnArgs* ap, void* stream_) {
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
     const int nmt = (a.L + 31) / 32;
+    if (g_attn_qb && nmt <= 4) {      // queries split over workgroups too (round 6; bitwise attention_kernel)
+        const size_t lds = (size_t)(DH * 32 * nmt + ((DH * (32 * nmt + 1) + 3) & ~3) + nmt * 16 * 64 + 4 * 32) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            const int mx = (int)((size_t)(DH * 128 + ((DH * 129 + 3) & ~3) + 4 * 16 * 64 + 4 * 32) * sizeof(float));
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qb_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention_qb_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+                return -3;
+            attr_set = true;
+        }
+        dim3 gq(a.B * a.H, nmt);       // the query blocks of one (utterance, head) are B H workgroup ids apart: the same XCD (its L2 holds their K / V) whenever B H % 8 == 0
+        switch (nmt) {
+            case 1: hipLaunchKernelGGL(attention_qb_kernel<1>, gq, dim3(256), lds, s, a); break;
+            case 2: hipLaunchKernelGGL(attention_qb_kernel<2>, gq, dim3(256), lds, s, a); break;
+            case 3: hipLaunchKernelGGL(attention_qb_kernel<3>, gq, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL(attention_qb_kernel<4>, gq, dim3(256), lds, s, a); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     dim3 grid(a.B * a.H);
     switch (nmt) {
         case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, s, a); break;

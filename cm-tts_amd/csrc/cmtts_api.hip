@@ -171,26 +171,6 @@ std::vector<float> to_wino_fragments(const std::vector<float>& p, int K, int M) 
     return f;
 }
 
-// The same transformed weights for the one-wave-per-SIMD stack (denoiser_persist4.hip): every wave reads ONE contiguous stream per layer,
-// [4 waves][2 passes][K/2 k-steps][2 m-tiles][64 lanes][4]: element tr of the fragment of (wave w, pass ps, k-step ks, i) at lane l is
-// transform tr of input channel 2 ks + (l >> 5), output row 32 ((2 w + ps) 2 + i) + (l & 31).  M = 512 only (16 m-tiles).
-constexpr int WINO4_PAD_STAGES = 8;   // ring stages of zero padding behind a layer's array (the last wave's ring runs past its stream's end)
-std::vector<float> to_wino4_fragments(const std::vector<float>& p, int K, int M) {
-    std::vector<float> f((size_t)4 * K * M + (size_t)WINO4_PAD_STAGES * 2 * 64 * 4, 0.0f);
-    const int NKS = K / 2;
-    for (int w = 0; w < 4; ++w)
-        for (int ps = 0; ps < 2; ++ps)
-            for (int ks = 0; ks < NKS; ++ks)
-                for (int i = 0; i < 2; ++i)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int mt = (2 * w + ps) * 2 + i, k = 2 * ks + (lane >> 5), mrow = 32 * mt + (lane & 31);
-                        const double g0 = p[((size_t)0 * K + k) * M + mrow], g1 = p[((size_t)1 * K + k) * M + mrow], g2 = p[((size_t)2 * K + k) * M + mrow];
-                        float* o = &f[((((((size_t)w * 2 + ps) * NKS + ks) * 2 + i) * 64) + lane) * 4];
-                        o[0] = (float)g0; o[1] = (float)(0.5 * (g0 + g1 + g2)); o[2] = (float)(0.5 * (g0 - g1 + g2)); o[3] = (float)g2;
-                    }
-    return f;
-}
-
 // Winograd F(4,3) form of the same conv for the persistent denoiser's WINO == 2 instances (points 0, +-1, +-2, inf): transformed weights
 // U0 = g0 / 4, U1 = -(g0 + g1 + g2) / 6, U2 = -(g0 - g1 + g2) / 6, U3 = g0 / 24 + g1 / 12 + g2 / 6, U4 = g0 / 24 - g1 / 12 + g2 / 6, U5 = g2
 // (formed in double, rounded once) as A fragments of v_mfma_f32_16x16x4_f32 in the kernel's iteration order
@@ -484,8 +464,8 @@ int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partia
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
 int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a Winograd form (NOT bitwise the direct form): 3 = F(4,3), the 8-wave WINO == 2 instances
-                                // of denoiser_persist.hip (default since round 5: half of the conv's MFMAs), 1 = F(2,3), the 8-wave WINO == 1 instances (2/3), 2 = the
-                                // one-wave-per-SIMD F(2,3) stack of denoiser_persist4.hip (same bits as 1; measured 4-10 % slower), 0 = direct
+                                // of denoiser_persist.hip (default since round 5: half of the conv's MFMAs), 1 = F(2,3), the 8-wave WINO == 1 instances (2/3), 0 = direct
+                                // (2 was round 5's one-wave-per-SIMD F(2,3) stack — same bits as 1, measured 4-10 % slower, out of the build since round 6: tools/attic/ — and runs as 1)
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
 int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch; 1 = dilation 1 and 3 everywhere + dilation 5 at C = 256 or k = 3 (default), 2 = only dilation 1, 3 = every dilation)
@@ -513,12 +493,18 @@ int g_persist = 1;              // residual layers in one persistent launch (den
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: 1 = a neighbour wait of the persistent kernel expired, 2 = a denoiser evaluation wrote a
                                  // non-finite mel value (persist_tail.h, mel_post_kernel: the sampler's post-scaling sees every output element), 3 = a conv
                                  // input of the fp16 / fp16x3 residual blocks left the fp16 range (denoiser_persist_lp.hip, resblock_fused_lp.hip)
-// Reads and clears the device flag word: what cmtts_poll_error() reports and what every denoiser call checks before it launches.
-int check_device_flag() {
+// Reads and clears the device flag word (one atomic exchange: a device store between a read and a clear cannot be lost).
+// cmtts_poll_error() reports every code.  A denoiser call checks the word before it launches (before_launch): only code 1 — a neighbour
+// wait that expired, i.e. a chip that did not hold the whole grid — refuses the launch; codes 2 / 3 describe the numerics of ONE earlier
+// request (possibly another model's, on another stream) and stay in the word for cmtts_poll_error(): they do not fail an unrelated call
+// (ADVICE r05).
+int check_device_flag(bool before_launch = false) {
     if (!g_tmo_host) return 0;
-    const unsigned v = *(volatile unsigned*)g_tmo_host;
+    unsigned v = __atomic_load_n(g_tmo_host, __ATOMIC_RELAXED);
     if (!v) return 0;
-    *(volatile unsigned*)g_tmo_host = 0;
+    if (before_launch && v != 1) return 0;
+    v = __atomic_exchange_n(g_tmo_host, 0u, __ATOMIC_ACQ_REL);
+    if (!v) return 0;
     if (v == 1) return fail(CMTTS_E_HIP, "persistent denoiser: a neighbour wait timed out (the affected utterances' mel is NaN)");
     if (v == 3) return fail(CMTTS_E_HIP, "denoiser, fp16 / fp16x3 operands: a conv input left the fp16 range (|u| > 65504) in an earlier evaluation — the "
                                          "mel is finite but wrong; use bf16 or fp32 for this model / input scale");
@@ -665,7 +651,6 @@ struct ResLayer {
     float *w3f = nullptr, *wof = nullptr;   // fragment-order copies for the fused kernel
     float* w3w = nullptr;                   // Winograd F(2,3) transformed conv weights as A fragments (persistent denoiser, 8-wave WINO instances)
     float* w3w43 = nullptr;                 // Winograd F(4,3) transformed conv weights (8-wave WINO == 2 instances: to_wino43_fragments)
-    float* w3w4 = nullptr;                  // the same as per-wave streams for the one-wave-per-SIMD stack (denoiser_persist4.hip)
     float* b3f = nullptr;                   // conv_layer bias in the fused kernel's row order
     void *w3f16[3] = {nullptr, nullptr, nullptr}, *wof16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies
 };
@@ -977,7 +962,6 @@ int finalize_model(cmtts_model* m) {
             CHK(pack_conv(scratch, *w3, b3, &perm16, &tmp, &hp));
             CHK(al.upload(to_fragment_order(hp, 3, C, 2 * C), &m->res[l].w3f));
             if (C == 256) CHK(al.upload(to_wino_fragments(hp, C, 2 * C), &m->res[l].w3w));
-            if (C == 256) CHK(al.upload(to_wino4_fragments(hp, C, 2 * C), &m->res[l].w3w4));
             if (C == 256) CHK(al.upload(to_wino43_fragments(hp, C, 2 * C), &m->res[l].w3w43));
             for (int mode = 1; mode <= 2; ++mode) {
                 const std::vector<unsigned short> f16 = to_fragment16(hp, 3, C, 2 * C, mode);
@@ -1433,7 +1417,7 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
                   const float* cond_ct, const float* spk, int B, int T, const MelPost& post, hipStream_t s, bool embed = true,
                   SideStream* pending = nullptr, float t_host = NAN,    // pending: a side branch (the conditioner GEMM) to join before the layers
                   const CondFactors* cfk = nullptr, bool* cp_ready = nullptr) {   // cfk: w.cp was NOT filled — the persistent kernel gathers the factors (FACT)
-    CHK(check_device_flag());
+    CHK(check_device_flag(true));
     const cmtts_config& c = m->cfg;
     const int C = c.res_channels, NL = c.res_layers, M = c.n_mels;
     const long cs = (long)C * T;
@@ -1468,11 +1452,10 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
             pa.out = post.out;
         }
         pa.wino = g_persist_wino && m->winograd && !prec && m->res[0].w3w && w.pst;
-        if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;      // one wave per SIMD (denoiser_persist4.hip)
         if (pa.wino && g_persist_wino == 3 && m->winograd == 1 && m->res[0].w3w43) pa.wino = 3;     // F(4,3) (model option "winograd" = 2 keeps F(2,3))
         pa.xst = w.pst;
         for (int l = 0; l < NL; ++l) {
-            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino == 3 ? m->res[l].w3w43 : pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f);
+            pa.W3f[l] = prec ? (const float*)m->res[l].w3f16[prec - 1] : (pa.wino == 3 ? m->res[l].w3w43 : pa.wino ? m->res[l].w3w : m->res[l].w3f);
             pa.Wof[l] = prec ? (const float*)m->res[l].wof16[prec - 1] : m->res[l].wof;
             pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
         }
@@ -2049,7 +2032,8 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
                 // the persistent launches gather the factors: w.cp (NL * C * T floats per utterance) is free and takes p1 with the channels
                 // contiguous, [B][NL][ldp][C] — one 57-MB transpose per sample call (bench shape, ~25 us) buys 16-byte gathers in every layer of
                 // every evaluation
-                k_transpose(cf->p1, w.cp, B * c.res_layers, c.res_channels, cf->ldp, s);
+                // (round 6: on the side stream — nothing before the first persistent launch reads it; it ran in front of the input projection)
+                k_transpose(cf->p1, w.cp, B * c.res_layers, c.res_channels, cf->ldp, ss ? ss->side : s);
                 cf_local = *cf;
                 cf_local.p1t = w.cp;
                 cfk = &cf_local;
@@ -2068,12 +2052,16 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
         const float c_in = 1.0f / rt;
         const float t_resc = 250.0f * logf(sg + 1e-44f);
         const bool new_sigma = i == 0 || sigmas[i] != sigmas[i - 1];
-        if (new_sigma) k_fill_float(w.tbuf, t_resc, B, s);
+        // the first evaluation's step embedding reads only the timestep (and the speaker vector): side stream, beside x_T's scaling and the
+        // input projection, joined with the conditioner branch before the residual layers (round 6; same kernels, same bits)
+        const bool embed_side = i == 0 && ss != nullptr;
+        if (new_sigma) k_fill_float(w.tbuf, t_resc, B, embed_side ? ss->side : s);
+        if (embed_side) CHK(step_embedding(m, w, w.tbuf, speaker_emb, B, ss->side, t_resc));
         const bool last = i + 1 == n_steps;
         const bool renoise = renoise_std[i] >= 0.0f;
         const MelPost post = {w.xcur, renoise ? noise + (long)(1 + i) * noise_stride : nullptr, c_out, c_skip,
                               renoise ? renoise_std[i] : 0.0f, last ? mel : w.xcur};
-        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma, i == 0 ? ss : nullptr, t_resc, cfk, &cp_ready));
+        CHK(denoiser_core(m, w, w.xcur, c_in, w.tbuf, cond_ct, speaker_emb, B, T, post, s, new_sigma && !embed_side, i == 0 ? ss : nullptr, t_resc, cfk, &cp_ready));
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2161,7 +2149,7 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
         }
         return 0;
     }
-    CHK(check_device_flag());
+    CHK(check_device_flag(true));
     // ---- which utterances share the persistent launch.  Every workgroup of that launch must be resident, so a shard with more active
     // tiles than CUs needs a second ROUND of 20 layers (2.7 ms per evaluation whatever its size).  When leaving out a few SMALL
     // utterances (<= 64 active tiles together: the range where the per-layer / split kernels take < 1 ms per evaluation,
@@ -2264,10 +2252,9 @@ int cmtts_sample_ragged(cmtts_model* m, const cmtts_sample_group* groups, int n_
     pa.wino = g_persist_wino && m->winograd && m->res[0].w3w;
     for (int g = 0; g < n_groups && pa.wino; ++g)
         if (keep[g] > 0 && !ws[g].pst) pa.wino = 0;
-    if (pa.wino && g_persist_wino == 2 && m->res[0].w3w4) pa.wino = 2;
     if (pa.wino && g_persist_wino == 3 && m->winograd == 1 && m->res[0].w3w43) pa.wino = 3;
     for (int l = 0; l < NL; ++l) {
-        pa.W3f[l] = pa.wino == 3 ? m->res[l].w3w43 : pa.wino == 2 ? m->res[l].w3w4 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
+        pa.W3f[l] = pa.wino == 3 ? m->res[l].w3w43 : pa.wino ? m->res[l].w3w : m->res[l].w3f; pa.Wof[l] = m->res[l].wof; pa.b3[l] = m->res[l].b3f; pa.bo[l] = m->res[l].outp.bias;
     }
     pa.n_groups = n_groups;
     if (fact_all) { pa.fact = 1; pa.p2 = m->cond_p2; pa.p2t = m->cond_p2t; pa.ld2 = c.pitch_bins; }
@@ -2781,7 +2768,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
-        {"persist_wino", &g_persist_wino, 0, 3},   // fp32 persistent denoiser: Winograd F(2,3) k = 3 conv (NOT bitwise: ~1e-6 relative per layer)
+        {"persist_wino", &g_persist_wino, 0, 3},   // fp32 persistent denoiser's k = 3 conv: 0 direct, 1 (and 2) Winograd F(2,3), 3 F(4,3) (NOT bitwise the direct form)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
         {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
         {"ffn_wino", &g_ffn_wino, 0, 1},           // FFN conv as F(4,3) tap groups in the fused launch (fp32; NOT bitwise the direct form)
@@ -2806,6 +2793,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };
     if (!strcmp(name, "voc_xl_split")) return cmtts_xl_set_split(value);
+    if (!strcmp(name, "attn_qb")) return cmtts_attention_set_qb(value);       // attention.hip: queries split over workgroups (round 6; same bits)
     if (!strcmp(name, "xres_nt")) return cmtts_xres_set_nt(value);            // conv_xres tile width for launches that do not choose one (measurements)      // conv_xl: m-tiles over several workgroups for launches of a few column tiles
     bool found;
     const int prev = knob_set(tab, sizeof(tab) / sizeof(tab[0]), name, value, &found);

@@ -1031,9 +1031,8 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
     a.dbg = g_pdbg;
     if ((a.wino == 1 || a.wino == 3) && !a.xst) return -2;     // the 8-wave Winograd instances keep the residual stream in `xst` between layers
     const int wsel = a.wino == 3 ? 2 : a.wino ? 1 : 0;         // instance: direct | F(2,3) | F(4,3)
-    const bool p4 = a.wino == 2;              // one wave per SIMD (denoiser_persist4.hip): 256 threads, state in registers
-    if (p4 && a.tail && a.n_mels > 128) return -2;
-    const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
+    if (a.wino == 2) return -2;               // (round 5's one-wave-per-SIMD stack: measured slower, out of the product build since round 6 — tools/attic/)
+    const int threads = 64 * NW;
     // instance table: [dbg][fact][wino]
 #define KFN(D, R, F, W) reinterpret_cast<const void*>(denoiser_persist_kernel<D, R, F, W>)
     static const void* const kfns[2][2][3] = {
@@ -1046,12 +1045,11 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             for (int f = 0; f < 2; ++f) {
                 for (int wn = 0; wn < 3; ++wn)
                     if (hipFuncSetAttribute(kfns[d][f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
-                if (hipFuncSetAttribute(cmtts_persist4_kernel(d, 0, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
             }
         attr_set = true;
     }
     if (a.fact && (!a.p1 || !a.p2 || !a.mel2ph || !a.pidx || a.ldp < 1 || a.ld2 < 1)) return -2;
-    if (a.fact && !p4 && (!a.p1t || !a.p2t)) return -2;      // the 8-wave FACT instances gather the channel-contiguous tables in their publish phase
+    if (a.fact && (!a.p1t || !a.p2t)) return -2;      // the 8-wave FACT instances gather the channel-contiguous tables in their publish phase
     // every granule tag must be stale (0) when a launch starts
     if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     // utterance chunks: all workgroups of a launch must be resident (one per CU); chunks are balanced so that the last
@@ -1082,9 +1080,9 @@ extern "C" int cmtts_launch_denoiser_persist(const PersistArgs* a_in, int max_bl
             c.noise = a.noise ? a.noise + off : nullptr;
             c.out = a.out + off;
         }
-        const void* kfn = p4 ? cmtts_persist4_kernel(a.dbg ? 1 : 0, 0, a.fact ? 1 : 0) : kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][wsel];
+        const void* kfn = kfns[a.dbg ? 1 : 0][a.fact ? 1 : 0][wsel];
         void* params[] = {(void*)&c};
-        const int variant = (p4 ? 3 : wsel) * 2 + (a.fact ? 1 : 0);        // one record per kernel instance (persist_args.h)
+        const int variant = wsel * 2 + (a.fact ? 1 : 0);        // one record per kernel instance (persist_args.h)
         if (!a.dbg && cmtts_persist_cooperative(variant, tiles, nb)) {
             if (hipLaunchCooperativeKernel(kfn, dim3(tiles, nb), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;
             cmtts_persist_validated(variant, tiles, nb);
@@ -1111,7 +1109,6 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         for (int f = 0; f < 2; ++f) {
             for (int wn = 0; wn < 3; ++wn)
                 if (hipFuncSetAttribute(kfns[f][wn], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
-            if (hipFuncSetAttribute(cmtts_persist4_kernel(0, 1, f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -3;
         }
         attr_set = true;
     }
@@ -1119,21 +1116,18 @@ extern "C" int cmtts_launch_denoiser_persist_ragged(const PersistArgs* a_in, voi
         if (!a.p2 || a.ld2 < 1) return -2;
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && (!a.grp[g].p1 || !a.grp[g].mel2ph || !a.grp[g].pidx || a.grp[g].ldp < 1)) return -2;
-        if (a.wino != 2) {
-            if (!a.p2t) return -2;
-            for (int g = 0; g < a.n_groups; ++g)
-                if (a.grp[g].B > 0 && !a.grp[g].p1t) return -2;
-        }
+        if (!a.p2t) return -2;
+        for (int g = 0; g < a.n_groups; ++g)
+            if (a.grp[g].B > 0 && !a.grp[g].p1t) return -2;
     }
     if (a.wino == 1 || a.wino == 3)   // the 8-wave Winograd instances keep the residual stream of every group in its `xst` buffer
         for (int g = 0; g < a.n_groups; ++g)
             if (a.grp[g].B > 0 && !a.grp[g].xst) return -2;
-    const bool p4 = a.wino == 2;
-    if (p4 && a.tail && a.n_mels > 128) return -2;
-    const int threads = p4 ? cmtts_persist4_threads() : 64 * NW;
+    if (a.wino == 2) return -2;
+    const int threads = 64 * NW;
     const int wsel = a.wino == 3 ? 2 : a.wino ? 1 : 0;
-    const void* kfn = p4 ? cmtts_persist4_kernel(0, 1, a.fact ? 1 : 0) : kfns[a.fact ? 1 : 0][wsel];
-    const int variant = 8 + (p4 ? 3 : wsel) * 2 + (a.fact ? 1 : 0);      // one record per kernel instance
+    const void* kfn = kfns[a.fact ? 1 : 0][wsel];
+    const int variant = 8 + wsel * 2 + (a.fact ? 1 : 0);      // one record per kernel instance
     void* params[] = {(void*)a_in};
     if (cmtts_persist_cooperative(variant, a.n_wg, -1)) {
         if (hipLaunchCooperativeKernel(kfn, dim3(a.n_wg), dim3(threads), params, (unsigned)lds, stream) != hipSuccess) return -3;

@@ -74,8 +74,7 @@ struct PersistArgs {
     const float* p2t;
     int wino;             // 3 (round 5, the default): the 8-wave F(4,3) instances (denoiser_persist.hip, WINO == 2) — W3f = six transformed weight sets as
                           // v_mfma_f32_16x16x4_f32 fragments (cmtts_api.hip: to_wino43_fragments), state as for 1.
-                          // 2 (round 5): the one-wave-per-SIMD stack of denoiser_persist4.hip — W3f = per-wave streams (cmtts_api.hip: to_wino4_fragments),
-                          // x and the skip sum stay in registers, `xst` unused.  1: fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
+                          // (2 was round 5's one-wave-per-SIMD stack: tools/attic/denoiser_persist4.hip, not built.)  1: fp32 kernel, round 4: W3f holds the Winograd F(2,3) transformed conv weights (cmtts_api.hip: to_wino_fragments) and `skip` is the
                           // kernel's between-layers storage of the skip sum (denoiser_persist.hip, WINO instances); NOT bitwise the direct form
     float* xst;           // WINO: [B][tiles][16384] kernel-private state — the residual stream x of every 64-frame tile between layers
                           // (cmtts_persist_state_floats(B, T) floats)
@@ -115,9 +114,6 @@ long long* cmtts_persist_get_debug(void);
 int cmtts_persist_set_cooperative(int on);
 void cmtts_persist_validated(int variant, int gx, int gy);    // the runtime accepted a cooperative launch of this grid
 int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant = kernel instance, denoiser_persist.hip)
-// one-wave-per-SIMD Winograd stack (denoiser_persist4.hip; PersistArgs.wino == 2): kernel instance and its workgroup size
-const void* cmtts_persist4_kernel(int dbg, int ragged, int fact);
-int cmtts_persist4_threads(void);
 int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
 }

@@ -184,9 +184,9 @@ class CMTotalTTS(torch.nn.Module):
         """Per-model numerics option (cmtts_model_set_option): "ffn2_split" 1 (default) | 0 — the FFN linear of the FFT blocks as
         eight K-segment partial GEMMs + one reduction, or as one launch (another fp32 summation order); "text16" 0 (default) | 1 — bf16 / fp16
         models: the in- / out-projections and FFN contractions of the FFT blocks and the variance predictors' convs with 16-bit operands as well (the integer stages — durations, pitch buckets, lengths —
-        then depend on the precision mode); "winograd" 1 (default) | 0 — fp32 models, large batches: the gated k = 3 conv of the persistent
-        denoiser stack as a Winograd F(2,3) convolution (2/3 of the conv's MFMAs; fp32 rounding differences ~4e-6 on a mel) or in the direct
-        form (bit for bit the per-layer kernels of small batches).  Returns the previous value."""
+        then depend on the precision mode); "winograd" 1 (default) | 2 | 0 — fp32 models, large batches: the gated k = 3 conv of the persistent
+        denoiser stack as a Winograd convolution — 1: F(4,3) (half of the conv's MFMAs; fp32 rounding differences ~8e-6 on a mel; since round 5 / ABI revision 5),
+        2: F(2,3) (2/3 of them; ~4e-6) — or (0) in the direct form (bit for bit the per-layer kernels of small batches).  Returns the previous value."""
         prev = self.lib.cmtts_model_set_option(self._h, name.encode() if isinstance(name, str) else name, int(value))
         if prev < 0:
             _lib.check(prev)
@@ -496,7 +496,7 @@ def sample_ragged(model: CMTotalTTS, groups, n_steps, tail_frames=0):
     groups: iterable of (cond_ct [B,H,T], speaker_emb [B,H] | None, noise [n_noise,B,1,T,80], active_frames | None[, CondFactors | None]);
     active_frames = host sequence of B ints (mel_len): the utterance is then only computed as far as those frames (+ tail_frames
     + the sampler's receptive field) need — they come out bit-identical to the untrimmed run in the direct and F(2,3) forms of the
-    stack and within fp32 rounding of it (<= 2e-6 measured) in the default F(4,3) form, whose frame quads round every output from all
+    stack and within fp32 rounding of it (<= 1.5e-5: include/cmtts_hip.h, tests/conftest.py WINO_TRIM_TOL; ~2e-6 typical) in the default F(4,3) form, whose frame quads round every output from all
     six inputs of the quad; frames beyond the computed range are zeros.
     Returns the list of mels [B,T,80]."""
     model._require()

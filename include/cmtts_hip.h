@@ -57,9 +57,11 @@ const char* cmtts_last_error(void);
 const char* cmtts_version(void);
 /* Binary-interface revision of this header: bumped whenever a struct layout or an existing signature changes (round 2
  * inserted cmtts_config.n_speaker and the `speakers` parameter of cmtts_text_forward: revision 2; round 3 adds entry
- * points only but starts the counter: 3; round 4 appends the conditioner factors to cmtts_sample_group: 4).  A host compares cmtts_abi_version() with the CMTTS_ABI_VERSION it was built
+ * points only but starts the counter: 3; round 4 appends the conditioner factors to cmtts_sample_group: 4;
+ * round 6: 5 — no layout change, but the MEANING of an existing option value changed in round 5 without a bump: cmtts_model_set_option(m, "winograd", 1) selects
+ * the F(4,3) form since then and 2 the F(2,3) form that 1 used to select, and cmtts_poll_error's codes 2 / 3 no longer fail the next launch).  A host compares cmtts_abi_version() with the CMTTS_ABI_VERSION it was built
  * against before it passes a struct (cmtts_amd/_lib.py does at load time). */
-#define CMTTS_ABI_VERSION 4
+#define CMTTS_ABI_VERSION 5
 int cmtts_abi_version(void);
 
 /* ---- weight import: replaces torch.load + load_state_dict (synthesize.py:79-83).
@@ -241,13 +243,18 @@ int cmtts_set_fused_resblock(int on);
  * GPU has CUs).  Bitwise identical to the per-layer kernels (tests); fp32 operands only.  Any other value only
  * queries.  Returns the previous mode. */
 int cmtts_set_persistent_denoiser(int mode);
-/* The persistent launch bounds every wait for a neighbouring tile (~2 s); when one expires the kernel poisons the
- * affected utterance (its mel comes out NaN, never plausible-but-wrong) and sets a pinned host word.
- * cmtts_poll_error() reads and clears that word: 0, or CMTTS_E_HIP with the message in cmtts_last_error().  It reflects
- * launches that have COMPLETED, so call it after synchronising the stream the mel was produced on (host.py does, at
- * every point where it hands host-visible data back: vocoder_infer, synthesize(sync=True), host.synchronize()).
- * The next denoiser call also checks the word before it launches.  There is no counterpart in the reference (its
- * errors are Python exceptions). */
+/* Asynchronous failures: one pinned host word that kernels set, read and cleared (one atomic exchange) by cmtts_poll_error(): 0, or
+ * CMTTS_E_HIP with the message in cmtts_last_error().  Codes:
+ *   1  the persistent launch bounds every wait for a neighbouring tile (~2 s); one expired: the kernel poisoned the affected utterance
+ *      (its mel comes out NaN, never plausible-but-wrong).  The chip did not hold the whole grid: the NEXT denoiser call checks for
+ *      this code before it launches and fails instead.
+ *   2  a denoiser evaluation produced a non-finite mel value (any precision mode: the sampler's post-scaling sees every output element).
+ *   3  a conv input of the fp16 / fp16x3 residual blocks left the fp16 range (|u| > 65504): that mel is finite and wrong.
+ * Codes 2 / 3 describe ONE earlier request's numerics; the word is process-wide (not per model or stream), so they are reported by
+ * cmtts_poll_error() only and never fail an unrelated later call (round 6; round 5 refused the next launch for them as well).
+ * The word reflects launches that have COMPLETED, so call cmtts_poll_error() after synchronising the stream the mel was produced on
+ * (host.py does, at every point where it hands host-visible data back: vocoder_infer, synthesize(sync=True), host.synchronize()).
+ * There is no counterpart in the reference (its errors are Python exceptions). */
 int cmtts_poll_error(void);
 /* Process-wide scheduling options.  None of them changes a result bit (tested); they are per process, not per model or
  * stream.  Returns the previous value (a value outside the option's range only queries) or CMTTS_E_INVALID for an

@@ -121,8 +121,7 @@ WINO_TOL = 3e-5
 def conv_form(request):
     from cmtts_amd import _lib
     import os
-    # "winograd" = the default Winograd stack (3: the 8-wave F(4,3) instances; CMTTS_TEST_WINO=1 runs the F(2,3) instances and
-    # CMTTS_TEST_WINO=2 the one-wave-per-SIMD stack of denoiser_persist4.hip through every conv_form test)
+    # "winograd" = the default Winograd stack (3: the 8-wave F(4,3) instances; CMTTS_TEST_WINO=1 runs the F(2,3) instances through every conv_form test)
     prev = _lib.internal_set("persist_wino", 0 if request.param == "direct" else int(os.environ.get("CMTTS_TEST_WINO", "3")))
     try:
         yield request.param

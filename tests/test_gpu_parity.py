@@ -762,6 +762,37 @@ def test_fused_attention_matches_three_launch_path(variant, B, L):
             assert torch.equal(one["enc_out"][0, :n], got["enc_out"][1, :n])
 
 
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 5, 128), ("LJSpeech", 3, 97), ("VCTK", 7, 33), ("LJSpeech", 2, 32), ("VCTK", 1, 25),
+                                         ("LJSpeech", 4, 1), ("LibriTTS", 9, 64)])
+def test_attention_qb_bitwise(variant, B, L):
+    """Round 6: attention_qb_kernel (attention.hip: a workgroup = one (utterance, head, block of 32 queries); key tiles over the waves, the
+    un-normalised probabilities through LDS, summed in attention_kernel's order; output channels over the waves) against attention_kernel
+    (a workgroup = one (utterance, head)): every accumulation chain has the same operands in the same order => the whole text side bit for
+    bit, at one to four key tiles, ragged lengths (key mask, a fully padded query block), L = 1."""
+    host = _host()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=23, dur_frames=3.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(1000 + L)
+    lens = np.maximum((rs.uniform(0.2, 1.0, size=B) * L).astype(np.int64), 1)
+    lens[0] = L
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts[np.arange(L)[None, :] >= lens[:, None]] = 0
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    prev = _lib.internal_set(b"attn_qb", 0)
+    try:
+        ref = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+        ref = {k: ref[k].clone() for k in ("enc_out", "mel_lens", "mel2ph", "cond_ct")}
+        assert _lib.internal_set(b"attn_qb", 1) == 0
+        got = model.duration_pitch_energy_net(None, torch.from_numpy(texts), torch.from_numpy(lens), spker_embeds=spk, max_mel_len=3 * L)
+        torch.cuda.synchronize()
+    finally:
+        _lib.internal_set(b"attn_qb", prev)
+    assert torch.isfinite(got["enc_out"]).all()
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
+
+
 @pytest.mark.parametrize("B,T", [(3, 96), (2, 77), (32, 512), (1, 5)])
 def test_fused_input_projection_bitwise(B, T):
     """inproj.hip (c_in scaling + [B,T,80] -> [B,80,T] + relu(input_projection) + clearing of the persistent kernel's halo
@@ -1524,10 +1555,9 @@ def test_model_without_pitch_table_factor_takes_the_dense_gemm():
 def test_winograd_stack_odd_shapes(variant, B, T):
     """VERDICT r04 #5a: the Winograd forms of the fp32 persistent stack work on frame PAIRS (F(2,3)) or QUADS (F(4,3), the default since
     round 5) — odd T, a one-frame utterance, a lone tail tile, utterance chunking (70 x 5 tiles > 256 CUs) and 79-tile utterances are
-    where a tile-wise transform breaks.  Four stacks on the same inputs: direct (bitwise the per-layer kernels, proven elsewhere), the
-    8-wave F(2,3) instances, the one-wave-per-SIMD F(2,3) stack (denoiser_persist4.hip, opt-in) and the 8-wave F(4,3) instances: the two
-    F(2,3) stacks bit for bit (same arithmetic per element, different ownership of rows / registers / LDS), every Winograd stack
-    within WINO_TOL of the direct form — one network evaluation and a T = 2 sample."""
+    where a tile-wise transform breaks.  Three stacks on the same inputs: direct (bitwise the per-layer kernels, proven elsewhere), the
+    F(2,3) instances and the F(4,3) instances (persist_wino = 2, round 5's one-wave-per-SIMD F(2,3) stack, left the build in round 6 —
+    tools/attic/ — and runs as 1): every Winograd stack within WINO_TOL of the direct form — one network evaluation and a T = 2 sample."""
     from conftest import WINO_TOL
     host = _host()
     lib = _lib.load()

@@ -287,7 +287,7 @@ def test_winograd_and_fp16x3_stress_statistics(case):
 def test_fp16_overflow_is_reported():
     """Activations beyond the fp16 range (|conv input| > 65504): the fp16 and fp16x3 stacks cannot represent their operands.  The result is
     FINITE AND WRONG (measured: |mel| <= 0.15 where fp32 gives 2.7) and the library says so — the kernels' operand conversions raise the
-    device flag that cmtts_poll_error() / the next denoiser call turn into an error — while fp32 and bf16 (8 exponent bits) take the same
+    device flag that cmtts_poll_error() turns into an error (since round 6 it does not fail the next, unrelated launch) — while fp32 and bf16 (8 exponent bits) take the same
     input.  (A non-finite mel in any mode is reported the same way by the sampler's post-scaling: code 2.)"""
     import dataclasses
     host = _host()
