@@ -54,12 +54,14 @@ SIGNATURES = {
     "cmtts_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_frame_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_frame_forward_sub": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "cmtts_frame_forward_sub_t": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "cmtts_length_regulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cmtts_denoiser_workspace_bytes": (_sz, [_vp, _i, _i]),
     "cmtts_denoiser_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "cmtts_schedule": (_i, [_vp, _i, C.POINTER(_f), C.POINTER(_f)]),
     "cmtts_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp]),
     "cmtts_sample_factored": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp, _vp, _i, _i, _vp, _vp]),
+    "cmtts_sample_factored_t": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _sz, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "cmtts_sample_ragged": (_i, [_vp, C.POINTER(SampleGroupStruct), _i, _i, C.POINTER(_f), C.POINTER(_f), _i, _vp]),
     "cmtts_vocoder_create": (_i, [C.POINTER(_vp)]),
     "cmtts_vocoder_set_tensor": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * m + acc_row(r, lane);
-                const float v = S[m][r] * a.scale;
-                S[m][r] = v;
+                const float v = __fmul_rn(S[m][r], a.scale);      // (explicitly rounded product and difference: left to the compiler, s * scale - max may or may not
+                S[m][r] = v;                                      // become one fma, kernel by kernel — attention_qb_kernel below must produce the same bits)
                 if (key < len) mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * m + acc_row(r, lane);
-                const float e = key < len ? expf(S[m][r] - mx) : 0.f;
+                const float e = key < len ? expf(__fsub_rn(S[m][r], mx)) : 0.f;
                 S[m][r] = e;
                 sum += e;
             }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attention_qb_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * w + acc_row(r, lane);
-            const float v = S[r] * a.scale;
+            const float v = __fmul_rn(S[r], a.scale);
             S[r] = v;
             if (key < len) mx = fmaxf(mx, v);
         }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void attention_qb_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * w + acc_row(r, lane);
-            Es[(w * 16 + r) * 64 + lane] = key < len ? expf(S[r] - mx) : 0.f;
+            Es[(w * 16 + r) * 64 + lane] = key < len ? expf(__fsub_rn(S[r], mx)) : 0.f;
         }
     }
     __syncthreads();

@@ -483,6 +483,7 @@ int g_attn_fused = 1;           // FFT-block attention as QKV projection + ONE f
 int g_voc_xl = 1;               // HiFi-GAN ResBlock convs of the C >= 128 stages through the X-resident kernel (conv_xl): 0 never, 1 yes
 int g_voc_pair = 1;             // HiFi-GAN ResBlock pairs of the C <= 64 stages as one launch (resblock_pair{,16}.hip): 0 never, 1 where it pays, 2 always
 int g_qkv_nt = 0;              // internal switch "qkv_nt": conv_xres tile width of the in-projection (0 = launcher's rule, 1, 3) — measurements
+int g_stats_mlp = 1;           // round 6: cwt_stats_layers as one launch (kernels.hip: stats_mlp_kernel; same bits); 0 = three dense_small launches
 int g_cwt_in_phoneme = 1;      // round 4: the pitch predictor's input projection applied before the length regulator (same bits); 0 = over the frames
 int g_xres_small = 1;          // round 4: conv_xres with 32-column tiles for text-side launches that cannot fill the chip (same bits); 0 = the generic kernel there
 int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip when the shape suits it (false: generic kernel)
@@ -1896,6 +1897,15 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
 int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T, float* cond_ct, int64_t* mel2ph,
                             float* cwt_out, float* f0_denorm, int64_t* p_idx, float* f0_stats, float* cond_p1, void* frame_ws,
                             size_t frame_ws_bytes, void* stream) {
+    return cmtts_frame_forward_sub_t(m, text_ws, B_all, L_all, b0, B, T, cond_ct, mel2ph, cwt_out, f0_denorm, p_idx, f0_stats, cond_p1, nullptr, frame_ws,
+                                     frame_ws_bytes, stream);
+}
+
+// ... and the factor's channel-contiguous copy cond_p1t [B][res_layers][Lp][res_channels] (round 6): written on the branch stream right behind the
+// GEMM that produces cond_p1, under the frame-level convs, instead of at the sampler's entry in front of the first evaluation.
+int cmtts_frame_forward_sub_t(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T, float* cond_ct, int64_t* mel2ph,
+                              float* cwt_out, float* f0_denorm, int64_t* p_idx, float* f0_stats, float* cond_p1, float* cond_p1t, void* frame_ws,
+                              size_t frame_ws_bytes, void* stream) {
     if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
     if (!text_ws || !frame_ws || !cond_ct || !mel2ph || B <= 0 || L_all <= 0 || T <= 0 || b0 < 0 || b0 + B > B_all)
         return fail(CMTTS_E_INVALID, "cmtts_frame_forward: bad argument");
@@ -1924,10 +1934,16 @@ int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int 
     // k = 5 convs instead and both took twice as long (profiles/r04_text_side.md)
     // (a model without the pitch-table factor — odd res_layers at C = 256, hidden != 256, a failed finalize-time GEMM — leaves cond_p1 untouched:
     // CondFactors::usable() is false for it and the sampler takes the dense GEMM, as it did before the factors existed)
-    if (cond_p1 && m->cond_p2) CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
-    k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
-    k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
-    k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
+    if (cond_p1t && !cond_p1) return fail(CMTTS_E_INVALID, "cmtts_frame_forward_sub_t: cond_p1t needs cond_p1");
+    if (cond_p1 && m->cond_p2) {
+        CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
+        if (cond_p1t) k_transpose(cond_p1, cond_p1t, B * c.res_layers, c.res_channels, Lp, sst);      // [B NL][C][Lp] -> [B NL][Lp][C]
+    }
+    if (!(g_stats_mlp && k_stats_mlp(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, m->st2_wt, m->st2_b, m->st4_wt, m->st4_b, f0_stats, B, H, CH, CH, 2, sst))) {
+        k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
+        k_dense_small(w.s1, CH, 1, m->st2_wt, m->st2_b, nullptr, w.s2, B, CH, CH, DENSE_RELU, sst);
+        k_dense_small(w.s2, CH, 1, m->st4_wt, m->st4_b, nullptr, f0_stats, B, CH, 2, DENSE_NONE, sst);
+    }
     k_mel2ph(tw.cum, mel2ph, B, L, T, s);
     // with the pitch predictor's input projection applied before the gather the length-regulated [B][H][T] tensor has ONE reader left, the pitch
     // embedding add at the end: that kernel gathers from out1 itself (k_lr_gather_add: the same values, one launch and 2 x 17 MB less)
@@ -2033,9 +2049,11 @@ int sample_core(cmtts_model* m, const DenWs& w, const float* noise, long noise_s
                 // contiguous, [B][NL][ldp][C] — one 57-MB transpose per sample call (bench shape, ~25 us) buys 16-byte gathers in every layer of
                 // every evaluation
                 // (round 6: on the side stream — nothing before the first persistent launch reads it; it ran in front of the input projection)
-                k_transpose(cf->p1, w.cp, B * c.res_layers, c.res_channels, cf->ldp, ss ? ss->side : s);
                 cf_local = *cf;
-                cf_local.p1t = w.cp;
+                if (!cf_local.p1t) {
+                    k_transpose(cf->p1, w.cp, B * c.res_layers, c.res_channels, cf->ldp, ss ? ss->side : s);
+                    cf_local.p1t = w.cp;
+                }
                 cfk = &cf_local;
             } else CHK(cond_factored(m, w, *cf, B, T, ss ? ss->side : s));
         } else CHK(cond_projections(m, w, cond_ct, B, T, ss ? ss->side : s));
@@ -2098,6 +2116,13 @@ int cmtts_sample(cmtts_model* m, const float* noise, const float* cond_ct, const
 int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
                           int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
                           void* stream, const float* cond_p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx) {
+    return cmtts_sample_factored_t(m, noise, cond_ct, speaker_emb, B, T, n_steps, sigmas, renoise_std, mel, ws, ws_bytes, stream, cond_p1, nullptr, p1_ld, L,
+                                   mel2ph, p_idx);
+}
+
+int cmtts_sample_factored_t(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb, int B, int T,
+                            int n_steps, const float* sigmas, const float* renoise_std, float* mel, void* ws, size_t ws_bytes,
+                            void* stream, const float* cond_p1, const float* cond_p1t, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx) {
     if (!m || !m->finalized) return fail(CMTTS_E_INVALID, "model not finalized");
     if (!noise || !cond_ct || !mel || !ws || !sigmas || !renoise_std || B <= 0 || T <= 0 || n_steps < 1)
         return fail(CMTTS_E_INVALID, "cmtts_sample_factored: bad argument");
@@ -2107,6 +2132,7 @@ int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_
     if (ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "denoiser workspace too small");
     CondFactors cf;
     cf.p1 = cond_p1; cf.ldp = p1_ld; cf.L = L; cf.mel2ph = mel2ph; cf.p_idx = p_idx;
+    cf.p1t = cond_p1 ? cond_p1t : nullptr;      // the caller's channel-contiguous copy (cmtts_frame_forward_sub_t): no transpose at the sampler's entry
     return sample_core(m, w, noise, (long)B * T * c.n_mels, cond_ct, speaker_emb, B, T, n_steps, sigmas, renoise_std, mel, (hipStream_t)stream,
                        cond_p1 ? &cf : nullptr);
 }
@@ -2790,6 +2816,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
+        {"stats_mlp", &g_stats_mlp, 0, 1},         // cwt_stats_layers as one launch (same bits)
         {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };
     if (!strcmp(name, "voc_xl_split")) return cmtts_xl_set_split(value);

@@ -22,6 +22,9 @@ void k_pos_embed_add_lr(const float* src, int ldl, const int64_t* mel2ph, const 
                         const float* tab, int tab_rows, int B, int C, int T, hipStream_t s);
 void k_chan_linear(const float* x, const float* W, const float* bias, float* out, const int64_t* lens,
                    int B, int C, int T, int ld, int O, hipStream_t s);
+// cwt_stats_layers as one launch (three dense_small<4> layers, same bits); false = shape not covered (the caller runs the three launches)
+bool k_stats_mlp(const float* in, long in_bs, long in_ks, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                 const float* b2, float* out, int B, int K0, int N0, int N1, int N2, hipStream_t s);
 void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, const float* bias,
                    const float* add, float* out, int B, int K, int N, int act, hipStream_t s);
 void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const float* e_target, float e_control,

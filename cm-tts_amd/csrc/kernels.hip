@@ -409,6 +409,50 @@ __global__ __launch_bounds__(64 * KS) void dense_small_kernel(const float* in, l
     }
 }
 
+// ---- cwt_stats_layers (model/modules.py:212-215,279): Linear(K0, N0) -> ReLU -> Linear(N0, N1) -> ReLU -> Linear(N1, N2) on one input row per
+// utterance, as ONE launch (round 6).  As three dense_small_kernel<4> launches (8 / 4 / 1 workgroups, every thread a serial walk over its
+// K slice behind scalar loads of the input) the MLP took 50-80 us per layer beside the frame-level convs and ended exactly where the pitch
+// chain joins it.  Workgroup = utterance, 512 threads = dense_small_kernel<4>'s four K slices x 128 output columns; the input row and the
+// hidden rows live in LDS; per output the same fmaf chain per slice and the same order of the slice sums, bias, ReLU => the same bits.
+constexpr int SM_COLS = 128;
+__global__ __launch_bounds__(4 * SM_COLS) void stats_mlp_kernel(const float* __restrict__ in, long in_bs, long in_ks, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                                const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                float* __restrict__ out, int K0, int N0, int N1, int N2) {
+    extern __shared__ float sm_lds[];          // x0[K0] | h1[N0] | h2[N1] | part[3][SM_COLS]
+    float* x0 = sm_lds;
+    float* h1 = x0 + K0;
+    float* h2 = h1 + N0;
+    float* part = h2 + N1;
+    const int nl = threadIdx.x & (SM_COLS - 1), ks = threadIdx.x / SM_COLS;
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < K0; k += blockDim.x) x0[k] = in[(long)b * in_bs + (long)k * in_ks];
+    __syncthreads();
+    auto layer = [&](const float* x, int K, const float* __restrict__ Wt, const float* __restrict__ bias, int N, bool relu, float* y) {
+        const int kq = (K + 3) / 4;
+        const int k0 = ks * kq, k1 = min(K, k0 + kq);
+        for (int n0 = 0; n0 < N; n0 += SM_COLS) {
+            const int n = n0 + nl, nc = min(n, N - 1);
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) acc = fmaf(x[k], Wt[(long)k * N + nc], acc);
+            if (ks > 0) part[(ks - 1) * SM_COLS + nl] = acc;
+            __syncthreads();
+            if (ks == 0 && n < N) {
+                float v = acc;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v += part[q * SM_COLS + nl];
+                if (bias) v += bias[n];
+                if (relu) v = v > 0.f ? v : 0.f;
+                y[n] = v;
+            }
+            __syncthreads();
+        }
+    };
+    layer(x0, K0, W0, b0, N0, true, h1);
+    layer(h1, N0, W1, b1, N1, true, h2);
+    layer(h2, N1, W2, b2, N2, false, out + (long)b * N2);
+}
+
 // ---- energy bucketize + embedding add (model/modules.py:319-329,358-363); torch.bucketize
 // right=False = first i with bins[i] >= v
 constexpr int ENE_CG = 32;
@@ -807,6 +851,13 @@ void k_dense_small(const float* in, long in_bs, long in_ks, const float* Wt, con
     else
         hipLaunchKernelGGL(dense_small_kernel<4>, dim3(cdiv(N, 64), cdiv(B, DB)), dim3(256), 0, s, in, in_bs, in_ks, Wt,
                            bias, add, out, B, K, N, act);
+}
+bool k_stats_mlp(const float* in, long in_bs, long in_ks, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                 const float* b2, float* out, int B, int K0, int N0, int N1, int N2, hipStream_t s) {
+    const size_t lds = (size_t)(K0 + N0 + N1 + 3 * SM_COLS) * sizeof(float);
+    if (lds > 48 * 1024) return false;
+    hipLaunchKernelGGL(stats_mlp_kernel, dim3(B), dim3(4 * SM_COLS), lds, s, in, in_bs, in_ks, W0, b0, W1, b1, W2, b2, out, K0, N0, N1, N2);
+    return true;
 }
 void k_energy_embed(const float* x, const float* e_pred, float* e_scaled, const float* e_target, float e_control,
                     const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, int B, int C, int L, int ld,

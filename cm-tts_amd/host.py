@@ -107,19 +107,20 @@ class CondFactors:
     (include/cmtts_hip.h): with it the sampler expands cp from (p1, mel2ph, p_idx) instead of running the stacked conditioner GEMM
     over the frames.  Bound to ONE conditioning tensor: `matches` refuses a different or since-modified cond_ct (the sampler then
     takes the dense GEMM on whatever it was given)."""
-    __slots__ = ("p1", "p1_ld", "L", "mel2ph", "p_idx", "_ptr", "_version", "_shape", "_aux")
+    __slots__ = ("p1", "p1t", "p1_ld", "L", "mel2ph", "p_idx", "_ptr", "_version", "_shape", "_aux")
 
-    def __init__(self, p1, p1_ld, L, mel2ph, p_idx, cond_ct):
+    def __init__(self, p1, p1_ld, L, mel2ph, p_idx, cond_ct, p1t=None):
         self.p1, self.p1_ld, self.L, self.mel2ph, self.p_idx = p1, int(p1_ld), int(L), mel2ph, p_idx
+        self.p1t = p1t          # [B, res_layers, p1_ld, res_channels]: the same factor with the channels contiguous (cmtts_frame_forward_sub_t), or None
         self._ptr, self._version, self._shape = cond_ct.data_ptr(), cond_ct._version, tuple(cond_ct.shape)
         # mel2ph and p_idx are the very tensors the caller received (out["mel2ph"], out["p_predictions"]["p_idx"]) and p1 is reachable too:
         # an in-place edit of any of them after the duration net would change the mel on the factored path only (ADVICE r04) — their
         # version counters are part of the match
-        self._aux = (p1._version, mel2ph._version, p_idx._version)
+        self._aux = (p1._version, mel2ph._version, p_idx._version, None if p1t is None else p1t._version)
 
     def matches(self, cond_ct):
         return (cond_ct.data_ptr() == self._ptr and cond_ct._version == self._version and tuple(cond_ct.shape) == self._shape and
-                (self.p1._version, self.mel2ph._version, self.p_idx._version) == self._aux)
+                (self.p1._version, self.mel2ph._version, self.p_idx._version, None if self.p1t is None else self.p1t._version) == self._aux)
 
 
 class CMTotalTTS(torch.nn.Module):
@@ -310,14 +311,15 @@ class DurationPitchSpeakerNet(torch.nn.Module):
                 # fp32 models: the phoneme-level factor of the conditioner projections rides along (CondFactors)
                 p1_ld = (L + 3) // 4 * 4
                 p1 = f(B, cfg.res_layers * cfg.res_channels, p1_ld) if getattr(o, "_precision_mode", 0) == 0 and o._cond_factors else None
-                _lib.check(lib.cmtts_frame_forward_sub(o._h, _ptr(tws), B, L, 0, B, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
-                                                       _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(p1), _ptr(fws), nf, _stream()))
+                p1t = None if p1 is None else f(B, cfg.res_layers, p1_ld, cfg.res_channels)      # channels contiguous: what the persistent stack gathers from
+                _lib.check(lib.cmtts_frame_forward_sub_t(o._h, _ptr(tws), B, L, 0, B, T, _ptr(cond_ct), _ptr(mel2ph), _ptr(cwt),
+                                                         _ptr(f0), _ptr(p_idx), _ptr(stats), _ptr(p1), _ptr(p1t), _ptr(fws), nf, _stream()))
             finally:
                 if vc is not None:
                     lib.cmtts_set_variance_controls(o._h, None)              # back to the inference defaults
                     torch.cuda.current_stream(dev).synchronize()             # targets must outlive the kernels
         mel_masks = get_mask_from_lengths(mel_len, T)
-        factors = None if p1 is None else CondFactors(p1, p1_ld, L, mel2ph, p_idx, cond_ct)
+        factors = None if p1 is None else CondFactors(p1, p1_ld, L, mel2ph, p_idx, cond_ct, p1t)
         cond_ct._cmtts_factors = factors       # rides along with THIS tensor object: sample_with_cond(cond_ct, ...) finds it (and re-checks it)
         return {
             "cond": cond_ct.transpose(1, 2),               # [B,T,H] view of the channel-major buffer
@@ -480,9 +482,9 @@ def sample_with_cond(model: CMTotalTTS, cond_ct, speaker_emb, n_steps, noise, fa
         if factors is None:
             factors = getattr(cond_ct, "_cmtts_factors", None)
         if factors is not None and factors.matches(cond_ct):
-            _lib.check(lib.cmtts_sample_factored(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
-                                                 _ptr(mel), _ptr(ws), nb, _stream(), _ptr(factors.p1), factors.p1_ld, factors.L,
-                                                 _ptr(factors.mel2ph), _ptr(factors.p_idx)))
+            _lib.check(lib.cmtts_sample_factored_t(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
+                                                   _ptr(mel), _ptr(ws), nb, _stream(), _ptr(factors.p1), _ptr(factors.p1t), factors.p1_ld, factors.L,
+                                                   _ptr(factors.mel2ph), _ptr(factors.p_idx)))
         else:
             _lib.check(lib.cmtts_sample(model._h, _ptr(noise), _ptr(cond_ct), _ptr(speaker_emb), B, T, n_steps, sig, std,
                                         _ptr(mel), _ptr(ws), nb, _stream()))
@@ -890,7 +892,7 @@ class StreamPipelinedSynthesizer:
         ev, out = self.ready
         torch.cuda.current_stream(self.model.device).wait_event(ev)
         f = out.get("cond_factors")
-        for v in (out["cond_ct"], out["speaker_emb"]) + ((f.p1, f.mel2ph, f.p_idx) if f is not None else ()):
+        for v in (out["cond_ct"], out["speaker_emb"]) + ((f.p1, f.p1t, f.mel2ph, f.p_idx) if f is not None else ()):
             if v is not None:
                 v.record_stream(torch.cuda.current_stream(self.model.device))
         self._keep = [out]

@@ -142,6 +142,15 @@ int cmtts_frame_forward(cmtts_model* m, const void* text_ws, int B, int L, int T
 int cmtts_frame_forward_sub(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T,
                             float* cond_ct, int64_t* mel2ph, float* cwt_out, float* f0_denorm, int64_t* p_idx,
                             float* f0_stats, float* cond_p1, void* frame_ws, size_t frame_ws_bytes, void* stream);
+/* cmtts_frame_forward_sub that also returns the phoneme-level factor with the CHANNELS contiguous (round 6):
+ *   cond_p1t fp32 [B, res_layers, p1_ld = L_all rounded up to 4, res_channels] (or NULL; needs cond_p1) — the layout the persistent denoiser's
+ *   factored instances gather from (16-byte loads of four consecutive channels).  Given here it is written on the library's branch
+ *   stream beside the frame-level predictors (a bandwidth-bound copy under MFMA-bound convs); cmtts_sample_factored_t then takes it as it
+ *   is, where cmtts_sample_factored transposes cond_p1 at the sampler's entry, in front of the first evaluation (38 us per call at
+ *   B = 32 x 88 phonemes).  The same values either way: bit-identical mels. */
+int cmtts_frame_forward_sub_t(cmtts_model* m, const void* text_ws, int B_all, int L_all, int b0, int B, int T,
+                              float* cond_ct, int64_t* mel2ph, float* cwt_out, float* f0_denorm, int64_t* p_idx,
+                              float* f0_stats, float* cond_p1, float* cond_p1t, void* frame_ws, size_t frame_ws_bytes, void* stream);
 
 /* ---- length regulator alone (LengthRegulator.forward, model/modules.py:446-448): bit-exact
  * gather x_ct [B,C,L] -> out_ct [B,C,T] given fp32 durations [B,L]; also emits mel2ph and mel_len.
@@ -176,6 +185,11 @@ int cmtts_sample_factored(cmtts_model* m, const float* noise, const float* cond_
                           int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
                           float* mel, void* ws, size_t ws_bytes, void* stream,
                           const float* cond_p1, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx);
+/* ... with cmtts_frame_forward_sub_t's channel-contiguous copy of the factor (cond_p1t NULL = cmtts_sample_factored). */
+int cmtts_sample_factored_t(cmtts_model* m, const float* noise, const float* cond_ct, const float* speaker_emb,
+                            int B, int T, int n_steps, const float* sigmas_host, const float* renoise_std_host,
+                            float* mel, void* ws, size_t ws_bytes, void* stream,
+                            const float* cond_p1, const float* cond_p1t, int p1_ld, int L, const int64_t* mel2ph, const int64_t* p_idx);
 
 /* ---- the same sampler for a RAGGED shard (BASELINE.json configs[3]: variable-length utterances dealt into static frame buckets;
  * new work — the reference synthesizes one padded batch at a time, synthesize.py:195-227).  Every group is one padded (B, T) batch

@@ -793,6 +793,47 @@ def test_attention_qb_bitwise(variant, B, L):
         assert torch.equal(got[k], ref[k]), (k, float((got[k].float() - ref[k].float()).abs().max()))
 
 
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 40), ("LibriTTS", 1, 7)])
+def test_stats_mlp_and_transposed_factor_bitwise(variant, B, L):
+    """Round 6, two launch-count changes on the frame-level half that must not move a bit: (a) cwt_stats_layers (model/modules.py:212-215) as ONE
+    launch (kernels.hip: stats_mlp_kernel — dense_small_kernel<4>'s K slices and sum order) against the three dense_small launches: f0 statistics,
+    pitch buckets and conditioning equal; (b) the conditioner factor's channel-contiguous copy produced by cmtts_frame_forward_sub_t on the branch
+    stream (CondFactors.p1t) against the sampler transposing cond_p1 at its entry (cmtts_sample_factored): the same mel."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=11, dur_frames=6.0, dur_spread=0.0))
+    rs = np.random.RandomState(77 + L)
+    texts = torch.from_numpy(rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64))
+    lens = torch.full((B,), L, dtype=torch.int64)
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    T = 6 * L
+    prev = _lib.internal_set(b"stats_mlp", 0)
+    try:
+        ref = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
+        ref = {"cond_ct": ref["cond_ct"].clone(), "p_idx": ref["p_predictions"]["p_idx"].clone(), "f0_mean": ref["p_predictions"]["f0_mean"].clone(),
+               "f0_std": ref["p_predictions"]["f0_std"].clone()}
+        assert _lib.internal_set(b"stats_mlp", 1) == 0
+        out = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
+    finally:
+        _lib.internal_set(b"stats_mlp", prev)
+    assert torch.equal(out["p_predictions"]["f0_mean"], ref["f0_mean"]) and torch.equal(out["p_predictions"]["f0_std"], ref["f0_std"])
+    assert torch.equal(out["p_predictions"]["p_idx"], ref["p_idx"]) and torch.equal(out["cond_ct"], ref["cond_ct"])
+    fac = out["cond_factors"]
+    assert fac is not None and fac.p1t is not None
+    assert torch.equal(fac.p1t, fac.p1.view(B, cfg.res_layers, cfg.res_channels, fac.p1_ld).transpose(2, 3).contiguous())
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=torch.Generator().manual_seed(4)).to(DEV)
+    spk_emb = out.get("speaker_emb")
+    prev_p = _lib.load().cmtts_set_persistent_denoiser(2)
+    try:
+        mel_t = host.sample_with_cond(model, out["cond_ct"], spk_emb, 2, noise).clone()
+        plain = host.CondFactors(fac.p1, fac.p1_ld, fac.L, fac.mel2ph, fac.p_idx, out["cond_ct"])      # no p1t: the sampler transposes
+        mel_s = host.sample_with_cond(model, out["cond_ct"], spk_emb, 2, noise, factors=plain).clone()
+    finally:
+        _lib.load().cmtts_set_persistent_denoiser(prev_p)
+    host.synchronize()
+    assert torch.isfinite(mel_t).all() and torch.equal(mel_t, mel_s)
+
+
 @pytest.mark.parametrize("B,T", [(3, 96), (2, 77), (32, 512), (1, 5)])
 def test_fused_input_projection_bitwise(B, T):
     """inproj.hip (c_in scaling + [B,T,80] -> [B,80,T] + relu(input_projection) + clearing of the persistent kernel's halo
