@@ -23,6 +23,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// No floating-point contraction in this file: attention_kernel and attention_qb_kernel must round s * scale - max the same way.  Left to the
+// compiler (-ffp-contract=fast-honor-pragmas, HIP's default) the first fused it into one fma where product and difference share a basic block,
+// the second — product before a barrier, difference behind it — could not: 1 ulp apart on every probability (__fmul_rn / __fsub_rn do not
+// stop the fusion: they are plain operators to the optimiser).
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int DH = 128;          // head dimension (hidden 256 / 2 heads)
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * m + acc_row(r, lane);
-                const float v = __fmul_rn(S[m][r], a.scale);      // (explicitly rounded product and difference: left to the compiler, s * scale - max may or may not
-                S[m][r] = v;                                      // become one fma, kernel by kernel — attention_qb_kernel below must produce the same bits)
+                const float v = S[m][r] * a.scale;      // (a rounded product: no contraction in this file, above)
+                S[m][r] = v;
                 if (key < len) mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(64 * NMT) void attention_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * m + acc_row(r, lane);
-                const float e = key < len ? expf(__fsub_rn(S[m][r], mx)) : 0.f;
+                const float e = key < len ? expf(S[m][r] - mx) : 0.f;
                 S[m][r] = e;
                 sum += e;
             }
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void attention_qb_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * w + acc_row(r, lane);
-            const float v = __fmul_rn(S[r], a.scale);
+            const float v = S[r] * a.scale;
             S[r] = v;
             if (key < len) mx = fmaxf(mx, v);
         }
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void attention_qb_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * w + acc_row(r, lane);
-            Es[(w * 16 + r) * 64 + lane] = key < len ? expf(__fsub_rn(S[r], mx)) : 0.f;
+            Es[(w * 16 + r) * 64 + lane] = key < len ? expf(S[r] - mx) : 0.f;
         }
     }
     __syncthreads();

@@ -271,8 +271,8 @@ std::vector<float> to_wino43_xres_fragments(const std::vector<float>& p, int tap
 // kernel is zero) and, for k = 7, of the seventh tap on its own (g, g/2, g/2, g) — formed in double, rounded once — as A fragments of v_mfma_f32_16x16x4_f32 in
 // the kernel's iteration order [K/4 k-steps][M/64 waves][points][64 lanes][4]: element i at lane l = input channel 4 ks + (l >> 4), output row 64 w + 16 i + (l & 15).
 std::vector<float> to_wino43_iter_fragments(const std::vector<float>& p, int taps, int K, int M) {
-    if ((taps != 3 && taps != 7 && taps != 11) || K % 4 || M % 64) return {};
-    const int ngrp = taps == 3 ? 1 : taps == 7 ? 2 : 4, npt = ngrp * 6 + (taps == 7 ? 4 : 0), NWV = M / 64;
+    if ((taps != 3 && taps != 5 && taps != 7 && taps != 11) || K % 4 || M % 64) return {};
+    const int ngrp = taps == 3 ? 1 : taps <= 7 ? 2 : 4, npt = ngrp * 6 + (taps == 7 ? 4 : 0), NWV = M / 64;
     std::vector<float> f((size_t)(K / 4) * NWV * npt * 256);
     for (int ks = 0; ks < K / 4; ++ks)
         for (int w = 0; w < NWV; ++w)
@@ -643,6 +643,7 @@ struct Predictor {
     std::vector<PackedConv> convs;
     std::vector<float*> convs_f;     // 256 -> 256 convs as MFMA A fragments in iteration order (conv_xl_kernel), else null
     std::vector<void*> convs_f16[2]; // bf16 / fp16 fragment-order copies (conv_mfma16.hip; the opt-in "text16"), else null
+    std::vector<float*> convs_q;     // k = 5 convs into 256 rows: F(4,3) transformed weights (conv_k5q.hip: to_wino43_iter_fragments), else null
     std::vector<float*> ln_g, ln_b;
     float *lin_w = nullptr, *lin_b = nullptr, *alpha = nullptr;
     int odim = 0;
@@ -883,6 +884,11 @@ int finalize_model(cmtts_model* m) {
                 P.convs_f.resize(n_layers, nullptr);
                 if ((cin == 256 || (cin == 128 && k == 5)) && c.pred_filter == 256 && P.convs[li].ld == 256)
                     CHK(al.upload(to_fragment_iter_order(hp, k, cin, c.pred_filter), &P.convs_f[li]));
+                P.convs_q.resize(n_layers, nullptr);
+                if (k == 5 && (cin == 256 || cin == 128) && c.pred_filter == 256 && P.convs[li].ld == 256) {
+                    const std::vector<float> wq = to_wino43_iter_fragments(hp, k, cin, c.pred_filter);
+                    if (!wq.empty()) CHK(al.upload(wq, &P.convs_q[li]));
+                }
                 for (int mode = 1; mode <= 2; ++mode) {
                     P.convs_f16[mode - 1].resize(n_layers, nullptr);
                     if (cin % 32 == 0 && c.pred_filter % 32 == 0 && P.convs[li].ld == c.pred_filter) {
@@ -1176,6 +1182,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 // conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
 // block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_internal_set("pred_head", 0)
 // mode16: 0, or the 16-bit operand mode (1 = bf16, 2 = fp16) of a model with the opt-in "text16": the convs on conv_mfma16.hip (bias + ReLU in fp32)
+int g_pred_wino = 1;            // round 6: the frame-level pitch predictor's k = 5 convs as F(4,3) tap groups (conv_k5q.hip; NOT bitwise the direct form: fp32 Winograd rounding), at every launch size
 int g_pred_xres = 1;            // round 4: phoneme-level 256 -> 256 predictor convs on conv_xres (32-column tiles), the previous block's LayerNorm as its prologue (same bits); 0 = generic kernel + LayerNorm launches
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
               const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0) {
@@ -1187,10 +1194,26 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         const PackedConv& w = P.convs[li];
         int rx = -2;
         float* dst = other(cur);
+        // frame-level k = 5 convs (the pitch predictor, round 6): F(4,3) tap groups over frame quads, the pending LayerNorm as the prologue — at
+        // EVERY launch size (conv_k5q.hip splits a tile's rows over workgroups when there are few tiles; the bits do not depend on it)
+        if (!mode16 && g_pred_wino && !ln_lens && li < P.convs_q.size() && P.convs_q[li] && w.taps == 5 && w.cout == 256 &&
+            (pend_ln < 0 || w.cin == 256)) {
+            ConvXlArgs xa;
+            memset(&xa, 0, sizeof(xa));
+            xa.x = cur; xa.y = dst; xa.wf = P.convs_q[li]; xa.bias = w.bias; xa.bstride = (long)w.cout * ld;
+            xa.B = B; xa.C = 256; xa.T = T; xa.ld = ld; xa.k = w.taps; xa.dil = 1; xa.slope = 1.0f; xa.relu = 1;
+            if (w.cin != 256) { xa.cin = w.cin; xa.xbstride = (long)w.cin * ldc; }
+            if (pend_ln >= 0) { xa.ln_g = P.ln_g[pend_ln]; xa.ln_b = P.ln_b[pend_ln]; xa.ln_eps = 1e-12f; }
+            if (ldc == ld || w.cin != 256) {
+                rx = cmtts_launch_conv_k5q(&xa, (void*)s);
+                if (rx == -3) return fail(CMTTS_E_HIP, "conv_k5q launch failed");
+                if (rx == 0) pend_ln = -2;
+            }
+        }
         // phoneme-level 256 -> 256 convs (round 4): X-resident, one 32-column n-tile per wave, the pending LayerNorm (eps 1e-12, length
         // mask) applied to the staged tile.  (Round 2 tried this with 96-column tiles: 64 workgroups of ~45 us — slower; deleted in round 3.)
         const bool small = (long)((T + 63) / 64) * B < 192;
-        if (!mode16 && g_pred_xres && small && P.convs_f[li] && w.cin == 256 && w.cout == 256 && ldc == ld) {
+        if (rx != 0 && !mode16 && g_pred_xres && small && P.convs_f[li] && w.cin == 256 && w.cout == 256 && ldc == ld) {
             ConvArgs a = conv_args(w, cur, T, ldc, (long)w.cin * ldc, dst, ld, (long)w.cout * ld, T);
             a.out[0].act = ACT_RELU;
             a.xres_nt = 1;
@@ -2816,6 +2839,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
+        {"pred_wino", &g_pred_wino, 0, 1},         // pitch predictor's k = 5 convs as F(4,3) tap groups (NOT bitwise the direct form)
         {"stats_mlp", &g_stats_mlp, 0, 1},         // cwt_stats_layers as one launch (same bits)
         {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };

@@ -32,6 +32,11 @@ struct ConvXlArgs {
     int cin;              // input channels when they differ from C (0 = C); x then has its own batch stride:
     long xbstride;
     int wino_force;       // cmtts_launch_conv_xlw: take the Winograd form whatever the launch size (tests: goldens are small)
+    // cmtts_launch_conv_k5q only (conv_k5q.hip, round 6; zero / null elsewhere):
+    const float* ln_g;    // LayerNorm over the 256 input channels of every frame, applied while the tile is staged (null: none)
+    const float* ln_b;
+    float ln_eps;
+    int row_split;        // 0 = the launcher's rule; 1 / 2 / 4 workgroups per frame tile (tests: the result does not depend on it)
 };
 
 // ---- Winograd form of a k-tap (dilated) Conv1d for the fp32 X-resident kernels (round 4; conv_xlw_kernel in resblock_pair.hip, weights packed by
@@ -59,6 +64,8 @@ int cmtts_launch_conv_xlw(const ConvXlArgs* a, void* stream);
 // the dilation-1 conv in its F(4,3) form (conv_xlq.hip; a->wf = to_wino43_iter_fragments of the same weights); -2 = shape not covered (C = 64 / 128 / 256, k = 3 / 7 / 11)
 // or a launch of fewer than 1024 column tiles without a->wino_force
 int cmtts_launch_conv_xlq(const ConvXlArgs* a, void* stream);
+// Conv1d(cin = 128 | 256 -> 256, k = 5) + bias [+ ReLU] as two F(4,3) tap groups, optional LayerNorm prologue (conv_k5q.hip: the frame-level pitch predictor; a->wf = to_wino43_iter_fragments, taps = 5)
+int cmtts_launch_conv_k5q(const ConvXlArgs* a, void* stream);
 // HiFi-GAN upsampler (ConvTranspose1d, kernel 2 s, stride s, padding s / 2), all phases in one X-resident launch (resblock_pair.hip)
 int cmtts_launch_convT(const float* x, float* y, const float* wf, const float* bias, long xbstride, long ybstride, int B, int cin,
                        int co, int Ti, int To, int ldx, int ldy, int s, float pre_div, float slope, void* stream);

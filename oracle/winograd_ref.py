@@ -104,13 +104,13 @@ def conv1d_f43(x, w):
 
 
 # conv_xlq.hip: QTab<k> — per k the entries (kind, tap offset): F(4,3) groups of three taps (a tap beyond the kernel is zero), k = 7's seventh tap alone
-# (k = 9: the FFT blocks' FFN conv, conv_xres.hip WQ instances — three groups)
-F43_TAPS = {3: [("f43", 0)], 7: [("f43", 0), ("f43", 3), ("one", 6)], 9: [("f43", 0), ("f43", 3), ("f43", 6)],
+# (k = 9: the FFT blocks' FFN conv, conv_xres.hip WQ instances — three groups; k = 5: the frame-level pitch predictor, conv_k5q.hip — two groups, the sixth tap zero)
+F43_TAPS = {3: [("f43", 0)], 5: [("f43", 0), ("f43", 3)], 7: [("f43", 0), ("f43", 3), ("one", 6)], 9: [("f43", 0), ("f43", 3), ("f43", 6)],
             11: [("f43", 0), ("f43", 3), ("f43", 6), ("f43", 9)]}
 
 
 def conv1d_f43_taps(x, w):
-    """The k = 3 / 7 / 9 / 11, dilation-1, padding-(k-1)/2 conv through conv_xlq_kernel's (k = 9: conv_xres_kernel<WQ>'s) products (cm-tts_amd/csrc/conv_xlq.hip; weights as
+    """The k = 3 / 5 / 7 / 9 / 11, dilation-1, padding-(k-1)/2 conv through conv_xlq_kernel's (k = 9: conv_xres_kernel<WQ>'s) products (cm-tts_amd/csrc/conv_xlq.hip; weights as
     cmtts_api.hip: to_wino43_iter_fragments forms them): all tap groups into six transform-domain accumulators, one output transform."""
     cout, cin, k = w.shape
     T = x.shape[1]

@@ -2388,6 +2388,94 @@ def test_conv_xlq_kernel_vs_oracle(Cc, k, dil, T, ld):
                 assert np.abs(got[b, :, :T] - own).max() < 3e-5      # (measured 1.3e-5 at C = 256: numpy's and the MFMA's K = 256 sums round differently)
 
 
+@pytest.mark.parametrize("cin,T,ld,B,ln", [(128, 131, 132, 2, False), (256, 200, 203, 2, True), (256, 64, 64, 3, False), (256, 5, 8, 1, True), (128, 513, 516, 2, False),
+                                           (256, 512, 512, 4, True)])
+def test_conv_k5q_kernel_vs_oracle(cin, T, ld, B, ln):
+    """Round 6: conv_k5q_kernel (the frame-level pitch predictor's Conv1d(cin -> 256, k = 5) + bias + ReLU as two F(4,3) tap groups over frame quads,
+    optionally with the previous block's LayerNorm applied to the staged tile) called alone against the oracle: the plain conv in float64 on the
+    float64 LayerNorm (oracle/winograd_ref.py: conv1d_direct) and the restatement of the kernel's own products in fp32 (conv1d_f43_taps, k = 5);
+    ragged quads / tiles, rows that are not 16-byte aligned (scalar epilogue), and every row split (1 / 2 / 4 workgroups per tile) bit for bit."""
+    import ctypes as C
+    from oracle import winograd_ref as W
+    lib = C.CDLL(_lib.LIB_PATH)
+
+    class XlArgs(C.Structure):
+        _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                    ("bstride", C.c_long), ("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("ld", C.c_int), ("k", C.c_int),
+                    ("dil", C.c_int), ("accum", C.c_int), ("slope", C.c_float), ("relu", C.c_int), ("cin", C.c_int), ("xbstride", C.c_long),
+                    ("wino_force", C.c_int), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float), ("row_split", C.c_int)]
+    lib.cmtts_launch_conv_k5q.restype = C.c_int
+    rs = np.random.RandomState(cin + T)
+    x = (rs.standard_normal((B, cin, ld)) * 1.5 + 0.3).astype(np.float32)
+    w = (rs.standard_normal((256, cin, 5)) / np.sqrt(cin * 5)).astype(np.float32)
+    bias = rs.standard_normal(256).astype(np.float32)
+    g = (1.0 + 0.1 * rs.standard_normal(256)).astype(np.float32)
+    be = (0.1 * rs.standard_normal(256)).astype(np.float32)
+    xd, bd, gd, bed = (torch.from_numpy(v).to(DEV) for v in (x, bias, g, be))
+    wf = torch.from_numpy(_pack_wino43(w)).to(DEV)
+    y0 = rs.standard_normal((B, 256, ld)).astype(np.float32)
+    outs = []
+    for split in (0, 1, 2, 4):
+        yd = torch.from_numpy(y0).to(DEV)
+        a = XlArgs(xd.data_ptr(), yd.data_ptr(), wf.data_ptr(), bd.data_ptr(), None, 256 * ld, B, 256, T, ld, 5, 1, 0, 1.0, 1, 0 if cin == 256 else cin, cin * ld,
+                   1, gd.data_ptr() if ln else None, bed.data_ptr() if ln else None, 1e-12, split)
+        assert lib.cmtts_launch_conv_k5q(C.byref(a), None) == 0
+        torch.cuda.synchronize()
+        outs.append(yd.cpu().numpy())
+    got = outs[0]
+    for o in outs[1:]:
+        assert np.array_equal(o, got)                                       # the row split never changes a bit
+    assert np.array_equal(got[:, :, T:], y0[:, :, T:])                      # nothing written beyond T
+    for b in range(B):
+        xin64 = x[b, :, :T].astype(np.float64)
+        xin32 = x[b, :, :T]
+        if ln:
+            mu, var = xin64.mean(0), xin64.var(0)
+            xin64 = (xin64 - mu) / np.sqrt(var + 1e-12) * g[:, None] + be[:, None]
+            xin32 = xin64.astype(np.float32)
+        ref = np.maximum(W.conv1d_direct(xin64, w.astype(np.float64), 1) + bias[:, None], 0.0)
+        err = np.abs(got[b, :, :T] - ref).max()
+        assert err < 2e-5, (b, err)
+        own = np.maximum(W.conv1d_f43_taps(xin32, w) + bias[:, None], 0.0)
+        assert np.abs(got[b, :, :T] - own).max() < 3e-5
+
+
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 1, 25), ("LibriTTS", 3, 40)])
+def test_pitch_predictor_winograd(variant, B, L):
+    """Round 6: the frame-level pitch predictor with its k = 5 convs as F(4,3) tap groups (conv_k5q.hip, the default at every batch size) against
+    the direct form (pred_wino = 0: conv_xl / conv_xres / generic kernels): cwt output within fp32 Winograd rounding, durations and mel2ph
+    untouched (they are upstream), pitch buckets equal on these batches; an utterance alone gets the bits it has inside the batch."""
+    host = _host()
+    cfg = get_config(variant)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=13, dur_frames=6.0, dur_spread=0.0))
+    rs = np.random.RandomState(500 + L)
+    texts = torch.from_numpy(rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64))
+    lens = torch.full((B,), L, dtype=torch.int64)
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    T = 6 * L
+    prev = _lib.internal_set(b"pred_wino", 0)
+    try:
+        ref = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
+        ref = {"cwt": ref["p_predictions"]["cwt"].clone(), "p_idx": ref["p_predictions"]["p_idx"].clone(), "mel2ph": ref["mel2ph"].clone(),
+               "cond_ct": ref["cond_ct"].clone()}
+        assert _lib.internal_set(b"pred_wino", 1) == 0
+        out = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
+        one = model.duration_pitch_energy_net(None, texts[B - 1:], lens[B - 1:], spker_embeds=None if spk is None else spk[B - 1:], max_mel_len=T)
+        torch.cuda.synchronize()
+    finally:
+        _lib.internal_set(b"pred_wino", prev)
+    d = float((out["p_predictions"]["cwt"] - ref["cwt"]).abs().max())
+    scale = float(ref["cwt"].abs().max())
+    flips = int((out["p_predictions"]["p_idx"] != ref["p_idx"]).sum())
+    report(f"PRED_WINO {variant} B={B} L={L}: max|d cwt| {d:.2e} on |cwt| <= {scale:.2f}; pitch-bucket flips vs the direct form {flips} of {ref['p_idx'].numel()}")
+    assert 0 < d < 2e-5 * max(1.0, scale)
+    assert torch.equal(out["mel2ph"], ref["mel2ph"])
+    assert flips == 0
+    assert torch.equal(out["cond_ct"], ref["cond_ct"])
+    assert torch.equal(one["p_predictions"]["cwt"][0], out["p_predictions"]["cwt"][B - 1])      # one form at every batch size
+    assert torch.equal(one["cond_ct"][0], out["cond_ct"][B - 1])
+
+
 @pytest.mark.parametrize("layers", [1, 2, 3])
 def test_persistent_stack_few_layers(layers):
     """The persistent stacks with one, two and three residual layers — the first layer is then (also) the last one: no publish phase, only the

@@ -62,7 +62,7 @@ def test_f43_fp32_error_and_its_growth_with_the_input_scale():
         assert e_43 < 3e-5 * scale
 
 
-@pytest.mark.parametrize("k", [3, 7, 9, 11])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
 def test_f43_tap_groups_equal_direct_conv(k):
     """conv_xlq_kernel's products (HiFi-GAN dilation-1 convs, round 5; k = 9: the FFT blocks' FFN conv in conv_xres.hip): F(4,3) groups of three taps
     + k = 7's single tap + k = 11's zero twelfth tap, all into six accumulators, reproduce the k-tap conv — exactly in float64 at ragged lengths, to fp32 rounding in float32."""
