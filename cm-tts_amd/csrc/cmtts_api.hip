@@ -1185,7 +1185,7 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 int g_pred_wino = 1;            // round 6: the frame-level pitch predictor's k = 5 convs as F(4,3) tap groups (conv_k5q.hip; NOT bitwise the direct form: fp32 Winograd rounding), at every launch size
 int g_pred_xres = 1;            // round 4: phoneme-level 256 -> 256 predictor convs on conv_xres (32-column tiles), the previous block's LayerNorm as its prologue (same bits); 0 = generic kernel + LayerNorm launches
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
-              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0) {
+              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0, bool frame_level = false) {
     const float* cur = in;
     int ldc = ld_in;
     auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
@@ -1195,8 +1195,9 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         int rx = -2;
         float* dst = other(cur);
         // frame-level k = 5 convs (the pitch predictor, round 6): F(4,3) tap groups over frame quads, the pending LayerNorm as the prologue — at
-        // EVERY launch size (conv_k5q.hip splits a tile's rows over workgroups when there are few tiles; the bits do not depend on it)
-        if (!mode16 && g_pred_wino && !ln_lens && li < P.convs_q.size() && P.convs_q[li] && w.taps == 5 && w.cout == 256 &&
+        // EVERY launch size (conv_k5q.hip splits a tile's rows over workgroups when there are few tiles; the bits do not depend on it).  Only the
+        // frame-level predictor: the phoneme-level energy predictor (k = 5 too) feeds a bucketize, has 1/6 of the columns and stays in the direct form
+        if (frame_level && !mode16 && g_pred_wino && !ln_lens && li < P.convs_q.size() && P.convs_q[li] && w.taps == 5 && w.cout == 256 &&
             (pend_ln < 0 || w.cin == 256)) {
             ConvXlArgs xa;
             memset(&xa, 0, sizeof(xa));
@@ -1981,7 +1982,7 @@ int cmtts_frame_forward_sub_t(cmtts_model* m, const void* text_ws, int B_all, in
         CHK(launch(a, EPI_PLAIN, B, s));
     }
     if (!hp_done) k_pos_embed_add(w.h128, w.hp, m->cwt.alpha, m->omega_cwt, m->pe_cwt, PE_ROWS, B, CH, T, T, s);
-    CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s, (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0));
+    CHK(predictor(m->cwt, w.hp, T, B, T, T, nullptr, nullptr, w.c1, w.c2, cwt_out, O, s, (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0, true));
     if (ss) CHK(branch_join(ss));
     if (m->vc.p_control != 1.0f) k_scale(cwt_out, cwt_out, (long)B * T * O, m->vc.p_control, s);   // :270
     if (m->vc.cwt_spec) {   // teacher-forced pitch: target spectrogram, statistics and uv (:379-390)

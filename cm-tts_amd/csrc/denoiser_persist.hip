@@ -840,37 +840,41 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                 int phj[NT], ixj[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) { phj[j] = idx_lds[2 * (1 + j * 32 + c31)]; ixj[j] = idx_lds[2 * (1 + j * 32 + c31) + 1]; }
+                // Round 6: the same 34 loads as compiler-VISIBLE buffer loads (one descriptor per table, the lane's byte offset in a
+                // VGPR, the run's offset an immediate) instead of one `asm volatile` per load with a hand-written s_waitcnt behind them: the compiler
+                // knew nothing of those loads' latency and was free to copy or spill their destination registers before the wait.  A buffer load
+                // needs no address arithmetic (what had serialised the plain-pointer form at 253 registers), and the compiler places the waits.
+                // Same loads of the same values, the same adds => the same bits (tests: test_cond_factored, FACT == expanded factors bitwise).
+                const __amdgpu_buffer_rsrc_t r1t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1tl), 0, ldp * C * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r2t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2tl), 0, a.ld2 * C * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1l), 0, C * ldp * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2l), 0, C * a.ld2 * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpn), 0, C * 4, 0x00020000);
                 f32x4 g1[NT][4], g2[NT][4];
-                unsigned h1 = (unsigned)(hm * ldp + (hph > 0 ? hph - 1 : 0)) * 4u, h2 = (unsigned)(hm * a.ld2 + hix) * 4u;
-                asm volatile("global_load_dword %0, %0, %1" : "+v"(h1) : "s"(p1l) : "memory");
-                asm volatile("global_load_dword %0, %0, %1" : "+v"(h2) : "s"(p2l) : "memory");
+                const float h1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)((unsigned)(hm * ldp + (hph > 0 ? hph - 1 : 0)) * 4u), 0, 0));
+                const float h2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (int)((unsigned)(hm * a.ld2 + hix) * 4u), 0, 0));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const unsigned o1 = (unsigned)((phj[j] > 0 ? phj[j] - 1 : 0) * C + mrow0 + 4 * (ln >> 5)) * 4u;
-                    const unsigned o2 = (unsigned)(ixj[j] * C + mrow0 + 4 * (ln >> 5)) * 4u;
+                    const int o1 = (int)((unsigned)((phj[j] > 0 ? phj[j] - 1 : 0) * C + mrow0 + 4 * (ln >> 5)) * 4u);
+                    const int o2 = (int)((unsigned)(ixj[j] * C + mrow0 + 4 * (ln >> 5)) * 4u);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {      // rows 8 q + 4 khalf + {0, 1, 2, 3} = accumulator registers 4 q .. 4 q + 3
-                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(g1[j][q]) : "v"(o1), "s"(p1tl), "n"(q * 32) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(g2[j][q]) : "v"(o2), "s"(p2tl), "n"(q * 32) : "memory");
+                        g1[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1t, o1 + q * 32, 0, 0));
+                        g2[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2t, o2 + q * 32, 0, 0));
                     }
                 }
                 {
-                    const unsigned od = (unsigned)(mrow0 + 4 * (ln >> 5)) * 4u;
+                    const int od = (int)((unsigned)(mrow0 + 4 * (ln >> 5)) * 4u);
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=&v"(dpr[r]) : "v"(od), "s"(dpn), "n"(((r & 3) + 8 * (r >> 2)) * 4) : "memory");
+                        dpr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, od + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 pstamp(l, 2);
-                asm volatile("" : "+v"(h1), "+v"(h2));
-                hcp = (hph > 0 ? __uint_as_float(h1) : 0.f) + __uint_as_float(h2);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(dpr[r]));
+                hcp = (hph > 0 ? h1 : 0.f) + h2;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        asm volatile("" : "+v"(g1[j][q]), "+v"(g2[j][q]));      // not before the wait
 #pragma unroll
                         for (int e = 0; e < 4; ++e) cpc[j][4 * q + e] = (phj[j] > 0 ? g1[j][q][e] : 0.f) + g2[j][q][e];
                     }
