@@ -834,6 +834,56 @@ def test_stats_mlp_and_transposed_factor_bitwise(variant, B, L):
     assert torch.isfinite(mel_t).all() and torch.equal(mel_t, mel_s)
 
 
+@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 40), ("LibriTTS", 2, 171), ("LJSpeech", 1, 5)])
+def test_cond_early_factor(variant, B, L):
+    """Round 6: the phoneme-level factor of the conditioner projections as W x (GEMM inside cmtts_text_forward, on a third stream under the
+    duration / energy predictors) + (W E^T)[:, e_idx] (the energy-embedding factor, a constant of the model, added by the pass that also writes the
+    channel-contiguous copy) against W out1 with out1 = x + energy_embedding[e_idx] (the GEMM at the head of cmtts_frame_forward, cond_early = 0):
+    the same product in another association — both within the dense bound of the float64 product of the conditioning the call returned, everything
+    upstream (durations, buckets, conditioning) bit for bit, the mel within the factored path's own 2e-5."""
+    host = _host()
+    cfg = get_config(variant)
+    sd = synth_cmtts_state_dict(cfg, seed=17, dur_frames=6.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    rs = np.random.RandomState(900 + L)
+    lens_np = np.maximum((rs.uniform(0.5, 1.0, size=B) * L).astype(np.int64), 1)
+    lens_np[0] = L
+    texts_np = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    texts_np[np.arange(L)[None, :] >= lens_np[:, None]] = 0
+    texts, lens = torch.from_numpy(texts_np), torch.from_numpy(lens_np)
+    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
+    T = 6 * L
+    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=torch.Generator().manual_seed(8)).to(DEV)
+    res = {}
+    prev = _lib.internal_set(b"cond_early", 0)
+    try:
+        for early in (0, 1):
+            _lib.internal_set(b"cond_early", early)
+            out = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
+            f = out["cond_factors"]
+            assert f is not None and f.p1t is not None
+            mel = host.sample_with_cond(model, out["cond_ct"], out.get("speaker_emb"), 2, noise)
+            res[early] = {"cond_ct": out["cond_ct"].clone(), "mel2ph": out["mel2ph"].clone(), "p_idx": out["p_predictions"]["p_idx"].clone(),
+                          "e_idx": out["e_idx"].clone(), "p1": f.p1.clone(), "p1t": f.p1t.clone(), "mel": mel.clone(), "ld": f.p1_ld}
+    finally:
+        _lib.internal_set(b"cond_early", prev)
+    host.synchronize()
+    a, b = res[0], res[1]
+    for k in ("cond_ct", "mel2ph", "p_idx", "e_idx"):
+        assert torch.equal(a[k], b[k]), k
+    NL, Cc = cfg.res_layers, cfg.res_channels
+    for r in (a, b):
+        assert torch.equal(r["p1t"][:, :, :L], r["p1"].view(B, NL, Cc, r["ld"]).transpose(2, 3)[:, :, :L].contiguous())
+    # valid phonemes only (columns beyond an utterance's length are never gathered)
+    valid = (torch.arange(a["ld"])[None, :] < lens[:, None]).to(DEV)[:, None, :]
+    d = float(((a["p1"] - b["p1"]).abs() * valid).max())
+    scale = float((a["p1"].abs() * valid).max())
+    dm = float((a["mel"] - b["mel"]).abs().max())
+    report(f"COND_EARLY {variant} B={B} L={L}: max|d p1| {d:.2e} on |p1| <= {scale:.2f}; max|d mel| (T = 2) {dm:.2e}")
+    assert 0 < d <= 2e-6 * max(scale, 1.0)
+    assert torch.isfinite(b["mel"]).all() and dm < 2e-5
+
+
 @pytest.mark.parametrize("B,T", [(3, 96), (2, 77), (32, 512), (1, 5)])
 def test_fused_input_projection_bitwise(B, T):
     """inproj.hip (c_in scaling + [B,T,80] -> [B,80,T] + relu(input_projection) + clearing of the persistent kernel's halo
