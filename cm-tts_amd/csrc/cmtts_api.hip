@@ -692,10 +692,6 @@ struct cmtts_model {
     // computed once at cmtts_finalize with cond_gemm_kernel itself; a zero bias vector for the phoneme-level factor
     float* cond_p2 = nullptr;
     float* cond_p2t = nullptr;             // [NL][pitch_bins][C]: cond_p2 with the channels contiguous (PersistArgs.p2t)
-    float* cond_pe = nullptr;              // [NL * C][energy_bins]: the energy-embedding factor W E^T of the phoneme-level factor (round 6: W out1 = W x + (W E^T)[:, e_idx])
-    // cmtts_text_forward ran the phoneme-level GEMM on x (before the energy embedding) into this workspace: cmtts_frame_forward_sub_t finishes it
-    const void* early_ws = nullptr;
-    int early_B = 0, early_L = 0;
     float* cond_zero_bias = nullptr;
     void* cond_all_f16[3] = {nullptr, nullptr, nullptr};   // bf16 / fp16 / fp16x3 (hi | lo) fragment-order copies (cond_gemm16.hip)
     float *mlp0_wt = nullptr, *mlp2_wt = nullptr, *dproj_wt = nullptr, *sproj_wt = nullptr;
@@ -1075,21 +1071,6 @@ int finalize_model(cmtts_model* m) {
             HIPCHK(hipStreamSynchronize(nullptr));
             m->cond_p2 = (float*)p2;
             m->cond_p2t = (float*)p2t;
-            // the energy-embedding factor: the same stacked GEMM on energy_embedding^T [H][energy_bins], no bias
-            if (m->energy_emb && c.energy_bins > 0) {
-                GET(ee2, va + "energy_embedding.weight", c.energy_bins, H);
-                float* eeT = nullptr;
-                void* pe = nullptr;
-                CHK(al.upload(transpose2d(ee2->data.data(), c.energy_bins, H), &eeT));
-                HIPCHK(hipMalloc(&pe, (size_t)NL * C * c.energy_bins * sizeof(float) + 256));
-                al.ptrs.push_back(pe);
-                CondGemmArgs ge = ga;
-                ge.X = eeT; ge.bias = m->cond_zero_bias; ge.Y = (float*)pe; ge.T = c.energy_bins;
-                if (cmtts_launch_cond_gemm(&ge, nullptr) == 0) {
-                    HIPCHK(hipStreamSynchronize(nullptr));
-                    m->cond_pe = (float*)pe;
-                }
-            }
         }
     }
 #undef GET
@@ -1106,12 +1087,12 @@ int finalize_model(cmtts_model* m) {
 // batch's values still do not depend on its size.
 constexpr int FFN2_SEG = 8;
 struct TextWs {
-    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *h128, *logd, *dround, *epred, *p1x;
+    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *h128, *logd, *dround, *epred;
     int* cum;
     int64_t *eidx, *mlen;
     size_t bytes;
 };
-TextWs carve_text(const cmtts_config& c, int B, int L, void* base, bool early = false) {      // early: + the conditioner factor's GEMM on x (models with cond_pe)
+TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
     const int Lp = round_up(L, 4), H = c.hidden;
     Carver cv(base);
     TextWs w;
@@ -1136,7 +1117,6 @@ TextWs carve_text(const cmtts_config& c, int B, int L, void* base, bool early = 
     w.epred = cv.take<float>((size_t)B * L);
     w.eidx = cv.take<int64_t>((size_t)B * L);
     w.mlen = cv.take<int64_t>((size_t)B);
-    w.p1x = early ? cv.take<float>((size_t)B * c.res_layers * c.res_channels * Lp) : nullptr;      // behind everything else: the other offsets do not depend on it
     w.bytes = cv.off + 256;
     return w;
 }
@@ -1333,7 +1313,6 @@ struct CondFactors {
     const int64_t* p_idx = nullptr;  // [B][T]
     bool usable(const cmtts_model* m) const;
 };
-int g_cond_early = 1;           // round 6: internal switch "cond_early": the phoneme-level conditioner GEMM on x inside cmtts_text_forward (+ the energy factor in cmtts_frame_forward); 0 = the GEMM on out1 in cmtts_frame_forward (NOT bitwise: W x + W e against W (x + e))
 int g_cond_factored = 1;        // internal switch "cond_factored": 0 = always the dense GEMM
 int g_cond_inkernel = 1;        // internal switch "cond_inkernel": the fp32 persistent kernel gathers the factors itself (FACT instances: no cp tensor, the
                                 // same bits as cond_expand_kernel + the plain instance); 0 = expand into cp first
@@ -1630,7 +1609,7 @@ void cmtts_destroy(cmtts_model* m) {
     delete m;
 }
 
-size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L) { return carve_text(m->cfg, B, L, nullptr, m->cond_pe != nullptr).bytes; }
+size_t cmtts_text_workspace_bytes(const cmtts_model* m, int B, int L) { return carve_text(m->cfg, B, L, nullptr).bytes; }
 size_t cmtts_frame_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_frame(m->cfg, B, T, nullptr).bytes; }
 size_t cmtts_denoiser_workspace_bytes(const cmtts_model* m, int B, int T) { return carve_den(m->cfg, B, T, nullptr).bytes; }
 
@@ -1864,7 +1843,7 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     const cmtts_config& c = m->cfg;
     if (c.multi_speaker && c.n_speaker > 0 && !speakers) return fail(CMTTS_E_INVALID, "speakers (ids into the speaker_emb table) are required (model/cmtts.py:78)");
     if (c.multi_speaker && c.n_speaker <= 0 && !spker_embeds) return fail(CMTTS_E_INVALID, "Speaker embedding should not be None (model/cmtts.py:80)");
-    TextWs w = carve_text(c, B, L, text_ws, m->cond_pe != nullptr);
+    TextWs w = carve_text(c, B, L, text_ws);
     if (text_ws_bytes < w.bytes) return fail(CMTTS_E_WORKSPACE, "text workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int H = c.hidden, Lp = round_up(L, 4);
@@ -1872,8 +1851,7 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     if (!d_rounded) d_rounded = w.dround;
     if (!mel_len) mel_len = w.mlen;
     if (!e_pred) e_pred = w.epred;
-    int64_t* e_idx_user = e_idx;      // (the bucket indices always land in the workspace: cmtts_frame_forward_sub_t reads them; a caller's buffer gets a copy)
-    e_idx = w.eidx;
+    if (!e_idx) e_idx = w.eidx;
 
     k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
     CHK(fft_stack(m, m->enc, w, src_lens, B, L, s, pad_lens));
@@ -1890,21 +1868,6 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     // The duration and the energy predictor both read x and nothing of each other: the energy branch runs on the side
     // stream with its own scratch (the encoder's q/k buffer is free by now)
     SideStream* ss = side_for(s);
-    // Round 6: the phoneme-level factor of the conditioner projections, W out1 for all residual layers (7.4 GFLOP at 32 x 88 phonemes), ran at the
-    // head of cmtts_frame_forward beside the frame-level k = 5 convs — two MFMA-bound jobs sharing the matrix pipes for ~90 us of the critical
-    // path.  out1 = x + energy_embedding[e_idx] (model/modules.py:358-363), so W out1 = W x + (W E^T)[:, e_idx]: the GEMM on x starts HERE, on a
-    // third stream, under the duration / energy predictors (latency-bound launches of 10 us of MFMAs each), and cmtts_frame_forward_sub_t adds
-    // the energy factor (a constant of the model, cmtts_finalize) in the pass that also writes the channel-contiguous copy.  fp32 rounding
-    // differs from W (x + e) at the 1e-7 level, like the pitch-table factor's (tests/test_gpu_parity.py::test_cond_factored).
-    m->early_ws = nullptr;
-    bool early = false;
-    if (ss && w.p1x && g_cond_early && g_cond_factored && m->precision == 0 && m->cond_p2 && m->cond_pe && g_fused_resblock && side2_ready(ss)) {
-        HIPCHK(hipEventRecord(ss->done0, s));
-        HIPCHK(hipStreamWaitEvent(ss->side2, ss->done0, 0));
-        CHK(cond_phoneme_factor(m, w.x, B, Lp, w.p1x, ss->side2));
-        HIPCHK(hipEventRecord(ss->join2, ss->side2));
-        early = true;
-    }
     hipStream_t se = ss ? ss->side : s;
     float* ec1 = ss ? w.qk : w.c1;
     float* ec2 = ss ? w.qk + (size_t)B * H * Lp : w.c2;
@@ -1932,7 +1895,6 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
         }
         if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
     }
-    if (e_idx_user) HIPCHK(hipMemcpyAsync(e_idx_user, w.eidx, (size_t)B * L * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
         HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
     if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
@@ -1940,10 +1902,6 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
         k_cumsum_durations(m->vc.d_target, w.cum, mel_len, B, L, s);
     } else {
         k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
-    }
-    if (early) {      // the workspace is complete when `stream` says so
-        HIPCHK(hipStreamWaitEvent(s, ss->join2, 0));
-        m->early_ws = text_ws; m->early_B = B; m->early_L = L;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1977,7 +1935,7 @@ int cmtts_frame_forward_sub_t(cmtts_model* m, const void* text_ws, int B_all, in
         return fail(CMTTS_E_INVALID, "cmtts_frame_forward: bad argument");
     const cmtts_config& c = m->cfg;
     const int L = L_all;
-    TextWs tw = carve_text(c, B_all, L_all, const_cast<void*>(text_ws), m->cond_pe != nullptr);
+    TextWs tw = carve_text(c, B_all, L_all, const_cast<void*>(text_ws));
     tw.out1 += (size_t)b0 * c.hidden * round_up(L_all, 4);
     tw.h128 += (size_t)b0 * c.cwt_hidden * round_up(L_all, 4);
     tw.cum += (size_t)b0 * L_all;
@@ -2002,14 +1960,8 @@ int cmtts_frame_forward_sub_t(cmtts_model* m, const void* text_ws, int B_all, in
     // CondFactors::usable() is false for it and the sampler takes the dense GEMM, as it did before the factors existed)
     if (cond_p1t && !cond_p1) return fail(CMTTS_E_INVALID, "cmtts_frame_forward_sub_t: cond_p1t needs cond_p1");
     if (cond_p1 && m->cond_p2) {
-        if (g_cond_early && m->early_ws == text_ws && m->early_B == B_all && m->early_L == L_all && tw.p1x && m->cond_pe) {
-            // cmtts_text_forward left W x in the workspace: + (W E^T)[:, e_idx], row-major and channel-contiguous in one pass
-            const int M = c.res_layers * c.res_channels;
-            k_cond_p1_finish(tw.p1x + (size_t)b0 * M * Lp, m->cond_pe, tw.eidx + (size_t)b0 * L_all, cond_p1, cond_p1t, B, M, Lp, L_all, c.res_channels, c.energy_bins, sst);
-        } else {
-            CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
-            if (cond_p1t) k_transpose(cond_p1, cond_p1t, B * c.res_layers, c.res_channels, Lp, sst);      // [B NL][C][Lp] -> [B NL][Lp][C]
-        }
+        CHK(cond_phoneme_factor(m, tw.out1, B, Lp, cond_p1, sst));
+        if (cond_p1t) k_transpose(cond_p1, cond_p1t, B * c.res_layers, c.res_channels, Lp, sst);      // [B NL][C][Lp] -> [B NL][Lp][C]
     }
     if (!(g_stats_mlp && k_stats_mlp(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, m->st2_wt, m->st2_b, m->st4_wt, m->st4_b, f0_stats, B, H, CH, CH, 2, sst))) {
         k_dense_small(tw.out1, (long)H * Lp, Lp, m->st0_wt, m->st0_b, nullptr, w.s1, B, H, CH, DENSE_RELU, sst);
@@ -2862,7 +2814,6 @@ int cmtts_internal_set(const char* name, int value) {
         {"pred_xres", &g_pred_xres, 0, 1},         // phoneme-level predictor convs on conv_xres with the LayerNorm prologue
         {"xres_small", &g_xres_small, 0, 1},       // FFT blocks of small batches on conv_xres with 32-column tiles
         {"cond_inkernel", &g_cond_inkernel, 0, 1}, // fp32 persistent denoiser gathers the conditioner factors itself (same bits as expanding them into cp first)
-        {"cond_early", &g_cond_early, 0, 1},       // phoneme-level conditioner GEMM on x under the predictors + energy factor (NOT bitwise the GEMM on out1)
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported

@@ -63,8 +63,6 @@ void k_conv_post(const float* x, const float* w, const float* bias, float pre_di
                  int C, int T, int ld, int KW, hipStream_t s);
 void k_wav_to_int16(const float* wav, int16_t* pcm, long n, float max_wav, hipStream_t s);
 void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t s);    // mask[b][t] = t >= lens[b]
-// p1 = p1x + pe[:, e_idx] ([B][M][Lp]; M % 32 == 0, C % 32 == 0) and, when p1t != null, its channel-contiguous copy [B][M / C][Lp][C]
-void k_cond_p1_finish(const float* p1x, const float* pe, const int64_t* e_idx, float* p1, float* p1t, int B, int M, int Lp, int L, int C, int EB, hipStream_t s);
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s);   // [B][R][Cn] -> [B][Cn][R]
 void k_fill_lens(int64_t* lens, int64_t v, int B, hipStream_t s);
 void k_gather_rows(const float* table, const int64_t* idx, float* out, int B, int C, int n_rows, hipStream_t s);

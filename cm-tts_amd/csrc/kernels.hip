@@ -955,42 +955,6 @@ __global__ void length_mask_kernel(const int64_t* __restrict__ lens, uint8_t* __
 void k_length_mask(const int64_t* lens, uint8_t* mask, int B, int W, hipStream_t s) {
     hipLaunchKernelGGL(length_mask_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, s, lens, mask, B, W);
 }
-// ---- the phoneme-level factor of the conditioner projections from its two halves (round 6; cmtts_api.hip: cmtts_frame_forward_sub_t):
-//   p1[b][r][l] = p1x[b][r][l] + pe[r][e_idx[b][l]]        (W out1 = W x + (W E^T)[:, e_idx] since out1 = x + energy_embedding[e_idx], model/modules.py:358-363)
-// written row-major [B][M][Lp] and — optionally — with the channels contiguous, p1t [B][M / C][Lp][C] (what the persistent denoiser gathers from):
-// one pass where the GEMM over out1 and a transpose ran.  Tile = 32 rows x 32 phonemes through LDS; reads along l, writes along l / along c.
-__global__ __launch_bounds__(256) void cond_p1_finish_kernel(const float* __restrict__ p1x, const float* __restrict__ pe, const int64_t* __restrict__ e_idx,
-                                                             float* __restrict__ p1, float* __restrict__ p1t, int M, int Lp, int L, int C, int EB) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int l0 = blockIdx.x * 32, r0 = blockIdx.y * 32, b = blockIdx.z;
-    const int l = l0 + tx;
-    long e = 0;
-    if (l < L) { e = e_idx[(long)b * L + l]; e = e < 0 ? 0 : (e >= EB ? EB - 1 : e); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty + 8 * i;
-        float v = 0.f;
-        if (l < Lp) {
-            const long o = ((long)b * M + r) * Lp + l;
-            v = p1x[o];
-            if (l < L) v += pe[(long)r * EB + e];
-            p1[o] = v;
-        }
-        tile[ty + 8 * i][tx] = v;
-    }
-    if (!p1t) return;
-    __syncthreads();
-    const int layer = r0 / C, c = r0 - layer * C + tx;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ll = l0 + ty + 8 * i;
-        if (ll < Lp) p1t[(((long)b * (M / C) + layer) * Lp + ll) * C + c] = tile[tx][ty + 8 * i];
-    }
-}
-void k_cond_p1_finish(const float* p1x, const float* pe, const int64_t* e_idx, float* p1, float* p1t, int B, int M, int Lp, int L, int C, int EB, hipStream_t s) {
-    hipLaunchKernelGGL(cond_p1_finish_kernel, dim3(cdiv(Lp, 32), M / 32, B), dim3(256), 0, s, p1x, pe, e_idx, p1, p1t, M, Lp, L, C, EB);
-}
 void k_transpose(const float* in, float* out, int B, int R, int Cn, hipStream_t s) {
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cn, 32), cdiv(R, 32), B), dim3(256), 0, s, in, out, R, Cn);
 }

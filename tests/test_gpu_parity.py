@@ -834,56 +834,6 @@ def test_stats_mlp_and_transposed_factor_bitwise(variant, B, L):
     assert torch.isfinite(mel_t).all() and torch.equal(mel_t, mel_s)
 
 
-@pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 3, 40), ("LibriTTS", 2, 171), ("LJSpeech", 1, 5)])
-def test_cond_early_factor(variant, B, L):
-    """Round 6: the phoneme-level factor of the conditioner projections as W x (GEMM inside cmtts_text_forward, on a third stream under the
-    duration / energy predictors) + (W E^T)[:, e_idx] (the energy-embedding factor, a constant of the model, added by the pass that also writes the
-    channel-contiguous copy) against W out1 with out1 = x + energy_embedding[e_idx] (the GEMM at the head of cmtts_frame_forward, cond_early = 0):
-    the same product in another association — both within the dense bound of the float64 product of the conditioning the call returned, everything
-    upstream (durations, buckets, conditioning) bit for bit, the mel within the factored path's own 2e-5."""
-    host = _host()
-    cfg = get_config(variant)
-    sd = synth_cmtts_state_dict(cfg, seed=17, dur_frames=6.0, dur_spread=0.0)
-    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
-    rs = np.random.RandomState(900 + L)
-    lens_np = np.maximum((rs.uniform(0.5, 1.0, size=B) * L).astype(np.int64), 1)
-    lens_np[0] = L
-    texts_np = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
-    texts_np[np.arange(L)[None, :] >= lens_np[:, None]] = 0
-    texts, lens = torch.from_numpy(texts_np), torch.from_numpy(lens_np)
-    spk = torch.from_numpy(rs.standard_normal(size=(B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
-    T = 6 * L
-    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=torch.Generator().manual_seed(8)).to(DEV)
-    res = {}
-    prev = _lib.internal_set(b"cond_early", 0)
-    try:
-        for early in (0, 1):
-            _lib.internal_set(b"cond_early", early)
-            out = model.duration_pitch_energy_net(None, texts, lens, spker_embeds=spk, max_mel_len=T)
-            f = out["cond_factors"]
-            assert f is not None and f.p1t is not None
-            mel = host.sample_with_cond(model, out["cond_ct"], out.get("speaker_emb"), 2, noise)
-            res[early] = {"cond_ct": out["cond_ct"].clone(), "mel2ph": out["mel2ph"].clone(), "p_idx": out["p_predictions"]["p_idx"].clone(),
-                          "e_idx": out["e_idx"].clone(), "p1": f.p1.clone(), "p1t": f.p1t.clone(), "mel": mel.clone(), "ld": f.p1_ld}
-    finally:
-        _lib.internal_set(b"cond_early", prev)
-    host.synchronize()
-    a, b = res[0], res[1]
-    for k in ("cond_ct", "mel2ph", "p_idx", "e_idx"):
-        assert torch.equal(a[k], b[k]), k
-    NL, Cc = cfg.res_layers, cfg.res_channels
-    for r in (a, b):
-        assert torch.equal(r["p1t"][:, :, :L], r["p1"].view(B, NL, Cc, r["ld"]).transpose(2, 3)[:, :, :L].contiguous())
-    # valid phonemes only (columns beyond an utterance's length are never gathered)
-    valid = (torch.arange(a["ld"])[None, :] < lens[:, None]).to(DEV)[:, None, :]
-    d = float(((a["p1"] - b["p1"]).abs() * valid).max())
-    scale = float((a["p1"].abs() * valid).max())
-    dm = float((a["mel"] - b["mel"]).abs().max())
-    report(f"COND_EARLY {variant} B={B} L={L}: max|d p1| {d:.2e} on |p1| <= {scale:.2f}; max|d mel| (T = 2) {dm:.2e}")
-    assert 0 < d <= 2e-6 * max(scale, 1.0)
-    assert torch.isfinite(b["mel"]).all() and dm < 2e-5
-
-
 @pytest.mark.parametrize("B,T", [(3, 96), (2, 77), (32, 512), (1, 5)])
 def test_fused_input_projection_bitwise(B, T):
     """inproj.hip (c_in scaling + [B,T,80] -> [B,80,T] + relu(input_projection) + clearing of the persistent kernel's halo
@@ -1205,6 +1155,41 @@ def test_denoiser_full_size_properties(conv_form):
         assert same_result(one[0], full[b], conv_form), f"utterance {b} depends on its batch ({float((one[0] - full[b]).abs().max()):.2e})"
     ref = O.denoiser_forward(sd, cfg, x[:2].numpy(), t[:2].numpy(), cond[:2].numpy(), None)
     assert np.abs(_np(full[:2]) - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("L,T", [(85, 512), (171, 1024)])
+def test_bench_step_vs_oracle(L, T):
+    """bench.py's OWN step — LJSpeech model and inputs of bench.make_inputs (B = 32 utterances of L phonemes x 6 frames, padded
+    to T), default options (the conditioner factors gathered inside the F(4,3) persistent stack, the F(4,3) FFN and pitch-predictor convs),
+    T = 4 sampling steps, text -> mel — against the oracle's synthesize on utterances 0 and 31 with the same noise (no arithmetic crosses
+    utterances, so the oracle on two of them is the oracle on the batch): durations / mel_len / mel2ph bit-exact, energy and pitch buckets equal
+    (counted), mel |d| < 1e-3 (north_star's fp32 bound; the measured value is reported).  (85, 512) = the headline shape, (171, 1024) = north_star's."""
+    import bench
+    host = _host()
+    cfg = get_config("LJSpeech")
+    sd = synth_cmtts_state_dict(cfg, seed=0, dur_frames=6.0, dur_spread=0.0)
+    model = host.CMTotalTTS(cfg, DEV).load_state_dict(sd)
+    B, n_steps = bench.BATCH, bench.N_STEPS
+    rs = np.random.RandomState(0)                                  # bench.make_inputs(cfg, seed = rank 0, ...)
+    texts = rs.randint(1, cfg.n_symbols, size=(B, L)).astype(np.int64)
+    lens = np.full((B,), L, np.int64)
+    noise = torch.randn(n_steps + 1, B, 1, T, cfg.n_mels, generator=torch.Generator(device="cpu").manual_seed(1234))
+    out = model.duration_pitch_energy_net(None, torch.from_numpy(texts).to(DEV), torch.from_numpy(lens).to(DEV), max_mel_len=T)
+    assert out["cond_factors"] is not None and out["cond_factors"].p1t is not None          # the step's default path
+    mel = host.sample_with_cond(model, out["cond_ct"], None, n_steps, noise.to(DEV), factors=out["cond_factors"])
+    host.synchronize()
+    sel = [0, B - 1]
+    ref, ref_len, st = O.synthesize(sd, cfg, texts[sel], lens[sel], None, n_steps, [noise[i][sel].numpy() for i in range(n_steps + 1)], max_mel_len=T)
+    assert np.array_equal(_np(out["mel_lens"])[sel], ref_len) and (ref_len == 6 * L).all()
+    assert np.array_equal(_np(out["d_rounded"])[sel], st["d_rounded"])
+    assert np.array_equal(_np(out["mel2ph"])[sel], st["mel2ph"])
+    e_flips = int((_np(out["e_idx"])[sel] != st["e_idx"]).sum())
+    p_flips = int((_np(out["p_predictions"]["p_idx"])[sel] != st["p_idx"]).sum())
+    err = float(np.abs(_np(mel)[sel] - ref).max())
+    report(f"BENCH_STEP L={L} T={T}: utterances 0 / {B - 1} vs the oracle: energy-bucket flips {e_flips}, pitch-bucket flips {p_flips} of {st['p_idx'].size}, "
+           f"max|d mel| (T = {n_steps}) {err:.2e}")
+    assert e_flips == 0 and p_flips == 0
+    assert torch.isfinite(mel).all() and err < 1e-3
 
 
 @pytest.mark.parametrize("variant,T", [("LJSpeech", 512), ("VCTK", 333), ("VCTK", 40)])
