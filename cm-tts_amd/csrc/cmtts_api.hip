@@ -266,6 +266,27 @@ std::vector<float> to_wino43_xres_fragments(const std::vector<float>& p, int tap
     return f;
 }
 
+// The same conv as three F(2,3) tap groups over output PAIRS (conv_xres.hip, WQ == 2 instances; round 6): per (k-step of four channels, 32-row m-tile, tap group) the four
+// transformed weights U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (formed in double, rounded once) for the m-tile's two 16-row halves, as two 16-byte
+// vectors per lane: [K/4][M/32][3][2][64 lanes][4], element (tr & 1) * 2 + i of vector tr / 2 at lane l = transform tr, input channel 4 ks + (l >> 4), output row 32 mt + 16 i + (l & 15).
+std::vector<float> to_wino23_xres_fragments(const std::vector<float>& p, int taps, int K, int M) {
+    if (taps != 9 || K % 4 || M % 32) return {};
+    const int MTn = M / 32;
+    std::vector<float> f((size_t)(K / 4) * MTn * 6 * 256);
+    for (int ks = 0; ks < K / 4; ++ks)
+        for (int mt = 0; mt < MTn; ++mt)
+            for (int g = 0; g < 3; ++g)
+                for (int tr = 0; tr < 4; ++tr)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 2; ++i) {
+                            const int k = 4 * ks + (lane >> 4), mrow = 32 * mt + 16 * i + (lane & 15), tau = 3 * g;
+                            const double g0 = p[((size_t)tau * K + k) * M + mrow], g1 = p[((size_t)(tau + 1) * K + k) * M + mrow], g2 = p[((size_t)(tau + 2) * K + k) * M + mrow];
+                            const double v = tr == 0 ? g0 : tr == 1 ? 0.5 * (g0 + g1 + g2) : tr == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+                            f[(((((size_t)ks * MTn + mt) * 3 + g) * 2 + tr / 2) * 64 + lane) * 4 + (tr & 1) * 2 + i] = (float)v;
+                        }
+    return f;
+}
+
 // F(4,3) form of a k-tap, dilation-1 conv for conv_xlq_kernel (conv_xlq.hip: QTab<KT>): per k-step of four input channels the transformed weights of
 // every group of three taps (U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6, U3 = g0/24 + g1/12 + g2/6, U4 = g0/24 - g1/12 + g2/6, U5 = g2; a tap beyond the
 // kernel is zero) and, for k = 7, of the seventh tap on its own (g, g/2, g/2, g) — formed in double, rounded once — as A fragments of v_mfma_f32_16x16x4_f32 in
@@ -456,10 +477,11 @@ struct Profile {
 
 bool g_fused_resblock = true;
 int g_persist_tail = 1;      // skip head + post-scaling inside the persistent denoiser launch (false: separate launches)
-extern "C" int cmtts_launch_conv_xresq(const ConvArgs* a, const float* wq, int nbatch, void* stream);      // conv_xres.hip
-int g_ffn_wino = 1;             // FFT blocks, fp32: the k = 9 FFN conv of the fused launch as three F(4,3) tap groups (conv_xres.hip WQ instances; NOT bitwise the direct form: fp32
-                                // rounding).  Every fp32 FFN whose shape the X-resident kernel covers then takes it — whatever L and B — so that the text side's bits, and
-                                // with them durations and lengths, still do not depend on the batch.
+extern "C" int cmtts_launch_conv_xresq(const ConvArgs* a, const float* wq, int nbatch, void* stream, int form);      // conv_xres.hip
+int g_ffn_wino = 1;             // FFT blocks, fp32: the k = 9 FFN conv of the fused launch as three Winograd tap groups (conv_xres.hip WQ instances; NOT bitwise the direct form: fp32
+                                // rounding): 1 (default since round 6) = F(2,3) over output pairs, 2 = F(4,3) over output quads (round 5's default), 0 = direct.  Every fp32 FFN
+                                // whose shape the X-resident kernel covers then takes it — whatever L and B — so that the text side's bits, and with them durations and lengths,
+                                // still do not depend on the batch.
 int g_ffn_fused = 1;            // FFT blocks: the FFN linear's K-segment partial products formed inside the k = 9 conv's launch (conv_xres.hip; same bits); 0 = its own launch
 int g_inproj_fused = 1;         // denoiser input: c_in scaling + transpose + input projection + halo clearing in one launch (same bits); 0 = three launches
 int g_step_cache = 1;           // cmtts_sample: reuse the timestep-only part of the step embedding across calls (same bits); 0 = recompute every call
@@ -629,7 +651,8 @@ struct EncLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     PackedConv qk, qkv, wo, ffn1, ffn2;     // qkv: the whole in_proj_weight as one [3H][H] contraction (fused attention path)
     float* ffn1_f = nullptr;   // ffn1 as MFMA A fragments in iteration order (conv_xres.hip)
-    float* ffn1_q = nullptr;   // ffn1 (k = 9, 256 input channels) as F(4,3) fragments (conv_xres.hip, WQ instances: to_wino43_xres_fragments), else null
+    float* ffn1_q = nullptr;   // ffn1 (k = 9, 256 input channels) as F(4,3) fragments (conv_xres.hip, WQ == 1 instances: to_wino43_xres_fragments), else null
+    float* ffn1_p = nullptr;   // ... as F(2,3) fragments (WQ == 2 instances: to_wino23_xres_fragments), else null
     float* qkv_f = nullptr;    // the same for the in-projection and the out-projection (round 2: LayerNorm + projection in one launch)
     float* wo_f = nullptr;
     float* ffn2_f = nullptr;   // the FFN linear as A fragments in iteration order: conv_xres.hip's FFN fusion
@@ -823,7 +846,10 @@ int finalize_model(cmtts_model* m) {
             if (L.ffn1.cin % 32 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
                 CHK(al.upload(to_fragment_iter_order(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_f));
             if (L.ffn1.taps == 9 && L.ffn1.cin == 256 && L.ffn1.cout % 128 == 0 && L.ffn1.ld == L.ffn1.cout)
+            {
                 CHK(al.upload(to_wino43_xres_fragments(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_q));
+                CHK(al.upload(to_wino23_xres_fragments(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout), &L.ffn1_p));
+            }
             if (L.ffn1.cin % 32 == 0 && L.ffn1.cout % 32 == 0 && L.ffn1.ld == L.ffn1.cout)
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, L.ffn1.taps, L.ffn1.cin, L.ffn1.cout, mode);
@@ -1768,7 +1794,8 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             // X-resident kernel when it fills the chip; LayerNorm2 is then its prologue
             // round 5: with the F(4,3) form available the X-resident fused launch is taken at EVERY L and B (the Winograd and the direct form differ by fp32
             // rounding: one form for all shapes keeps the text side independent of the batch)
-            const bool wq = g_ffn_wino && g_ffn_xres && g_ffn_fused && (g_text_xres & 4) && E.ffn1_q && E.ffn2_f && m->ffn2_split && E.ffn2.cin % FFN2_SEG == 0 &&
+            const float* wqf = g_ffn_wino == 2 ? E.ffn1_q : E.ffn1_p;
+            const bool wq = g_ffn_wino && g_ffn_xres && g_ffn_fused && (g_text_xres & 4) && wqf && E.ffn2_f && m->ffn2_split && E.ffn2.cin % FFN2_SEG == 0 &&
                             E.ffn2.taps == 1 && E.ffn1.cout == FFN2_SEG * 128 && H == 256;
             const bool xr = wq || (xres_cols && E.ffn1_f && ((long)t96 * ((E.ffn1.cout + 127) / 128) * B >= 128 || xres_small));
             const bool ln_ffn = xr && (g_text_xres & 4);
@@ -1781,7 +1808,7 @@ int fft_stack(cmtts_model* m, const std::vector<EncLayer>& layers, const TextWs&
             if (xr && g_ffn_fused && ffn2_seg && E.ffn2_f && E.ffn1.cout == FFN2_SEG * 128) {
                 // ... and the FFN linear's partial products in the same launch: the activated rows never leave the CU
                 a.w2frag = E.ffn2_f; a.part = w.part; a.part_zs0 = (long)FFN2_SEG * hs; a.part_zs1 = hs; a.part_ld = Lp; a.M2 = H;
-                rc = wq ? cmtts_launch_conv_xresq(&a, E.ffn1_q, B, (void*)s) : -2;
+                rc = wq ? cmtts_launch_conv_xresq(&a, wqf, B, (void*)s, g_ffn_wino == 2 ? 1 : 2) : -2;
                 if (rc == -2) rc = cmtts_launch_conv_xres(&a, E.ffn1_f, B, (void*)s);
                 if (rc == 0) ffn_fused = true;
                 else { a.w2frag = nullptr; a.part = nullptr; }
@@ -2821,7 +2848,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"persist_wino", &g_persist_wino, 0, 3},   // fp32 persistent denoiser's k = 3 conv: 0 direct, 1 (and 2) Winograd F(2,3), 3 F(4,3) (NOT bitwise the direct form)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch
         {"ffn_xres", &g_ffn_xres, 0, 1},           // k = 9 FFN conv on conv_xres.hip
-        {"ffn_wino", &g_ffn_wino, 0, 1},           // FFN conv as F(4,3) tap groups in the fused launch (fp32; NOT bitwise the direct form)
+        {"ffn_wino", &g_ffn_wino, 0, 2},           // FFN conv as Winograd tap groups in the fused launch (fp32; NOT bitwise the direct form): 1 = F(2,3) pairs (default), 2 = F(4,3) quads
         {"ffn_fused", &g_ffn_fused, 0, 1},         // FFN linear's partial products inside the FFN conv's launch
         {"text_xres", &g_text_xres, 0, 15},        // bit mask: 1 LN1 + in-projection, 2 out-projection, 4 LN2 + FFN conv on conv_xres.hip
         {"attn_fused", &g_attn_fused, 0, 1},       // fused attention kernel vs three launches

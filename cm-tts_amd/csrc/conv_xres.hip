@@ -38,7 +38,13 @@ constexpr int RING = 4;
 // one).  wfrag = cmtts_api.hip: to_wino43_xres_fragments ([K/4][M/32][9][64 lanes][4]: element (pt & 1) * 2 + i of vector pt / 2 = transform pt, m-tile i).  Every
 // output element sees the same products in the same order whatever the tile width, so the 96- and 32-column instances agree bit for bit; against the direct form the
 // difference is fp32 rounding (tests/test_gpu_parity.py).  Everything around the K loop — staging, LayerNorm prologue, GELU, the FFN linear's partial product — is unchanged.
-template <bool LN, int NT, bool WQ = false>
+// WQ == 2 (round 6, the default for fp32 models): the same three tap groups as F(2,3) over output PAIRS (points 0, +-1, inf: m0 = (d0 - d2) g0, m1 = (d1 + d2) (g0 + g1 + g2) / 2,
+// m2 = (d2 - d1) (g0 - g1 + g2) / 2, m3 = (d1 - d3) g2; y(2p) = m0 + m1 + m2, y(2p + 1) = m1 - m2 - m3).  A 96-column tile is 48 pairs = THREE full n-tiles of 16 pair lanes where it
+// is 24 quads = one and a half n-tiles of quad lanes: 4 transforms x 3 n-tiles = the 6 x 2 MFMAs of the F(4,3) form per (k-step, tap group, m-tile) — the same matrix work — with 3
+// instead of 16 VALU operations per transformed n-tile, four transformed weight sets instead of six, and F(2,3)'s smaller rounding error (an output depends on its own taps only); a
+// 32-column tile is ONE full n-tile of pairs (F(4,3): six transforms on half an n-tile of quads: 1.5 x the MFMAs).  wfrag = cmtts_api.hip: to_wino23_xres_fragments
+// ([K/4][M/32][3 groups][2][64 lanes][4]: element (tr & 1) * 2 + i of vector tr / 2 = transform tr, m-tile half i).
+template <bool LN, int NT, int WQ = 0>
 __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel(const ConvArgs a, const float* __restrict__ wfrag, long long* dbg) {
     constexpr int BN = 32 * NT;          // columns per workgroup
     constexpr int X_LD = BN + HALO;      // 104 / 40
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
         dst = *reinterpret_cast<const f32x4*>(wl + (long)min(it, total - 1) * MTn * 256);
     };
     f32x4 A[RING];
-    if constexpr (!WQ) {
+    if constexpr (WQ == 0) {
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) load_a(A[s], s);
     }
@@ -210,14 +216,79 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
     stamp(2);
 
     constexpr int NTQ = NT == 3 ? 2 : 1;
-    f32x4 Mq[WQ ? 2 : 1][WQ ? NTQ : 1][6];
+    f32x4 Mq[WQ == 1 ? 2 : 1][WQ == 1 ? NTQ : 1][6];
+    f32x4 Mp[WQ == 2 ? 2 : 1][WQ == 2 ? NT : 1][4];      // F(2,3): [m-tile half][n-tile of 16 pairs][transform]
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const float* bl = xs + khalf * X_LD + l31;
-    if constexpr (WQ) {
+    if constexpr (WQ == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Mp[i][nt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int R = 3, U = 2;      // ring of three entries (tap groups); two k-steps = six entries per unrolled round
+        const int NKS = a.K / 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, NKS * MTn * 6 * 1024, 0x00020000);
+        const int voff = lane * 16;
+        const int mtu = __builtin_amdgcn_readfirstlane(mtc);
+        f32x4 Ap[R][2];
+        auto load_ap = [&](f32x4 (&dst)[2], int ks0, int n) {      // entry n of the round starting at k-step ks0: k-step ks0 + n / 3 (clamped: the last one again, never used), tap group n % 3
+            const int soff = ((min(ks0 + n / 3, NKS - 1) * MTn + mtu) * 3 + (n % 3)) * 2048;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + j * 1024, soff, 0));
+        };
+        // raw inputs: pair P = p + 16 nt reads columns 2 P + 3 g .. + 3 of row 4 ks + (lane >> 4) (column c of the tile <-> t = n0 - pad + c, pad = 4): 8-byte aligned reads
+        const float* xl = xs + (lane >> 4) * X_LD + 2 * (lane & 15);
+        float D[2][NT][4];
+        auto load_dp = [&](float (&d)[NT][4], int ks0, int n) {
+            const int g = n % 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float* r = xl + min(ks0 + n / 3, NKS - 1) * (4 * X_LD) + nt * 32;
+                if (g == 1) {          // columns 3 .. 6
+                    const f32x2 q = *reinterpret_cast<const f32x2*>(r + 4);
+                    d[nt][0] = r[3]; d[nt][1] = q.x; d[nt][2] = q.y; d[nt][3] = r[6];
+                } else {               // columns 0 .. 3 / 6 .. 9
+                    const f32x2 p = *reinterpret_cast<const f32x2*>(r + 3 * g), q = *reinterpret_cast<const f32x2*>(r + 3 * g + 2);
+                    d[nt][0] = p.x; d[nt][1] = p.y; d[nt][2] = q.x; d[nt][3] = q.y;
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) load_ap(Ap[s], 0, s);
+        load_dp(D[0], 0, 0);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < NKS; ks0 += U) {
+#pragma unroll
+            for (int n = 0; n < U * 3; ++n) {
+                const int slot = n % R;
+                float V[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float (&d)[4] = D[n & 1][nt];
+                    const f32x2 P01 = {d[0], d[1]}, P23 = {d[2], d[3]};
+                    const f32x2 V03 = P01 - P23;                   // d0 - d2, d1 - d3
+                    V[nt][0] = V03.x; V[nt][1] = d[1] + d[2]; V[nt][2] = d[2] - d[1]; V[nt][3] = V03.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_ap(Ap[(slot + R - 1) % R], ks0, n + R - 1);
+                load_dp(D[(n + 1) & 1], ks0, n + 1);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            Mp[i][nt][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[slot][p >> 1][(p & 1) * 2 + i], V[nt][p], Mp[i][nt][p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if constexpr (WQ == 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -351,7 +422,32 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) bi[r] = o.bias ? o.bias[(unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf)] : 0.f;
         __syncthreads();                                 // every wave is done with the X tile
-        if constexpr (WQ) {
+        if constexpr (WQ == 2) {
+            // output transform (y(2p) = (m0 + m1) + m2, y(2p + 1) = (m1 - m2) - m3), then the direct form's epilogue per element; the lane's pair of a row as one 8-byte LDS store
+            const int p16 = lane & 15, rq = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowl = w * 32 + 16 * i + 4 * rq + r;
+                    const float bq = o.bias ? o.bias[(unsigned)(mt * 32 + 16 * i + 4 * rq + r)] : 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float m0 = Mp[i][nt][0][r], m1 = Mp[i][nt][1][r], m2 = Mp[i][nt][2][r], m3 = Mp[i][nt][3][r];
+                        f32x2 y;
+                        y.x = (m0 + m1) + m2;
+                        y.y = (m1 - m2) - m3;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float v = y[c];
+                            if (o.bias) v += bq;
+                            v *= o.alpha;
+                            y[c] = act_apply(v, ACT_GELU_ERF);
+                        }
+                        *reinterpret_cast<f32x2*>(xs + rowl * X_LD + 2 * (p16 + 16 * nt)) = y;
+                    }
+                }
+        } else if constexpr (WQ == 1) {
             // output transform (y0 = m0 + (m1 + m2) + (m3 + m4), y1 = (m1 - m2) + 2 (m3 - m4), y2 = (m1 + m2) + 4 (m3 + m4), y3 = (m1 - m2) + 8 (m3 - m4) + m5), then the
             // direct form's epilogue per element; the lane's quad of a row as one 16-byte LDS store
             const int q4 = lane & 15, rq = lane >> 4;
@@ -504,7 +600,7 @@ extern "C" int cmtts_launch_conv_xres(const ConvArgs* ap, const float* wfrag, in
 
 // The fused FFN launch (a.w2frag set: k = 9 conv + GELU + the FFN linear's K-segment partial product) with the conv as three F(4,3) tap groups (template parameter WQ);
 // wfrag = to_wino43_xres_fragments of the same weights.  Returns 0, -2 (not that launch: use cmtts_launch_conv_xres) or -3.
-extern "C" int cmtts_launch_conv_xresq(const ConvArgs* ap, const float* wfrag, int nbatch, void* stream_) {
+extern "C" int cmtts_launch_conv_xresq(const ConvArgs* ap, const float* wfrag, int nbatch, void* stream_, int form) {      // form: 1 = F(4,3) quads (to_wino43_xres_fragments), 2 = F(2,3) pairs (to_wino23_xres_fragments)
     const ConvArgs& a = *ap;
     if (a.M <= 0 || a.N <= 0 || nbatch <= 0) return 0;
     if (!wfrag || a.zdiv != 1 || a.split != INT_MAX || a.dil <= 0 || a.K % 32 != 0 || a.K > KMAX || (a.taps - 1) * a.dil > HALO ||
@@ -526,10 +622,14 @@ extern "C" int cmtts_launch_conv_xresq(const ConvArgs* ap, const float* wfrag, i
     const size_t lds = (size_t)a.K * x_ld * sizeof(float) + (a.ln_g ? 2 * 256 * sizeof(float) : 0);
     if (!attr_set) {
         const int mx = (int)((size_t)KMAX * (96 + HALO) * sizeof(float) + 2 * 256 * sizeof(float));
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<false, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xres_kernel<true, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
             return -3;
         attr_set = true;
     }
@@ -540,12 +640,20 @@ extern "C" int cmtts_launch_conv_xresq(const ConvArgs* ap, const float* wfrag, i
         if (want && atoi(want) != a.M) dbg = nullptr;
     }
     hipStream_t st = (hipStream_t)stream_;
-    if (nt == 3) {
-        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 3, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
-        else hipLaunchKernelGGL((conv_xres_kernel<false, 3, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
+    if (form == 2) {
+        if (nt == 3) {
+            if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 3, 2>), grid, dim3(256), lds, st, a, wfrag, dbg);
+            else hipLaunchKernelGGL((conv_xres_kernel<false, 3, 2>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        } else {
+            if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1, 2>), grid, dim3(256), lds, st, a, wfrag, dbg);
+            else hipLaunchKernelGGL((conv_xres_kernel<false, 1, 2>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        }
+    } else if (nt == 3) {
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 3, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 3, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
     } else {
-        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
-        else hipLaunchKernelGGL((conv_xres_kernel<false, 1, true>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        if (a.ln_g) hipLaunchKernelGGL((conv_xres_kernel<true, 1, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
+        else hipLaunchKernelGGL((conv_xres_kernel<false, 1, 1>), grid, dim3(256), lds, st, a, wfrag, dbg);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -28,7 +28,7 @@ def _one(t):
     return [(0, t, 0, 0, 0, t), (3, t + 1, 0, 0, 4, t)]
 
 
-WINO_TAB = {3: _f23(0), 7: _f23(0) + _f23(3) + _one(6), 11: _f23(0) + _f23(3) + _f23(6) + _f22(9)}
+WINO_TAB = {3: _f23(0), 7: _f23(0) + _f23(3) + _one(6), 9: _f23(0) + _f23(3) + _f23(6), 11: _f23(0) + _f23(3) + _f23(6) + _f22(9)}      # 9: the FFT blocks' FFN conv (conv_xres.hip, WQ == 2)
 
 
 def wino_weight(g, kind, tau):

@@ -1503,10 +1503,12 @@ def test_ffn_fused_bitwise(models):
     assert torch.equal(one["enc_out"][0], outs[0][1]["enc_out"][0])
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("variant,B,L", [("LJSpeech", 32, 85), ("VCTK", 16, 100), ("LJSpeech", 5, 128), ("LibriTTS", 3, 300)])
-def test_ffn_winograd(variant, B, L):
-    """Round 5: the FFT blocks' k = 9 FFN conv as three F(4,3) tap groups inside the fused launch (conv_xres.hip, WQ instances; the default for fp32 models) against
-    the direct form: encoder output by fp32 rounding only, durations and mel lengths equal.  And the property the direct form had by construction: ONE form at every
+def test_ffn_winograd(variant, B, L, form):
+    """The FFT blocks' k = 9 FFN conv as three Winograd tap groups inside the fused launch (conv_xres.hip, WQ instances; fp32 models) — form 1: F(2,3) over output pairs
+    (the default since round 6: three full n-tiles of pair lanes per 96-column tile, 3 VALU operations per transformed n-tile), form 2: F(4,3) over output quads (round 5) —
+    against the direct form: encoder output by fp32 rounding only, durations and mel lengths equal.  And the property the direct form had by construction: ONE form at every
     shape — the 96-column tiles of a chip-filling batch, the 32-column tiles of a single request, lengths at which the direct form takes the generic kernel — so an
     utterance's encoder output does not depend on the batch it is in (bit for bit)."""
     host = _host()
@@ -1520,7 +1522,7 @@ def test_ffn_winograd(variant, B, L):
     spk = torch.from_numpy(rs.standard_normal((B, cfg.external_speaker_dim)).astype(np.float32)) if cfg.multi_speaker else None
     tx, ln = torch.from_numpy(texts), torch.from_numpy(lens)
     run = lambda nb: model.duration_pitch_energy_net(None, tx[:nb], ln[:nb], spker_embeds=None if spk is None else spk[:nb])
-    prev = _lib.internal_set(b"ffn_wino", 1)
+    prev = _lib.internal_set(b"ffn_wino", form)
     try:
         got, one = run(B), run(1)
         _lib.internal_set(b"ffn_wino", 0)
@@ -1529,7 +1531,7 @@ def test_ffn_winograd(variant, B, L):
         _lib.internal_set(b"ffn_wino", prev)
     torch.cuda.synchronize()
     d = float((got["enc_out"] - ref["enc_out"]).abs().max())
-    report(f"FFN_WINOGRAD {variant} B={B} L={L}: max|d enc_out| vs the direct form {d:.2e} (scale {float(ref['enc_out'].abs().max()):.2f}); "
+    report(f"FFN_WINOGRAD {'F(2,3)' if form == 1 else 'F(4,3)'} {variant} B={B} L={L}: max|d enc_out| vs the direct form {d:.2e} (scale {float(ref['enc_out'].abs().max()):.2f}); "
            f"log-durations {float((got['log_d_predictions'] - ref['log_d_predictions']).abs().max()):.2e}")
     assert torch.isfinite(got["enc_out"]).all() and 0 < d <= 2e-5
     assert torch.equal(got["mel_lens"], ref["mel_lens"]) and torch.equal(got["mel2ph"], ref["mel2ph"])

@@ -6,7 +6,7 @@ import pytest
 from oracle import winograd_ref as W
 
 
-@pytest.mark.parametrize("k,dil", [(3, 1), (3, 3), (3, 5), (7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11, 5)])
+@pytest.mark.parametrize("k,dil", [(3, 1), (3, 3), (3, 5), (7, 1), (7, 3), (7, 5), (9, 1), (11, 1), (11, 3), (11, 5)])
 def test_winograd_table_equals_direct_conv(k, dil):
     rs = np.random.RandomState(100 * k + dil)
     for T in (1, 2, 59, 60, 61, 64, 137):
@@ -19,8 +19,8 @@ def test_winograd_table_equals_direct_conv(k, dil):
 
 
 def test_winograd_products_per_pair():
-    # 4 / 10 / 15 products per output pair instead of 6 / 14 / 22
-    assert {k: len(t) for k, t in W.WINO_TAB.items()} == {3: 4, 7: 10, 11: 15}
+    # 4 / 10 / 15 products per output pair instead of 6 / 14 / 22 (k = 9, the FFT blocks' FFN conv: 12 instead of 18)
+    assert {k: len(t) for k, t in W.WINO_TAB.items()} == {3: 4, 7: 10, 9: 12, 11: 15}
     for k, tab in W.WINO_TAB.items():
         assert all(0 <= acc <= 3 and max(a, b) <= k for acc, a, b, sgn, kind, tau in tab)
 
@@ -28,7 +28,7 @@ def test_winograd_products_per_pair():
 def test_winograd_fp32_error_is_rounding_level():
     rs = np.random.RandomState(7)
     x = rs.standard_normal((128, 300)).astype(np.float32)
-    for k, dil in ((3, 1), (7, 3), (11, 5)):
+    for k, dil in ((3, 1), (7, 3), (9, 1), (11, 5)):
         w = (rs.standard_normal((64, 128, k)) / np.sqrt(128 * k)).astype(np.float32)
         ref64 = W.conv1d_direct(x.astype(np.float64), w.astype(np.float64), dil)
         e_dir = np.abs(W.conv1d_direct(x, w, dil) - ref64).max()
