@@ -14,7 +14,6 @@
 // compiled per activation (the run-time switch of the generic epilogue cost 32 k of this kernel's 315 k cycles per wave).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
-#include <stdint.h>
 #include "conv_args.h"
 #include "conv_epilogue.h"
 
@@ -512,35 +511,6 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
                         acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[it][i][kk], b2[j], acc2[i][j], 0, 0, 0);
             }
         float* pb = a.part + z * a.part_zs0 + by * a.part_zs1;
-        if (NT == 3 && gridDim.x == 1 && (a.part_ld & 3) == 0 && ((uintptr_t)pb & 15) == 0) {
-            // Round 6: the workgroup owns whole rows of its slab ([256][part_ld], contiguous): the tile goes through LDS and leaves as 16-byte stores of
-            // consecutive addresses.  As 96 row-piece stores per wave (128 bytes at a 352-byte pitch: every piece straddles two cache lines) the phase
-            // took ~330 cycles per store instruction — the memory side, not the issue, set it (tools/xres_phases.py).  Same values.
-            constexpr int YLD = BN + 4;
-            __syncthreads();                             // every wave is done reading the activated rows
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        xs[((2 * w + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * YLD + j * 32 + l31] = acc2[i][j][r] * 1.0f;
-            __syncthreads();
-            const int ncol = min(a.N, o.Tout), nv = (ncol + 3) >> 2;
-            for (int idx = tid; idx < 256 * nv; idx += 256) {
-                const int row = idx / nv, c4 = idx - row * nv;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xs + row * YLD + 4 * c4);
-                float* dst = pb + (unsigned)row * (unsigned)a.part_ld + 4 * c4;
-                if (4 * c4 + 3 < ncol) *reinterpret_cast<f32x4*>(dst) = v;
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * c4 + e < ncol) dst[e] = v[e];
-                }
-            }
-            stamp(4);
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -552,42 +522,6 @@ __global__ __launch_bounds__(256, NT == 1 ? XRES_OCC1 : 1) void conv_xres_kernel
                         pb[(unsigned)((2 * w + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * (unsigned)a.part_ld + (unsigned)n] = acc2[i][j][r] * 1.0f;
                 }
             }
-        stamp(4);
-        return;
-    }
-    if (NT == 3 && gridDim.x == 1 && epi_simple(o) && !o.res && !o.lens && (o.ldy & 3) == 0 && (((uintptr_t)(o.Y + z * o.y_zs0)) & 15) == 0 && o.Tout <= o.ldy) {
-        // Round 6: one column tile per utterance = the workgroup owns whole rows of the output ([128 rows][ldy], contiguous): through LDS, out as
-        // 16-byte stores of consecutive addresses (see the FFN slab above).  epi_tile_simple's arithmetic in its order: the same bits.
-        constexpr int YLD = BN + 4;
-        float bi[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bi[r] = o.bias ? o.bias[(unsigned)min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, a.M - 1)] : 0.f;
-        __syncthreads();                                 // every wave is done with the X tile
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[j][r];
-                if (o.bias) v += bi[r];
-                v *= o.alpha;
-                v = o.act == ACT_GELU_ERF ? act_apply(v, ACT_GELU_ERF) : o.act == ACT_RELU ? act_apply(v, ACT_RELU) : o.act == ACT_NONE ? v : act_apply(v, o.act);
-                xs[(w * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * YLD + j * 32 + l31] = v;
-            }
-        __syncthreads();
-        const int ncol = min(a.N, o.Tout), nv = (ncol + 3) >> 2;
-        const int rows = min(128, a.M - by * 128);
-        float* yb = o.Y + z * o.y_zs0 + (long)(by * 128) * o.ldy;
-        for (int idx = tid; idx < rows * nv; idx += 256) {
-            const int row = idx / nv, c4 = idx - row * nv;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xs + row * YLD + 4 * c4);
-            float* dst = yb + (unsigned)row * (unsigned)o.ldy + 4 * c4;
-            if (4 * c4 + 3 < ncol) *reinterpret_cast<f32x4*>(dst) = v;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * c4 + e < ncol) dst[e] = v[e];
-            }
-        }
         stamp(4);
         return;
     }
