@@ -1902,6 +1902,14 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     // duration predictor (masked) -> log_d
     const int t16mode = (m->text16 && (m->precision == 1 || m->precision == 2)) ? m->precision : 0;
     CHK(predictor(m->dur, w.x, Lp, B, L, Lp, src_lens, src_lens, w.c1, w.c2, log_d, 1, s, t16mode));
+    // durations -> cumulative frame counts, mel_len: they need log_d only and run here, in the shadow of the (longer) energy branch (round 6; they
+    // sat behind the join, the energy embedding and the pitch predictor's input projection)
+    if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
+        HIPCHK(hipMemcpyAsync(d_rounded, m->vc.d_target, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
+        k_cumsum_durations(m->vc.d_target, w.cum, mel_len, B, L, s);
+    } else {
+        k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
+    }
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
     CHK(predictor(m->energy, w.h, Lp, B, L, Lp, pad_lens, pad_lens, ec1, ec2, e_pred, 1, se, t16mode));
@@ -1924,12 +1932,6 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     }
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
         HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
-    if (m->vc.d_target) {   // teacher-forced durations (model/modules.py:365-367)
-        HIPCHK(hipMemcpyAsync(d_rounded, m->vc.d_target, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
-        k_cumsum_durations(m->vc.d_target, w.cum, mel_len, B, L, s);
-    } else {
-        k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
-    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -17,7 +17,11 @@ from cmtts_amd.weights import synth_cmtts_state_dict, synth_hifigan_state_dict
 from oracle import cmtts_oracle as O
 from conftest import golden_noise, pitch_margin_mask, pitch_flips, near_flip_mask, report, conv_form, same_result, WINO_TOL, voc_form, same_wav, same_pcm, VOC_WINO_TOL, same_trimmed, trim_exact  # noqa: F401
 
-KNOWN_ORACLE_FLIPS = {"energy": 0, "pitch": 0}      # test_bucketed_ragged_shard_vs_oracle: measured on MI355X (round 2): none
+# test_bucketed_ragged_shard_vs_oracle (unsearched inputs: no margins): measured on MI355X.  Rounds 2-5: none.  Round 6: ONE pitch frame of 4096 — the text side's
+# fp32 rounding changed (FFN conv as F(2,3) tap groups, the pitch predictor's k = 5 convs as F(4,3) tap groups, the softmax's roundings pinned) and one frame
+# whose pre-rounding bucket value lies within conftest.FLIP_MARGIN of a rounding boundary went to the neighbouring bucket; the test asserts exactly that
+# (on a boundary, off by one).
+KNOWN_ORACLE_FLIPS = {"energy": 0, "pitch": 1}
 
 pytestmark = pytest.mark.gpu
 VARIANTS = ["LJSpeech", "VCTK", "LibriTTS"]
@@ -1084,6 +1088,10 @@ def test_bucketed_ragged_shard_vs_oracle():
     n_e, n_p = int((~e_same).sum()), int((~p_same).sum())
     report(f"BUCKET_FLIPS bucketed LibriTTS shard vs oracle: energy {n_e} of {int(valid.sum())} phonemes, pitch {n_p} of {p_same.size} frames")
     assert n_e <= KNOWN_ORACLE_FLIPS["energy"] and n_p <= KNOWN_ORACLE_FLIPS["pitch"]
+    from conftest import FLIP_MARGIN
+    on_boundary = ~pitch_margin_mask(st["f0_denorm"], FLIP_MARGIN)
+    assert not (~p_same & ~on_boundary).any(), "a pitch bucket differs away from a rounding boundary"
+    assert (np.abs(_np(out["p_predictions"]["p_idx"]) - st["p_idx"]) <= 1).all()
     # frames fed by agreeing energy buckets and pitch buckets must match the oracle's conditioning
     ph = np.clip(ref_m2p - 1, 0, L - 1)
     ok = p_same & np.take_along_axis(e_same, ph, 1)
