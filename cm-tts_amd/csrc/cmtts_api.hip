@@ -1113,7 +1113,7 @@ int finalize_model(cmtts_model* m) {
 // batch's values still do not depend on its size.
 constexpr int FFN2_SEG = 8;
 struct TextWs {
-    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *h128, *logd, *dround, *epred;
+    float *x, *h, *qk, *vt, *st, *o, *f, *part, *c1, *c2, *spk, *out1, *h128, *logd, *dround, *epred, *escaled;
     int* cum;
     int64_t *eidx, *mlen;
     size_t bytes;
@@ -1143,6 +1143,7 @@ TextWs carve_text(const cmtts_config& c, int B, int L, void* base) {
     w.epred = cv.take<float>((size_t)B * L);
     w.eidx = cv.take<int64_t>((size_t)B * L);
     w.mlen = cv.take<int64_t>((size_t)B);
+    w.escaled = cv.take<float>((size_t)B * L);      // energy prediction x control (behind everything else: the other offsets do not depend on it)
     w.bytes = cv.off + 256;
     return w;
 }
@@ -1208,10 +1209,16 @@ DenWs carve_den(const cmtts_config& c, int B, int T, void* base) {
 // conv -> ReLU -> LayerNorm blocks of a predictor followed by its linear head (model/modules.py:470-506, 520-554): the last
 // block's LayerNorm and the head are one launch (ln_linear_kernel) unless cmtts_internal_set("pred_head", 0)
 // mode16: 0, or the 16-bit operand mode (1 = bf16, 2 = fp16) of a model with the opt-in "text16": the convs on conv_mfma16.hip (bias + ReLU in fp32)
+struct EnergyHead {        // round 6: get_energy_embedding + the embedding add (model/modules.py:318-328,358-363) as the epilogue of the energy predictor's head (kernels.hip: ln_linear_kernel<1, true>)
+    const float* xin; const float* e_target; float e_control; const float* bins; int nbins; const float* E; float* out1; int64_t* e_idx; float* e_scaled;
+    bool done;
+};
+int g_energy_head = 1;          // internal switch "energy_head": 1 = in the head's launch (same bits), 0 = energy_embed_kernel behind the join
 int g_pred_wino = 1;            // round 6: the frame-level pitch predictor's k = 5 convs as F(4,3) tap groups (conv_k5q.hip; NOT bitwise the direct form: fp32 Winograd rounding), at every launch size
 int g_pred_xres = 1;            // round 4: phoneme-level 256 -> 256 predictor convs on conv_xres (32-column tiles), the previous block's LayerNorm as its prologue (same bits); 0 = generic kernel + LayerNorm launches
 int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int ld, const int64_t* ln_lens,
-              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0, bool frame_level = false) {
+              const int64_t* out_lens, float* bufA, float* bufB, float* out, int O, hipStream_t s, int mode16 = 0, bool frame_level = false,
+              EnergyHead* eh = nullptr) {      // eh: the energy predictor — bucketize + embedding add inside the head's launch (eh->done reports it)
     const float* cur = in;
     int ldc = ld_in;
     auto other = [&](const float* p) { return p == bufA ? bufB : bufA; };
@@ -1281,6 +1288,12 @@ int predictor(const Predictor& P, const float* in, int ld_in, int B, int T, int 
         }
         cur = dst;
         ldc = ld;
+        if (g_pred_head && eh && g_energy_head && O == 1 && li + 1 == P.convs.size() && w.cout == 256) {
+            k_ln_linear_energy(cur, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, eh->xin, eh->e_target, eh->e_control,
+                               eh->bins, eh->nbins, eh->E, eh->out1, eh->e_idx, eh->e_scaled, s);
+            eh->done = true;
+            return 0;
+        }
         if (g_pred_head && li + 1 == P.convs.size() && w.cout == 256 &&
             k_ln_linear(cur, P.ln_g[li], P.ln_b[li], 1e-12f, P.lin_w, P.lin_b, out, ln_lens, out_lens, B, T, ld, O, s))
             return 0;
@@ -1912,10 +1925,12 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     }
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
-    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, pad_lens, pad_lens, ec1, ec2, e_pred, 1, se, t16mode));
+    EnergyHead eh{w.x, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1, e_idx, w.escaled, false};
+    CHK(predictor(m->energy, w.h, Lp, B, L, Lp, pad_lens, pad_lens, ec1, ec2, e_pred, 1, se, t16mode, false, H == 256 ? &eh : nullptr));
     if (ss) CHK(branch_join(ss));
-    k_energy_embed(w.x, e_pred, w.c1, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
-                   w.out1, e_idx, B, H, L, Lp, s);
+    if (!eh.done)
+        k_energy_embed(w.x, e_pred, w.escaled, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb,
+                       w.out1, e_idx, B, H, L, Lp, s);
     {   // cwt_predictor[0]: Linear(H -> cwt_hidden) (model/modules.py:204-205).  The reference applies it to the length-regulated frames;
         // a k = 1 contraction commutes with the gather (frame t copies phoneme mel2ph[t] - 1, a padding frame is W 0 + b = b), so it runs
         // over the L phonemes here and cmtts_frame_forward gathers its output: the same bits (tests/test_gpu_parity.py goldens,
@@ -1931,7 +1946,7 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
         if (rc != 0) CHK(launch(a, EPI_PLAIN, B, s));
     }
     if (!m->vc.e_target && m->vc.e_control != 1.0f)     // the reference returns prediction * control (:326)
-        HIPCHK(hipMemcpyAsync(e_pred, w.c1, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(e_pred, w.escaled, (size_t)B * L * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2870,6 +2885,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_upsT", &g_voc_upsT, 0, 1},           // upsamplers on convT_xl
         {"post_v4", &g_post_v4, 0, 1},             // conv_post with 16-byte loads
         {"pred_wino", &g_pred_wino, 0, 1},         // pitch predictor's k = 5 convs as F(4,3) tap groups (NOT bitwise the direct form)
+        {"energy_head", &g_energy_head, 0, 1},     // energy bucketize + embedding add inside the energy predictor's head launch (same bits)
         {"stats_mlp", &g_stats_mlp, 0, 1},         // cwt_stats_layers as one launch (same bits)
         {"text_xt16", &g_conv_xt16, 0, 1},         // text16 convs with K = 256 on the X-resident 16-bit kernel (conv_xt16.hip) instead of the chunked one
     };

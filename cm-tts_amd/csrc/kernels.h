@@ -40,6 +40,10 @@ void k_add_rows(const float* a, const float* b, float* out, long n, hipStream_t 
 void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
                        int L, int ld, hipStream_t s);
 // LayerNorm(256 channels) + Linear(256 -> O) in one launch, O in {1, 10, 11} (false: not covered); out is time-major [B][T][O]
+// ln_linear (O = 1) + bucketize + out1 = xin + energy_embedding[bucket] in one launch (the energy predictor's head; same bits as k_ln_linear + k_energy_embed)
+void k_ln_linear_energy(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
+                        const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, const float* xin, const float* e_target, float e_control,
+                        const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, float* e_scaled, hipStream_t s);
 bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
                  const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s);
 void k_cumsum_durations(const float* dur, int* cum, int64_t* mel_len, int B, int L, hipStream_t s);

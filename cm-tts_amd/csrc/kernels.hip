@@ -255,11 +255,27 @@ __global__ __launch_bounds__(256) void chan_linear_kernel(const float* x, const 
 // — no LDS scratch, no barrier after the weights are staged.  ln_lens: positions >= ln_lens[b] enter the linear layer as
 // zeros (the masked LayerNorm output); out_lens: those positions are written as 0.
 constexpr int LNL_PAD = 65;      // a quarter's 64 weights + 1: the four quarters of one lane group hit different LDS banks
-template <int O>
+// EE (round 6, O == 1: the energy predictor's head): the energy embedding in the same launch — get_energy_embedding + the add of
+// model/modules.py:318-328,358-363: the position's prediction (x control, or the teacher-forced target) is bucketized and every lane
+// adds its 64 channels of energy_embedding[bucket] to the encoder output column, out1 = xin + E[idx].  energy_embed_kernel's expressions
+// (the same bucketize, the same single add per element): the same bits; one launch and its dependent boundary less on the chain
+// energy predictor -> out1 -> pitch predictor input.
+struct EnergyEpi {
+    const float* xin;       // [B][256][ld]: the variance adaptor's input x (speaker vector added)
+    const float* e_target;  // teacher-forced energy [B][T] or null
+    float e_control;
+    const float* bins;      // [nbins] ascending
+    int nbins;
+    const float* E;         // energy_embedding.weight [nbins + 1][256]
+    float* out1;            // [B][256][ld]
+    int64_t* e_idx;         // [B][T]
+    float* e_scaled;        // [B][T]: prediction x control (written when control != 1 and no target)
+};
+template <int O, bool EE = false>
 __global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        const int64_t* ln_lens, const int64_t* out_lens, int T, int ld) {
+                                                        const int64_t* ln_lens, const int64_t* out_lens, int T, int ld, const EnergyEpi ee = EnergyEpi{}) {
     constexpr int C = 256, CQ = 64;
     constexpr int NV = (O + 2) * C / 4;            // float4 of W rows, gamma, beta
     constexpr int PER = (NV + 255) / 256;
@@ -322,10 +338,31 @@ __global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict_
         acc[o] += __shfl_xor(acc[o], 16);
         acc[o] += __shfl_xor(acc[o], 32);
     }
+    const bool keep = !(out_lens && (int64_t)t >= out_lens[b]);
     if (q == 0 && t < T) {
-        const bool keep = !(out_lens && (int64_t)t >= out_lens[b]);
 #pragma unroll
         for (int o = 0; o < O; ++o) out[((long)b * T + t) * O + o] = keep ? acc[o] + bias[o] : 0.f;
+    }
+    if constexpr (EE) {
+        static_assert(!EE || O == 1, "energy head");
+        if (t < T) {      // all four quarter lanes of the column hold the prediction
+            const float pred = keep ? acc[0] + bias[0] : 0.f;
+            float v;
+            if (ee.e_target) v = ee.e_target[(long)b * T + t];
+            else { v = pred * ee.e_control; if (q == 0 && ee.e_control != 1.0f) ee.e_scaled[(long)b * T + t] = v; }
+            int lo = 0, hi = ee.nbins;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ee.bins[mid] >= v) hi = mid; else lo = mid + 1; }
+            if (v != v) lo = ee.nbins;   // NaN sorts last
+            if (q == 0) ee.e_idx[(long)b * T + t] = lo;
+            const float* e = ee.E + (long)lo * C + q * CQ;
+            const float* xi = ee.xin + ((long)b * C + q * CQ) * ld + t;
+            float* o1 = ee.out1 + ((long)b * C + q * CQ) * ld + t;
+            float xv[CQ], ev[CQ];
+#pragma unroll
+            for (int i = 0; i < CQ; ++i) { xv[i] = xi[(long)i * ld]; ev[i] = e[i]; }
+#pragma unroll
+            for (int i = 0; i < CQ; ++i) o1[(long)i * ld] = xv[i] + ev[i];
+        }
     }
 }
 
@@ -884,6 +921,13 @@ void k_add_rows(const float* a, const float* b, float* out, long n, hipStream_t 
 void k_reduce_partials(const float* part, int nseg, const float* bias, const float* res, const int64_t* lens, float* out, int B, int C,
                        int L, int ld, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(L, 64), cdiv(C, 4), B), dim3(256), 0, s, part, nseg, bias, res, lens, out, C, L, ld);
+}
+// the energy predictor's head with the energy embedding in the same launch (EE instance)
+void k_ln_linear_energy(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
+                        const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, const float* xin, const float* e_target, float e_control,
+                        const float* bins, int nbins, const float* E, float* out1, int64_t* e_idx, float* e_scaled, hipStream_t s) {
+    const EnergyEpi ee{xin, e_target, e_control, bins, nbins, E, out1, e_idx, e_scaled};
+    hipLaunchKernelGGL((ln_linear_kernel<1, true>), dim3(cdiv(T, 64), B), dim3(256), 0, s, x, gamma, beta, eps, W, bias, out, ln_lens, out_lens, T, ld, ee);
 }
 bool k_ln_linear(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
                  const int64_t* ln_lens, const int64_t* out_lens, int B, int T, int ld, int O, hipStream_t s) {
