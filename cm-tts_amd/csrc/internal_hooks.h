@@ -5,8 +5,10 @@
 // cond_gemm16 (16-bit against fp32 operands of the conditioner GEMM in bf16 / fp16 / fp16x3 models: a numerics switch — since
 // round 3 the 16-bit form is the default for EVERY shape of a 16-bit model, which changed those models' default numerics against
 // round 2), persist_wino (the fp32 persistent stack's k = 3 conv in a Winograd form — the process-wide A/B twin of the model option "winograd":
-// 3 (default since round 5) F(4,3), <= 1.8e-5 per network evaluation against the direct form; 1 F(2,3) (round 4), <= 1e-5; 2 the one-wave-per-SIMD
-// F(2,3) stack; 0 direct), voc_wino43 (round 5: the Winograd path's convs as F(4,3) tap groups over output quads, conv_xlq_kernel: 1 (default)
+// 3 (default since round 5) F(4,3), <= 1.8e-5 per network evaluation against the direct form; 1 F(2,3) (round 4), <= 1e-5; 2 runs as 1 (round 5's
+// one-wave-per-SIMD F(2,3) stack left the build in round 6: tools/attic/); 0 direct), ffn_wino (the FFT blocks' k = 9 FFN conv as Winograd tap groups in the fused launch: 1 (default
+// since round 6) F(2,3) over output pairs, ~2.5e-6 on the encoder output against the direct form; 2 F(4,3) over quads (round 5), ~4.5e-6; 0 direct), pred_wino (round 6: the frame-level
+// pitch predictor's k = 5 convs as F(4,3) tap groups, conv_k5q.hip, at every launch size: ~7e-6 on the cwt output; 0 = the direct kernels), voc_wino43 (round 5: the Winograd path's convs as F(4,3) tap groups over output quads, conv_xlq_kernel: 1 (default)
 // dilation 1 and 3 everywhere + dilation 5 at C = 256 or k = 3, 2 only dilation 1, 3 every conv, 0 none), voc_wino (round 4: the fp32 generator's C >= 128 ResBlock
 // convs in their Winograd form — 0 never, 1 (default) launches of >= 1024 column tiles, 2 always; <= 1.2e-6 on the waveform).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
 // (cmtts_amd/_lib.py: internal_set).
@@ -16,7 +18,9 @@ extern "C" {
 #endif
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
-// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16, persist_wino, ffn_wino (round 5: the FFT blocks' k = 9 FFN conv as F(4,3) tap groups in the fused launch, fp32; 4e-6 on the encoder output against the direct form), voc_wino, voc_wino43, voc_wino64, voc_wino64_k (cmtts_api.hip: cmtts_internal_set).
+// voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16,
+// persist_wino, ffn_wino, pred_wino, voc_wino, voc_wino43, voc_wino64, voc_wino64_k, xres_nt, and (round 6, same bits on / off) attn_qb (attention with the queries split over workgroups),
+// stats_mlp (cwt_stats_layers as one launch), energy_head (energy bucketize + embedding add inside the energy predictor's head launch)   (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 // Test hook: the stacked conditioner projections alone, with the model's current precision mode.  cond_ct [B][hidden][T] -> cp [B][NL * C][T]
 // (device pointers).  Returns a cmtts_status.
