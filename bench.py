@@ -632,7 +632,9 @@ def main():
     # ---- headline: timed region with HIP events around the dominant kernel
     # persistent mode: ONE launch runs all residual layers of a sampler step (4 launches per step: bracket them all)
     persistent = (not args.unfused) and lib.cmtts_set_persistent_denoiser(-1) != 0 and BATCH * ((FRAMES_PAD + 63) // 64) * 2 > 256
-    stride = 1 if persistent else PROFILE_STRIDE
+    # persistent launches: every third one is bracketed (3 is coprime to the 4 evaluations of a step: all sigmas are sampled; a pair of event records
+    # per launch put ~10 us of barrier packets around every evaluation of the timed step)
+    stride = 3 if persistent else PROFILE_STRIDE
     dt = timed(step, args.steps, args.warmup, world, flush=flush,
                before=lambda: _lib.check(lib.cmtts_profile_begin(args.steps * N_STEPS * cfg.res_layers, stride)))
     tot_ms, n_l = C.c_double(), C.c_int()

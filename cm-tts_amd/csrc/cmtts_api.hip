@@ -544,7 +544,18 @@ struct PersistInFlight { hipEvent_t ev; hipStream_t stream; int blocks; };
 std::vector<PersistInFlight> g_persist_inflight;    // oldest first
 std::vector<hipEvent_t> g_persist_free_events;
 
+// Round 6: as long as ONE stream has ever launched persistent grids, its launches run one after the other by themselves and need neither
+// admission nor an event behind every launch (an event record is a barrier packet: ~5 us between a launch and the next evaluation's input
+// projection, four times per T = 4 sample).  The first launch from a second stream drains the device once and switches the tracking on.
+hipStream_t g_persist_only_stream = (hipStream_t)(intptr_t)-1;
+bool g_persist_multi = false;
 int persist_admit(hipStream_t s, int blocks, int capacity) {
+    if (!g_persist_multi) {
+        if (g_persist_only_stream == (hipStream_t)(intptr_t)-1) g_persist_only_stream = s;
+        if (s == g_persist_only_stream) return 0;
+        HIPCHK(hipDeviceSynchronize());          // launches so far carry no event: nothing of them may still be running when tracking starts
+        g_persist_multi = true;
+    }
     // drop launches that have certainly finished
     for (size_t i = 0; i < g_persist_inflight.size();) {
         if (hipEventQuery(g_persist_inflight[i].ev) == hipSuccess) {
@@ -577,6 +588,7 @@ int persist_admit(hipStream_t s, int blocks, int capacity) {
     return 0;
 }
 int persist_launched(hipStream_t s, int blocks) {
+    if (!g_persist_multi) return 0;
     hipEvent_t ev;
     if (!g_persist_free_events.empty()) { ev = g_persist_free_events.back(); g_persist_free_events.pop_back(); }
     else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
