@@ -35,9 +35,6 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #ifndef WINO_ABL
 #define WINO_ABL 0
 #endif
-#ifndef SPLIT_PROJ
-#define SPLIT_PROJ 1        // WINO == 2: the output projection as two loops with the publish phase's first part between them (round 6); 0 = one loop, publish at the layer's end
-#endif
 #ifndef WINO_L2PF
 #define WINO_L2PF 0        // 1: touch the next layer's transformed weights into L2 during the projection (measured: no effect on the conv loop)
 #endif
@@ -267,18 +264,6 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
     };
     using first_t = std::integral_constant<bool, true>;
     using later_t = std::integral_constant<bool, false>;
-    // ... m-tiles I0 .. I1 - 1 only
-    auto mma_part = [&](auto first, const f32x4 (&af)[MT], const float (&bv)[4][NT], auto i0, auto i1) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int I0 = decltype(i0)::value, I1 = decltype(i1)::value;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = I0; i < I1; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bv[kk][j], FIRST && kk == 0 ? zero16 : acc[i][j], 0, 0, 0);
-    };
 
     const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
     // -DPUB_STAMP (timing-only builds, tools/persist_timing.py PUB=1): slots 0..5 take the publish phase's own steps instead of the layer's
@@ -710,12 +695,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         stamp(l, 4);
 
         // =========================================================== phase C: output projection
-        // half: 0 = both m-tiles of the wave (rows 32 w .. of the residual half and of the skip half) in one loop, 1 = the residual half alone, 2 = the skip half
-        // alone (the LAST layer — nobody reads its x' — and, round 6, the second loop of the SPLIT projection below); reinit: the weight ring holds nothing of
-        // this half yet (the split projection's second loop)
-        auto run_projection = [&](auto half, auto reinit) {
-            constexpr int HALF = decltype(half)::value;
-            constexpr int I0 = HALF == 2 ? 1 : 0, I1 = HALF == 1 ? 1 : MT;
+        {
             constexpr int NG = NGC;
             // Round 5: no VALU address arithmetic in this loop either — the weights through a buffer descriptor (lane offset constant, k-group
             // offset scalar; groups past the end are out of range and read as zeros: no clamps), z through one LDS pointer per ring round
@@ -724,13 +704,9 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             const int wvo = (w * 64 + lane) * 16;
             auto load_aob = [&](f32x4 (&dst)[MT], int group) {
 #pragma unroll
-                for (int i = I0; i < I1; ++i)
+                for (int i = 0; i < MT; ++i)
                     dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo + i * (NW * 1024), group * ((2 * C / 32) * 1024), 0));
             };
-            if constexpr (decltype(reinit)::value) {
-#pragma unroll
-                for (int s = 0; s < RING - 1; ++s) load_aob(A[s], s);
-            }
             float Bv[2][4][NT];
             const float* zb0 = z_lds + khalf * U_LD + l31;
             auto load_bz = [&](float (&dst)[4][NT], const float* zb, int goff) {      // goff: groups beyond zb's
@@ -741,7 +717,7 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             };
             need_z(0);
             load_bz(Bv[0], zb0, 0);
-            auto ring_round = [&](int it, auto first) {
+            auto ring_round = [&](int it, auto first, auto i0) {
                 const float* zb = zb0 + it * 8 * U_LD;
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
@@ -750,75 +726,77 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
                     load_bz(Bv[(s + 1) & 1], zb, s + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (it + s < NG) {       // NG need not be a multiple of the ring depth
-                        if (decltype(first)::value && s == 0) mma_part(first_t{}, A[s], Bv[s & 1], std::integral_constant<int, I0>{}, std::integral_constant<int, I1>{});
-                        else mma_part(later_t{}, A[s], Bv[s & 1], std::integral_constant<int, I0>{}, std::integral_constant<int, I1>{});
+                        if (decltype(first)::value && s == 0) mma_group(first_t{}, A[s], Bv[s & 1], i0);
+                        else mma_group(later_t{}, A[s], Bv[s & 1], i0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if constexpr (HALF == 2 && !decltype(reinit)::value) {      // the last layer: only the skip half (its x' has no reader): half of this loop's MFMAs, 0.6 % of a launch
+            if (more) {
+                ring_round(0, first_t{}, std::integral_constant<int, 0>{});
+#pragma unroll 1
+                for (int it = RING; it < NG; it += RING) ring_round(it, later_t{}, std::integral_constant<int, 0>{});
+            } else {      // the last layer: only the skip half of the projection (its x' has no reader): half of this loop's MFMAs, 0.6 % of a launch
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[0][j] = zero16;
-            }
-            ring_round(0, first_t{});
+                ring_round(0, first_t{}, std::integral_constant<int, 1>{});
 #pragma unroll 1
-            for (int it = RING; it < NG; it += RING) ring_round(it, later_t{});
-        };
-        // ---- epilogue in registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:].  part: 0 = both, 1 = x' only, 2 = the skip sum only
-        // WINO: eight accumulators leave the conv loop no room for all 64 registers of state: the skip sum stays resident, the residual
-        // stream x waits in memory (`xst`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
-        // the element (its own earlier stores: program order), requested ahead of the projection loop (st[0] holds the loaded x
-        // here).  x' stays in registers for the publish phase below.
-        auto run_epilogue = [&](auto part) {
-            constexpr int PART = decltype(part)::value;
+                for (int it = RING; it < NG; it += RING) ring_round(it, later_t{}, std::integral_constant<int, 1>{});
+            }
+        }
+        stamp(l, 5);
+        // ---- epilogue in registers: tile 0: x' = (o[:C] + (x + d)) / sqrt(2); tile 1: skip (+)= o[C:]
+        {
             const float* bo = a.bo[l];
             const float* dl = dv_b + (long)l * C;
             const int ln = opaque(lane);
             float bor[MT][16], ddr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {            // all loads in flight before the first use
-                if (PART != 2) bor[0][r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
-                if (PART != 1) bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
-                if (PART != 2) ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
+                bor[0][r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
+                bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
+                ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
             }
-            if (WINO && PART != 2) asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
+            // WINO: eight accumulators leave the conv loop no room for all 64 registers of state: the skip sum stays resident, the residual
+            // stream x waits in memory (`xst`: L2 / Infinity Cache resident) between layers — read-modify-write by the lane that owns
+            // the element (its own earlier stores: program order), requested ahead of the projection loop (st[0] holds the loaded x
+            // here).  x' stays in registers for the publish phase below.
+            if (WINO) asm volatile("" ::"v"(l2touch));      // (the L2-warming load's destination stays reserved until here)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (PART != 2) {
-                        const float o = acc[0][j][r] + bor[0][r];
-                        st[0][j][r] = (o + (st[0][j][r] + ddr[r])) * CMTTS_RSQRT2;
-                    }
-                    if (PART != 1) {
-                        const float os = acc[1][j][r] + bor[1][r];
-                        st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
-                    }
+                    const float o = acc[0][j][r] + bor[0][r];
+                    st[0][j][r] = (o + (st[0][j][r] + ddr[r])) * CMTTS_RSQRT2;
+                    const float os = acc[1][j][r] + bor[1][r];
+                    st[1][j][r] = l > 0 ? os + st[1][j][r] : os;
                 }
-        };
-        // ---- publish: this tile's edge columns of x' to the neighbours, the next layer's u rows into LDS, the neighbours' edge columns into its halo
+        }
+        if (!more) break;
+        stamp(l, 6);
+        pstamp(l, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand the edge columns of x' to the neighbouring tiles first (their latency is what the neighbours wait for)
         const float* dpn = dp_b + (long)(l + 1) * C;
         const unsigned tag = (unsigned)l + 1;
         unsigned long long* hbase = halo_g + ((((long)(l & 1) * B_g + b) * tiles_g) * 2) * C;    // [parity][b][tile][side][C]
-        auto pub_edges = [&]() {      // the edge columns of x' first (their latency is what the neighbours wait for)
-            {
-                const int ln = opaque(lane), c31 = ln & 31;
-                // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1).  The two columns sit in four lanes (16 registers
-                // each): stored from there they were 32 store instructions of two active lanes — ~100 cycles of issue apiece, 3-5 k per wave and
-                // layer at the head of the phase the neighbours wait for (round 5, -DPUB_STAMP).  Through 64 floats of LDS (a wave's own LDS
-                // operations execute in order: no barrier) every lane owns one granule and the wave stores them with ONE coalesced instruction.
-                float* edge = reinterpret_cast<float*>(smem + 2 * C * U_LD) + (FN + 2) * 2 + w * 64;
-                if (c31 == 0) {
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = st[0][0][r];
-                }
-                if (c31 == 31) {
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = st[0][NT - 1][r];
-                }
-                store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + (ln & 31), tag, edge[ln]);
+        {
+            const int ln = opaque(lane), c31 = ln & 31;
+            // column 0 of this tile -> slot (tile, side 0); column FN-1 -> slot (tile, side 1).  The two columns sit in four lanes (16 registers
+            // each): stored from there they were 32 store instructions of two active lanes — ~100 cycles of issue apiece, 3-5 k per wave and
+            // layer at the head of the phase the neighbours wait for (round 5, -DPUB_STAMP).  Through 64 floats of LDS (a wave's own LDS
+            // operations execute in order: no barrier) every lane owns one granule and the wave stores them with ONE coalesced instruction.
+            float* edge = reinterpret_cast<float*>(smem + 2 * C * U_LD) + (FN + 2) * 2 + w * 64;
+            if (c31 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = st[0][0][r];
             }
-        };
+            if (c31 == 31) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = st[0][NT - 1][r];
+            }
+            store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + (ln & 31), tag, edge[ln]);
+        }
         // ---- halo columns of the next layer's u.  Every wave fetches the two halo entries of ITS OWN 32 rows (lanes 0-31: left halo
         // frame t0 - 1, lanes 32-63: right halo frame t0 + FN): one cp value and one granule per lane, requested here — before the wave's
         // own u rows — and checked after them.  (Until round 4 the last two waves fetched all 256 rows of one side each, four granules
@@ -830,182 +808,132 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
         const unsigned long long* hg = hbase + ((long)(hinside ? (hside ? tile + 1 : tile - 1) : tile) * 2 + (hside ? 0 : 1)) * C + hm;
         float hcp = 0.f;
         int hph = 0, hix = 0;
-        unsigned long long hv = 0;
-        auto pub_halo_setup = [&]() {
-            {
-                const int thc = min(max(hth, 0), T - 1);
-                if (FACT) { hph = idx_lds[2 * (hside ? FN + 1 : 0)]; hix = idx_lds[2 * (hside ? FN + 1 : 0) + 1]; }   // (its two gathers ride with the wave's below)
-                else hcp = (cp_b + (long)(l + 1) * C * T)[(unsigned)(hm * T + thc)];
-            }
-        };
-        auto pub_halo_request = [&]() { hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        auto pub_rows = [&]() {      // next layer's u rows of this wave: cp (L2-warm, accumulator layout) + (x' + dp)
-            {
-                const float* cpn = cp_b + (long)(l + 1) * C * T;
-                const int ln = opaque(lane), c31 = ln & 31;
-                f32x16 cpc[NT];
-                float dpr[16];
-                if constexpr (FACT) {
-                    // Round 5: every load of this phase is ISSUED BY HAND before the first wait — the frame indices of both n-tiles and of the
-                    // halo frame first (one round trip), then the wave's 64 gathers, the halo entry's two and the 16 per-row dp values (one more).
-                    // Left to the compiler (at 253 of 256 registers) every element became mad_i64 / shift / add / load / s_waitcnt vmcnt(0): 32
-                    // dependent L2 round trips per wave and layer, then the index loads of the second n-tile behind the first tile's gathers, then
-                    // the dp loads one by one between the LDS stores — most of the publish phase's 15-20 k cycles.  The byte offset of an element
-                    // is formed in 32 bits in the register the load then overwrites (saddr form: uniform layer base + lane offset); row
-                    // (r & 3) + 8 (r >> 2) of the tile is a uniform multiple of the row pitch.  Same values as cp_fact: the same two loads, the
-                    // same add.
-                    const float* p1l = p1_b + (long)(l + 1) * C * ldp;
-                    const float* p2l = a.p2 + (long)(l + 1) * C * a.ld2;
-                    // the wave's own elements come from the channel-contiguous copies (persist_args.h: p1t [NL][ldp][C], p2t [NL][ld2][C]): a lane's 16 rows
-                    // of a tile are four runs of four consecutive channels = four 16-byte loads per factor and n-tile (the row-major tables took 16
-                    // scattered dwords each, and the phase was bound by the cache lines its gathers touch)
-                    const float* p1tl = p1t_b + (long)(l + 1) * ldp * C;
-                    const float* p2tl = a.p2t + (long)(l + 1) * a.ld2 * C;
-                    int phj[NT], ixj[NT];
-    #pragma unroll
-                    for (int j = 0; j < NT; ++j) { phj[j] = idx_lds[2 * (1 + j * 32 + c31)]; ixj[j] = idx_lds[2 * (1 + j * 32 + c31) + 1]; }
-                    // Round 6: the same 34 loads as compiler-VISIBLE buffer loads (one descriptor per table, the lane's byte offset in a
-                    // VGPR, the run's offset an immediate) instead of one `asm volatile` per load with a hand-written s_waitcnt behind them: the compiler
-                    // knew nothing of those loads' latency and was free to copy or spill their destination registers before the wait.  A buffer load
-                    // needs no address arithmetic (what had serialised the plain-pointer form at 253 registers), and the compiler places the waits.
-                    // Same loads of the same values, the same adds => the same bits (tests: test_cond_factored, FACT == expanded factors bitwise).
-                    const __amdgpu_buffer_rsrc_t r1t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1tl), 0, ldp * C * 4, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t r2t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2tl), 0, a.ld2 * C * 4, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1l), 0, C * ldp * 4, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2l), 0, C * a.ld2 * 4, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpn), 0, C * 4, 0x00020000);
-                    f32x4 g1[NT][4], g2[NT][4];
-                    const float h1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)((unsigned)(hm * ldp + (hph > 0 ? hph - 1 : 0)) * 4u), 0, 0));
-                    const float h2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (int)((unsigned)(hm * a.ld2 + hix) * 4u), 0, 0));
-    #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int o1 = (int)((unsigned)((phj[j] > 0 ? phj[j] - 1 : 0) * C + mrow0 + 4 * (ln >> 5)) * 4u);
-                        const int o2 = (int)((unsigned)(ixj[j] * C + mrow0 + 4 * (ln >> 5)) * 4u);
-    #pragma unroll
-                        for (int q = 0; q < 4; ++q) {      // rows 8 q + 4 khalf + {0, 1, 2, 3} = accumulator registers 4 q .. 4 q + 3
-                            g1[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1t, o1 + q * 32, 0, 0));
-                            g2[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2t, o2 + q * 32, 0, 0));
-                        }
-                    }
-                    {
-                        const int od = (int)((unsigned)(mrow0 + 4 * (ln >> 5)) * 4u);
-    #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            dpr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, od + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
-                    }
-                    pstamp(l, 2);
-                    hcp = (hph > 0 ? h1 : 0.f) + h2;
-    #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-    #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-    #pragma unroll
-                            for (int e = 0; e < 4; ++e) cpc[j][4 * q + e] = (phj[j] > 0 ? g1[j][q][e] : 0.f) + g2[j][q][e];
-                        }
-                } else {
-    #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int t_c = min(t0 + j * 32 + c31, T - 1);
-    #pragma unroll
-                        for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
-                    }
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) dpr[r] = ldg(dpn, (unsigned)(mrow0 + acc_row(r, ln)));
-                }
-    #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int t = t0 + j * 32 + c31;
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mrow0 + acc_row(r, ln);
-                        const float uv = cpc[j][r] + (st[0][j][r] + dpr[r]);
-                        u_lds[m * U_LD + uidx(j * 32 + c31)] = t < Tc ? uv : 0.f;
-                    }
-                }
-            }
-        };
-        auto pub_halo_finish = [&]() {
-            {   // the halo entries: wait for the neighbours' tags (lanes without a neighbour frame never wait)
-                if (!gave_up) {
-                    unsigned spins = 0;
-                    while (!__all(!hinside || (unsigned)(hv >> 32) == tag)) {
-                        if (++spins > SPIN_LIMIT) {      // wave-uniform: a neighbour never arrived
-                            if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
-                            gave_up = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
-                        hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                // after a timeout the halo column is poisoned: the utterance's mel comes out NaN (spreading one tile per layer) instead of
-                // plausible-but-wrong, and cmtts_poll_error() reports the timeout
-                const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
-                const float uh = hcp + (xh + dpn[hm]);
-                u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
-            }
-        };
-        auto pub_store_x = [&]() {
-            if constexpr (WINO) {      // x' goes back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
-                                       // the acknowledgement of these stores (one counter for loads and stores)
-                f32x4* px = reinterpret_cast<f32x4*>(pst_b) + (w * 8) * 64 + opaque(lane);
-    #pragma unroll
-                for (int j = 0; j < NT; ++j)
-    #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 vx;
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) vx[e] = st[0][j][4 * q + e];
-                        px[(j * 4 + q) * 64] = vx;
-                    }
-            }
-        };
-        // Round 6 (WINO == 2): the projection as TWO loops — the residual half first, then the skip half — with the first part of the publish
-        // phase BETWEEN them.  Joint, the publish phase ran at the layer's end, when both waves of a SIMD are out of MFMA work: its granule stores, the
-        // factor gathers' round trip and 3-6 k cycles of waiting for the NEIGHBOURS' edge columns were exposed (11-17 k of the layer's 206 k cycles).
-        // Split, x' is final after the first loop: its edge columns leave then, the gathers and the u rows run under the sibling wave's MFMAs, x' goes
-        // back to `xst`, and the neighbours' columns have a whole skip-half loop (~33 k cycles) to arrive before the halo entries are read.  Cost: z is
-        // read from LDS twice.  Same MFMA chains per accumulator, same epilogue expressions: the same bits.
-        constexpr bool SPLITP = WINO == 2 && SPLIT_PROJ;
-        if (SPLITP && more) {
-            run_projection(std::integral_constant<int, 1>{}, std::false_type{});
-            stamp(l, 5);
-            run_epilogue(std::integral_constant<int, 1>{});
-            stamp(l, 6);
-            pstamp(l, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            pub_edges();
-            pub_halo_setup();
-            pstamp(l, 1);
-            pub_rows();
-            pstamp(l, 3);
-            pub_store_x();
-            run_projection(std::integral_constant<int, 2>{}, std::true_type{});
-            run_epilogue(std::integral_constant<int, 2>{});
-            pub_halo_request();
-            pub_halo_finish();
-            pstamp(l, 4);
-            pstamp(l, 5);
-        } else {
-            if (more) run_projection(std::integral_constant<int, 0>{}, std::false_type{});
-            else run_projection(std::integral_constant<int, 2>{}, std::false_type{});
-            stamp(l, 5);
-            run_epilogue(std::integral_constant<int, 0>{});
-            if (!more) break;
-            stamp(l, 6);
-            pstamp(l, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            pub_edges();
-            pub_halo_setup();
-            pub_halo_request();
-            pstamp(l, 1);
-            pub_rows();
-            pstamp(l, 3);
-            pub_halo_finish();
-            pstamp(l, 4);
-            pub_store_x();
-            pstamp(l, 5);
+        {
+            const int thc = min(max(hth, 0), T - 1);
+            if (FACT) { hph = idx_lds[2 * (hside ? FN + 1 : 0)]; hix = idx_lds[2 * (hside ? FN + 1 : 0) + 1]; }   // (its two gathers ride with the wave's below)
+            else hcp = (cp_b + (long)(l + 1) * C * T)[(unsigned)(hm * T + thc)];
         }
+        unsigned long long hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pstamp(l, 1);
+        // ---- next layer's u rows of this wave: cp (L2-warm, accumulator layout) + (x' + dp)
+        {
+            const float* cpn = cp_b + (long)(l + 1) * C * T;
+            const int ln = opaque(lane), c31 = ln & 31;
+            f32x16 cpc[NT];
+            float dpr[16];
+            if constexpr (FACT) {
+                // Round 5: every load of this phase is ISSUED BY HAND before the first wait — the frame indices of both n-tiles and of the
+                // halo frame first (one round trip), then the wave's 64 gathers, the halo entry's two and the 16 per-row dp values (one more).
+                // Left to the compiler (at 253 of 256 registers) every element became mad_i64 / shift / add / load / s_waitcnt vmcnt(0): 32
+                // dependent L2 round trips per wave and layer, then the index loads of the second n-tile behind the first tile's gathers, then
+                // the dp loads one by one between the LDS stores — most of the publish phase's 15-20 k cycles.  The byte offset of an element
+                // is formed in 32 bits in the register the load then overwrites (saddr form: uniform layer base + lane offset); row
+                // (r & 3) + 8 (r >> 2) of the tile is a uniform multiple of the row pitch.  Same values as cp_fact: the same two loads, the
+                // same add.
+                const float* p1l = p1_b + (long)(l + 1) * C * ldp;
+                const float* p2l = a.p2 + (long)(l + 1) * C * a.ld2;
+                // the wave's own elements come from the channel-contiguous copies (persist_args.h: p1t [NL][ldp][C], p2t [NL][ld2][C]): a lane's 16 rows
+                // of a tile are four runs of four consecutive channels = four 16-byte loads per factor and n-tile (the row-major tables took 16
+                // scattered dwords each, and the phase was bound by the cache lines its gathers touch)
+                const float* p1tl = p1t_b + (long)(l + 1) * ldp * C;
+                const float* p2tl = a.p2t + (long)(l + 1) * a.ld2 * C;
+                int phj[NT], ixj[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { phj[j] = idx_lds[2 * (1 + j * 32 + c31)]; ixj[j] = idx_lds[2 * (1 + j * 32 + c31) + 1]; }
+                // Round 6: the same 34 loads as compiler-VISIBLE buffer loads (one descriptor per table, the lane's byte offset in a
+                // VGPR, the run's offset an immediate) instead of one `asm volatile` per load with a hand-written s_waitcnt behind them: the compiler
+                // knew nothing of those loads' latency and was free to copy or spill their destination registers before the wait.  A buffer load
+                // needs no address arithmetic (what had serialised the plain-pointer form at 253 registers), and the compiler places the waits.
+                // Same loads of the same values, the same adds => the same bits (tests: test_cond_factored, FACT == expanded factors bitwise).
+                const __amdgpu_buffer_rsrc_t r1t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1tl), 0, ldp * C * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r2t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2tl), 0, a.ld2 * C * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p1l), 0, C * ldp * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p2l), 0, C * a.ld2 * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpn), 0, C * 4, 0x00020000);
+                f32x4 g1[NT][4], g2[NT][4];
+                const float h1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)((unsigned)(hm * ldp + (hph > 0 ? hph - 1 : 0)) * 4u), 0, 0));
+                const float h2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (int)((unsigned)(hm * a.ld2 + hix) * 4u), 0, 0));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int o1 = (int)((unsigned)((phj[j] > 0 ? phj[j] - 1 : 0) * C + mrow0 + 4 * (ln >> 5)) * 4u);
+                    const int o2 = (int)((unsigned)(ixj[j] * C + mrow0 + 4 * (ln >> 5)) * 4u);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {      // rows 8 q + 4 khalf + {0, 1, 2, 3} = accumulator registers 4 q .. 4 q + 3
+                        g1[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1t, o1 + q * 32, 0, 0));
+                        g2[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2t, o2 + q * 32, 0, 0));
+                    }
+                }
+                {
+                    const int od = (int)((unsigned)(mrow0 + 4 * (ln >> 5)) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dpr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, od + ((r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+                }
+                pstamp(l, 2);
+                hcp = (hph > 0 ? h1 : 0.f) + h2;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cpc[j][4 * q + e] = (phj[j] > 0 ? g1[j][q][e] : 0.f) + g2[j][q][e];
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int t_c = min(t0 + j * 32 + c31, T - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpr[r] = ldg(dpn, (unsigned)(mrow0 + acc_row(r, ln)));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int t = t0 + j * 32 + c31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow0 + acc_row(r, ln);
+                    const float uv = cpc[j][r] + (st[0][j][r] + dpr[r]);
+                    u_lds[m * U_LD + uidx(j * 32 + c31)] = t < Tc ? uv : 0.f;
+                }
+            }
+        }
+        pstamp(l, 3);
+        {   // the halo entries: wait for the neighbours' tags (lanes without a neighbour frame never wait)
+            if (!gave_up) {
+                unsigned spins = 0;
+                while (!__all(!hinside || (unsigned)(hv >> 32) == tag)) {
+                    if (++spins > SPIN_LIMIT) {      // wave-uniform: a neighbour never arrived
+                        if (lane == 0 && a.tmo) *(volatile unsigned*)a.tmo = 1u;
+                        gave_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                    hv = __hip_atomic_load((gu64*)hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // after a timeout the halo column is poisoned: the utterance's mel comes out NaN (spreading one tile per layer) instead of
+            // plausible-but-wrong, and cmtts_poll_error() reports the timeout
+            const float xh = gave_up ? __builtin_nanf("") : (hinside ? __uint_as_float((unsigned)hv) : 0.f);
+            const float uh = hcp + (xh + dpn[hm]);
+            u_lds[hm * U_LD + uidx(hside ? FN : -1)] = hinside ? uh : 0.f;
+        }
+        pstamp(l, 4);
+        if constexpr (WINO) {      // x' goes back to memory LAST: in front of the publish phase's loads, every wait of that phase also waited for
+                                   // the acknowledgement of these stores (one counter for loads and stores)
+            f32x4* px = reinterpret_cast<f32x4*>(pst_b) + (w * 8) * 64 + opaque(lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 vx;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vx[e] = st[0][j][4 * q + e];
+                    px[(j * 4 + q) * 64] = vx;
+                }
+        }
+        pstamp(l, 5);
         stamp(l, 7);
     }
 
