@@ -30,6 +30,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
+// No floating-point contraction in this file: x' = (o + (x + d)) * 2^-1/2 feeds u = cp + (x' + dp) in the same loop body here, and the compiler fused the
+// multiply into that add (one rounding less than the 64-frame kernel and the per-layer kernels, where x' passes through registers of another block / through
+// memory): 1 ulp of fp32 that flips a bf16 rounding of u once in ~1e5 elements and then spreads a frame per layer (found by test_persistent_denoiser_lp128_bitwise).
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int C = 256;
