@@ -177,6 +177,13 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
     };
 
     bool gave_up = false;
+    // -DLP_STAMP (timing-only builds loaded through CMTTS_LIB, tools/lp128_phases.py): cycle stamps of layer NL / 2 per wave
+#ifdef LP_STAMP
+    const int bid_dbg = blockIdx.x + gridDim.x * blockIdx.y;
+#define LPSTAMP(slot) do { if (a.dbg && l == a.NL / 2 && lane == 0) a.dbg[((long)bid_dbg * NW + w) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LPSTAMP(slot) do { } while (0)
+#endif
     for (int l = 0; l < a.NL; ++l) {
         const bool more = l + 1 < a.NL;
         constexpr int NGB = 3 * (C / 16);        // k = 3 conv: group = tap * 16 + k-group
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
         u32x4 A[RING][MT];
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) load_a(A[s], a.W3f[l], s);         // the weight stream does not depend on u
+        LPSTAMP(0);
         __syncthreads();   // (1) u^T of layer l complete
+        LPSTAMP(1);
         if (more) {        // pull the next layer's cp tile towards L2: one dword per 128-B line
             const float* cpn = cp_b + (long)(l + 1) * C * T;
             const int tl = opaque(tid);
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
                 }
             }
         }
+        LPSTAMP(2);
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) load_ao(A[s], a.Wof[l], min(s, NGC - 1));
         {   // gate -> z^T (own buffer: no barrier between the conv and the gate)
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
                         put2<MODE>(zt, (j * 32 + (ln & 31)) * RS + ch, z0, z1, true);
                     }
         }
+        LPSTAMP(3);
         // (3) per-wave flags instead of a barrier (denoiser_persist_lp.hip): the projection's K loop acquires the flag of the block it is about to read
         if (lane == 0) __hip_atomic_store(zflag + w, l + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         unsigned zready = 0;
@@ -256,106 +267,164 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
             }
         };
 
-        // =========================================================== phase C: output projection, 16 k-groups
-        {
-            zero_acc();
-            u32x4 Bv[2][NT];
-            need_z(0);
-            load_b(Bv[0], zt, 0, 0);
-#pragma unroll 1
-            for (int it = 0; it < NGC; it += RING) {
-#pragma unroll
-                for (int s = 0; s < RING; ++s) {
-                    load_ao(A[(s + RING - 1) % RING], a.Wof[l], min(it + s + RING - 1, NGC - 1));
-                    if (((it + s + 1) & 1) == 0) need_z((it + s + 1) >> 1);      // k-group it + s + 1 opens the next wave's channels
-                    load_b(Bv[(s + 1) & 1], zt, min(it + s + 1, NGC - 1), 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (it + s < NGC) mma_group(A[s], Bv[s & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- epilogue + publish, n-tile by n-tile, the state streaming through registers:
-        //   x' = (o[:C] + (x + d)) / sqrt(2) -> xst;  skip (+)= o[C:] -> xst;  next layer's u^T rows = cvt(cp + (x' + dp));  the tile's two edge columns of x'
-        // (a wave writes the next u^T only after its projection loop, i.e. after it has consumed all eight z blocks: every wave has left the conv)
+        LPSTAMP(4);
+        // =========================================================== phase C: output projection (16 k-groups) + epilogue, as TWO loops of four accumulators:
+        // the residual half (rows 32 w .. of o[:C]) with the x state and the next layer's cp tile requested IN FRONT of it — they land under its MFMAs — then
+        // x' / the u^T rows / the edge columns; the skip half (rows 32 w .. of o[C:]) with the skip state requested in front of it, then the skip sum.  (As one
+        // loop of eight accumulators the state had to be fetched n-tile by n-tile behind it: four exposed round trips to the Infinity Cache, 32 k cycles per
+        // layer.)  z^T is read twice; every accumulator's chain is unchanged.
         const float* dpn = dp_b + (long)(l + 1) * C;
         const unsigned tag = (unsigned)l + 1;
         unsigned long long* hbase = a.halo + ((((long)(l & 1) * a.B + b) * a.tiles) * 2) * C;
         float* edge = reinterpret_cast<float*>(lds16 + IMG) + w * 64;
         {
+            const int ln = opaque(lane), c31 = ln & 31;
+            f32x4* px = reinterpret_cast<f32x4*>(st_x) + (w * NT * 4) * 64 + ln;
+            f32x4* ps = reinterpret_cast<f32x4*>(st_s) + (w * NT * 4) * 64 + ln;
+            f32x16 (&accp)[NT] = acc[0];
+            auto proj_half = [&](auto half) {
+                constexpr int I = decltype(half)::value;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accp[j][r] = 0.f;
+                u32x4 Bv[2][NT];
+                if (I == 0) need_z(0);
+                load_b(Bv[0], zt, 0, 0);
+#pragma unroll 1
+                for (int it = 0; it < NGC; it += RING) {
+#pragma unroll
+                    for (int s = 0; s < RING; ++s) {
+                        A[(s + RING - 1) % RING][I] = *(reinterpret_cast<const u32x4*>(a.Wof[l]) + ((long)min(it + s + RING - 1, NGC - 1) * (2 * C / 32) + I * NW + w) * 64 + lane);
+                        if (I == 0 && ((it + s + 1) & 1) == 0) need_z((it + s + 1) >> 1);      // k-group it + s + 1 opens the next wave's channels
+                        load_b(Bv[(s + 1) & 1], zt, min(it + s + 1, NGC - 1), 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (it + s < NGC) {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) accp[j] = mma16<MODE>(A[s][I], Bv[s & 1][j], accp[j]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            // ---- residual half
             const float* bo = a.bo[l];
             const float* dl = dv_b + (long)l * C;
             const float* cpn = cp_b + (long)(l + 1) * C * T;
-            const int ln = opaque(lane), c31 = ln & 31;
-            float bor[MT][16], ddr[16], dpr[16];
+            {
+                // (the x state — Infinity-Cache latency — is requested in front of the loop; cp, L2-warm since the layer's start, and the per-row vectors behind it,
+                // all n-tiles in one batch: with them in flight across the loop as well the wave needs 300 registers)
+                float bor[16], ddr[16], dpr[16];
+                f32x16 xo[NT], cpc[NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bor[0][r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
-                bor[1][r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
-                ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
-                dpr[r] = more ? ldg(dpn, (unsigned)(mrow0 + acc_row(r, ln))) : 0.f;
+                for (int j = 0; j < NT; ++j) {
+                    const int t_c = min(t0 + j * 32 + c31, T - 1);
+                    if (l == 0) {      // x enters in the public [C][T] layout
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xo[j][r] = ldg(x0_b, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 vx = px[(j * 4 + q) * 64];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xo[j][4 * q + e] = vx[e];
+                        }
+                    }
+                }
+                proj_half(std::integral_constant<int, 0>{});
+                LPSTAMP(5);
+                if (more) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bor[r] = ldg(bo, (unsigned)(mrow0 + acc_row(r, ln)));
+                        ddr[r] = ldg(dl, (unsigned)(mrow0 + acc_row(r, ln)));
+                    }
+                    // pass 1: x' (frees the accumulators), back to `xst`; the tile's edge columns
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float o = accp[j][r] + bor[r];
+                            xo[j][r] = (o + (xo[j][r] + ddr[r])) * CMTTS_RSQRT2;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 vx;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vx[e] = xo[j][4 * q + e];
+                            px[(j * 4 + q) * 64] = vx;
+                        }
+                        if (j == 0 && c31 == 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = xo[j][r];
+                        }
+                        if (j == NT - 1 && c31 == 31) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = xo[j][r];
+                        }
+                    }
+                    // the edge columns leave now: the neighbours get the whole skip-half loop to receive them
+                    store_granule(hbase + ((long)tile * 2 + (ln >> 5)) * C + mrow0 + (ln & 31), tag, edge[ln]);
+                    // pass 2: the next layer's u^T rows = cvt(cp + (x' + dp)): cp (L2-warm) for all n-tiles in one batch
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dpr[r] = ldg(dpn, (unsigned)(mrow0 + acc_row(r, ln)));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int t_c = min(t0 + j * 32 + c31, T - 1);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) cpc[j][r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int t = t0 + j * 32 + c31;
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const int m = mrow0 + acc_row(r, ln);
+                            const float u0 = cpc[j][r] + (xo[j][r] + dpr[r]);
+                            const float u1 = cpc[j][r + 1] + (xo[j][r + 1] + dpr[r + 1]);
+                            put2<MODE>(ut, (1 + j * 32 + c31) * RS + m, u0, u1, t < T);
+                            note_range<MODE>(ovf, u0, u1, t < T);
+                        }
+                    }
+                }
             }
-            f32x4* px = reinterpret_cast<f32x4*>(st_x) + (w * NT * 4) * 64 + ln;
-            f32x4* ps = reinterpret_cast<f32x4*>(st_s) + (w * NT * 4) * 64 + ln;
+            // ---- skip half
+            {
+                float bor[16];
+                f32x16 so[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int t = t0 + j * 32 + c31;
-                const int t_c = min(t, T - 1);
-                f32x16 xo, so, cpc;
-                if (l == 0) {      // x enters in the public [C][T] layout; no skip sum yet
+                for (int r = 0; r < 16; ++r) bor[r] = ldg(bo, (unsigned)(C + mrow0 + acc_row(r, ln)));
+                if (l > 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xo[r] = ldg(x0_b, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
-                } else {
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 vs = ps[(j * 4 + q) * 64];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) so[j][4 * q + e] = vs[e];
+                        }
+                }
+                proj_half(std::integral_constant<int, 1>{});
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float os = accp[j][r] + bor[r];
+                        so[j][r] = l > 0 ? os + so[j][r] : os;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 vx = px[(j * 4 + q) * 64], vs = ps[(j * 4 + q) * 64];
+                        f32x4 vs;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { xo[4 * q + e] = vx[e]; so[4 * q + e] = vs[e]; }
-                    }
-                }
-                if (more) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cpc[r] = ldg(cpn, (unsigned)((mrow0 + acc_row(r, ln)) * T + t_c));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float o = acc[0][j][r] + bor[0][r];
-                    xo[r] = (o + (xo[r] + ddr[r])) * CMTTS_RSQRT2;
-                    const float os = acc[1][j][r] + bor[1][r];
-                    so[r] = l > 0 ? os + so[r] : os;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 vx, vs;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vx[e] = xo[4 * q + e]; vs[e] = so[4 * q + e]; }
-                    if (more) px[(j * 4 + q) * 64] = vx;
-                    ps[(j * 4 + q) * 64] = vs;
-                }
-                if (more) {
-                    if (j == 0 && c31 == 0) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) edge[acc_row(r, ln)] = xo[r];
-                    }
-                    if (j == NT - 1 && c31 == 31) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) edge[32 + acc_row(r, ln)] = xo[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int m = mrow0 + acc_row(r, ln);
-                        const float u0 = cpc[r] + (xo[r] + dpr[r]);
-                        const float u1 = cpc[r + 1] + (xo[r + 1] + dpr[r + 1]);
-                        put2<MODE>(ut, (1 + j * 32 + c31) * RS + m, u0, u1, t < T);
-                        note_range<MODE>(ovf, u0, u1, t < T);
+                        for (int e = 0; e < 4; ++e) vs[e] = so[j][4 * q + e];
+                        ps[(j * 4 + q) * 64] = vs;
                     }
                 }
             }
         }
         if (!more) break;
         __builtin_amdgcn_sched_barrier(0);
-        // edge columns of x' (fp32) to the neighbouring tiles: one coalesced 64-lane granule store through the wave's own LDS scratch
-        store_granule(hbase + ((long)tile * 2 + (opaque(lane) >> 5)) * C + mrow0 + (opaque(lane) & 31), tag, edge[opaque(lane)]);
+        LPSTAMP(6);
         // ---- halo columns of the next layer's u^T: every wave fetches the two halo entries of ITS OWN 32 channels (lanes 0-31: frame t0 - 1, lanes 32-63: frame t0 + FN)
         const int hside = opaque(lane) >> 5, hm = mrow0 + (opaque(lane) & 31);
         const int hth = hside ? t0 + FN : t0 - 1;
@@ -381,6 +450,7 @@ __global__ __launch_bounds__(64 * NW, 1) void denoiser_persist_lp128_kernel(cons
             put1<MODE>(ut, (hside ? FN + 1 : 0) * RS + hm, uh, hinside);
             note_range<MODE>(ovf, uh, 0.f, hinside);
         }
+        LPSTAMP(7);
     }
 
     if (MODE >= 2 && ovf && a.tmo && *(volatile unsigned*)a.tmo == 0u) *(volatile unsigned*)a.tmo = 3u;
@@ -472,7 +542,11 @@ extern "C" int cmtts_launch_denoiser_persist_lp128(const PersistArgs* a_in, int 
     if (a.NL < 1 || a.NL > PERSIST_MAX_LAYERS || tiles > max_blocks || (long)C * a.T >= (1L << 30) || (mode != 1 && mode != 2) || !a.xst) return -2;
     if (a.tail && a.n_mels > 128) return -2;
     a.tiles = tiles;
+#ifdef LP_STAMP
+    a.dbg = cmtts_persist_get_debug();
+#else
     a.dbg = nullptr;
+#endif
     if (!a.halo_zeroed && hipMemsetAsync(a.halo, 0, cmtts_persist_halo_bytes(a.B, a.T), stream) != hipSuccess) return -3;
     return mode == 1 ? launch_mode<1>(a, tiles, max_blocks, stream) : launch_mode<2>(a, tiles, max_blocks, stream);
 }
