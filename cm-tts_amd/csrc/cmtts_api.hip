@@ -512,7 +512,6 @@ int g_ffn_xres = 1;            // encoder k=9 FFN conv through conv_xres.hip whe
 int g_split_resblock = 1;       // fp32 residual block as two launches over 4x the CUs (resblock_split.hip): 0 never, 1 small batches, 2 always
 int g_cond_gemm16 = 1;          // bf16 / fp16 / fp16x3 models: conditioner GEMM with 16-bit operands (cond_gemm16.hip); 0 = fp32 operands as until round 3 (different numerics)
 int g_cond_gemm = 1;            // stacked conditioner GEMM through cond_gemm.hip: 0 never (generic kernel), 1 when it pays, 2 whenever supported
-int g_persist_lp128 = 1;       // round 6: bf16 / fp16 persistent stack with 128-frame tiles (denoiser_persist_lp128.hip; same bits): 0 never, 1 when the batch has more 64-frame tiles than CUs, 2 whenever the persistent path is taken (tests)
 int g_persist = 1;              // residual layers in one persistent launch (denoiser_persist.hip): 0 never, 1 when it pays, 2 whenever supported
 unsigned* g_tmo_host = nullptr;  // pinned, device-visible: 1 = a neighbour wait of the persistent kernel expired, 2 = a denoiser evaluation wrote a
                                  // non-finite mel value (persist_tail.h, mel_post_kernel: the sampler's post-scaling sees every output element), 3 = a conv
@@ -1541,15 +1540,8 @@ int denoiser_core(cmtts_model* m, const DenWs& w, const float* x_src, float in_s
         const int need = cmtts_persist_plan(B, T, NL, persist_blocks(), g_persist == 2);
         if (need) CHK(persist_admit(s, need, persist_blocks()));
         if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-        int rc = -2;
-        // bf16 / fp16 models, more 64-frame tiles than CUs (the 64-frame kernel would run in rounds): 128-frame tiles — every weight fragment used for two
-        // sub-tiles, x and the skip sum in `xst` between layers (denoiser_persist_lp128.hip, round 6; bitwise the 64-frame kernel)
-        if ((prec == 1 || prec == 2) && g_persist_lp128 && w.pst &&
-            (g_persist_lp128 == 2 || (long)((T + 63) / 64) * B > persist_blocks()))
-            rc = cmtts_launch_denoiser_persist_lp128(&pa, prec, persist_blocks(), (void*)s);
-        if (rc == -2)
-            rc = prec ? cmtts_launch_denoiser_persist_lp(&pa, prec, persist_blocks(), g_persist == 2, (void*)s)
-                      : cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
+        const int rc = prec ? cmtts_launch_denoiser_persist_lp(&pa, prec, persist_blocks(), g_persist == 2, (void*)s)
+                            : cmtts_launch_denoiser_persist(&pa, persist_blocks(), g_persist == 2, (void*)s);
         if (rc == -3) return fail(CMTTS_E_HIP, "persistent denoiser launch failed");
         if (rc == 0) {
             CHK(persist_launched(s, need));
@@ -2881,7 +2873,6 @@ int cmtts_internal_set(const char* name, int value) {
         {"cond_factored", &g_cond_factored, 0, 1}, // fp32 models: conditioner projections expanded from their phoneme-level / pitch-table factors when the caller hands them over (NOT bitwise the dense GEMM: W a + W b against W (a + b))
         {"cond_gemm16", &g_cond_gemm16, 0, 1},     // 16-bit models: conditioner GEMM with 16-bit operands (NOT bitwise: another operand precision)
         {"cond_gemm", &g_cond_gemm, 0, 2},         // stacked conditioner GEMM on cond_gemm.hip: 0 never, 1 when it pays, 2 whenever supported
-        {"persist_lp128", &g_persist_lp128, 0, 2}, // 16-bit persistent stack with 128-frame tiles: 0 never, 1 more 64-frame tiles than CUs, 2 always (same bits)
         {"persist_tail", &g_persist_tail, 0, 1},   // skip head + post-scaling inside the persistent launch
         {"persist_wino", &g_persist_wino, 0, 3},   // fp32 persistent denoiser's k = 3 conv: 0 direct, 1 (and 2) Winograd F(2,3), 3 F(4,3) (NOT bitwise the direct form)
         {"inproj_fused", &g_inproj_fused, 0, 1},   // denoiser input as one launch

@@ -965,7 +965,7 @@ int g_process_group = 0;
 // per kernel instance: the LARGEST grid (workgroups) whose co-residency the runtime has confirmed.  Instances differ in registers and
 // threads, so every one has its own record: fp32 uniform 0..7 = (direct | 8-wave F(2,3) | 8-wave F(4,3) | one wave per SIMD) x (cp | factors),
 // fp32 ragged 8..15 likewise, the 16-bit modes 16 + MODE (shared slots let one kernel's validation vouch for another)
-constexpr int N_VARIANTS = 32;
+constexpr int N_VARIANTS = 24;
 int g_validated_wg[N_VARIANTS] = {};
 
 }  // namespace
@@ -1013,10 +1013,7 @@ extern "C" int cmtts_persist_plan(int B, int T, int NL, int max_blocks, int forc
 
 extern "C" size_t cmtts_persist_state_floats(int B, int T) {
     const long tiles = (T + FN - 1) / FN;
-    // ... or, for the 16-bit stack's 128-frame-tile instance (denoiser_persist_lp128.hip, round 6), x AND the skip sum of every 128-frame tile: 2 x 256 x 128 floats
-    const long tiles128 = (T + 127) / 128;
-    const size_t a = (size_t)B * tiles * (NW * 8 * 64 * 4), b = (size_t)B * tiles128 * (2 * 256 * 128);
-    return a > b ? a : b;
+    return (size_t)B * tiles * (NW * 8 * 64 * 4);
 }
 
 extern "C" size_t cmtts_persist_halo_bytes(int B, int T) {

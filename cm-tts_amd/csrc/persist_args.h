@@ -114,8 +114,6 @@ long long* cmtts_persist_get_debug(void);
 int cmtts_persist_set_cooperative(int on);
 void cmtts_persist_validated(int variant, int gx, int gy);    // the runtime accepted a cooperative launch of this grid
 int cmtts_persist_cooperative(int variant, int gx, int gy);   // should THIS launch be cooperative? (variant = kernel instance, denoiser_persist.hip)
-// the 16-bit stack with 128-frame tiles (denoiser_persist_lp128.hip): mode 1 = bf16, 2 = fp16; 0, -2 (not covered: use cmtts_launch_denoiser_persist_lp) or -3
-int cmtts_launch_denoiser_persist_lp128(const PersistArgs* a, int mode, int max_blocks, void* stream);
 int cmtts_persist_note_process_group(int on);   // cmtts_comm_init_rank and the Python host (torch.distributed initialised) call this
 #ifdef __cplusplus
 }

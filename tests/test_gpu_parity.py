@@ -2159,50 +2159,6 @@ def test_persistent_denoiser_lp_bitwise(variant, B, T, dtype):
     assert torch.equal(one2, ref)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("variant,B,T", [("VCTK", 2, 200), ("LJSpeech", 64, 512), ("VCTK", 40, 300), ("LJSpeech", 3, 129), ("LJSpeech", 70, 500), ("VCTK", 5, 65),
-                                         ("LJSpeech", 1, 1), ("VCTK", 3, 128), ("LJSpeech", 2, 1000)])
-def test_persistent_denoiser_lp128_bitwise(variant, B, T, dtype):
-    """Round 6: denoiser_persist_lp128.hip — the 16-bit persistent stack with 128-FRAME tiles (every weight fragment multiplies two 64-frame
-    sub-tiles; x and the skip sum live in memory between layers) — against the 64-frame persistent kernel and the per-layer 16-bit kernels: the same
-    conversions, the same (tap, k-group) accumulation order, the same epilogue expressions: bit for bit.  Forced at every shape (persist_lp128 = 2): odd T, a
-    lone tail sub-tile (T = 129: the second tile holds one frame), T = 65 / 1 (the second SUB-tile empty), utterance chunking (70 x 4 tiles > 256 CUs); one
-    network evaluation and a T = 2 sample through the in-kernel tail."""
-    host = _host()
-    lib = _lib.load()
-    cfg = get_config(variant)
-    model = host.CMTotalTTS(cfg, DEV).load_state_dict(synth_cmtts_state_dict(cfg, seed=6))
-    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
-    cond = torch.randn(B, T, cfg.hidden, generator=gen)
-    x = torch.randn(B, 1, T, cfg.n_mels, generator=gen)
-    spk = torch.randn(B, cfg.hidden, generator=gen) if cfg.multi_speaker else None
-    t = torch.full((B,), 1095.5)
-    noise = torch.randn(3, B, 1, T, cfg.n_mels, generator=gen).to(DEV)
-    cond_ct = cond.transpose(1, 2).contiguous().to(DEV)
-    spk_d = None if spk is None else spk.to(DEV)
-    prev = lib.cmtts_set_persistent_denoiser(2)
-    prev128 = _lib.internal_set(b"persist_lp128", 2)
-    model.set_precision(dtype)
-    try:
-        one = model.net(x, t, cond, spk).clone()
-        one2 = model.net(x, t, cond, spk).clone()       # back to back: granule slots and state are per launch
-        mel128 = host.sample_with_cond(model, cond_ct, spk_d, 2, noise).clone()
-        _lib.internal_set(b"persist_lp128", 0)
-        ref64 = model.net(x, t, cond, spk).clone()
-        mel64 = host.sample_with_cond(model, cond_ct, spk_d, 2, noise).clone()
-        lib.cmtts_set_persistent_denoiser(0)
-        ref = model.net(x, t, cond, spk).clone()
-    finally:
-        _lib.internal_set(b"persist_lp128", prev128)
-        lib.cmtts_set_persistent_denoiser(prev)
-        model.set_precision("fp32")
-    host.synchronize()
-    assert torch.isfinite(one).all() and torch.isfinite(mel128).all()
-    assert torch.equal(one, ref64), float((one - ref64).abs().max())
-    assert torch.equal(one, ref) and torch.equal(one2, ref)
-    assert torch.equal(mel128, mel64), float((mel128 - mel64).abs().max())
-
-
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_vocoder_mrf_streams_bitwise(dtype):
     """Small batches: the three ResBlocks of an MRF stage run on three streams, their sum still accumulates in ResBlock
