@@ -699,7 +699,10 @@ __global__ __launch_bounds__(64 * NW, 2) void denoiser_persist_kernel(const Pers
             constexpr int NG = NGC;
             // Round 5: no VALU address arithmetic in this loop either — the weights through a buffer descriptor (lane offset constant, k-group
             // offset scalar; groups past the end are out of range and read as zeros: no clamps), z through one LDS pointer per ring round
-            // with immediate offsets (the reads past the last group land behind z, inside the allocation, and are not used)
+            // with immediate offsets.  The ring's look-ahead reads k-groups 32 .. 36 of z: up to 40 rows (~10.9 KB) past the z tile, of which only the
+            // index table (2.6 KB) lies inside the workgroup's allocation — the rest is beyond it.  Those reads are never USED (the groups do
+            // not exist: `it + s < NG` guards the MFMAs), and an LDS read beyond the workgroup's allocation is bounds-checked by the hardware and returns
+            // zero; clamping them costs a v_min per read in the loop next to fp32 MFMAs, where every VALU instruction is issue time (0.25 % per instruction)
             const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wof[l]), 0, NG * (2 * C / 32) * 256 * 4, 0x00020000);
             const int wvo = (w * 64 + lane) * 16;
             auto load_aob = [&](f32x4 (&dst)[MT], int group) {
