@@ -1908,7 +1908,9 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     k_embed_tokens(texts, src_lens, m->embed, m->omega_h, m->pe_h, PE_ROWS, w.x, B, L, Lp, H, (float)sqrt((double)H), s);
     CHK(fft_stack(m, m->enc, w, src_lens, B, L, s, pad_lens));
     k_layernorm_ct(w.x, w.x, m->encln_g, m->encln_b, 1e-5f, src_lens, B, L, Lp, s);
-    if (enc_out_ct)
+    // the encoder output for the caller: a copy of x BEFORE the speaker vector is added; a single-speaker model never modifies x again, so its copy waits until
+    // the duration predictor is through (round 6: in the shadow of the longer energy branch instead of in front of both predictors)
+    if (enc_out_ct && c.multi_speaker)
         k_copy_rows(enc_out_ct, L, w.x, Lp, L, (long)B * H, s);
     if (c.multi_speaker) {
         if (c.n_speaker > 0) k_gather_rows(m->spk_table, speakers, w.spk, B, H, c.n_speaker, s);
@@ -1935,6 +1937,8 @@ int cmtts_text_forward_ragged(cmtts_model* m, const int64_t* texts, const int64_
     } else {
         k_durations(log_d, d_control, d_rounded, w.cum, mel_len, B, L, s);
     }
+    if (enc_out_ct && !c.multi_speaker)
+        k_copy_rows(enc_out_ct, L, w.x, Lp, L, (long)B * H, s);
     // energy predictor (unmasked, positions from x[...,0] != 0) -> bucketize -> embedding add
     k_pos_embed_add(w.x, w.h, m->energy.alpha, m->omega_h, m->pe_h, PE_ROWS, B, H, L, Lp, se);
     EnergyHead eh{w.x, m->vc.e_target, m->vc.e_control, m->energy_bins, c.energy_bins - 1, m->energy_emb, w.out1, e_idx, w.escaled, false};
