@@ -102,7 +102,8 @@ def vocoder_issued_flops_per_frame(winograd):
     """MFMA FLOPs the fp32 HiFi-GAN generator issues per mel frame (universal config: upsample 8, 8, 2, 2 from 512 channels; ResBlock kernels 3 / 7 / 11 x
     dilations 1 / 3 / 5), following the launcher's dispatch (cmtts_api.hip: cmtts_vocoder_forward) at its default switches for a launch of
     >= 1024 column tiles: products per output of a k-tap conv — direct k; F(4,3) tap groups (conv_xlq.hip) 6 / 16 / 24 per quad = 1.5 / 4 / 6; F(2,3) tap
-    groups (conv_xlw) 4 / 10 / 15 per pair = 2 / 5 / 7.5.  A ResBlock = conv1 at dilation 1 / 3 / 5, each followed by a dilation-1 conv2."""
+    groups (conv_xlw) 4 / 10 / 15 per pair = 2 / 5 / 7.5.  A ResBlock = conv1 at dilation 1 / 3 / 5, each followed by a dilation-1 conv2.  (The fused pair
+    kernels of the narrow stages recompute conv2's halo as well — 1-8 % of conv1, resblock_pair.hip — which this count has never included.)"""
     F43 = {3: 1.5, 7: 4.0, 11: 6.0}
     F23 = {3: 2.0, 7: 5.0, 11: 7.5}
     forms = {"direct": 0, "F(4,3)": 0, "F(2,3)": 0}
@@ -111,9 +112,13 @@ def vocoder_issued_flops_per_frame(winograd):
     for C_, up in ((256, 8), (128, 8), (64, 2), (32, 2)):
         rate *= up
         for k in (3, 7, 11):
-            for dil in (1, 1, 3, 1, 5, 1):          # conv1 d = 1, conv2, conv1 d = 3, conv2, conv1 d = 5, conv2
-                if not winograd or C_ == 32 or (C_ == 64 and k == 3):
+            for ci, dil in enumerate((1, 1, 3, 1, 5, 1)):          # conv1 d = 1, conv2, conv1 d = 3, conv2, conv1 d = 5, conv2
+                if not winograd or C_ == 32:
                     per, form = float(k), "direct"
+                elif k == 3 and C_ in (64, 128):
+                    # round 6: the k = 3 pair in ONE launch (conv_xlq_pair.hip): conv1 recomputes conv2's halo — 64 xt frames per 60 outputs
+                    # at dilation 1, 60 per 56 at dilation 3 / 5
+                    per, form = F43[k] * ((64.0 / 60.0 if dil == 1 else 60.0 / 56.0) if ci % 2 == 0 else 1.0), "F(4,3)"
                 elif dil in (1, 3) or C_ == 256 or k == 3:
                     per, form = F43[k], "F(4,3)"
                 else:

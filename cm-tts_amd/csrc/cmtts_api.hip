@@ -491,6 +491,7 @@ int g_persist_wino = 3;         // fp32 persistent denoiser: the k = 3 conv in a
 int g_voc_wino = 1;             // fp32 HiFi-GAN, C >= 128: ResBlock convs in their Winograd form (conv_xlw_kernel; NOT bitwise the direct form): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64_k = 7;          // smallest kernel size of the C = 64 stage that takes the two-launch Winograd form (measurement switch voc_wino64_k)
 int g_voc_wino43 = 1;           // fp32 HiFi-GAN: the convs of the Winograd path in the F(4,3) form (conv_xlq_kernel) instead of F(2,3) tap groups (measurement switch; 1 = dilation 1 and 3 everywhere + dilation 5 at C = 256 or k = 3 (default), 2 = only dilation 1, 3 = every dilation)
+int g_voc_qpair = 1;            // fp32 HiFi-GAN, k = 3 pairs at C = 64 / 128 of the Winograd path: both convs F(4,3) in ONE launch, xt on the CU (conv_xlq_pair.hip; NOT bitwise the two conv_xlq launches: the quads of its conv1 start one frame earlier): 0 never, 1 launches of >= 1024 column tiles, 2 always (tests)
 int g_voc_wino64 = 1;           // fp32 HiFi-GAN, C = 64, k >= 7: two Winograd launches per pair instead of the pair kernel (measurement switch)
 int g_voc_pair3 = 1;            // fp16x3 HiFi-GAN, C <= 128: ResBlock pair as ONE X-resident launch (resblock_pair16x3.hip; same bits); 0 = two conv16 launches per pair
 int g_voc_pairw = 1;            // 16-bit HiFi-GAN, C = 128: ResBlock pair as ONE launch with one in-place LDS image, two workgroups per CU (resblock_pairw16.hip; same bits); 0 = two conv_xl16 launches
@@ -2486,7 +2487,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 CHK(pack_conv(al, *w1, b1, nullptr, &v->c1[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c1f32[r][mi]));
                 if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1w32[r][mi])); }
-                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1q32[r][mi])); }
+                if (co >= 64) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c1q32[r][mi])); }     // (C = 64, k = 3: the fused F(4,3) pair, conv_xlq_pair.hip)
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c1f[r][mi][mode - 1]));
@@ -2498,7 +2499,7 @@ int cmtts_vocoder_finalize(cmtts_vocoder* v) {
                 CHK(pack_conv(al, *w2, b2, nullptr, &v->c2[r][mi], &hp));
                 CHK(al.upload(to_fragment_iter_order(hp, v->rb_kernel[j], co, co), &v->c2f32[r][mi]));
                 if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2w32[r][mi])); }
-                if (co >= 128 || (co == 64 && v->rb_kernel[j] >= 7)) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2q32[r][mi])); }
+                if (co >= 64) { const std::vector<float> wf = to_wino43_iter_fragments(hp, v->rb_kernel[j], co, co); if (!wf.empty()) CHK(al.upload(wf, &v->c2q32[r][mi])); }
                 for (int mode = 1; mode <= 2; ++mode) {
                     const std::vector<unsigned short> f16 = to_fragment16(hp, v->rb_kernel[j], co, co, mode);
                     CHK(al.upload_bytes(f16.data(), f16.size() * 2, &v->c2f[r][mi][mode - 1]));
@@ -2655,6 +2656,27 @@ int cmtts_vocoder_forward(cmtts_vocoder* v, const float* mel_ct, int B, int T, f
             const bool xw64 = g_voc_wino64 && g_voc_wino && v->winograd && !v->precision && co == 64 && rk >= g_voc_wino64_k && v->c1w32[r][0] && v->c2w32[r][0] &&
                               (g_voc_wino == 2 || (long)((To + 63) / 64) * B >= 1024);
             if (xw64) pair_ok = false;
+            // round 6: k = 3 pairs at C = 64 / 128 with both convs in the F(4,3) form and xt kept on the CU (conv_xlq_pair.hip): at C = 128 the two conv_xlq
+            // launches below without xt's trip through HBM and the residual's second read (five tensor passes -> two; the same products on quads one frame apart: fp32
+            // Winograd rounding between the two); at C = 64 half the MFMAs of the direct pair kernel.  64.4 -> 62.9 ms per 32 x 512-frame batch
+            bool qpair = g_voc_qpair && g_voc_wino && g_voc_wino43 && v->winograd && !v->precision && rk == 3 && (co == 64 || co == 128) &&
+                         (g_voc_qpair == 2 || g_voc_wino == 2 || (long)((To + 63) / 64) * B >= 1024);
+            for (int mi = 0; mi < 3 && qpair; ++mi) qpair = v->c1q32[r][mi] && v->c2q32[r][mi];
+            for (int mi = 0; mi < 3 && qpair; ++mi) {
+                const bool lastm = mi == 2;
+                if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
+                PairArgs pa;
+                memset(&pa, 0, sizeof(pa));
+                pa.x = xr; pa.y = lastm ? bufS : (mi == 0 ? bR : bT);
+                pa.b1 = v->c1[r][mi].bias; pa.b2 = v->c2[r][mi].bias;
+                pa.w1f = v->c1q32[r][mi]; pa.w2f = v->c2q32[r][mi];
+                pa.bstride = cs; pa.B = B; pa.C = co; pa.T = To; pa.ld = ld; pa.k = rk; pa.dil = v->rb_dil[mi];
+                pa.accum = lastm && j > 0; pa.slope = 0.1f;
+                if (cmtts_launch_conv_xlq_pair(&pa, (void*)q) != 0) return fail(CMTTS_E_HIP, "conv_xlq_pair launch failed");
+                if (ss && lastm && j < 2) HIPCHK(hipEventRecord(j == 0 ? ss->done0 : ss->done1, q));
+                xr = pa.y;
+            }
+            if (qpair) continue;
             for (int mi = 0; mi < 3 && pair_ok; ++mi) {
                 const bool lastm = mi == 2;
                 if (ss && lastm && j > 0) HIPCHK(hipStreamWaitEvent(q, j == 1 ? ss->done0 : ss->done1, 0));
@@ -2895,6 +2917,7 @@ int cmtts_internal_set(const char* name, int value) {
         {"voc_xl", &g_voc_xl, 0, 1},               // fp32 wide-stage convs on conv_xl
         {"voc_wino64_k", &g_voc_wino64_k, 3, 99},
         {"voc_wino43", &g_voc_wino43, 0, 3},       // fp32 dilation-1 convs of the Winograd path as F(4,3) (conv_xlq_kernel; NOT bitwise F(2,3) or direct)
+        {"voc_qpair", &g_voc_qpair, 0, 2},         // fp32 k = 3 pairs at C = 64 / 128 of the Winograd path as ONE F(4,3) launch (conv_xlq_pair.hip; NOT bitwise the forms it replaces)
         {"voc_wino64", &g_voc_wino64, 0, 1},       // fp32 C = 64 stage, k >= voc_wino64_k: two conv_xlw launches per pair (with voc_wino) instead of the pair kernel
         {"voc_wino", &g_voc_wino, 0, 2},           // fp32 wide-stage convs in their Winograd form (NOT bitwise: the A/B twin of the vocoder option "winograd")
         {"voc_xl16", &g_voc_xl16, 0, 1},           // 16-bit wide-stage convs on conv_xl16

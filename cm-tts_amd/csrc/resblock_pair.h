@@ -64,6 +64,9 @@ int cmtts_launch_conv_xlw(const ConvXlArgs* a, void* stream);
 // the dilation-1 conv in its F(4,3) form (conv_xlq.hip; a->wf = to_wino43_iter_fragments of the same weights); -2 = shape not covered (C = 64 / 128 / 256, k = 3 / 7 / 11)
 // or a launch of fewer than 1024 column tiles without a->wino_force
 int cmtts_launch_conv_xlq(const ConvXlArgs* a, void* stream);
+// a k = 3 pair (conv1 at dilation 1 / 3 / 5, LeakyReLU, conv2, + x [+ the MRF sum]) with both convs in that form and xt kept on the CU (conv_xlq_pair.hip, round 6;
+// a->w1f / a->w2f = to_wino43_iter_fragments; within fp32 Winograd rounding of the two conv_xlq launches: its conv1 quads start one frame earlier); -2 = shape not covered (C = 64 / 128, k = 3)
+int cmtts_launch_conv_xlq_pair(const PairArgs* a, void* stream);
 // Conv1d(cin = 128 | 256 -> 256, k = 5) + bias [+ ReLU] as two F(4,3) tap groups, optional LayerNorm prologue (conv_k5q.hip: the frame-level pitch predictor; a->wf = to_wino43_iter_fragments, taps = 5)
 int cmtts_launch_conv_k5q(const ConvXlArgs* a, void* stream);
 // HiFi-GAN upsampler (ConvTranspose1d, kernel 2 s, stride s, padding s / 2), all phases in one X-resident launch (resblock_pair.hip)

@@ -579,6 +579,9 @@ def test_vocoder_winograd_odd_shapes(B, T):
         got = voc(mel).clone()
         _lib.internal_set(b"voc_wino43", 1)
         got_default = voc(mel).clone()
+        prevq = _lib.internal_set(b"voc_qpair", 0)         # round 6: without the fused k = 3 pairs (C = 128: two conv_xlq launches; C = 64: the direct pair kernel)
+        got_noq = voc(mel).clone()
+        _lib.internal_set(b"voc_qpair", prevq)
         _lib.internal_set(b"voc_wino43", 0)
         got23 = voc(mel).clone()
         _lib.internal_set(b"voc_wino", 0)
@@ -592,6 +595,8 @@ def test_vocoder_winograd_odd_shapes(B, T):
     assert got.shape == ref.shape == (B, 1, T * 256) and torch.isfinite(got).all() and torch.isfinite(got23).all() and torch.isfinite(got_default).all()
     assert 0 < d <= VOC_WINO_TOL and 0 < d23 <= VOC_WINO_TOL and 0 < dd <= VOC_WINO_TOL, (d, d23, dd)
     assert not torch.equal(got, got23)
+    dq = float((got_default - got_noq).abs().max())
+    assert 0 < dq <= VOC_WINO_TOL, dq          # (the k = 3 pairs of the C = 64 / 128 stages change form: fp32 Winograd rounding)
 
 
 @pytest.mark.parametrize("B,T", [(24, 350), (9, 1000), (32, 512)])
@@ -2468,6 +2473,77 @@ def test_conv_xlq_kernel_vs_oracle(Cc, k, dil, T, ld):
             if dil == 1 and not accum:      # the restatement of the kernel's own products, fp32: same sums up to the MFMA's accumulation order
                 own = W.conv1d_f43_taps(act[b], w) + bias[:, None] + res[b, :, :T]
                 assert np.abs(got[b, :, :T] - own).max() < 3e-5      # (measured 1.3e-5 at C = 256: numpy's and the MFMA's K = 256 sums round differently)
+
+
+@pytest.mark.parametrize("Cc,dil,T,ld", [(128, 1, 66, 68), (128, 3, 200, 203), (128, 5, 59, 64), (128, 1, 257, 260), (128, 5, 512, 512), (64, 1, 131, 131), (64, 3, 5, 8),
+                                          (64, 5, 300, 300), (128, 3, 1, 4), (64, 1, 60, 60), (128, 3, 56, 56), (64, 5, 113, 116)])
+def test_conv_xlq_pair_vs_oracle(Cc, dil, T, ld):
+    """Round 6 (VERDICT r05 #4 ii): conv_xlq_pair3_kernel — a k = 3 ResBlock pair (conv1 at dilation 1 / 3 / 5 -> LeakyReLU -> conv2 -> + x [+ the MRF sum]) with
+    both convs in the F(4,3) form in ONE launch, xt in LDS, conv2's halo recomputed — against the oracle's plain pair in float64 (oracle/winograd_ref.py:
+    conv1d_direct) and against the two conv_xlq launches it replaces (the same F(4,3) products on quads that start one frame earlier — the fused tile's conv1
+    covers [t0 - 1, ..) — so the two agree to fp32 Winograd rounding, not bit for bit): every dilation, ragged quads / tiles (60- and 56-frame tiles), one-frame
+    and one-tile inputs, rows that are not 16-byte aligned, with and without accumulation; an utterance alone gets the bits it has in the batch."""
+    import ctypes as C
+    from oracle import winograd_ref as W
+    lib = C.CDLL(_lib.LIB_PATH)
+
+    class XlArgs(C.Structure):
+        _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                    ("bstride", C.c_long), ("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("ld", C.c_int), ("k", C.c_int),
+                    ("dil", C.c_int), ("accum", C.c_int), ("slope", C.c_float), ("relu", C.c_int), ("cin", C.c_int), ("xbstride", C.c_long),
+                    ("wino_force", C.c_int), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float), ("row_split", C.c_int)]
+
+    class PairArgs(C.Structure):
+        _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w1f", C.c_void_p), ("b1", C.c_void_p), ("w2f", C.c_void_p), ("b2", C.c_void_p),
+                    ("bstride", C.c_long), ("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("ld", C.c_int), ("k", C.c_int), ("dil", C.c_int),
+                    ("accum", C.c_int), ("slope", C.c_float), ("dbg", C.c_void_p)]
+    lib.cmtts_launch_conv_xlq.restype = C.c_int
+    lib.cmtts_launch_conv_xlq_pair.restype = C.c_int
+    rs = np.random.RandomState(Cc + 7 * dil + T)
+    B = 2
+    x = rs.standard_normal((B, Cc, ld)).astype(np.float32)
+    y0 = rs.standard_normal((B, Cc, ld)).astype(np.float32)
+    w1 = (rs.standard_normal((Cc, Cc, 3)) / np.sqrt(Cc * 3)).astype(np.float32)
+    w2 = (rs.standard_normal((Cc, Cc, 3)) / np.sqrt(Cc * 3)).astype(np.float32)
+    b1 = rs.standard_normal(Cc).astype(np.float32)
+    b2 = rs.standard_normal(Cc).astype(np.float32)
+    xd, b1d, b2d = (torch.from_numpy(v).to(DEV) for v in (x, b1, b2))
+    w1f = torch.from_numpy(_pack_wino43(w1)).to(DEV)
+    w2f = torch.from_numpy(_pack_wino43(w2)).to(DEV)
+    lk = lambda v: np.where(v > 0, v, v * 0.1)
+    for accum in (0, 1):
+        # the two-launch form: xt = conv1(leaky(x)) + b1 through HBM, y = (conv2(leaky(xt)) + b2) + x [+ y_old]
+        xt = torch.full((B, Cc, ld), 7.0, device=DEV)
+        yref = torch.from_numpy(y0).to(DEV)
+        a1 = XlArgs(xd.data_ptr(), xt.data_ptr(), w1f.data_ptr(), b1d.data_ptr(), None, Cc * ld, B, Cc, T, ld, 3, dil, 0, 0.1, 0, 0, 0, 1, None, None, 0.0, 0)
+        assert lib.cmtts_launch_conv_xlq(C.byref(a1), None) == 0
+        a2 = XlArgs(xt.data_ptr(), yref.data_ptr(), w2f.data_ptr(), b2d.data_ptr(), xd.data_ptr(), Cc * ld, B, Cc, T, ld, 3, 1, accum, 0.1, 0, 0, 0, 1, None, None, 0.0, 0)
+        assert lib.cmtts_launch_conv_xlq(C.byref(a2), None) == 0
+        yd = torch.from_numpy(y0).to(DEV)
+        pa = PairArgs(xd.data_ptr(), yd.data_ptr(), w1f.data_ptr(), b1d.data_ptr(), w2f.data_ptr(), b2d.data_ptr(), Cc * ld, B, Cc, T, ld, 3, dil, accum, 0.1, None)
+        assert lib.cmtts_launch_conv_xlq_pair(C.byref(pa), None) == 0
+        torch.cuda.synchronize()
+        got, two = yd.cpu().numpy(), yref.cpu().numpy()
+        assert np.array_equal(got[:, :, T:], y0[:, :, T:])                  # nothing written beyond T
+        assert np.abs(got - two).max() < 1e-5, (accum, float(np.abs(got - two).max()))      # (measured <= 4.3e-6 on outputs of a few units)
+        if not accum:
+            y1 = torch.from_numpy(y0[1:]).to(DEV)
+            pa1 = PairArgs(xd[1:].data_ptr(), y1.data_ptr(), w1f.data_ptr(), b1d.data_ptr(), w2f.data_ptr(), b2d.data_ptr(), Cc * ld, 1, Cc, T, ld, 3, dil, 0, 0.1, None)
+            assert lib.cmtts_launch_conv_xlq_pair(C.byref(pa1), None) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(y1.cpu().numpy()[0], got[1])
+        for b in range(B):
+            xt64 = W.conv1d_direct(lk(x[b, :, :T].astype(np.float64)), w1.astype(np.float64), dil) + b1[:, None]
+            ref = W.conv1d_direct(lk(xt64), w2.astype(np.float64), 1) + b2[:, None] + x[b, :, :T]
+            if accum:
+                ref = ref + y0[b, :, :T]
+            err = np.abs(got[b, :, :T] - ref).max()
+            assert err < 3e-5, (accum, b, err)
+    # the shapes the kernel does not take are refused, not mangled
+    pa = PairArgs(xd.data_ptr(), yd.data_ptr(), w1f.data_ptr(), b1d.data_ptr(), w2f.data_ptr(), b2d.data_ptr(), Cc * ld, B, Cc, T, ld, 7, dil, 0, 0.1, None)
+    assert lib.cmtts_launch_conv_xlq_pair(C.byref(pa), None) == -2
+    pa = PairArgs(xd.data_ptr(), yd.data_ptr(), w1f.data_ptr(), b1d.data_ptr(), w2f.data_ptr(), b2d.data_ptr(), Cc * ld, B, Cc, T, ld, 3, 2, 0, 0.1, None)
+    assert lib.cmtts_launch_conv_xlq_pair(C.byref(pa), None) == -2
 
 
 @pytest.mark.parametrize("cin,T,ld,B,ln", [(128, 131, 132, 2, False), (256, 200, 203, 2, True), (256, 64, 64, 3, False), (256, 5, 8, 1, True), (128, 513, 516, 2, False),
