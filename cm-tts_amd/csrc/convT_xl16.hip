@@ -2,6 +2,10 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "conv_loop16.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 namespace {
 
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(64 * NW, 2) void convT_xl16_kernel(const ConvT16Arg
     extern __shared__ __attribute__((aligned(16))) unsigned short xt16[];   // [NS][XROWS][RS], row j <-> m = t0 - 1 + j
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31;
-    const int b = blockIdx.y, t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_, t0 = bx_ * BN;
     const int Ti = a.Ti;
     const float* xb = a.x + (long)b * a.xbstride;
     {

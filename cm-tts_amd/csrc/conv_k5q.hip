@@ -24,6 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "resblock_pair.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 namespace {
 
@@ -48,8 +52,10 @@ __global__ __launch_bounds__(256, 2) void conv_k5q_kernel(const ConvXlArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
     const int wl = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
     const int w = blockIdx.z * nwv + wl;          // this wave's block of 64 output rows
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * (a.cin ? a.xbstride : a.bstride);
     float* gs = Xs + CIN * XW;

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #define CL16_PAD 8          // image rows a multiple of 16 bytes: a B fragment is one ds_read_b128 (bf16 vocoder 14.93 -> 14.80 ms; no gain in the pair kernels)
 #include "conv_loop16.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 #include <type_traits>
 
 namespace {
@@ -26,8 +30,10 @@ __global__ __launch_bounds__(C * 2 / MT, MT == 2 ? 2 : (C == 128 ? 3 : 2)) void 
     extern __shared__ __attribute__((aligned(16))) unsigned short xl16[];   // [XROWS][RS]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * BN;
     const int T = a.T, dil = a.dil;
     const int pad = dil * ((KT - 1) / 2);
     const int xw = BN + 2 * pad;

@@ -24,6 +24,11 @@
 // oracle/winograd_ref.py (conv1d_f43_taps) and checked against the plain conv on the CPU.
 #include <hip/hip_runtime.h>
 #include "resblock_pair.h"
+#include "xcd_map.h"
+
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 namespace {
 
@@ -56,8 +61,10 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_kernel(const ConvXl
     extern __shared__ __attribute__((aligned(16))) float Xs[];      // [C][DIL][CP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
     if constexpr (DIL > 1 && C == 256) {      // (measured: at C = 256 the dword form, lanes along the frame axis, beats the 16-byte form's four scattered LDS writes per item by 4 %)

@@ -20,6 +20,11 @@
 // Lane (q = l & 15, k = l >> 4) owns quad q of the tile in channel 4 ks + k; a wave owns 64 output rows (four 16-row m-tiles x six transforms); C / 64 waves.
 #include <hip/hip_runtime.h>
 #include "resblock_pair.h"
+#include "xcd_map.h"
+
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 namespace {
 
@@ -117,8 +122,10 @@ __global__ __launch_bounds__(64 * (C / 64), 2) void conv_xlq_pair3_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float Xs[];      // [C][DIL][CP] (x, activated), then [C][XW2] (xt, activated)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
     {

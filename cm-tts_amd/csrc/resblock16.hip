@@ -2,6 +2,10 @@
 // resblock_pair16.hip: three translation units compile in parallel instead of one for a quarter of an hour).
 #include <hip/hip_runtime.h>
 #include "conv_loop16.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 #ifndef RB16_W
 #define RB16_W 384
@@ -70,8 +74,10 @@ __global__ __launch_bounds__(C * 8, RB16_OCC) void resblock16_kernel(const Rb16A
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mt = w / WPM, nq = w % WPM;
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * NOUT;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * NOUT;
     const int tb = t0 - H;                                  // time of tile column 0
     const int T = a.T;
     const float slope = a.slope;

@@ -29,6 +29,10 @@
 // [+ y_old]) => BITWISE equal to the two-launch path (tests/test_gpu_parity.py::test_vocoder_pair_kernel_bitwise).
 #include <hip/hip_runtime.h>
 #include "resblock_pair.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -195,8 +199,10 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_kernel(const PairArgs a)
     constexpr int WPM = NWAVES / (C / 32);      // waves per m-tile
     const int mt = w / WPM, nq = w % WPM;
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * TT;
     const int T = a.T, dil = a.dil;
     const int r1 = dil * R2;
     const int xw = N1 + 2 * r1;                 // x columns this tile needs
@@ -344,8 +350,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == C / 32 ? 2 : 1) void conv_xl_kerne
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mt = (int)blockIdx.z * NWV + w;                // this wave's m-tile
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * XL_BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * XL_BN;
     const int T = a.T, dil = a.dil;
     const int pad = dil * ((KT - 1) / 2);
     const int xw = XL_BN + 2 * pad;
@@ -438,8 +446,10 @@ __global__ __launch_bounds__(64 * (C / (32 * MT)), 2) void conv_xlw_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mt0 = w * MT;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * BN;
     const int T = a.T;
     const float* xb = a.x + (long)b * a.bstride;
     {
@@ -668,8 +678,10 @@ __global__ __launch_bounds__(64 * NW, CIN >= 512 ? 2 : (NW >= 8 ? 4 : 2)) void c
     float* Xs = smem;                                        // [CIN][XW] act(x), column j <-> m = t0 - 1 + j
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * XL_BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * XL_BN;
     const int Ti = a.Ti;
     const float* xb = a.x + (long)b * a.xbstride;
     {

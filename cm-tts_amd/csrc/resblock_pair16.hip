@@ -14,6 +14,10 @@
 //     order and the same epilogue expressions as conv_mfma16.hip => BITWISE equal to the two-launch 16-bit path.
 #include <hip/hip_runtime.h>
 #include "resblock_pair.h"
+#include "xcd_map.h"
+#ifndef XCD_MAP
+#define XCD_MAP 1
+#endif
 #include "cvt16.h"
 
 #include "conv_loop16.h"
@@ -36,8 +40,10 @@ __global__ __launch_bounds__(C == 128 ? 512 : 256, 2) void resblock_pair16_kerne
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mt = w / WPM, nq = w % WPM;
     const int l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (XCD_MAP) xcd_tile(bx_, by_);          // consecutive tiles of an utterance on ONE XCD (xcd_map.h)
+    const int b = by_;
+    const int t0 = bx_ * TT;
     const int T = a.T, dil = a.dil;
     const int r1 = dil * R2;
     const int xw = N1 + 2 * r1;
