@@ -10,7 +10,9 @@
 // since round 6) F(2,3) over output pairs, ~2.5e-6 on the encoder output against the direct form; 2 F(4,3) over quads (round 5), ~4.5e-6; 0 direct), pred_wino (round 6: the frame-level
 // pitch predictor's k = 5 convs as F(4,3) tap groups, conv_k5q.hip, at every launch size: ~7e-6 on the cwt output; 0 = the direct kernels), voc_wino43 (round 5: the Winograd path's convs as F(4,3) tap groups over output quads, conv_xlq_kernel: 1 (default)
 // dilation 1 and 3 everywhere + dilation 5 at C = 256 or k = 3, 2 only dilation 1, 3 every conv, 0 none), voc_wino (round 4: the fp32 generator's C >= 128 ResBlock
-// convs in their Winograd form — 0 never, 1 (default) launches of >= 1024 column tiles, 2 always; <= 1.2e-6 on the waveform).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
+// convs in their Winograd form — 0 never, 1 (default) launches of >= 1024 column tiles, 2 always; <= 1.2e-6 on the waveform), voc_qpair (round 6: the k = 3 pairs of the
+// C = 64 / 128 stages of that path as ONE fused F(4,3) launch, conv_xlq_pair.hip — 0 the forms it replaces (C = 128: two conv_xlq launches; C = 64: the direct pair kernel), 1 (default)
+// with voc_wino's launch-size rule, 2 always; <= 1e-6 on the waveform between the arms).  The switches are process-wide and unsynchronised.  Exported from libcmtts_hip.so so that ctypes can reach it
 // (cmtts_amd/_lib.py: internal_set).
 #pragma once
 #ifdef __cplusplus
@@ -19,7 +21,7 @@ extern "C" {
 // Returns the previous value (a value outside the switch's range only queries) or CMTTS_E_INVALID for an unknown name.
 // Names: cond_gemm, persist_tail, inproj_fused, ffn_xres, ffn_fused, text_xres, attn_fused, pred_xl, pred_head, voc_pair,
 // voc_pair3, voc_pairw, voc_pair128, voc_rb16, voc_xl, voc_xl16, voc_upsT, post_v4, cond_gemm16, cond_factored, cond_inkernel, xres_small, pred_xres, cwt_in_phoneme, voc_xl_split, text_xt16,
-// persist_wino, ffn_wino, pred_wino, voc_wino, voc_wino43, voc_wino64, voc_wino64_k, xres_nt, and (round 6, same bits on / off) attn_qb (attention with the queries split over workgroups),
+// persist_wino, ffn_wino, pred_wino, voc_wino, voc_wino43, voc_wino64, voc_wino64_k, voc_qpair, xres_nt, and (round 6, same bits on / off) attn_qb (attention with the queries split over workgroups),
 // stats_mlp (cwt_stats_layers as one launch), energy_head (energy bucketize + embedding add inside the energy predictor's head launch)   (cmtts_api.hip: cmtts_internal_set).
 int cmtts_internal_set(const char* name, int value);
 // Test hook: the stacked conditioner projections alone, with the model's current precision mode.  cond_ct [B][hidden][T] -> cp [B][NL * C][T]
